@@ -1,0 +1,166 @@
+/*
+ * lightloam_hip.h -- C ABI of the MI355X-native (gfx950) Light-LOAM per-scan hot path.
+ *
+ * The reference (BrenYi/Light-LOAM, paths relative to /root/reference/) has no FFI/plugin interface; the
+ * seams a replacement sits behind are its node callback, one free function and the Ceres cost-functor
+ * factories.  Each entry point below names the reference code it replaces.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes; no C++/torch types.  Every function returns LL_OK (0) or a
+ *    negative ll_status; nothing throws across the boundary.
+ *  - ll_ctx owns all device memory and one HIP stream.  One ctx per host thread; not re-entrant
+ *    (neither is the reference: file-scope arrays, scanRegistration.cpp:34-40; single-threaded spinner :475).
+ *  - A ctx holds `batch` scan SLOTS resident in HBM.  The *_batch entry points run a stage for a
+ *    contiguous range of slots in one set of kernel launches (this is how 256 CUs are filled: one scan
+ *    is only 64 ring-sized work items).  The single-scan convenience calls at the end operate on slot 0.
+ *  - Points are pcl::PointXYZI packed to 16 B: x, y, z, intensity (= scanID + 0.1*relTime,
+ *    scanRegistration.cpp:208).  Quaternions are (x, y, z, w) like para_q (laserOdometry.cpp:61).
+ *  - "host" pointers are ordinary host memory; they are copied on the ctx stream and the call returns
+ *    after the copy completed.  Device-resident use: upload once, run stages, download what is needed.
+ *  - There is no CPU fallback: if no gfx950 device/HIP runtime is usable, ll_create fails with LL_ERR_DEVICE.
+ */
+#ifndef LIGHTLOAM_HIP_H
+#define LIGHTLOAM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LL_ABI_VERSION 1
+
+typedef struct ll_ctx ll_ctx;
+
+typedef struct { float x, y, z, intensity; } ll_point;     /* pcl::PointXYZI, common.h:7 */
+
+typedef enum {
+    LL_OK = 0,
+    LL_ERR_DEVICE = -1,       /* no usable HIP device / kernel image (product path never falls back to CPU) */
+    LL_ERR_ARG = -2,
+    LL_ERR_BAD_RINGS = -3,    /* scan_line not in {16,32,64} with ring_model 0: ROS_BREAK / return 0 in the reference
+                                 (scanRegistration.cpp:170-174, :447-451) */
+    LL_ERR_CAPACITY = -4,     /* more points than max_points (reference: fixed 400000 arrays, :34-40) or a ring
+                                 longer than max_ring_points */
+    LL_ERR_EMPTY = -5,        /* no point survives the NaN / minimum-range filters (reference dereferences points[0]) */
+    LL_ERR_HIP = -6,          /* a HIP runtime call failed; ll_last_error() has the text */
+    LL_ERR_STATE = -7         /* stage called before its inputs exist (e.g. associate before set_target) */
+} ll_status;
+
+/* Node parameters (scanRegistration.cpp:435-443, laserOdometry.cpp:23-30) + capacities. */
+typedef struct {
+    int   n_scans;            /* "scan_line": 16 / 32 / 64 */
+    int   ring_model;         /* 0: reference switch on n_scans; 1: the linear 64-ring formula (:162) for any n_scans */
+    float minimum_range;      /* "minimum_range" (launch: 5 for HDL-64, 0.3 for VLP-16/HDL-32) */
+    float lower_bound;        /* "lowerBound" default -24.9 */
+    float up_bound;           /* "upBound" default 2 */
+    int   max_points;         /* per-scan point capacity (<= 400000 like the reference arrays) */
+    int   max_ring_points;    /* per-ring capacity of the feature kernel's LDS staging */
+    int   batch;              /* scan slots resident in HBM */
+    /* thresholds; ll_default_params() fills the reference constants */
+    float curv_threshold;     /* 0.1  (:266, :321) compared as double like the reference */
+    float gap_sq_threshold;   /* 0.05 (:293 ...) */
+    float leaf_size;          /* 0.2  (:373) */
+    float nn_dist_sq_max;     /* DISTANCE_SQ_THRESHOLD 25 (laserOdometry.cpp:29) */
+    float nearby_scan;        /* NEARBY_SCAN 2.5 (laserOdometry.cpp:30) */
+    float huber_delta;        /* HuberLoss(0.1) (laserOdometry.cpp:475); <= 0 disables the loss */
+    int   write_curvature;    /* also store cloudCurvature[] to HBM (debug / parity output; off on the hot path) */
+} ll_params;
+
+/* Per-scan sizes produced by the extract stage. */
+typedef struct {
+    int status;               /* ll_status of this slot's last extract */
+    int n_in;                 /* points uploaded */
+    int n;                    /* laserCloud size after filtering + ring rejection (cloudSize, :212) */
+    int n_sharp, n_less_sharp, n_flat, n_less_flat;
+    int max_ring;             /* longest ring */
+} ll_scan_info;
+
+/* Per-pair sizes produced by associate / vote. */
+typedef struct {
+    int n_edge;               /* corner_correspondence (laserOdometry.cpp:617) */
+    int n_plane;              /* plane_correspondence (:790) */
+    int n_plane_selected;     /* selected_idx.size() after the vote (:796); == n_plane when vote disabled */
+} ll_pair_info;
+
+/* ---------------------------------------------------------------- lifecycle */
+void        ll_default_params(ll_params *p, int n_scans);
+int         ll_create(int device, const ll_params *p, ll_ctx **out);
+void        ll_destroy(ll_ctx *ctx);
+const char *ll_last_error(const ll_ctx *ctx);      /* ctx may be NULL: last create error */
+int         ll_abi_version(void);
+void       *ll_stream(ll_ctx *ctx);                 /* hipStream_t the ctx launches on (for HIP-event timing) */
+int         ll_synchronize(ll_ctx *ctx);
+
+/* ---------------------------------------------------------------- input
+ * Replaces pcl::fromROSMsg of the /rslidar_points message (scanRegistration.cpp:105-106, :453).
+ * xyz: n points of `stride_floats` floats each (>= 3; 4 = KITTI .bin / PointXYZ padding).              */
+int ll_upload_scan(ll_ctx *ctx, int slot, const float *host_xyz, int stride_floats, int n);
+
+/* ---------------------------------------------------------------- a1-a4: laserCloudHandler
+ * scanRegistration.cpp:87-428 for slots [first, first+count): removeNaN + removeClosedPointCloud (:58-85,
+ * :109-110), ring / relTime assignment and stable ring bucketing (:113-221), curvature (:225-235),
+ * per-segment sort + greedy pick (:246-368), per-ring VoxelGrid of the less-flat points (:370-376).
+ * Per-slot failures (empty scan, capacity) are reported in ll_scan_info.status; the call itself
+ * fails only on argument / runtime errors.                                                            */
+int ll_extract_batch(ll_ctx *ctx, int first, int count);
+int ll_get_scan_info(ll_ctx *ctx, int slot, ll_scan_info *info);
+
+/* Downloads (what the node publishes, :382-410, plus the file-scope arrays for parity checks).
+ * Any pointer may be NULL.  Capacities are in elements; LL_ERR_CAPACITY if too small.                  */
+int ll_download_cloud(ll_ctx *ctx, int slot, ll_point *cloud, int cap, int *scan_start, int *scan_end /* n_scans each */);
+int ll_download_labels(ll_ctx *ctx, int slot, int8_t *label, float *curvature /* needs write_curvature */, int cap);
+int ll_download_features(ll_ctx *ctx, int slot,
+                         ll_point *sharp, int cap_sharp, ll_point *less_sharp, int cap_less_sharp,
+                         ll_point *flat, int cap_flat, ll_point *less_flat, int cap_less_flat);
+
+/* ---------------------------------------------------------------- a5-a7: data association
+ * Replaces the kd-tree rebuild (laserOdometry.cpp:882-896) + the two correspondence loops (:491-620, :653-793)
+ * for pairs (slot k, its target).  Targets of slot k are the less-sharp / less-flat clouds of slot k-1;
+ * slot `first`'s target is the ctx "carry" target (the previous batch's last scan, or whatever
+ * ll_set_target uploaded).  pose_guess: count x 7 doubles (qx,qy,qz,qw,tx,ty,tz) = para_q/para_t at entry
+ * (:61-62); NULL = identity.                                                                           */
+int ll_set_target(ll_ctx *ctx, const ll_point *host_corner_last, int m_c, const ll_point *host_surf_last, int m_s);
+int ll_set_target_from_slot(ll_ctx *ctx, int slot);   /* device-to-device: slot's less-sharp/less-flat become the carry */
+int ll_associate_batch(ll_ctx *ctx, int first, int count, const double *host_pose_guess);
+int ll_get_pair_info(ll_ctx *ctx, int slot, ll_pair_info *info);
+/* edge: (src index into sharp, a, b into corner_last); plane: (src into flat, a, b, c into surf_last).  */
+int ll_download_edge_corr(ll_ctx *ctx, int slot, int *src, int *a, int *b, int cap);
+int ll_download_plane_corr(ll_ctx *ctx, int slot, int *src, int *a, int *b, int *c, int cap);
+
+/* ---------------------------------------------------------------- a8: graph vote
+ * graph_based_correspondence_vote_simple (laserOdometry.cpp:165-342, call :796) on the plane
+ * correspondences of each pair.  enable = 0 reproduces the now_frame <= 5 branch (:781-787): all kept, weight 1. */
+int ll_vote_batch(ll_ctx *ctx, int first, int count, int enable);
+/* per plane correspondence (in correspondence order): incompatibility count, selected flag, weight      */
+int ll_download_vote(ll_ctx *ctx, int slot, int *count, uint8_t *selected, float *weight, int cap);
+
+/* ---------------------------------------------------------------- a9-a10: residuals, Jacobians, GN
+ * Residual blocks in Ceres order: n_edge LidarEdgeFactor blocks (3 rows, lidarFactor.hpp:9-52) then the
+ * selected LidarPlaneFactor_modify blocks (1 row, :203-251, weight = vote weight), all with s = 1
+ * (DISTORTION 0, laserOdometry.cpp:23).  pose: count x 7 doubles, NULL = the pose the ctx currently holds
+ * for the slot (guess, or the result of the last ll_gn_step_batch).                                      */
+int ll_normal_equations_batch(ll_ctx *ctx, int first, int count, const double *host_pose);
+/* H: 36 doubles row-major over (dtheta[3], dt[3]) in the EigenQuaternionManifold tangent; g = J^T r; cost = sum rho/2 */
+int ll_download_normal_equations(ll_ctx *ctx, int slot, double *H36, double *g6, double *cost);
+/* Solve H d = -g (Cholesky, f64) on device, q <- Plus(q, d[0:3]), t += d[3:6]; one Gauss-Newton iteration.  */
+int ll_gn_step_batch(ll_ctx *ctx, int first, int count);
+int ll_download_pose(ll_ctx *ctx, int slot, double *pose7);
+/* What ceres::CostFunction::Evaluate would return for the slot's blocks at `pose7`: residuals (rows),
+ * jacobians[0] rows x 4 (ambient x,y,z,w) and jacobians[1] rows x 3, row-major; loss NOT applied
+ * (Ceres applies it outside Evaluate).  rows = 3*n_edge + n_plane_selected.                             */
+int ll_residual_jacobian(ll_ctx *ctx, int slot, const double *pose7, double *r, double *Jq, double *Jt, int cap_rows);
+
+/* ---------------------------------------------------------------- whole hot path
+ * One pass: extract + associate + vote + normal equations + one GN step for slots [first, first+count),
+ * everything device-resident, no host synchronisation inside.  `vote_enable` as above.                   */
+int ll_hot_path_batch(ll_ctx *ctx, int first, int count, const double *host_pose_guess, int vote_enable);
+
+/* Algorithmic HBM bytes of the last ll_hot_path_batch / stage calls, summed over the slots they covered,
+ * by SURVEY.md section 8d's formula (B_ext, B_assoc, B_vote, B_rj).                                      */
+int ll_algorithmic_bytes(ll_ctx *ctx, int first, int count, double *b_ext, double *b_assoc, double *b_vote, double *b_rj);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIGHTLOAM_HIP_H */

@@ -1,0 +1,236 @@
+"""ctypes binding of the C ABI (include/lightloam_hip.h) -- plumbing for tests, smoke and bench.
+
+Fails loudly when the HIP library is missing or no gfx950 device is usable: there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .build import lib_path
+
+POINT = np.dtype([("x", "f4"), ("y", "f4"), ("z", "f4"), ("intensity", "f4")])
+
+LL_OK = 0
+STATUS = {0: "LL_OK", -1: "LL_ERR_DEVICE", -2: "LL_ERR_ARG", -3: "LL_ERR_BAD_RINGS", -4: "LL_ERR_CAPACITY",
+          -5: "LL_ERR_EMPTY", -6: "LL_ERR_HIP", -7: "LL_ERR_STATE"}
+
+EXPORTS = [
+    "ll_default_params", "ll_create", "ll_destroy", "ll_last_error", "ll_abi_version", "ll_stream", "ll_synchronize",
+    "ll_upload_scan", "ll_extract_batch", "ll_get_scan_info", "ll_download_cloud", "ll_download_labels",
+    "ll_download_features", "ll_set_target", "ll_set_target_from_slot", "ll_associate_batch", "ll_get_pair_info",
+    "ll_download_edge_corr", "ll_download_plane_corr", "ll_vote_batch", "ll_download_vote",
+    "ll_normal_equations_batch", "ll_download_normal_equations", "ll_gn_step_batch", "ll_download_pose",
+    "ll_residual_jacobian", "ll_hot_path_batch", "ll_algorithmic_bytes",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [("n_scans", C.c_int), ("ring_model", C.c_int), ("minimum_range", C.c_float),
+                ("lower_bound", C.c_float), ("up_bound", C.c_float), ("max_points", C.c_int),
+                ("max_ring_points", C.c_int), ("batch", C.c_int), ("curv_threshold", C.c_float),
+                ("gap_sq_threshold", C.c_float), ("leaf_size", C.c_float), ("nn_dist_sq_max", C.c_float),
+                ("nearby_scan", C.c_float), ("huber_delta", C.c_float), ("write_curvature", C.c_int)]
+
+
+class ScanInfo(C.Structure):
+    _fields_ = [("status", C.c_int), ("n_in", C.c_int), ("n", C.c_int), ("n_sharp", C.c_int),
+                ("n_less_sharp", C.c_int), ("n_flat", C.c_int), ("n_less_flat", C.c_int), ("max_ring", C.c_int)]
+
+
+class PairInfo(C.Structure):
+    _fields_ = [("n_edge", C.c_int), ("n_plane", C.c_int), ("n_plane_selected", C.c_int)]
+
+
+class LightLoamError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__(f"{STATUS.get(code, code)}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree HIP library.  Raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} not built: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+        _lib = C.CDLL(path)
+        _lib.ll_last_error.restype = C.c_char_p
+        _lib.ll_last_error.argtypes = [C.c_void_p]
+        _lib.ll_stream.restype = C.c_void_p
+        _lib.ll_stream.argtypes = [C.c_void_p]
+        _lib.ll_create.argtypes = [C.c_int, C.POINTER(Params), C.POINTER(C.c_void_p)]
+        _lib.ll_destroy.argtypes = [C.c_void_p]
+    return _lib
+
+
+def default_params(n_scans=64, **kw):
+    p = Params()
+    load_library().ll_default_params(C.byref(p), n_scans)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One ll_ctx: `batch` scan slots resident in HBM on one GPU."""
+
+    def __init__(self, params, device=0):
+        self.lib = load_library()
+        self.params = params
+        h = C.c_void_p()
+        rc = self.lib.ll_create(device, C.byref(params), C.byref(h))
+        if rc != LL_OK:
+            raise LightLoamError(rc, self.lib.ll_last_error(None).decode())
+        self.h = h
+        self.R = params.n_scans
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ll_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != LL_OK:
+            raise LightLoamError(rc, self.lib.ll_last_error(self.h).decode())
+
+    @property
+    def stream(self):
+        return self.lib.ll_stream(self.h)
+
+    def synchronize(self):
+        self._ck(self.lib.ll_synchronize(self.h))
+
+    # ---- input
+    def upload_scan(self, slot, xyz):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        n, stride = (0, 4) if xyz.size == 0 else xyz.shape
+        self._ck(self.lib.ll_upload_scan(self.h, slot, _ptr(xyz), stride, n))
+
+    # ---- stages
+    def extract(self, first=0, count=1):
+        self._ck(self.lib.ll_extract_batch(self.h, first, count))
+
+    def scan_info(self, slot=0):
+        info = ScanInfo()
+        self._ck(self.lib.ll_get_scan_info(self.h, slot, C.byref(info)))
+        return info
+
+    def cloud(self, slot=0):
+        info = self.scan_info(slot)
+        cloud = np.zeros((max(info.n, 1), 4), np.float32)
+        ss = np.zeros(self.R, np.int32); se = np.zeros(self.R, np.int32)
+        self._ck(self.lib.ll_download_cloud(self.h, slot, _ptr(cloud), len(cloud), _ptr(ss), _ptr(se)))
+        return cloud[:info.n], ss, se
+
+    def labels(self, slot=0, curvature=False):
+        info = self.scan_info(slot)
+        lab = np.zeros(max(info.n, 1), np.int8)
+        cv = np.zeros(max(info.n, 1), np.float32) if curvature else None
+        self._ck(self.lib.ll_download_labels(self.h, slot, _ptr(lab), _ptr(cv), len(lab)))
+        return (lab[:info.n], cv[:info.n]) if curvature else lab[:info.n]
+
+    def features(self, slot=0):
+        info = self.scan_info(slot)
+        arr = lambda n: np.zeros((max(n, 1), 4), np.float32)
+        sh, ls, fl, lf = arr(info.n_sharp), arr(info.n_less_sharp), arr(info.n_flat), arr(info.n_less_flat)
+        self._ck(self.lib.ll_download_features(self.h, slot, _ptr(sh), len(sh), _ptr(ls), len(ls), _ptr(fl), len(fl),
+                                               _ptr(lf), len(lf)))
+        return dict(sharp=sh[:info.n_sharp], less_sharp=ls[:info.n_less_sharp], flat=fl[:info.n_flat],
+                    less_flat=lf[:info.n_less_flat])
+
+    def set_target(self, corner_last, surf_last):
+        c = np.ascontiguousarray(corner_last, np.float32).reshape(-1, 4)
+        s = np.ascontiguousarray(surf_last, np.float32).reshape(-1, 4)
+        self._ck(self.lib.ll_set_target(self.h, _ptr(c), len(c), _ptr(s), len(s)))
+
+    def set_target_from_slot(self, slot):
+        self._ck(self.lib.ll_set_target_from_slot(self.h, slot))
+
+    @staticmethod
+    def _poses(pose, count):
+        if pose is None:
+            return None
+        p = np.ascontiguousarray(pose, np.float64).reshape(-1, 7)
+        if len(p) == 1 and count > 1:
+            p = np.repeat(p, count, axis=0)
+        assert len(p) == count
+        return np.ascontiguousarray(p)
+
+    def associate(self, first=0, count=1, pose=None):
+        p = self._poses(pose, count)
+        self._ck(self.lib.ll_associate_batch(self.h, first, count, _ptr(p)))
+
+    def vote(self, first=0, count=1, enable=True):
+        self._ck(self.lib.ll_vote_batch(self.h, first, count, int(bool(enable))))
+
+    def pair_info(self, slot=0):
+        info = PairInfo()
+        self._ck(self.lib.ll_get_pair_info(self.h, slot, C.byref(info)))
+        return info
+
+    def edge_corr(self, slot=0):
+        n = self.pair_info(slot).n_edge
+        a = [np.zeros(max(n, 1), np.int32) for _ in range(3)]
+        self._ck(self.lib.ll_download_edge_corr(self.h, slot, _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), len(a[0])))
+        return tuple(x[:n] for x in a)
+
+    def plane_corr(self, slot=0):
+        n = self.pair_info(slot).n_plane
+        a = [np.zeros(max(n, 1), np.int32) for _ in range(4)]
+        self._ck(self.lib.ll_download_plane_corr(self.h, slot, _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(a[3]), len(a[0])))
+        return tuple(x[:n] for x in a)
+
+    def vote_result(self, slot=0):
+        n = self.pair_info(slot).n_plane
+        cnt = np.zeros(max(n, 1), np.int32); sel = np.zeros(max(n, 1), np.uint8); w = np.zeros(max(n, 1), np.float32)
+        self._ck(self.lib.ll_download_vote(self.h, slot, _ptr(cnt), _ptr(sel), _ptr(w), len(cnt)))
+        return cnt[:n], sel[:n].astype(bool), w[:n]
+
+    def normal_equations(self, first=0, count=1, pose=None):
+        p = self._poses(pose, count)
+        self._ck(self.lib.ll_normal_equations_batch(self.h, first, count, _ptr(p)))
+
+    def normal_equations_result(self, slot=0):
+        H = np.zeros((6, 6)); g = np.zeros(6); cost = C.c_double(0)
+        self._ck(self.lib.ll_download_normal_equations(self.h, slot, _ptr(H), _ptr(g), C.byref(cost)))
+        return H, g, cost.value
+
+    def gn_step(self, first=0, count=1):
+        self._ck(self.lib.ll_gn_step_batch(self.h, first, count))
+
+    def pose(self, slot=0):
+        p = np.zeros(7)
+        self._ck(self.lib.ll_download_pose(self.h, slot, _ptr(p)))
+        return p
+
+    def residual_jacobian(self, slot=0, pose=None):
+        pi = self.pair_info(slot)
+        rows = 3 * pi.n_edge + pi.n_plane_selected
+        r = np.zeros(max(rows, 1)); Jq = np.zeros((max(rows, 1), 4)); Jt = np.zeros((max(rows, 1), 3))
+        p = None if pose is None else np.ascontiguousarray(pose, np.float64)
+        self._ck(self.lib.ll_residual_jacobian(self.h, slot, _ptr(p), _ptr(r), _ptr(Jq), _ptr(Jt), len(r)))
+        return r[:rows], Jq[:rows], Jt[:rows]
+
+    def hot_path(self, first=0, count=1, pose=None, vote=True):
+        p = self._poses(pose, count)
+        self._ck(self.lib.ll_hot_path_batch(self.h, first, count, _ptr(p), int(bool(vote))))
+
+    def algorithmic_bytes(self, first=0, count=1):
+        b = [C.c_double(0) for _ in range(4)]
+        self._ck(self.lib.ll_algorithmic_bytes(self.h, first, count, *[C.byref(x) for x in b]))
+        return dict(ext=b[0].value, assoc=b[1].value, vote=b[2].value, rj=b[3].value)

@@ -1,0 +1,57 @@
+"""In-tree builds: the HIP C-ABI library (hipcc, gfx950) and the host-side synthetic-scan generator (gcc)."""
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+_HOST = os.path.join(_HERE, "host")
+_ROOT = os.path.dirname(_HERE)
+
+HIP_SOURCES = ["ll_api.hip", "ll_organize.hip", "ll_features.hip", "ll_associate.hip", "ll_vote.hip", "ll_factors.hip"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               # parity: the reference build has no FMA (baseline x86-64); contraction would change f32 results
+               "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
+               "-Wall", "-Wno-unused-function"]
+
+
+def lib_path():
+    return os.path.join(_HERE, "liblightloam_hip.so")
+
+
+def synth_lib_path():
+    return os.path.join(_HERE, "libll_synth.so")
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def _all_files(d, exts):
+    return [os.path.join(d, f) for f in sorted(os.listdir(d)) if f.endswith(exts)]
+
+
+def build_synth(force=False):
+    src = os.path.join(_HOST, "ll_synth.c")
+    out = synth_lib_path()
+    if force or _newer(out, [src]):
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-fopenmp", "-std=c99", "-o", out, src, "-lm"])
+    return out
+
+
+def build_hip(force=False, extra_flags=()):
+    out = lib_path()
+    deps = _all_files(_CSRC, (".hip", ".h", ".hpp")) + [os.path.join(_ROOT, "include", "lightloam_hip.h")]
+    if force or _newer(out, deps):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        cmd = [hipcc] + HIPCC_FLAGS + list(extra_flags) + ["-I", os.path.join(_ROOT, "include"), "-I", _CSRC,
+                                                          "-o", out] + [os.path.join(_CSRC, s) for s in HIP_SOURCES]
+        subprocess.check_call(cmd)
+    return out
+
+
+def build_all(force=False):
+    build_synth(force)
+    build_hip(force)

@@ -1,0 +1,505 @@
+/*
+ * ll_api.hip -- the C ABI of include/lightloam_hip.h: context, HBM-resident state, stage launches, transfers.
+ * No CPU fallback anywhere: every stage is a HIP kernel launch on the ctx stream; if the device or the gfx950
+ * code object is unusable, ll_create fails with LL_ERR_DEVICE.
+ */
+#include "lightloam_hip.h"
+#include "ll_common.h"
+#include <string>
+#include <vector>
+#include <cstring>
+#include <cstdio>
+#include <cmath>
+
+struct ll_ctx {
+    ll_params p;
+    LLView V;
+    hipStream_t stream = nullptr;
+    int device = 0;
+    std::vector<void *> allocs;
+    std::string err;
+    size_t feat_lds = 0;
+    float4 *h_stage = nullptr;      /* pinned staging for uploads */
+    size_t h_stage_pts = 0;
+    double *d_tmp_pose = nullptr, *d_rows = nullptr;
+    size_t rows_cap = 0;
+    std::vector<int> n_in_host;
+    hipEvent_t ev[16];
+    bool ev_ok = false;
+};
+
+static std::string g_create_err;
+
+#define LL_HIP(call)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                    \
+            return LL_ERR_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+extern "C" int ll_abi_version(void) { return LL_ABI_VERSION; }
+
+extern "C" void ll_default_params(ll_params *p, int n_scans)
+{
+    std::memset(p, 0, sizeof(*p));
+    p->n_scans = n_scans;
+    p->ring_model = 0;
+    /* launch/aloam_velodyne_HDL_64.launch:8 (5), VLP_16 / HDL_32 launch files (0.3); node default 0.1 (scanRegistration.cpp:438) */
+    p->minimum_range = (n_scans == 64) ? 5.0f : 0.3f;
+    p->lower_bound = -24.9f;     /* scanRegistration.cpp:439 */
+    p->up_bound = 2.0f;          /* :440 */
+    p->max_points = 262144;
+    p->max_ring_points = 2304;
+    p->batch = 1;
+    p->curv_threshold = 0.1f; p->gap_sq_threshold = 0.05f; p->leaf_size = 0.2f;
+    p->nn_dist_sq_max = 25.0f; p->nearby_scan = 2.5f; p->huber_delta = 0.1f;
+    p->write_curvature = 0;
+}
+
+extern "C" const char *ll_last_error(const ll_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+extern "C" void *ll_stream(ll_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+template <typename T>
+static bool dev_alloc(ll_ctx *ctx, T *&ptr, size_t count, bool zero = true)
+{
+    void *p = nullptr;
+    const size_t bytes = (count ? count : 1) * sizeof(T);
+    if (hipMalloc(&p, bytes) != hipSuccess) { g_create_err = "hipMalloc failed (" + std::to_string(bytes) + " bytes)"; return false; }
+    if (zero && hipMemsetAsync(p, 0, bytes, ctx->stream) != hipSuccess) { g_create_err = "hipMemset failed"; return false; }
+    ctx->allocs.push_back(p);
+    ptr = (T *)p;
+    return true;
+}
+
+extern "C" void ll_destroy(ll_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (void *p : ctx->allocs) (void)hipFree(p);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    if (ctx->ev_ok) for (auto &e : ctx->ev) (void)hipEventDestroy(e);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int ll_create(int device, const ll_params *p, ll_ctx **out)
+{
+    if (!p || !out) return LL_ERR_ARG;
+    *out = nullptr;
+    if (p->n_scans < 1 || p->n_scans > LL_MAX_RINGS || p->batch < 1 || p->max_points < 32 || p->max_points > 400000 ||
+        p->max_ring_points < 32 || p->max_ring_points > 16384) { g_create_err = "bad parameter"; return LL_ERR_ARG; }
+    if (p->ring_model == 0 && p->n_scans != 16 && p->n_scans != 32 && p->n_scans != 64) {
+        g_create_err = "only support velodyne with 16, 32 or 64 scan line (scanRegistration.cpp:447-451); use ring_model 1 for the linear model";
+        return LL_ERR_BAD_RINGS;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        g_create_err = "no usable HIP device (this library has no CPU fallback)";
+        return LL_ERR_DEVICE;
+    }
+    if (hipSetDevice(device) != hipSuccess) { g_create_err = "hipSetDevice failed"; return LL_ERR_DEVICE; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { g_create_err = "hipGetDeviceProperties failed"; return LL_ERR_DEVICE; }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_err = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+        return LL_ERR_DEVICE;
+    }
+    ll_ctx *ctx = new ll_ctx();
+    ctx->p = *p; ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { g_create_err = "hipStreamCreate failed"; delete ctx; return LL_ERR_DEVICE; }
+    for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { g_create_err = "hipEventCreate failed"; ll_destroy(ctx); return LL_ERR_DEVICE; }
+    ctx->ev_ok = true;
+
+    LLView &V = ctx->V;
+    std::memset(&V, 0, sizeof(V));
+    const int B = p->batch, R = p->n_scans;
+    const int NP = (p->max_points + LL_TILE - 1) / LL_TILE * LL_TILE;
+    V.B = B; V.NP = NP; V.T = NP / LL_TILE; V.R = R; V.ring_model = p->ring_model;
+    V.max_ring = p->max_ring_points; V.write_curv = p->write_curvature;
+    V.thres = p->minimum_range; V.lower_bound = p->lower_bound;
+    V.factor = (float)(R - 1) / (p->up_bound - p->lower_bound);                 /* scanRegistration.cpp:441 */
+    /* the reference compares f32 values with the double literals 0.1 / 0.05; a float param widened to double is not
+     * the same number, so the defaults are mapped back to the exact double literals */
+    V.curv_thr = (p->curv_threshold == 0.1f) ? 0.1 : (double)p->curv_threshold;
+    V.gap_thr = (p->gap_sq_threshold == 0.05f) ? 0.05 : (double)p->gap_sq_threshold;
+    V.leaf = p->leaf_size; V.inv_leaf = 1.0f / p->leaf_size;
+    V.nn_max = p->nn_dist_sq_max; V.nearby = (double)p->nearby_scan;
+    V.huber = (p->huber_delta == 0.1f) ? 0.1 : (double)p->huber_delta;
+    V.cap_sharp = R * LL_SEGS * LL_SHARP_PER_SEG; V.cap_lsharp = R * LL_SEGS * LL_LSHARP_PER_SEG; V.cap_flat = R * LL_SEGS * LL_FLAT_PER_SEG;
+    V.carry_slot = 0;
+
+    const size_t BN = (size_t)B * NP, BT = (size_t)B * V.T;
+    bool ok = true;
+    float4 *raw = nullptr; int *n_in = nullptr;
+    ok = ok && dev_alloc(ctx, raw, BN, false) && dev_alloc(ctx, n_in, B);
+    V.raw = raw; V.n_in = n_in;
+    ok = ok && dev_alloc(ctx, V.ori, BN, false) && dev_alloc(ctx, V.ring, BN, false);
+    ok = ok && dev_alloc(ctx, V.tile_hist, BT * R) && dev_alloc(ctx, V.tile_base, BT * R) && dev_alloc(ctx, V.tile_first_p, BT) &&
+         dev_alloc(ctx, V.tile_first_kept, BT) && dev_alloc(ctx, V.tile_last_kept, BT);
+    ok = ok && dev_alloc(ctx, V.hdr, B) && dev_alloc(ctx, V.ring_off, (size_t)B * (R + 1));
+    ok = ok && dev_alloc(ctx, V.cloud, BN, false) && dev_alloc(ctx, V.label, BN) && dev_alloc(ctx, V.curv, p->write_curvature ? BN : 1);
+    ok = ok && dev_alloc(ctx, V.sharp_slot, (size_t)B * V.cap_sharp, false) && dev_alloc(ctx, V.lsharp_slot, (size_t)B * V.cap_lsharp, false) &&
+         dev_alloc(ctx, V.flat_slot, (size_t)B * V.cap_flat, false) && dev_alloc(ctx, V.lflat_slot, BN, false) && dev_alloc(ctx, V.ring_feat_cnt, (size_t)B * R * 4);
+    ok = ok && dev_alloc(ctx, V.sharp, (size_t)B * V.cap_sharp, false) && dev_alloc(ctx, V.lsharp, (size_t)B * V.cap_lsharp, false) &&
+         dev_alloc(ctx, V.flat, (size_t)B * V.cap_flat, false) && dev_alloc(ctx, V.lflat, BN, false);
+    ok = ok && dev_alloc(ctx, V.carry_corner, V.cap_lsharp) && dev_alloc(ctx, V.carry_surf, NP) && dev_alloc(ctx, V.carry_cnt, 2);
+    ok = ok && dev_alloc(ctx, V.eq_a, (size_t)B * V.cap_sharp) && dev_alloc(ctx, V.eq_b, (size_t)B * V.cap_sharp);
+    ok = ok && dev_alloc(ctx, V.pq_a, (size_t)B * V.cap_flat) && dev_alloc(ctx, V.pq_b, (size_t)B * V.cap_flat) && dev_alloc(ctx, V.pq_c, (size_t)B * V.cap_flat);
+    ok = ok && dev_alloc(ctx, V.e_src, (size_t)B * V.cap_sharp) && dev_alloc(ctx, V.e_a, (size_t)B * V.cap_sharp) && dev_alloc(ctx, V.e_b, (size_t)B * V.cap_sharp);
+    ok = ok && dev_alloc(ctx, V.p_src, (size_t)B * V.cap_flat) && dev_alloc(ctx, V.p_a, (size_t)B * V.cap_flat) && dev_alloc(ctx, V.p_b, (size_t)B * V.cap_flat) && dev_alloc(ctx, V.p_c, (size_t)B * V.cap_flat);
+    ok = ok && dev_alloc(ctx, V.v_count, (size_t)B * V.cap_flat) && dev_alloc(ctx, V.v_sel, (size_t)B * V.cap_flat) && dev_alloc(ctx, V.v_w, (size_t)B * V.cap_flat);
+    ok = ok && dev_alloc(ctx, V.pair, B) && dev_alloc(ctx, V.pose, (size_t)B * 7) && dev_alloc(ctx, V.neq, (size_t)B * LL_NEQ_STRIDE);
+    ok = ok && dev_alloc(ctx, ctx->d_tmp_pose, 7);
+    if (!ok) { ll_destroy(ctx); return LL_ERR_HIP; }
+    ctx->feat_lds = ll_features_lds_bytes(p->max_ring_points);
+    if (ctx->feat_lds > 160 * 1024) { g_create_err = "max_ring_points needs more than 160 KiB of LDS"; ll_destroy(ctx); return LL_ERR_ARG; }
+    /* identity pose guesses; status = "nothing extracted yet" */
+    std::vector<double> ident((size_t)B * 7, 0.0);
+    for (int b = 0; b < B; ++b) ident[(size_t)b * 7 + 3] = 1.0;
+    if (hipMemcpyAsync(V.pose, ident.data(), ident.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) { g_create_err = "initial upload failed"; ll_destroy(ctx); return LL_ERR_HIP; }
+    ctx->h_stage_pts = NP;
+    if (hipHostMalloc((void **)&ctx->h_stage, (size_t)NP * sizeof(float4), hipHostMallocDefault) != hipSuccess) { g_create_err = "hipHostMalloc failed"; ll_destroy(ctx); return LL_ERR_HIP; }
+    ctx->n_in_host.assign(B, 0);
+    *out = ctx;
+    return LL_OK;
+}
+
+extern "C" int ll_synchronize(ll_ctx *ctx)
+{
+    if (!ctx) return LL_ERR_ARG;
+    LL_HIP(hipStreamSynchronize(ctx->stream));
+    return LL_OK;
+}
+
+static int check_range(ll_ctx *ctx, int first, int count)
+{
+    if (!ctx) return LL_ERR_ARG;
+    if (first < 0 || count < 1 || first + count > ctx->p.batch) { ctx->err = "slot range out of bounds"; return LL_ERR_ARG; }
+    return LL_OK;
+}
+
+extern "C" int ll_upload_scan(ll_ctx *ctx, int slot, const float *xyz, int stride, int n)
+{
+    int rc = check_range(ctx, slot, 1); if (rc) return rc;
+    if (n < 0 || stride < 3 || (!xyz && n > 0)) { ctx->err = "bad upload arguments"; return LL_ERR_ARG; }
+    if (n > ctx->p.max_points) { ctx->err = "scan larger than max_points"; return LL_ERR_CAPACITY; }
+    LLView &V = ctx->V;
+    float4 *dst = const_cast<float4 *>(V.raw) + (size_t)slot * V.NP;
+    if (n > 0) {
+        if (stride == 4) std::memcpy(ctx->h_stage, xyz, (size_t)n * 16);
+        else for (int i = 0; i < n; ++i) ctx->h_stage[i] = make_float4(xyz[(size_t)i * stride], xyz[(size_t)i * stride + 1], xyz[(size_t)i * stride + 2], 0.0f);
+        LL_HIP(hipMemcpyAsync(dst, ctx->h_stage, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+    }
+    ctx->n_in_host[slot] = n;
+    LL_HIP(hipMemcpyAsync(const_cast<int *>(V.n_in) + slot, &ctx->n_in_host[slot], sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    LL_HIP(hipStreamSynchronize(ctx->stream));
+    return LL_OK;
+}
+
+/* ------------------------------------------------------------------ stages */
+extern "C" int ll_extract_batch(ll_ctx *ctx, int first, int count)
+{
+    int rc = check_range(ctx, first, count); if (rc) return rc;
+    ll_launch_organize(ctx->V, first, count, ctx->stream);
+    ll_launch_features(ctx->V, first, count, ctx->feat_lds, ctx->stream);
+    LL_HIP(hipGetLastError());
+    return LL_OK;
+}
+
+static int upload_poses(ll_ctx *ctx, int first, int count, const double *host_pose)
+{
+    if (host_pose) {
+        LL_HIP(hipMemcpyAsync(ctx->V.pose + (size_t)first * 7, host_pose, (size_t)count * 7 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        LL_HIP(hipStreamSynchronize(ctx->stream));    /* host buffer may be reused by the caller */
+    }
+    return LL_OK;
+}
+
+extern "C" int ll_set_target(ll_ctx *ctx, const ll_point *corner, int m_c, const ll_point *surf, int m_s)
+{
+    if (!ctx) return LL_ERR_ARG;
+    LLView &V = ctx->V;
+    if (m_c < 0 || m_s < 0 || m_c > V.cap_lsharp || m_s > V.NP) { ctx->err = "target larger than capacity"; return LL_ERR_CAPACITY; }
+    if (m_c) LL_HIP(hipMemcpyAsync(V.carry_corner, corner, (size_t)m_c * 16, hipMemcpyHostToDevice, ctx->stream));
+    if (m_s) LL_HIP(hipMemcpyAsync(V.carry_surf, surf, (size_t)m_s * 16, hipMemcpyHostToDevice, ctx->stream));
+    const int cnt[2] = {m_c, m_s};
+    LL_HIP(hipMemcpyAsync(V.carry_cnt, cnt, sizeof(cnt), hipMemcpyHostToDevice, ctx->stream));
+    LL_HIP(hipStreamSynchronize(ctx->stream));
+    return LL_OK;
+}
+
+__global__ void k_copy_carry(LLView V, int slot)
+{
+    const ScanHdr h = V.hdr[slot];
+    const int mc = h.status == 0 ? h.n_less_sharp : 0, ms = h.status == 0 ? h.n_less_flat : 0;
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+    for (int i = gtid; i < mc; i += gsz) V.carry_corner[i] = V.lsharp[(size_t)slot * V.cap_lsharp + i];
+    for (int i = gtid; i < ms; i += gsz) V.carry_surf[i] = V.lflat[(size_t)slot * V.NP + i];
+    if (gtid == 0) { V.carry_cnt[0] = mc; V.carry_cnt[1] = ms; }
+}
+
+extern "C" int ll_set_target_from_slot(ll_ctx *ctx, int slot)
+{
+    int rc = check_range(ctx, slot, 1); if (rc) return rc;
+    hipLaunchKernelGGL(k_copy_carry, dim3(64), dim3(256), 0, ctx->stream, ctx->V, slot);
+    LL_HIP(hipGetLastError());
+    return LL_OK;
+}
+
+extern "C" int ll_associate_batch(ll_ctx *ctx, int first, int count, const double *host_pose_guess)
+{
+    int rc = check_range(ctx, first, count); if (rc) return rc;
+    rc = upload_poses(ctx, first, count, host_pose_guess); if (rc) return rc;
+    ctx->V.carry_slot = first;
+    ll_launch_associate(ctx->V, first, count, ctx->stream);
+    LL_HIP(hipGetLastError());
+    return LL_OK;
+}
+
+extern "C" int ll_vote_batch(ll_ctx *ctx, int first, int count, int enable)
+{
+    int rc = check_range(ctx, first, count); if (rc) return rc;
+    ctx->V.carry_slot = first;
+    ll_launch_vote(ctx->V, first, count, enable, ctx->stream);
+    LL_HIP(hipGetLastError());
+    return LL_OK;
+}
+
+extern "C" int ll_normal_equations_batch(ll_ctx *ctx, int first, int count, const double *host_pose)
+{
+    int rc = check_range(ctx, first, count); if (rc) return rc;
+    rc = upload_poses(ctx, first, count, host_pose); if (rc) return rc;
+    ctx->V.carry_slot = first;
+    ll_launch_normal_equations(ctx->V, first, count, 0, ctx->stream);
+    LL_HIP(hipGetLastError());
+    return LL_OK;
+}
+
+extern "C" int ll_gn_step_batch(ll_ctx *ctx, int first, int count)
+{
+    int rc = check_range(ctx, first, count); if (rc) return rc;
+    ll_launch_gn_step(ctx->V, first, count, ctx->stream);
+    LL_HIP(hipGetLastError());
+    return LL_OK;
+}
+
+extern "C" int ll_hot_path_batch(ll_ctx *ctx, int first, int count, const double *host_pose_guess, int vote_enable)
+{
+    int rc = check_range(ctx, first, count); if (rc) return rc;
+    rc = upload_poses(ctx, first, count, host_pose_guess); if (rc) return rc;
+    ctx->V.carry_slot = first;
+    ll_launch_organize(ctx->V, first, count, ctx->stream);
+    ll_launch_features(ctx->V, first, count, ctx->feat_lds, ctx->stream);
+    ll_launch_associate(ctx->V, first, count, ctx->stream);
+    ll_launch_vote(ctx->V, first, count, vote_enable, ctx->stream);
+    ll_launch_normal_equations(ctx->V, first, count, 1, ctx->stream);
+    LL_HIP(hipGetLastError());
+    return LL_OK;
+}
+
+/* ------------------------------------------------------------------ downloads */
+static int dl(ll_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (!dst || !bytes) return LL_OK;
+    LL_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return LL_OK;
+}
+
+static int fetch_hdr(ll_ctx *ctx, int slot, ScanHdr *h)
+{
+    LL_HIP(hipMemcpyAsync(h, ctx->V.hdr + slot, sizeof(ScanHdr), hipMemcpyDeviceToHost, ctx->stream));
+    LL_HIP(hipStreamSynchronize(ctx->stream));
+    return LL_OK;
+}
+
+extern "C" int ll_get_scan_info(ll_ctx *ctx, int slot, ll_scan_info *info)
+{
+    int rc = check_range(ctx, slot, 1); if (rc) return rc;
+    if (!info) return LL_ERR_ARG;
+    ScanHdr h; rc = fetch_hdr(ctx, slot, &h); if (rc) return rc;
+    info->status = h.status; info->n_in = ctx->n_in_host[slot]; info->n = h.n;
+    info->n_sharp = h.n_sharp; info->n_less_sharp = h.n_less_sharp; info->n_flat = h.n_flat; info->n_less_flat = h.n_less_flat;
+    info->max_ring = h.max_ring;
+    return LL_OK;
+}
+
+extern "C" int ll_download_cloud(ll_ctx *ctx, int slot, ll_point *cloud, int cap, int *scan_start, int *scan_end)
+{
+    int rc = check_range(ctx, slot, 1); if (rc) return rc;
+    ScanHdr h; rc = fetch_hdr(ctx, slot, &h); if (rc) return rc;
+    LLView &V = ctx->V;
+    if (cloud) {
+        if (cap < h.n) { ctx->err = "cloud capacity too small"; return LL_ERR_CAPACITY; }
+        rc = dl(ctx, cloud, V.cloud + (size_t)slot * V.NP, (size_t)h.n * 16); if (rc) return rc;
+    }
+    std::vector<int> off(V.R + 1);
+    rc = dl(ctx, off.data(), V.ring_off + (size_t)slot * (V.R + 1), (size_t)(V.R + 1) * sizeof(int)); if (rc) return rc;
+    LL_HIP(hipStreamSynchronize(ctx->stream));
+    for (int r = 0; r < V.R; ++r) {
+        if (scan_start) scan_start[r] = off[r] + 5;          /* scanRegistration.cpp:218 */
+        if (scan_end) scan_end[r] = off[r + 1] - 6;          /* :220 */
+    }
+    return LL_OK;
+}
+
+extern "C" int ll_download_labels(ll_ctx *ctx, int slot, int8_t *label, float *curvature, int cap)
+{
+    int rc = check_range(ctx, slot, 1); if (rc) return rc;
+    ScanHdr h; rc = fetch_hdr(ctx, slot, &h); if (rc) return rc;
+    LLView &V = ctx->V;
+    if (cap < h.n) { ctx->err = "label capacity too small"; return LL_ERR_CAPACITY; }
+    if (curvature && !V.write_curv) { ctx->err = "curvature requested but write_curvature = 0"; return LL_ERR_STATE; }
+    rc = dl(ctx, label, V.label + (size_t)slot * V.NP, (size_t)h.n); if (rc) return rc;
+    rc = dl(ctx, curvature, V.curv + (size_t)slot * V.NP, (size_t)h.n * 4); if (rc) return rc;
+    LL_HIP(hipStreamSynchronize(ctx->stream));
+    return LL_OK;
+}
+
+extern "C" int ll_download_features(ll_ctx *ctx, int slot, ll_point *sharp, int cap_sharp, ll_point *less_sharp, int cap_ls,
+                                    ll_point *flat, int cap_flat, ll_point *less_flat, int cap_lf)
+{
+    int rc = check_range(ctx, slot, 1); if (rc) return rc;
+    ScanHdr h; rc = fetch_hdr(ctx, slot, &h); if (rc) return rc;
+    LLView &V = ctx->V;
+    if ((sharp && cap_sharp < h.n_sharp) || (less_sharp && cap_ls < h.n_less_sharp) || (flat && cap_flat < h.n_flat) ||
+        (less_flat && cap_lf < h.n_less_flat)) { ctx->err = "feature capacity too small"; return LL_ERR_CAPACITY; }
+    rc = dl(ctx, sharp, V.sharp + (size_t)slot * V.cap_sharp, (size_t)h.n_sharp * 16); if (rc) return rc;
+    rc = dl(ctx, less_sharp, V.lsharp + (size_t)slot * V.cap_lsharp, (size_t)h.n_less_sharp * 16); if (rc) return rc;
+    rc = dl(ctx, flat, V.flat + (size_t)slot * V.cap_flat, (size_t)h.n_flat * 16); if (rc) return rc;
+    rc = dl(ctx, less_flat, V.lflat + (size_t)slot * V.NP, (size_t)h.n_less_flat * 16); if (rc) return rc;
+    LL_HIP(hipStreamSynchronize(ctx->stream));
+    return LL_OK;
+}
+
+static int fetch_pair(ll_ctx *ctx, int slot, PairHdr *p)
+{
+    LL_HIP(hipMemcpyAsync(p, ctx->V.pair + slot, sizeof(PairHdr), hipMemcpyDeviceToHost, ctx->stream));
+    LL_HIP(hipStreamSynchronize(ctx->stream));
+    return LL_OK;
+}
+
+extern "C" int ll_get_pair_info(ll_ctx *ctx, int slot, ll_pair_info *info)
+{
+    int rc = check_range(ctx, slot, 1); if (rc) return rc;
+    if (!info) return LL_ERR_ARG;
+    PairHdr p; rc = fetch_pair(ctx, slot, &p); if (rc) return rc;
+    info->n_edge = p.n_edge; info->n_plane = p.n_plane; info->n_plane_selected = p.n_plane_sel;
+    return LL_OK;
+}
+
+extern "C" int ll_download_edge_corr(ll_ctx *ctx, int slot, int *src, int *a, int *b, int cap)
+{
+    int rc = check_range(ctx, slot, 1); if (rc) return rc;
+    PairHdr p; rc = fetch_pair(ctx, slot, &p); if (rc) return rc;
+    if (cap < p.n_edge) { ctx->err = "edge capacity too small"; return LL_ERR_CAPACITY; }
+    LLView &V = ctx->V; const size_t o = (size_t)slot * V.cap_sharp, by = (size_t)p.n_edge * sizeof(int);
+    rc = dl(ctx, src, V.e_src + o, by); if (rc) return rc;
+    rc = dl(ctx, a, V.e_a + o, by); if (rc) return rc;
+    rc = dl(ctx, b, V.e_b + o, by); if (rc) return rc;
+    LL_HIP(hipStreamSynchronize(ctx->stream));
+    return LL_OK;
+}
+
+extern "C" int ll_download_plane_corr(ll_ctx *ctx, int slot, int *src, int *a, int *b, int *c, int cap)
+{
+    int rc = check_range(ctx, slot, 1); if (rc) return rc;
+    PairHdr p; rc = fetch_pair(ctx, slot, &p); if (rc) return rc;
+    if (cap < p.n_plane) { ctx->err = "plane capacity too small"; return LL_ERR_CAPACITY; }
+    LLView &V = ctx->V; const size_t o = (size_t)slot * V.cap_flat, by = (size_t)p.n_plane * sizeof(int);
+    rc = dl(ctx, src, V.p_src + o, by); if (rc) return rc;
+    rc = dl(ctx, a, V.p_a + o, by); if (rc) return rc;
+    rc = dl(ctx, b, V.p_b + o, by); if (rc) return rc;
+    rc = dl(ctx, c, V.p_c + o, by); if (rc) return rc;
+    LL_HIP(hipStreamSynchronize(ctx->stream));
+    return LL_OK;
+}
+
+extern "C" int ll_download_vote(ll_ctx *ctx, int slot, int *count, uint8_t *selected, float *weight, int cap)
+{
+    int rc = check_range(ctx, slot, 1); if (rc) return rc;
+    PairHdr p; rc = fetch_pair(ctx, slot, &p); if (rc) return rc;
+    if (cap < p.n_plane) { ctx->err = "vote capacity too small"; return LL_ERR_CAPACITY; }
+    LLView &V = ctx->V; const size_t o = (size_t)slot * V.cap_flat;
+    rc = dl(ctx, count, V.v_count + o, (size_t)p.n_plane * sizeof(int)); if (rc) return rc;
+    rc = dl(ctx, selected, V.v_sel + o, (size_t)p.n_plane); if (rc) return rc;
+    rc = dl(ctx, weight, V.v_w + o, (size_t)p.n_plane * sizeof(float)); if (rc) return rc;
+    LL_HIP(hipStreamSynchronize(ctx->stream));
+    return LL_OK;
+}
+
+extern "C" int ll_download_normal_equations(ll_ctx *ctx, int slot, double *H36, double *g6, double *cost)
+{
+    int rc = check_range(ctx, slot, 1); if (rc) return rc;
+    double buf[LL_NEQ_STRIDE];
+    rc = dl(ctx, buf, ctx->V.neq + (size_t)slot * LL_NEQ_STRIDE, sizeof(buf)); if (rc) return rc;
+    LL_HIP(hipStreamSynchronize(ctx->stream));
+    if (H36) std::memcpy(H36, buf, 36 * sizeof(double));
+    if (g6) std::memcpy(g6, buf + 36, 6 * sizeof(double));
+    if (cost) *cost = buf[42];
+    return LL_OK;
+}
+
+extern "C" int ll_download_pose(ll_ctx *ctx, int slot, double *pose7)
+{
+    int rc = check_range(ctx, slot, 1); if (rc) return rc;
+    rc = dl(ctx, pose7, ctx->V.pose + (size_t)slot * 7, 7 * sizeof(double)); if (rc) return rc;
+    LL_HIP(hipStreamSynchronize(ctx->stream));
+    return LL_OK;
+}
+
+extern "C" int ll_residual_jacobian(ll_ctx *ctx, int slot, const double *pose7, double *r, double *Jq, double *Jt, int cap_rows)
+{
+    int rc = check_range(ctx, slot, 1); if (rc) return rc;
+    PairHdr p; rc = fetch_pair(ctx, slot, &p); if (rc) return rc;
+    const size_t rows = (size_t)3 * p.n_edge + p.n_plane_sel;
+    if ((size_t)cap_rows < rows) { ctx->err = "row capacity too small"; return LL_ERR_CAPACITY; }
+    if (rows == 0) return LL_OK;
+    if (ctx->rows_cap < rows) {
+        void *q = nullptr;
+        LL_HIP(hipMalloc(&q, rows * 8 * sizeof(double)));
+        ctx->allocs.push_back(q); ctx->d_rows = (double *)q; ctx->rows_cap = rows;
+    }
+    const double *dpose = ctx->V.pose + (size_t)slot * 7;
+    if (pose7) {
+        LL_HIP(hipMemcpyAsync(ctx->d_tmp_pose, pose7, 7 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        dpose = ctx->d_tmp_pose;
+    }
+    double *dr = ctx->d_rows, *dJq = dr + rows, *dJt = dJq + rows * 4;
+    ctx->V.carry_slot = ctx->V.carry_slot;   /* unchanged: rows use the same target selection as the last stage call */
+    ll_launch_rows(ctx->V, slot, dpose, dr, dJq, dJt, ctx->stream);
+    LL_HIP(hipGetLastError());
+    rc = dl(ctx, r, dr, rows * sizeof(double)); if (rc) return rc;
+    rc = dl(ctx, Jq, dJq, rows * 4 * sizeof(double)); if (rc) return rc;
+    rc = dl(ctx, Jt, dJt, rows * 3 * sizeof(double)); if (rc) return rc;
+    LL_HIP(hipStreamSynchronize(ctx->stream));
+    return LL_OK;
+}
+
+extern "C" int ll_algorithmic_bytes(ll_ctx *ctx, int first, int count, double *b_ext, double *b_assoc, double *b_vote, double *b_rj)
+{
+    int rc = check_range(ctx, first, count); if (rc) return rc;
+    LLView &V = ctx->V;
+    std::vector<ScanHdr> h(count); std::vector<PairHdr> p(count);
+    int carry[2] = {0, 0};
+    rc = dl(ctx, h.data(), V.hdr + first, sizeof(ScanHdr) * count); if (rc) return rc;
+    rc = dl(ctx, p.data(), V.pair + first, sizeof(PairHdr) * count); if (rc) return rc;
+    rc = dl(ctx, carry, V.carry_cnt, sizeof(carry)); if (rc) return rc;
+    LL_HIP(hipStreamSynchronize(ctx->stream));
+    double be = 0, ba = 0, bv = 0, br = 0;
+    for (int i = 0; i < count; ++i) {
+        const ScanHdr &s = h[i];
+        if (s.status != 0) { be += 16.0 * ctx->n_in_host[first + i]; continue; }
+        /* SURVEY.md section 8d */
+        be += 16.0 * ctx->n_in_host[first + i] + 16.0 * s.n + 16.0 * (s.n_sharp + s.n_less_sharp + s.n_flat + s.n_less_flat) + 1.0 * s.n;
+        const int mc = (i == 0) ? carry[0] : h[i - 1].n_less_sharp, ms = (i == 0) ? carry[1] : h[i - 1].n_less_flat;
+        ba += 16.0 * (s.n_sharp + s.n_flat) + 16.0 * (mc + ms) + 8.0 * p[i].n_edge + 12.0 * p[i].n_plane;
+        bv += 32.0 * p[i].n_plane + 8.0 * p[i].n_plane_sel;
+        br += 48.0 * p[i].n_edge + 64.0 * p[i].n_plane_sel + 216.0;
+    }
+    if (b_ext) *b_ext = be; if (b_assoc) *b_assoc = ba; if (b_vote) *b_vote = bv; if (b_rj) *b_rj = br;
+    return LL_OK;
+}

@@ -1,0 +1,113 @@
+/*
+ * ll_common.h -- device-side view of a context's HBM-resident state + helpers shared by the kernels.
+ *
+ * HBM layout (B = batch slots, NP = max_points rounded up to a whole tile, R = n_scans, T = NP / LL_TILE):
+ *   raw        float4 [B][NP]      uploaded points (x, y, z, reflectance/pad) -- KITTI .bin / PointXYZ stride
+ *   ori        float  [B][NP]      -atan2f(y,x) per input point (scanRegistration.cpp:177)
+ *   ring       int8   [B][NP]      scanID per input point, -1 = filtered / rejected
+ *   tile_hist  int    [B][T][R]    per-tile ring histogram      -> tile_base (exclusive, in laserCloud positions)
+ *   hdr        ScanHdr[B]          startOri / endOri / halfPassed index / sizes / status
+ *   ring_off   int    [B][R+1]     ring r occupies laserCloud[ring_off[r], ring_off[r+1])
+ *   cloud      float4 [B][NP]      laserCloud: ring-major, (x, y, z, intensity)
+ *   label      int8   [B][NP]      cloudLabel   curv float [B][NP] (optional)
+ *   *_slot     per-ring fixed-capacity feature slots written by the ring kernel, then compacted into
+ *   sharp / less_sharp / flat / less_flat float4 [B][cap] in the reference's publication order.
+ *   carry_*    target clouds for the first slot of a batch (previous batch's last scan).
+ *   corr / vote / neq / pose arrays for the odometry stages.
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ll_exact_math.h"
+
+#define LL_TILE 1024          /* points per organise tile: 256 threads x 4 */
+#define LL_BLOCK 256
+#define LL_MAX_RINGS 128
+#define LL_SHARP_PER_SEG 2
+#define LL_LSHARP_PER_SEG 20
+#define LL_FLAT_PER_SEG 4
+#define LL_SEGS 6
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+struct ScanHdr {
+    float start_ori, end_ori;
+    int first_kept, last_kept;     /* indices into raw[] (INT_MAX / -1 when none) */
+    int half_idx;                  /* first valid-ring point whose (ori - startOri) > pi: halfPassed is true for i > half_idx */
+    int n;                         /* cloudSize (:212) */
+    int status;
+    int max_ring;
+    int n_sharp, n_less_sharp, n_flat, n_less_flat;
+};
+
+struct PairHdr {
+    int n_edge, n_plane, n_plane_sel;
+    int target_slot;               /* -1 = carry */
+};
+
+struct LLView {
+    /* configuration */
+    int B, NP, T, R, ring_model, max_ring, write_curv;
+    float thres, lower_bound, factor;
+    double curv_thr, gap_thr;      /* 0.1 / 0.05 as double: the reference compares f32 against double literals */
+    float leaf, inv_leaf;
+    float nn_max;                  /* 25 */
+    double nearby;                 /* 2.5 */
+    double huber;
+    int cap_sharp, cap_lsharp, cap_flat;      /* per-scan capacities R*12, R*120, R*24 */
+    /* organise */
+    const float4 *raw; const int *n_in;
+    float *ori; int8_t *ring;
+    int *tile_hist; int *tile_base; int *tile_first_p; int *tile_first_kept; int *tile_last_kept;
+    ScanHdr *hdr; int *ring_off;
+    float4 *cloud; int8_t *label; float *curv;
+    /* features */
+    float4 *sharp_slot, *lsharp_slot, *flat_slot, *lflat_slot; int *ring_feat_cnt;   /* [B][R][4] */
+    float4 *sharp, *lsharp, *flat, *lflat;
+    /* targets */
+    float4 *carry_corner, *carry_surf; int *carry_cnt;    /* carry_cnt[2] */
+    /* association (per query, then compacted) */
+    int *eq_a, *eq_b;              /* [B][cap_sharp]  -1 = no correspondence */
+    int *pq_a, *pq_b, *pq_c;       /* [B][cap_flat] */
+    int *e_src, *e_a, *e_b;        /* compacted */
+    int *p_src, *p_a, *p_b, *p_c;
+    int *v_count; uint8_t *v_sel; float *v_w;
+    PairHdr *pair;
+    double *pose;                  /* [B][7] qx qy qz qw tx ty tz */
+    double *neq;                   /* [B][44]: H[36] row-major, g[6], cost, rows */
+    int carry_slot;                /* the slot whose target is the carry (first slot of the batch) */
+};
+
+#define LL_NEQ_STRIDE 44
+
+__device__ __forceinline__ int ll_trunc_to_int(double v)
+{
+    /* x86-64 cvttsd2si semantics: NaN / out of range -> INT_MIN ("integer indefinite") */
+    if (!(v > -2147483649.0 && v < 2147483648.0)) return (int)0x80000000;
+    return (int)v;
+}
+
+/* target clouds of slot s: features of slot s-1, or the carry for the batch's first slot */
+__device__ __forceinline__ void ll_targets(const LLView &V, int s, const float4 *&corner, int &mc, const float4 *&surf, int &ms)
+{
+    if (s == V.carry_slot) {
+        corner = V.carry_corner; mc = V.carry_cnt[0]; surf = V.carry_surf; ms = V.carry_cnt[1];
+    } else {
+        const int t = s - 1;
+        corner = V.lsharp + (size_t)t * V.cap_lsharp; mc = V.hdr[t].n_less_sharp;
+        surf = V.lflat + (size_t)t * V.NP; ms = V.hdr[t].n_less_flat;
+        if (V.hdr[t].status != 0) { mc = 0; ms = 0; }
+    }
+}
+
+/* launchers implemented in the per-stage .hip files */
+void ll_launch_organize(const LLView &V, int first, int count, hipStream_t st);
+void ll_launch_features(const LLView &V, int first, int count, size_t lds_bytes, hipStream_t st);
+void ll_launch_associate(const LLView &V, int first, int count, hipStream_t st);
+void ll_launch_vote(const LLView &V, int first, int count, int enable, hipStream_t st);
+void ll_launch_normal_equations(const LLView &V, int first, int count, int do_step, hipStream_t st);
+void ll_launch_gn_step(const LLView &V, int first, int count, hipStream_t st);
+void ll_launch_rows(const LLView &V, int slot, const double *pose7_dev, double *r, double *Jq, double *Jt, hipStream_t st);
+size_t ll_features_lds_bytes(int max_ring);

@@ -1,0 +1,277 @@
+/*
+ * ll_factors.hip -- a9 + a10: point-to-line / point-to-plane residuals, Jacobians, Huber, normal equations,
+ * one Gauss-Newton step.
+ * Replaces, of /root/reference: lidarFactor.hpp:9-52 (LidarEdgeFactor), :203-251 (LidarPlaneFactor_modify),
+ * the per-block loss + manifold handling Ceres applies around them (laserOdometry.cpp:475-482, :615-616,
+ * :797-808) and, for the "one GN iteration" unit of work, the linear solve inside ceres::Solve (:820-825).
+ *
+ * The reference evaluates Jacobians with forward-mode Jets (AutoDiffCostFunction<., R, 4, 3>).  Here they are
+ * closed-form, at s = 1 (DISTORTION 0, laserOdometry.cpp:23): with lp = q*cp + t by Eigen's
+ * _transformVector formula f(u,w) = v + w*(2 u x v) + u x (2 u x v),
+ *     d lp / d w = 2 u x v,   d lp / d u = -2w [v]x + 2((u.v) I + u v^T - 2 v u^T),   d lp / d t = I,
+ * (the derivative of that exact formula, valid for non-unit q as autodiff is), edge: d r / d lp = [b-a]x / |a-b|,
+ * plane: d r / d lp = weight * n^T.  Local (tangent) Jacobian = ambient * EigenQuaternionManifold::PlusJacobian.
+ * Everything is f64.  One workgroup per scan pair; each thread walks residual blocks, accumulates the 21 + 6 + 1
+ * unique normal-equation terms in registers, then a 64-lane shuffle tree + LDS combine.  No atomics.
+ */
+#include "ll_common.h"
+
+struct Pose { double q[4], t[3]; };
+
+__device__ __forceinline__ void ll_lp_and_jac(const Pose &P, const double v[3], double lp[3], double Jq[3][4])
+{
+    const double ux = P.q[0], uy = P.q[1], uz = P.q[2], w = P.q[3];
+    double uvx = uy * v[2] - uz * v[1], uvy = uz * v[0] - ux * v[2], uvz = ux * v[1] - uy * v[0];
+    uvx += uvx; uvy += uvy; uvz += uvz;
+    lp[0] = ((v[0] + w * uvx) + (uy * uvz - uz * uvy)) + P.t[0];
+    lp[1] = ((v[1] + w * uvy) + (uz * uvx - ux * uvz)) + P.t[1];
+    lp[2] = ((v[2] + w * uvz) + (ux * uvy - uy * uvx)) + P.t[2];
+    const double udv = ux * v[0] + uy * v[1] + uz * v[2];
+    const double u[3] = {ux, uy, uz};
+    /* d lp / d u = -2w [v]x + 2((u.v) I + u v^T - 2 v u^T) */
+    const double vx[3][3] = {{0.0, -v[2], v[1]}, {v[2], 0.0, -v[0]}, {-v[1], v[0], 0.0}};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            Jq[i][j] = -2.0 * w * vx[i][j] + 2.0 * ((i == j ? udv : 0.0) + u[i] * v[j] - 2.0 * v[i] * u[j]);
+    Jq[0][3] = uvx; Jq[1][3] = uvy; Jq[2][3] = uvz;              /* d lp / d w = 2 u x v */
+}
+
+/* rows x 4 ambient -> rows x 3 tangent: J * PlusJacobian(q), P rows x:[w,z,-y] y:[-z,w,x] z:[y,-x,w] w:[-x,-y,-z] */
+__device__ __forceinline__ void ll_to_local(const Pose &P, const double Ja[4], double Jl[3])
+{
+    const double x = P.q[0], y = P.q[1], z = P.q[2], w = P.q[3];
+    Jl[0] = Ja[0] * w - Ja[1] * z + Ja[2] * y - Ja[3] * x;
+    Jl[1] = Ja[0] * z + Ja[1] * w - Ja[2] * x - Ja[3] * y;
+    Jl[2] = -Ja[0] * y + Ja[1] * x + Ja[2] * w - Ja[3] * z;
+}
+
+/* LidarEdgeFactor (lidarFactor.hpp:9-52): r[3], ambient Jq[3][4], Jt[3][3] */
+__device__ __forceinline__ void ll_edge(const Pose &P, const float4 c, const float4 a4, const float4 b4,
+                                        double r[3], double Jq[3][4], double Jt[3][3])
+{
+    const double cp[3] = {c.x, c.y, c.z}, a[3] = {a4.x, a4.y, a4.z}, b[3] = {b4.x, b4.y, b4.z};
+    double lp[3], A[3][4];
+    ll_lp_and_jac(P, cp, lp, A);
+    const double pa[3] = {lp[0] - a[0], lp[1] - a[1], lp[2] - a[2]}, pb[3] = {lp[0] - b[0], lp[1] - b[1], lp[2] - b[2]};
+    const double nu[3] = {pa[1] * pb[2] - pa[2] * pb[1], pa[2] * pb[0] - pa[0] * pb[2], pa[0] * pb[1] - pa[1] * pb[0]};   /* :32 */
+    const double de[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]};                                                        /* :33 */
+    const double n = sqrt(de[0] * de[0] + (de[1] * de[1] + de[2] * de[2]));
+    r[0] = nu[0] / n; r[1] = nu[1] / n; r[2] = nu[2] / n;                                                                /* :35-37 */
+    /* d r / d lp = [b - a]x / n = -[de]x / n */
+    const double D[3][3] = {{0.0, de[2] / n, -de[1] / n}, {-de[2] / n, 0.0, de[0] / n}, {de[1] / n, -de[0] / n, 0.0}};
+    for (int i = 0; i < 3; ++i) {
+        for (int k = 0; k < 4; ++k) Jq[i][k] = D[i][0] * A[0][k] + D[i][1] * A[1][k] + D[i][2] * A[2][k];
+        for (int k = 0; k < 3; ++k) Jt[i][k] = D[i][k];
+    }
+}
+
+/* LidarPlaneFactor_modify (lidarFactor.hpp:203-251) */
+__device__ __forceinline__ void ll_plane(const Pose &P, const float4 c, const float4 j4, const float4 l4, const float4 m4,
+                                         double weight, double &r, double Jq[4], double Jt[3])
+{
+    const double cp[3] = {c.x, c.y, c.z}, j[3] = {j4.x, j4.y, j4.z};
+    const double a[3] = {j[0] - (double)l4.x, j[1] - (double)l4.y, j[2] - (double)l4.z};
+    const double b[3] = {j[0] - (double)m4.x, j[1] - (double)m4.y, j[2] - (double)m4.z};
+    double n[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};     /* :210 */
+    const double z = (n[0] * n[0] + n[1] * n[1]) + n[2] * n[2];
+    if (z > 0.0) { const double nn = sqrt(z); n[0] /= nn; n[1] /= nn; n[2] /= nn; }                      /* :211 normalize() */
+    double lp[3], A[3][4];
+    ll_lp_and_jac(P, cp, lp, A);
+    const double d[3] = {lp[0] - j[0], lp[1] - j[1], lp[2] - j[2]};
+    r = (d[0] * n[0] + (d[1] * n[1] + d[2] * n[2])) * weight;                                              /* :233 */
+    for (int k = 0; k < 4; ++k) Jq[k] = (n[0] * A[0][k] + n[1] * A[1][k] + n[2] * A[2][k]) * weight;
+    for (int k = 0; k < 3; ++k) Jt[k] = n[k] * weight;
+}
+
+/* ceres HuberLoss(a) + Corrector (rho'' <= 0 branch): scale = sqrt(rho'), cost += rho/2 */
+__device__ __forceinline__ double ll_huber_scale(double sq, double a, double &cost)
+{
+    if (a <= 0.0) { cost += 0.5 * sq; return 1.0; }
+    const double b = a * a;
+    if (sq > b) {
+        const double rn = sqrt(sq);
+        cost += 0.5 * (2.0 * a * rn - b);
+        double rho1 = a / rn; if (rho1 < 2.2250738585072014e-308) rho1 = 2.2250738585072014e-308;
+        return sqrt(rho1);
+    }
+    cost += 0.5 * sq;
+    return 1.0;
+}
+
+#define LL_NACC 28   /* 21 upper-triangular H + 6 g + cost */
+
+__device__ __forceinline__ void ll_acc_row(double acc[LL_NACC], const double J[6], double r)
+{
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = a; b < 6; ++b) acc[k++] += J[a] * J[b];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * r;
+}
+
+__device__ __forceinline__ int ll_chol_solve(const double H[36], const double g[6], double d[6])
+{
+    double Lm[36];
+    for (int i = 0; i < 36; ++i) Lm[i] = 0.0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double sacc = H[i * 6 + j];
+            for (int k = 0; k < j; ++k) sacc -= Lm[i * 6 + k] * Lm[j * 6 + k];
+            if (i == j) { if (!(sacc > 0.0)) return -1; Lm[i * 6 + i] = sqrt(sacc); }
+            else Lm[i * 6 + j] = sacc / Lm[j * 6 + j];
+        }
+    double y[6];
+    for (int i = 0; i < 6; ++i) { double sacc = -g[i]; for (int k = 0; k < i; ++k) sacc -= Lm[i * 6 + k] * y[k]; y[i] = sacc / Lm[i * 6 + i]; }
+    for (int i = 5; i >= 0; --i) { double sacc = y[i]; for (int k = i + 1; k < 6; ++k) sacc -= Lm[k * 6 + i] * d[k]; d[i] = sacc / Lm[i * 6 + i]; }
+    return 0;
+}
+
+/* EigenQuaternionManifold::Plus: q+ = [sin|d| d/|d|, cos|d|] (x) q ; t += dt  (laserOdometry.cpp:476-477) */
+__device__ __forceinline__ void ll_pose_plus(double *pose, const double d[6])
+{
+    const double n2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    double ax, ay, az, aw;
+    if (n2 != 0.0) { const double n = sqrt(n2), sn = sin(n) / n; aw = cos(n); ax = sn * d[0]; ay = sn * d[1]; az = sn * d[2]; }
+    else { aw = 1.0; ax = d[0]; ay = d[1]; az = d[2]; }
+    const double bx = pose[0], by = pose[1], bz = pose[2], bw = pose[3];
+    pose[3] = aw * bw - ax * bx - ay * by - az * bz;
+    pose[0] = aw * bx + ax * bw + ay * bz - az * by;
+    pose[1] = aw * by - ax * bz + ay * bw + az * bx;
+    pose[2] = aw * bz + ax * by - ay * bx + az * bw;
+    pose[4] += d[3]; pose[5] += d[4]; pose[6] += d[5];
+}
+
+__global__ __launch_bounds__(LL_BLOCK) void k_normal_equations(LLView V, int first, int count, int do_step)
+{
+    if ((int)blockIdx.x >= count) return;
+    const int s = first + blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const PairHdr ph = V.pair[s];
+    Pose P;
+    double *pose = V.pose + (size_t)s * 7;
+    for (int k = 0; k < 4; ++k) P.q[k] = pose[k];
+    for (int k = 0; k < 3; ++k) P.t[k] = pose[4 + k];
+    const float4 *corner, *surf; int mc, ms;
+    ll_targets(V, s, corner, mc, surf, ms);
+    const float4 *sharp = V.sharp + (size_t)s * V.cap_sharp, *flat = V.flat + (size_t)s * V.cap_flat;
+    const int *es = V.e_src + (size_t)s * V.cap_sharp, *ea = V.e_a + (size_t)s * V.cap_sharp, *eb = V.e_b + (size_t)s * V.cap_sharp;
+    const int *ps = V.p_src + (size_t)s * V.cap_flat, *pa = V.p_a + (size_t)s * V.cap_flat, *pb = V.p_b + (size_t)s * V.cap_flat, *pc = V.p_c + (size_t)s * V.cap_flat;
+    const uint8_t *vs = V.v_sel + (size_t)s * V.cap_flat; const float *vw = V.v_w + (size_t)s * V.cap_flat;
+
+    double acc[LL_NACC];
+#pragma unroll
+    for (int k = 0; k < LL_NACC; ++k) acc[k] = 0.0;
+    for (int i = tid; i < ph.n_edge; i += LL_BLOCK) {
+        double r[3], Jq[3][4], Jt[3][3];
+        ll_edge(P, sharp[es[i]], corner[ea[i]], corner[eb[i]], r, Jq, Jt);
+        const double sc = ll_huber_scale(r[0] * r[0] + r[1] * r[1] + r[2] * r[2], V.huber, acc[27]);
+        for (int row = 0; row < 3; ++row) {
+            double J[6];
+            ll_to_local(P, Jq[row], J);
+            J[3] = Jt[row][0]; J[4] = Jt[row][1]; J[5] = Jt[row][2];
+            for (int k = 0; k < 6; ++k) J[k] *= sc;
+            ll_acc_row(acc, J, r[row] * sc);
+        }
+    }
+    for (int i = tid; i < ph.n_plane; i += LL_BLOCK) {
+        if (!vs[i]) continue;
+        double r, Jq[4], Jt[3], J[6];
+        ll_plane(P, flat[ps[i]], surf[pa[i]], surf[pb[i]], surf[pc[i]], (double)vw[i], r, Jq, Jt);
+        const double sc = ll_huber_scale(r * r, V.huber, acc[27]);
+        ll_to_local(P, Jq, J);
+        J[3] = Jt[0]; J[4] = Jt[1]; J[5] = Jt[2];
+        for (int k = 0; k < 6; ++k) J[k] *= sc;
+        ll_acc_row(acc, J, r * sc);
+    }
+    __shared__ double red[LL_BLOCK / 64][LL_NACC];
+#pragma unroll
+    for (int k = 0; k < LL_NACC; ++k) {
+        double v = acc[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double tot[LL_NACC];
+        for (int k = 0; k < LL_NACC; ++k) { double v = 0.0; for (int w = 0; w < LL_BLOCK / 64; ++w) v += red[w][k]; tot[k] = v; }
+        double H[36], g[6];
+        int k = 0;
+        for (int a = 0; a < 6; ++a) for (int b = a; b < 6; ++b) { H[a * 6 + b] = tot[k]; H[b * 6 + a] = tot[k]; ++k; }
+        for (int a = 0; a < 6; ++a) g[a] = tot[21 + a];
+        double *out = V.neq + (size_t)s * LL_NEQ_STRIDE;
+        for (int i = 0; i < 36; ++i) out[i] = H[i];
+        for (int i = 0; i < 6; ++i) out[36 + i] = g[i];
+        out[42] = tot[27];
+        out[43] = (double)(3 * ph.n_edge + ph.n_plane_sel);
+        if (do_step) {
+            double d[6];
+            if (ll_chol_solve(H, g, d) == 0) ll_pose_plus(pose, d);
+        }
+    }
+}
+
+__global__ void k_gn_step(LLView V, int first, int count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int s = first + i;
+    const double *in = V.neq + (size_t)s * LL_NEQ_STRIDE;
+    double H[36], g[6], d[6];
+    for (int k = 0; k < 36; ++k) H[k] = in[k];
+    for (int k = 0; k < 6; ++k) g[k] = in[36 + k];
+    if (ll_chol_solve(H, g, d) == 0) ll_pose_plus(V.pose + (size_t)s * 7, d);
+}
+
+/* What CostFunction::Evaluate returns per block (no loss): rows of r, Jq (x4 ambient), Jt (x3). */
+__global__ __launch_bounds__(LL_BLOCK) void k_rows(LLView V, int s, const double *pose7, double *r_out, double *Jq_out, double *Jt_out)
+{
+    const PairHdr ph = V.pair[s];
+    Pose P;
+    for (int k = 0; k < 4; ++k) P.q[k] = pose7[k];
+    for (int k = 0; k < 3; ++k) P.t[k] = pose7[4 + k];
+    const float4 *corner, *surf; int mc, ms;
+    ll_targets(V, s, corner, mc, surf, ms);
+    const float4 *sharp = V.sharp + (size_t)s * V.cap_sharp, *flat = V.flat + (size_t)s * V.cap_flat;
+    const int *es = V.e_src + (size_t)s * V.cap_sharp, *ea = V.e_a + (size_t)s * V.cap_sharp, *eb = V.e_b + (size_t)s * V.cap_sharp;
+    const int *ps = V.p_src + (size_t)s * V.cap_flat, *pa = V.p_a + (size_t)s * V.cap_flat, *pb = V.p_b + (size_t)s * V.cap_flat, *pc = V.p_c + (size_t)s * V.cap_flat;
+    const uint8_t *vs = V.v_sel + (size_t)s * V.cap_flat; const float *vw = V.v_w + (size_t)s * V.cap_flat;
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+    for (int i = gtid; i < ph.n_edge; i += gsz) {
+        double r[3], Jq[3][4], Jt[3][3];
+        ll_edge(P, sharp[es[i]], corner[ea[i]], corner[eb[i]], r, Jq, Jt);
+        for (int row = 0; row < 3; ++row) {
+            const size_t R0 = (size_t)3 * i + row;
+            r_out[R0] = r[row];
+            for (int k = 0; k < 4; ++k) Jq_out[R0 * 4 + k] = Jq[row][k];
+            for (int k = 0; k < 3; ++k) Jt_out[R0 * 3 + k] = Jt[row][k];
+        }
+    }
+    /* selected planes keep correspondence order: row index = 3*n_edge + rank among selected */
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        size_t R0 = (size_t)3 * ph.n_edge;
+        for (int i = 0; i < ph.n_plane; ++i) {
+            if (!vs[i]) continue;
+            double r, Jq[4], Jt[3];
+            ll_plane(P, flat[ps[i]], surf[pa[i]], surf[pb[i]], surf[pc[i]], (double)vw[i], r, Jq, Jt);
+            r_out[R0] = r;
+            for (int k = 0; k < 4; ++k) Jq_out[R0 * 4 + k] = Jq[k];
+            for (int k = 0; k < 3; ++k) Jt_out[R0 * 3 + k] = Jt[k];
+            ++R0;
+        }
+    }
+}
+
+void ll_launch_normal_equations(const LLView &V, int first, int count, int do_step, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_normal_equations, dim3(count), dim3(LL_BLOCK), 0, st, V, first, count, do_step);
+}
+void ll_launch_gn_step(const LLView &V, int first, int count, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_gn_step, dim3((count + 63) / 64), dim3(64), 0, st, V, first, count);
+}
+void ll_launch_rows(const LLView &V, int slot, const double *pose7_dev, double *r, double *Jq, double *Jt, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_rows, dim3(8), dim3(LL_BLOCK), 0, st, V, slot, pose7_dev, r, Jq, Jt);
+}

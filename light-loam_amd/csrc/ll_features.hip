@@ -1,0 +1,395 @@
+/*
+ * ll_features.hip -- a2 + a3 + a4: curvature, per-segment sort, greedy feature pick, less-flat VoxelGrid.
+ * Replaces scanRegistration.cpp:225-235, :246-368, :370-376 of /root/reference.
+ *
+ * One 256-thread workgroup per (scan, ring): the ring is the reference's unit of sequential dependence
+ * (cloudNeighborPicked marks leak from segment j into segment j+1 of the same ring, never across rings,
+ * because scanStartInd/EndInd keep a 5-point margin).  Everything between reading laserCloud and writing
+ * labels + feature points stays on chip:
+ *   phase 1  1024-point tiles of x/y/z (+5 halo, the flat array is used like the reference: curvature
+ *            crosses ring boundaries) staged in LDS -> 11-tap curvature (strict left-to-right f32, no FMA),
+ *            consecutive-point gap flags (1 bit/point) and 64-bit sort keys (curvature bits << 32 | local index)
+ *   phase 2  bitonic network (all comparators ascending, so virtual +inf padding never moves) over the six
+ *            segments in place; key order = (curvature, index): std::sort leaves equal curvatures
+ *            unspecified, this path and the oracle define ascending index
+ *   phase 3  wave 0 replays the greedy pick: 64 candidates per step, ballot -> first eligible lane ->
+ *            neighbour suppression from the gap bits with one ballot
+ *   phase 4  less-flat points (label <= 0) compacted in index order, voxel index per PCL's formula, sorted by
+ *            (voxel, input order) with the same network, one thread per voxel run sums in input order
+ *   phase 5  labels + feature slots out; k_compact turns per-ring slots into the published clouds.
+ * HBM traffic per ring point: 16 B read (+ L2-hot re-reads for the centroid gather), 1 B label, features.
+ */
+#include "ll_common.h"
+#include <limits.h>
+
+__device__ __forceinline__ bool ll_xcd_map2(int id, int per_scan, int count, int &scan, int &item)
+{
+    const int xcd = id & 7, j = id >> 3;
+    scan = (j / per_scan) * 8 + xcd;
+    item = j % per_scan;
+    return scan < count;
+}
+
+typedef unsigned long long u64;
+
+struct FeatLds {
+    u64 *keys;            /* [max_ring] */
+    float *tx, *ty, *tz;  /* [LL_TILE + 10] */
+    unsigned *picked, *gapf;   /* bitmaps over local index */
+    int8_t *lab;          /* [max_ring] */
+    unsigned short *lf_list;   /* [max_ring] */
+    int *lists;           /* sharp[12] lsharp[120] flat[24] */
+    int *scratch;         /* [LL_BLOCK + 16] */
+};
+
+size_t ll_features_lds_bytes(int max_ring)
+{
+    const size_t mr = (size_t)((max_ring + 63) / 64 * 64);
+    size_t b = 8 * mr;                       /* keys */
+    b += 3 * 4 * (size_t)(LL_TILE + 16);     /* tile x,y,z */
+    b += 2 * 4 * (mr / 32 + 2);              /* bitmaps */
+    b += mr;                                 /* labels */
+    b += 2 * mr;                             /* less-flat list */
+    b += 4 * 160;                            /* lists */
+    b += 4 * (LL_BLOCK + 16) * 2;            /* scratch */
+    return (b + 15) / 16 * 16 + 64;
+}
+
+__device__ __forceinline__ FeatLds ll_carve(unsigned char *base, int max_ring)
+{
+    const size_t mr = (size_t)((max_ring + 63) / 64 * 64);
+    FeatLds L;
+    unsigned char *p = base;
+    L.keys = (u64 *)p; p += 8 * mr;
+    L.tx = (float *)p; p += 4 * (LL_TILE + 16);
+    L.ty = (float *)p; p += 4 * (LL_TILE + 16);
+    L.tz = (float *)p; p += 4 * (LL_TILE + 16);
+    L.picked = (unsigned *)p; p += 4 * (mr / 32 + 2);
+    L.gapf = (unsigned *)p; p += 4 * (mr / 32 + 2);
+    L.lists = (int *)p; p += 4 * 160;
+    L.scratch = (int *)p; p += 4 * (LL_BLOCK + 16) * 2;
+    L.lf_list = (unsigned short *)p; p += 2 * mr;
+    L.lab = (int8_t *)p;
+    return L;
+}
+
+__device__ __forceinline__ void ll_ce(u64 *k, int i, int l)
+{
+    const u64 a = k[i], b = k[l];
+    if (a > b) { k[i] = b; k[l] = a; }
+}
+
+/* Sort nseg independent key ranges [b(j), b(j+1)) ascending.  seg_begin(j) = L*j/nseg for the six curvature
+ * segments (scanRegistration.cpp:253-254) or the single voxel range.  All comparators are ascending, so
+ * positions >= the segment length behave as +inf padding that never has to move. */
+__device__ __forceinline__ void ll_bitonic_segments(u64 *keys, int L, int nseg, int tid)
+{
+    int lmax = 0;
+    for (int j = 0; j < nseg; ++j) lmax = max(lmax, (int)((long long)L * (j + 1) / nseg - (long long)L * j / nseg));
+    if (lmax < 2) return;
+    int p2 = 2; while (p2 < lmax) p2 <<= 1;
+    const int half = p2 >> 1;
+    for (int k = 2; k <= p2; k <<= 1) {
+        const int hk = k >> 1;
+        for (int p = tid; p < nseg * half; p += LL_BLOCK) {           /* flip: i <-> block_start + (k-1-t) */
+            const int sg = p / half, q = p - sg * half;
+            const int b0 = (int)((long long)L * sg / nseg), len = (int)((long long)L * (sg + 1) / nseg) - b0;
+            const int blk = q / hk, t = q - blk * hk;
+            const int i = blk * k + t, l = blk * k + (k - 1 - t);
+            if (l < len) ll_ce(keys + b0, i, l);
+        }
+        __syncthreads();
+        for (int j = hk >> 1; j > 0; j >>= 1) {
+            for (int p = tid; p < nseg * half; p += LL_BLOCK) {
+                const int sg = p / half, q = p - sg * half;
+                const int b0 = (int)((long long)L * sg / nseg), len = (int)((long long)L * (sg + 1) / nseg) - b0;
+                const int i = ((q / j) * 2 * j) + (q % j), l = i + j;
+                if (l < len) ll_ce(keys + b0, i, l);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ __forceinline__ bool ll_bit(const unsigned *bm, int i) { return (bm[i >> 5] >> (i & 31)) & 1u; }
+
+/* neighbour suppression (:288-311 / :334-357) for the pick at local index sel; whole wave participates */
+__device__ __forceinline__ void ll_mark(const FeatLds &L, int sel, int lane)
+{
+    bool g = false;
+    if (lane < 5) g = ll_bit(L.gapf, sel + lane + 1);              /* forward l = lane+1: gap(sel+l, sel+l-1) */
+    else if (lane < 10) g = ll_bit(L.gapf, sel - (lane - 5));      /* backward l = -(m+1): gap(sel+l, sel+l+1) = gapf[sel-m] */
+    const unsigned long long b = __ballot(g);
+    const unsigned fm = (unsigned)(b & 0x1f), bm = (unsigned)((b >> 5) & 0x1f);
+    const int fn = fm ? (__ffs(fm) - 1) : 5, bn = bm ? (__ffs(bm) - 1) : 5;
+    const int lo = sel - bn, hi = sel + fn;
+    const int idx = lo + lane;
+    if (idx <= hi) atomicOr(&L.picked[idx >> 5], 1u << (idx & 31));
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char ll_smem[];
+
+__global__ __launch_bounds__(LL_BLOCK) void k_ring_features(LLView V, int first, int count)
+{
+    int sl, r;
+    if (!ll_xcd_map2(blockIdx.x, V.R, count, sl, r)) return;
+    const int s = first + sl;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const ScanHdr h = V.hdr[s];
+    int *fcnt = V.ring_feat_cnt + ((size_t)s * V.R + r) * 4;
+    if (h.status != 0) { if (tid < 4) fcnt[tid] = 0; return; }
+    const int N = h.n;
+    const int off = V.ring_off[(size_t)s * (V.R + 1) + r];
+    const int nr = V.ring_off[(size_t)s * (V.R + 1) + r + 1] - off;
+    if (nr <= 0) { if (tid < 4) fcnt[tid] = 0; return; }
+    const int S = off + 5, E = off + nr - 6;                          /* scanStartInd / scanEndInd (:218-220) */
+    const bool active = (E - S >= 6);                                 /* :248 */
+    const int Lseg = active ? (E - S) : 0;                            /* indices S .. E-1 are in segments */
+    const float4 *cloud = V.cloud + (size_t)s * V.NP;
+    FeatLds L = ll_carve(ll_smem, V.max_ring);
+
+    const int nwords = (nr + 31) / 32 + 1;
+    for (int i = tid; i < nwords; i += LL_BLOCK) { L.picked[i] = 0; L.gapf[i] = 0; }
+    for (int i = tid; i < nr; i += LL_BLOCK) L.lab[i] = 0;
+    if (tid < 3) L.lists[156 + tid] = 0;                              /* n_sharp, n_lsharp, n_flat */
+    __syncthreads();
+
+    /* ---------------- phase 1: curvature + gap flags + keys ---------------- */
+    for (int c0 = 0; c0 < nr; c0 += LL_TILE) {
+        const int g0 = off + c0;                                      /* global index of tile slot 5 */
+        for (int t = tid; t < LL_TILE + 10; t += LL_BLOCK) {
+            const int g = g0 - 5 + t;
+            if (g >= 0 && g < N) { const float4 p = cloud[g]; L.tx[t] = p.x; L.ty[t] = p.y; L.tz[t] = p.z; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < LL_TILE / LL_BLOCK; ++k) {
+            const int li = c0 + k * LL_BLOCK + tid;
+            if (li >= nr) continue;
+            const int g = off + li, t = li - c0 + 5;
+            if (g >= 1) {                                             /* gap to the previous point (:290-293) */
+                const float dx = L.tx[t] - L.tx[t - 1], dy = L.ty[t] - L.ty[t - 1], dz = L.tz[t] - L.tz[t - 1];
+                if ((double)(dx * dx + dy * dy + dz * dz) > V.gap_thr) atomicOr(&L.gapf[li >> 5], 1u << (li & 31));
+            }
+            if (g >= 5 && g < N - 5) {                                /* :225-235, strict left-to-right */
+                const float *X = L.tx + t, *Y = L.ty + t, *Z = L.tz + t;
+                const float dX = X[-5] + X[-4] + X[-3] + X[-2] + X[-1] - 10 * X[0] + X[1] + X[2] + X[3] + X[4] + X[5];
+                const float dY = Y[-5] + Y[-4] + Y[-3] + Y[-2] + Y[-1] - 10 * Y[0] + Y[1] + Y[2] + Y[3] + Y[4] + Y[5];
+                const float dZ = Z[-5] + Z[-4] + Z[-3] + Z[-2] + Z[-1] - 10 * Z[0] + Z[1] + Z[2] + Z[3] + Z[4] + Z[5];
+                const float cv = dX * dX + dY * dY + dZ * dZ;
+                if (V.write_curv) V.curv[(size_t)s * V.NP + g] = cv;
+                if (active && g >= S && g < E) L.keys[g - S] = ((u64)ll_f2u(cv) << 32) | (unsigned)li;
+            }
+        }
+        __syncthreads();
+    }
+
+    /* ---------------- phase 2: sort the six segments (:251-257) ---------------- */
+    if (active) ll_bitonic_segments(L.keys, Lseg, LL_SEGS, tid);
+    __syncthreads();
+
+    /* ---------------- phase 3: greedy pick, wave 0 ---------------- */
+    if (active && tid < 64) {
+        int ns = 0, nls = 0, nf = 0;
+        for (int j = 0; j < LL_SEGS; ++j) {
+            const int sp = Lseg * j / 6, ep = Lseg * (j + 1) / 6 - 1;     /* key slots; = (:253-254) - S */
+            const int len = ep - sp + 1;
+            /* corners: descending curvature (:261-313) */
+            int largest = 0; bool done = false;
+            for (int c0 = 0; c0 < len && !done; c0 += 64) {
+                const bool have = c0 + lane < len;
+                const u64 key = have ? L.keys[ep - (c0 + lane)] : 0ull;
+                const int li = (int)(unsigned)key;
+                const bool cand = have && ((double)ll_u2f((unsigned)(key >> 32)) > V.curv_thr);
+                if (__ballot(cand) == 0ull) break;
+                for (;;) {
+                    const bool elig = cand && !ll_bit(L.picked, li);
+                    const unsigned long long m = __ballot(elig);
+                    if (!m) break;
+                    const int f = __ffsll((long long)m) - 1;
+                    const int sel = __shfl(li, f);
+                    largest++;
+                    if (largest > LL_LSHARP_PER_SEG) { done = true; break; }      /* :281-284 */
+                    if (lane == 0) {
+                        if (largest <= LL_SHARP_PER_SEG) { L.lab[sel] = 2; L.lists[ns] = sel; }
+                        else L.lab[sel] = 1;
+                        L.lists[12 + nls] = sel;
+                    }
+                    if (largest <= LL_SHARP_PER_SEG) ns++;
+                    nls++;
+                    ll_mark(L, sel, lane);
+                }
+                if (__ballot(have && !cand) != 0ull) break;                         /* rest is <= threshold */
+            }
+            /* flats: ascending curvature (:316-359) */
+            int smallest = 0; done = false;
+            for (int c0 = 0; c0 < len && !done; c0 += 64) {
+                const bool have = c0 + lane < len;
+                const u64 key = have ? L.keys[sp + c0 + lane] : 0ull;
+                const int li = (int)(unsigned)key;
+                const bool cand = have && ((double)ll_u2f((unsigned)(key >> 32)) < V.curv_thr);
+                if (__ballot(cand) == 0ull) break;
+                for (;;) {
+                    const bool elig = cand && !ll_bit(L.picked, li);
+                    const unsigned long long m = __ballot(elig);
+                    if (!m) break;
+                    const int f = __ffsll((long long)m) - 1;
+                    const int sel = __shfl(li, f);
+                    if (lane == 0) { L.lab[sel] = -1; L.lists[132 + nf] = sel; }
+                    nf++;
+                    smallest++;
+                    if (smallest >= LL_FLAT_PER_SEG) { done = true; break; }         /* :328-331: before marking */
+                    ll_mark(L, sel, lane);
+                }
+                if (__ballot(have && !cand) != 0ull) break;
+            }
+        }
+        if (lane == 0) { L.lists[156] = ns; L.lists[157] = nls; L.lists[158] = nf; }
+    }
+    __syncthreads();
+
+    /* ---------------- phase 4: less-flat compaction + VoxelGrid (:361-376) ---------------- */
+    int n_lf_out = 0;
+    if (active) {
+        const int per = (Lseg + LL_BLOCK - 1) / LL_BLOCK;
+        const int a0 = min(Lseg, tid * per), a1 = min(Lseg, a0 + per);          /* slots -> local index slot + 5 */
+        int cntl = 0;
+        float mnx = INFINITY, mny = INFINITY, mnz = INFINITY, mxx = -INFINITY, mxy = -INFINITY, mxz = -INFINITY;
+        for (int q = a0; q < a1; ++q) {
+            if (L.lab[q + 5] <= 0) {
+                cntl++;
+                const float4 p = cloud[off + q + 5];
+                mnx = fminf(mnx, p.x); mny = fminf(mny, p.y); mnz = fminf(mnz, p.z);
+                mxx = fmaxf(mxx, p.x); mxy = fmaxf(mxy, p.y); mxz = fmaxf(mxz, p.z);
+            }
+        }
+        int *sc = L.scratch;
+        sc[tid] = cntl;
+        float *fs = (float *)(L.scratch + LL_BLOCK + 16);
+        /* wave reduce min/max, then across the 4 waves through LDS */
+        for (int o = 32; o > 0; o >>= 1) {
+            mnx = fminf(mnx, __shfl_xor(mnx, o)); mny = fminf(mny, __shfl_xor(mny, o)); mnz = fminf(mnz, __shfl_xor(mnz, o));
+            mxx = fmaxf(mxx, __shfl_xor(mxx, o)); mxy = fmaxf(mxy, __shfl_xor(mxy, o)); mxz = fmaxf(mxz, __shfl_xor(mxz, o));
+        }
+        if (lane == 0) { float *w = fs + (tid >> 6) * 6; w[0] = mnx; w[1] = mny; w[2] = mnz; w[3] = mxx; w[4] = mxy; w[5] = mxz; }
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0;
+            for (int i = 0; i < LL_BLOCK; ++i) { const int c = sc[i]; sc[i] = run; run += c; }
+            sc[LL_BLOCK] = run;
+            for (int w = 1; w < LL_BLOCK / 64; ++w)
+                for (int c = 0; c < 3; ++c) { fs[c] = fminf(fs[c], fs[w * 6 + c]); fs[3 + c] = fmaxf(fs[3 + c], fs[w * 6 + 3 + c]); }
+        }
+        __syncthreads();
+        const int m = sc[LL_BLOCK];
+        {
+            int pos = sc[tid];
+            for (int q = a0; q < a1; ++q) if (L.lab[q + 5] <= 0) L.lf_list[pos++] = (unsigned short)(q + 5);
+        }
+        const float mn[3] = {fs[0], fs[1], fs[2]}, mx[3] = {fs[3], fs[4], fs[5]};
+        __syncthreads();
+        if (m > 0) {
+            /* pcl::VoxelGrid::applyFilter (PCL 1.10), restated */
+            const float inv = V.inv_leaf;
+            long long d[3]; int min_b[3], div_b[3];
+            for (int c = 0; c < 3; ++c) {
+                d[c] = (long long)((mx[c] - mn[c]) * inv) + 1;
+                min_b[c] = (int)floorf(mn[c] * inv);
+                div_b[c] = (int)floorf(mx[c] * inv) - min_b[c] + 1;
+            }
+            const bool too_small = d[0] * d[1] * d[2] > (long long)INT_MAX;        /* "leaf size too small": output = input */
+            const int mul1 = div_b[0], mul2 = div_b[0] * div_b[1];
+            for (int jx = tid; jx < m; jx += LL_BLOCK) {
+                const float4 p = cloud[off + L.lf_list[jx]];
+                unsigned idx;
+                if (too_small) idx = (unsigned)jx;
+                else {
+                    const int i0 = (int)(floorf(p.x * inv) - (float)min_b[0]);
+                    const int i1 = (int)(floorf(p.y * inv) - (float)min_b[1]);
+                    const int i2 = (int)(floorf(p.z * inv) - (float)min_b[2]);
+                    idx = (unsigned)(i0 + i1 * mul1 + i2 * mul2);
+                }
+                L.keys[jx] = ((u64)idx << 32) | (unsigned)jx;
+            }
+            __syncthreads();
+            ll_bitonic_segments(L.keys, m, 1, tid);
+            __syncthreads();
+            /* run heads -> output rank */
+            const int perm = (m + LL_BLOCK - 1) / LL_BLOCK;
+            const int b0 = min(m, tid * perm), b1 = min(m, b0 + perm);
+            int heads = 0;
+            for (int p = b0; p < b1; ++p)
+                if (p == 0 || (unsigned)(L.keys[p] >> 32) != (unsigned)(L.keys[p - 1] >> 32)) heads++;
+            sc[tid] = heads;
+            __syncthreads();
+            if (tid == 0) {
+                int run = 0;
+                for (int i = 0; i < LL_BLOCK; ++i) { const int c = sc[i]; sc[i] = run; run += c; }
+                sc[LL_BLOCK] = run;
+            }
+            __syncthreads();
+            n_lf_out = sc[LL_BLOCK];
+            float4 *out = V.lflat_slot + (size_t)s * V.NP + off;
+            int o = sc[tid];
+            for (int p = b0; p < b1; ++p) {
+                const unsigned vid = (unsigned)(L.keys[p] >> 32);
+                if (p != 0 && vid == (unsigned)(L.keys[p - 1] >> 32)) continue;
+                /* CentroidPoint<PointXYZI>: f32 sums in input order, divided by float(n) */
+                float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f; int cn = 0;
+                for (int q = p; q < m && (unsigned)(L.keys[q] >> 32) == vid; ++q) {
+                    const float4 pt = cloud[off + L.lf_list[(unsigned)L.keys[q]]];
+                    sx += pt.x; sy += pt.y; sz += pt.z; si += pt.w; cn++;
+                }
+                const float fn = (float)cn;
+                out[o++] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
+            }
+        }
+    }
+
+    /* ---------------- phase 5: labels + feature slots ---------------- */
+    int8_t *label = V.label + (size_t)s * V.NP + off;
+    for (int i = tid; i < nr; i += LL_BLOCK) label[i] = L.lab[i];
+    const int ns = L.lists[156], nls = L.lists[157], nf = L.lists[158];
+    const size_t ring_id = (size_t)s * V.R + r;
+    if (tid < ns) V.sharp_slot[ring_id * 12 + tid] = cloud[off + L.lists[tid]];
+    if (tid < nls) V.lsharp_slot[ring_id * 120 + tid] = cloud[off + L.lists[12 + tid]];
+    if (tid < nf) V.flat_slot[ring_id * 24 + tid] = cloud[off + L.lists[132 + tid]];
+    if (tid == 0) { fcnt[0] = ns; fcnt[1] = nls; fcnt[2] = nf; fcnt[3] = n_lf_out; }
+}
+
+/* per-ring slots -> clouds in publication order (ring, segment, pick order; :273-279, :325, :376) */
+__global__ __launch_bounds__(128) void k_compact(LLView V, int first, int count)
+{
+    int sl, r;
+    if (!ll_xcd_map2(blockIdx.x, V.R, count, sl, r)) return;
+    const int s = first + sl;
+    const int tid = threadIdx.x;
+    __shared__ int pre[4], mine[4];
+    const int *fc = V.ring_feat_cnt + (size_t)s * V.R * 4;
+    if (tid < 4) {
+        int run = 0;
+        for (int q = 0; q < r; ++q) run += fc[q * 4 + tid];
+        pre[tid] = run; mine[tid] = fc[r * 4 + tid];
+    }
+    __syncthreads();
+    const size_t ring_id = (size_t)s * V.R + r;
+    for (int i = tid; i < mine[0]; i += 128) V.sharp[(size_t)s * V.cap_sharp + pre[0] + i] = V.sharp_slot[ring_id * 12 + i];
+    for (int i = tid; i < mine[1]; i += 128) V.lsharp[(size_t)s * V.cap_lsharp + pre[1] + i] = V.lsharp_slot[ring_id * 120 + i];
+    for (int i = tid; i < mine[2]; i += 128) V.flat[(size_t)s * V.cap_flat + pre[2] + i] = V.flat_slot[ring_id * 24 + i];
+    const int off = V.ring_off[(size_t)s * (V.R + 1) + r];
+    for (int i = tid; i < mine[3]; i += 128) V.lflat[(size_t)s * V.NP + pre[3] + i] = V.lflat_slot[(size_t)s * V.NP + off + i];
+    if (r == V.R - 1 && tid == 0) {
+        ScanHdr *h = &V.hdr[s];
+        h->n_sharp = pre[0] + mine[0]; h->n_less_sharp = pre[1] + mine[1];
+        h->n_flat = pre[2] + mine[2]; h->n_less_flat = pre[3] + mine[3];
+    }
+}
+
+void ll_launch_features(const LLView &V, int first, int count, size_t lds_bytes, hipStream_t st)
+{
+    const int groups = (count + 7) / 8;
+    const int grid = 8 * V.R * groups;
+    hipLaunchKernelGGL(k_ring_features, dim3(grid), dim3(LL_BLOCK), lds_bytes, st, V, first, count);
+    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(128), 0, st, V, first, count);
+}

@@ -1,0 +1,244 @@
+/*
+ * ll_organize.hip -- a1: NaN / minimum-range filter, ring + azimuth assignment, stable ring bucketing.
+ * Replaces scanRegistration.cpp:58-85 (removeClosedPointCloud), :105-221 of /root/reference.
+ *
+ * The reference loop is sequential (one push_back per point, one halfPassed flag).  Restated data-parallel:
+ *   k_classify  per 1024-point tile: keep test, scanID, ori = -atan2f(y,x), the state-free predicate
+ *               P(i) = "(ori_i adjusted against startOri) - startOri > pi" whose first hit is where
+ *               halfPassed flips (:189-192), per-tile ring histogram / first-P / first & last kept index.
+ *   k_offsets   per scan: exclusive scan of the tile histograms -> laserCloud position of every
+ *               (tile, ring) bucket, scanStartInd / scanEndInd (:218-220), endOri (:115-126), cloudSize.
+ *   k_scatter   per tile: relTime / intensity (:207-208) and a stable multi-split by ring using 64-lane
+ *               ballot matching (rank inside the wave) + per-(wave, ring) counters in LDS.
+ * HBM traffic per input point: classify 16 B read + 5 B write, scatter 21 B read + 16 B write per kept point.
+ * Block b runs on XCD b % 8 (observed); ll_xcd_map keeps all tiles of one scan on one XCD so the ori/ring
+ * arrays written by k_classify are read by k_scatter from the same L2.
+ */
+#include "ll_common.h"
+#include <limits.h>
+
+__device__ __forceinline__ bool ll_xcd_map(int id, int per_scan, int count, int &scan, int &item)
+{
+    const int xcd = id & 7, j = id >> 3;
+    scan = (j / per_scan) * 8 + xcd;
+    item = j % per_scan;
+    return scan < count;
+}
+
+__device__ __forceinline__ bool ll_keep(const float4 p, float thres)
+{
+    /* pcl::removeNaNFromPointCloud (:109) then x*x + y*y + z*z < thres*thres -> drop (:72), all f32 */
+    if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) return false;
+    return !(p.x * p.x + p.y * p.y + p.z * p.z < thres * thres);
+}
+
+__device__ __forceinline__ int ll_scan_id(const LLView &V, const float4 p)
+{
+    /* float angle = atan(z / sqrt(x*x + y*y)) * 180 / M_PI  (:139): f32 atan, f32 product, f64 division, f32 store */
+    const float angle = (float)((double)(ll_atanf(p.z / sqrtf(p.x * p.x + p.y * p.y)) * 180.0f) / M_PI);
+    int id;
+    if (V.ring_model == 0 && V.R == 16)       id = ll_trunc_to_int((double)((angle + 15.0f) / 2.0f) + 0.5);       /* :144 */
+    else if (V.ring_model == 0 && V.R == 32)  id = ll_trunc_to_int(((double)angle + 92.0 / 3.0) * 3.0 / 4.0);      /* :153 */
+    else                                      id = ll_trunc_to_int((double)((angle - V.lower_bound) * V.factor) + 0.5); /* :162 */
+    return (id > V.R - 1 || id < 0) ? -1 : id;
+}
+
+__global__ __launch_bounds__(LL_BLOCK) void k_classify(LLView V, int first, int count)
+{
+    int sl, tile;
+    if (!ll_xcd_map(blockIdx.x, V.T, count, sl, tile)) return;
+    const int s = first + sl;
+    const int n_in = V.n_in[s];
+    const int base = tile * LL_TILE;
+    if (base >= n_in && !(tile == 0)) return;
+    const int tid = threadIdx.x;
+    const float4 *raw = V.raw + (size_t)s * V.NP;
+
+    __shared__ int sh_first, sh_first_p, sh_fk, sh_lk;
+    __shared__ int hist[LL_MAX_RINGS];
+    if (tid == 0) { sh_first = INT_MAX; sh_first_p = INT_MAX; sh_fk = INT_MAX; sh_lk = -1; }
+    if (tid < LL_MAX_RINGS) hist[tid] = 0;
+    __syncthreads();
+
+    /* first kept point of the scan -> startOri (:114).  Usually index 0: one iteration. */
+    for (int c = 0; c < n_in; c += LL_BLOCK) {
+        const int i = c + tid;
+        const bool kept = i < n_in && ll_keep(raw[i], V.thres);
+        if (__syncthreads_or(kept ? 1 : 0)) {
+            if (kept) atomicMin(&sh_first, i);
+            break;
+        }
+    }
+    __syncthreads();
+    const int fk = sh_first;
+    float start_ori = 0.0f;
+    if (fk != INT_MAX) { const float4 p0 = raw[fk]; start_ori = -ll_atan2f(p0.y, p0.x); }
+
+    float *ori = V.ori + (size_t)s * V.NP;
+    int8_t *ring = V.ring + (size_t)s * V.NP;
+#pragma unroll
+    for (int k = 0; k < LL_TILE / LL_BLOCK; ++k) {
+        const int i = base + k * LL_BLOCK + tid;
+        if (i >= n_in) continue;
+        const float4 p = raw[i];
+        int id = -1; float o = 0.0f;
+        if (ll_keep(p, V.thres)) {
+            atomicMin(&sh_fk, i); atomicMax(&sh_lk, i);
+            o = -ll_atan2f(p.y, p.x);                                                 /* :177 (also start/endOri source) */
+            id = ll_scan_id(V, p);
+            if (id >= 0) {
+                atomicAdd(&hist[id], 1);
+                /* the !halfPassed branch (:180-192) evaluated as if the flag were still false */
+                float a = o;
+                if ((double)a < (double)start_ori - M_PI / 2)            a = (float)((double)a + 2 * M_PI);
+                else if ((double)a > (double)start_ori + M_PI * 3 / 2)   a = (float)((double)a - 2 * M_PI);
+                if ((double)(a - start_ori) > M_PI) atomicMin(&sh_first_p, i);
+            }
+        }
+        ori[i] = o;
+        ring[i] = (int8_t)id;
+    }
+    __syncthreads();
+    const size_t tb = ((size_t)s * V.T + tile);
+    if (tid < V.R) V.tile_hist[tb * V.R + tid] = hist[tid];
+    if (tid == 0) {
+        V.tile_first_p[tb] = sh_first_p;
+        V.tile_first_kept[tb] = sh_fk;
+        V.tile_last_kept[tb] = sh_lk;
+        if (tile == 0) { V.hdr[s].start_ori = start_ori; V.hdr[s].first_kept = fk; }
+    }
+}
+
+__global__ __launch_bounds__(LL_BLOCK) void k_offsets(LLView V, int first, int count)
+{
+    const int s = first + blockIdx.x;
+    if (blockIdx.x >= count) return;
+    const int tid = threadIdx.x;
+    const int n_in = V.n_in[s];
+    const int nt = (n_in + LL_TILE - 1) / LL_TILE;
+    __shared__ int ring_cnt[LL_MAX_RINGS + 1];
+    __shared__ int ring_off[LL_MAX_RINGS + 1];
+    __shared__ int sh_first_p, sh_lk;
+    if (tid == 0) { sh_first_p = INT_MAX; sh_lk = -1; }
+    __syncthreads();
+    const size_t tb = (size_t)s * V.T;
+    if (tid < V.R) {
+        int run = 0;
+        for (int t = 0; t < nt; ++t) run += V.tile_hist[(tb + t) * V.R + tid];
+        ring_cnt[tid] = run;
+    }
+    int fp = INT_MAX, lk = -1;
+    for (int t = tid; t < nt; t += LL_BLOCK) {
+        fp = min(fp, V.tile_first_p[tb + t]);
+        lk = max(lk, V.tile_last_kept[tb + t]);
+    }
+    if (fp != INT_MAX) atomicMin(&sh_first_p, fp);
+    if (lk >= 0) atomicMax(&sh_lk, lk);
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0, mx = 0;
+        for (int r = 0; r < V.R; ++r) { ring_off[r] = run; run += ring_cnt[r]; mx = max(mx, ring_cnt[r]); }
+        ring_off[V.R] = run;
+        ScanHdr h = V.hdr[s];
+        h.n = run; h.max_ring = mx; h.half_idx = sh_first_p; h.last_kept = sh_lk;
+        h.n_sharp = h.n_less_sharp = h.n_flat = h.n_less_flat = 0;
+        h.status = 0;
+        if (n_in <= 0 || sh_lk < 0) { h.status = -5; h.n = 0; }                    /* LL_ERR_EMPTY */
+        else {
+            /* endOri (:115-126): -atan2f(last kept) + 2*pi in f64, stored f32, then the 3*pi / pi adjustment */
+            const float so = h.start_ori;
+            float eo = (float)((double)V.ori[(size_t)s * V.NP + sh_lk] + 2 * M_PI);
+            if ((double)(eo - so) > 3 * M_PI)     eo = (float)((double)eo - 2 * M_PI);
+            else if ((double)(eo - so) < M_PI)    eo = (float)((double)eo + 2 * M_PI);
+            h.end_ori = eo;
+            if (mx > V.max_ring) h.status = -4;                                      /* LL_ERR_CAPACITY */
+        }
+        V.hdr[s] = h;
+    }
+    __syncthreads();
+    if (tid <= V.R) V.ring_off[(size_t)s * (V.R + 1) + tid] = ring_off[tid];
+    if (tid < V.R) {
+        int run = ring_off[tid];
+        for (int t = 0; t < nt; ++t) {
+            const size_t idx = (tb + t) * V.R + tid;
+            const int h = V.tile_hist[idx];
+            V.tile_base[idx] = run;
+            run += h;
+        }
+    }
+}
+
+__global__ __launch_bounds__(LL_BLOCK) void k_scatter(LLView V, int first, int count)
+{
+    int sl, tile;
+    if (!ll_xcd_map(blockIdx.x, V.T, count, sl, tile)) return;
+    const int s = first + sl;
+    const int n_in = V.n_in[s];
+    const int base = tile * LL_TILE;
+    if (base >= n_in) return;
+    const ScanHdr h = V.hdr[s];
+    if (h.status == -5) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NK = LL_TILE / LL_BLOCK, NW = LL_BLOCK / 64;
+    __shared__ int cnt[NK * NW][LL_MAX_RINGS];
+    for (int i = tid; i < NK * NW * LL_MAX_RINGS; i += LL_BLOCK) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+
+    const float4 *raw = V.raw + (size_t)s * V.NP;
+    const float *ori = V.ori + (size_t)s * V.NP;
+    const int8_t *ring = V.ring + (size_t)s * V.NP;
+    int bits = 0; while ((1 << bits) < V.R) ++bits;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+    int my_ring[NK], my_rank[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int i = base + k * LL_BLOCK + tid;
+        const int r = (i < n_in) ? (int)ring[i] : -1;
+        unsigned long long m = __ballot(r >= 0);
+        for (int b = 0; b < bits; ++b) {
+            const bool bit = (r >> b) & 1;
+            const unsigned long long bal = __ballot(bit);
+            m &= bit ? bal : ~bal;
+        }
+        my_ring[k] = r;
+        my_rank[k] = __popcll(m & lt);
+        if (r >= 0 && my_rank[k] == 0) cnt[k * NW + wave][r] = __popcll(m);
+    }
+    __syncthreads();
+    if (tid < V.R) {
+        int run = V.tile_base[((size_t)s * V.T + tile) * V.R + tid];
+        for (int kw = 0; kw < NK * NW; ++kw) { const int c = cnt[kw][tid]; cnt[kw][tid] = run; run += c; }
+    }
+    __syncthreads();
+    float4 *cloud = V.cloud + (size_t)s * V.NP;
+    const float so = h.start_ori, eo = h.end_ori;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int r = my_ring[k];
+        if (r < 0) continue;
+        const int i = base + k * LL_BLOCK + tid;
+        float o = ori[i];
+        if (i <= h.half_idx) {                                                          /* !halfPassed (:178-193) */
+            if ((double)o < (double)so - M_PI / 2)            o = (float)((double)o + 2 * M_PI);
+            else if ((double)o > (double)so + M_PI * 3 / 2)   o = (float)((double)o - 2 * M_PI);
+        } else {                                                                        /* :194-205 */
+            o = (float)((double)o + 2 * M_PI);
+            if ((double)o < (double)eo - M_PI * 3 / 2)        o = (float)((double)o + 2 * M_PI);
+            else if ((double)o > (double)eo + M_PI / 2)       o = (float)((double)o - 2 * M_PI);
+        }
+        const float rel = (o - so) / (eo - so);                                         /* :207 */
+        const float4 p = raw[i];
+        const int pos = cnt[k * NW + wave][r] + my_rank[k];
+        cloud[pos] = make_float4(p.x, p.y, p.z, (float)((double)r + 0.1 * (double)rel)); /* :208 */
+    }
+}
+
+void ll_launch_organize(const LLView &V, int first, int count, hipStream_t st)
+{
+    const int groups = (count + 7) / 8;
+    const int grid = 8 * V.T * groups;
+    hipLaunchKernelGGL(k_classify, dim3(grid), dim3(LL_BLOCK), 0, st, V, first, count);
+    hipLaunchKernelGGL(k_offsets, dim3(count), dim3(LL_BLOCK), 0, st, V, first, count);
+    hipLaunchKernelGGL(k_scatter, dim3(grid), dim3(LL_BLOCK), 0, st, V, first, count);
+}

@@ -1,0 +1,115 @@
+/*
+ * ll_vote.hip -- correspondence compaction + a8: graph_based_correspondence_vote_simple.
+ * Replaces laserOdometry.cpp:153-342 (call site :796) of /root/reference, plus the push_back order of the
+ * correspondence lists (:574-585, :745-757).
+ *
+ * One workgroup per scan pair.  Per-query association results are compacted in query order (the order the
+ * reference appends them).  The vote is the reference's dense all-pairs test inside each of 10 contiguous
+ * regions: thread i counts the j of its region with | |src_i-src_j| - |tgt_i-tgt_j| |^2 >= T, where
+ * "std::exp(-gap^2) < 0.96f" is replaced by the bit-exact threshold of ll_exact_math.h.  src/tgt points of
+ * the region are staged once in LDS and broadcast-read.  Selection: count <= 0.9f*m, weight 5 if count <= 50
+ * else 1 (:299-322).  Output is per correspondence (count, selected, weight); the reference's output ORDER
+ * (ascending count, std::sort ties unspecified) only permutes residual blocks and is reproduced on the host
+ * side where needed (include/lightloam_host.hpp).
+ */
+#include "ll_common.h"
+
+extern __shared__ __attribute__((aligned(16))) unsigned char ll_vsm[];
+
+/* stable compaction of flags[0..n) by one workgroup; returns total, writes exclusive positions through cb */
+template <typename F>
+__device__ __forceinline__ int ll_block_compact(int n, int *sc, F emit, const int *valid_src)
+{
+    const int tid = threadIdx.x;
+    const int per = (n + LL_BLOCK - 1) / LL_BLOCK;
+    const int a0 = min(n, tid * per), a1 = min(n, a0 + per);
+    int c = 0;
+    for (int i = a0; i < a1; ++i) c += valid_src[i] >= 0;
+    sc[tid] = c;
+    __syncthreads();
+    if (tid == 0) { int run = 0; for (int i = 0; i < LL_BLOCK; ++i) { const int t = sc[i]; sc[i] = run; run += t; } sc[LL_BLOCK] = run; }
+    __syncthreads();
+    int pos = sc[tid];
+    for (int i = a0; i < a1; ++i) if (valid_src[i] >= 0) emit(i, pos++);
+    const int total = sc[LL_BLOCK];
+    __syncthreads();
+    return total;
+}
+
+__global__ __launch_bounds__(LL_BLOCK) void k_vote(LLView V, int first, int count, int enable)
+{
+    if ((int)blockIdx.x >= count) return;
+    const int s = first + blockIdx.x;
+    const int tid = threadIdx.x;
+    __shared__ int sc[LL_BLOCK + 1];
+    __shared__ int nsel_sh;
+    const ScanHdr h = V.hdr[s];
+    const bool ok = h.status == 0;
+    const int ns = ok ? h.n_sharp : 0, nf = ok ? h.n_flat : 0;
+    const float4 *corner, *surf; int mc, ms;
+    ll_targets(V, s, corner, mc, surf, ms);
+
+    /* edges (:574-617) */
+    const int *eqa = V.eq_a + (size_t)s * V.cap_sharp, *eqb = V.eq_b + (size_t)s * V.cap_sharp;
+    int *es = V.e_src + (size_t)s * V.cap_sharp, *ea = V.e_a + (size_t)s * V.cap_sharp, *eb = V.e_b + (size_t)s * V.cap_sharp;
+    const int n_e = ll_block_compact(ns, sc, [&](int i, int pos) { es[pos] = i; ea[pos] = eqa[i]; eb[pos] = eqb[i]; }, eqa);
+    /* planes (:745-790) */
+    const int *pqa = V.pq_a + (size_t)s * V.cap_flat, *pqb = V.pq_b + (size_t)s * V.cap_flat, *pqc = V.pq_c + (size_t)s * V.cap_flat;
+    int *ps = V.p_src + (size_t)s * V.cap_flat, *pa = V.p_a + (size_t)s * V.cap_flat, *pb = V.p_b + (size_t)s * V.cap_flat, *pc = V.p_c + (size_t)s * V.cap_flat;
+    const int n_p = ll_block_compact(nf, sc, [&](int i, int pos) { ps[pos] = i; pa[pos] = pqa[i]; pb[pos] = pqb[i]; pc[pos] = pqc[i]; }, pqa);
+
+    /* stage Corre_Match.src (raw current point, :753) and .tgt (closest target point, :754) */
+    float *S3 = (float *)ll_vsm;                 /* [n_p][3] */
+    float *T3 = S3 + 3 * (size_t)V.cap_flat;     /* [n_p][3] */
+    const float4 *flat = V.flat + (size_t)s * V.cap_flat;
+    if (tid == 0) nsel_sh = 0;
+    __syncthreads();                              /* p_src / p_a written above are visible after the barrier in ll_block_compact */
+    for (int i = tid; i < n_p; i += LL_BLOCK) {
+        const float4 a = flat[ps[i]], b = surf[pa[i]];
+        S3[3 * i] = a.x; S3[3 * i + 1] = a.y; S3[3 * i + 2] = a.z;
+        T3[3 * i] = b.x; T3[3 * i + 1] = b.y; T3[3 * i + 2] = b.z;
+    }
+    __syncthreads();
+
+    int *vc = V.v_count + (size_t)s * V.cap_flat; uint8_t *vs = V.v_sel + (size_t)s * V.cap_flat; float *vw = V.v_w + (size_t)s * V.cap_flat;
+    const int number_of_region = 10;             /* plane case (:186-187) */
+    const int chunk = n_p / number_of_region;    /* cor_size_all / number_of_region (:202) */
+    int my_sel = 0;
+    for (int i = tid; i < n_p; i += LL_BLOCK) {
+        int cnt = 0, sel = 1; float w = 1.0f;
+        if (enable) {
+            int rg = (chunk > 0) ? min(i / chunk, number_of_region - 1) : number_of_region - 1;
+            const int b0 = chunk * rg, b1 = (rg == number_of_region - 1) ? n_p : chunk * (rg + 1);
+            const float ax = S3[3 * i], ay = S3[3 * i + 1], az = S3[3 * i + 2];
+            const float bx = T3[3 * i], by = T3[3 * i + 1], bz = T3[3 * i + 2];
+            for (int j = b0; j < b1; ++j) {
+                if (j == i) continue;
+                /* Distance() (:153-162): f32 sqrt of dx*dx + dy*dy + dz*dz; operand order (i, j) with i < j in the
+                 * reference -- squares make the order irrelevant bit-for-bit */
+                float dx = ax - S3[3 * j], dy = ay - S3[3 * j + 1], dz = az - S3[3 * j + 2];
+                const float s1 = sqrtf(dx * dx + dy * dy + dz * dz);
+                dx = bx - T3[3 * j]; dy = by - T3[3 * j + 1]; dz = bz - T3[3 * j + 2];
+                const float s2 = sqrtf(dx * dx + dy * dy + dz * dz);
+                const float gap = fabsf(s1 - s2);
+                cnt += ll_vote_incompatible(gap * gap) ? 1 : 0;
+            }
+            const float num_selected = 0.90f * (float)(b1 - b0);                 /* :299-300 */
+            sel = !((float)cnt > num_selected);                                   /* :312 */
+            w = ((float)cnt <= 50.0f) ? 5.0f : 1.0f;                              /* :317-322 */
+        }
+        vc[i] = cnt; vs[i] = (uint8_t)sel; vw[i] = w;
+        my_sel += sel;
+    }
+    if (my_sel) atomicAdd(&nsel_sh, my_sel);
+    __syncthreads();
+    if (tid == 0) {
+        PairHdr p; p.n_edge = n_e; p.n_plane = n_p; p.n_plane_sel = nsel_sh; p.target_slot = (s == V.carry_slot) ? -1 : s - 1;
+        V.pair[s] = p;
+    }
+}
+
+void ll_launch_vote(const LLView &V, int first, int count, int enable, hipStream_t st)
+{
+    const size_t lds = (size_t)V.cap_flat * 24;
+    hipLaunchKernelGGL(k_vote, dim3(count), dim3(LL_BLOCK), lds, st, V, first, count, enable);
+}

@@ -1,0 +1,752 @@
+/*
+ * ll_oracle.c -- CPU ORACLE (test infrastructure; see ll_oracle.h header comment).
+ * PARITY UNPINNED: restatement of /root/reference sources + published third-party algorithms;
+ * no reference-held golden vectors exist and the reference cannot be built here.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math (baseline x86-64: f32 stays f32, no FMA),
+ * matching the reference build (CMakeLists.txt:4-6: -O3, no -march).
+ *
+ * Float/double promotion in every expression below follows the C++ source of the reference:
+ * comments show the original expression where the promotion is not obvious.
+ */
+#include "ll_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <limits.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* x86-64 cvttsd2si: NaN / out-of-range -> "integer indefinite" 0x80000000 */
+static int trunc_to_int(double v)
+{
+    if (!(v > -2147483649.0 && v < 2147483648.0)) return INT_MIN;
+    return (int)v;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a1  scanRegistration.cpp:58-85 (removeClosedPointCloud), :105-221                           */
+/* ------------------------------------------------------------------------------------------ */
+int orc_organize(const float *xyz, int stride, int n_in, const orc_params *P,
+                 orc_point *cloud, int *n_out, int *scan_start, int *scan_end)
+{
+    const int N_SCANS = P->n_scans;
+    if (P->ring_model == 0 && N_SCANS != 16 && N_SCANS != 32 && N_SCANS != 64)
+        return ORC_ERR_BAD_RINGS;                       /* :447-451, :170-174 */
+    if (N_SCANS < 1) return ORC_ERR_BAD_RINGS;
+
+    float *kept = (float *)malloc((size_t)(n_in > 0 ? n_in : 1) * 3 * sizeof(float));
+    int cloudSize = 0;
+    /* pcl::removeNaNFromPointCloud (:109) then removeClosedPointCloud(thres = MINIMUM_RANGE) (:110) */
+    const float thres = (float)P->minimum_range;        /* double -> float parameter conversion (:60, :110) */
+    for (int i = 0; i < n_in; ++i) {
+        const float x = xyz[(size_t)i * stride], y = xyz[(size_t)i * stride + 1], z = xyz[(size_t)i * stride + 2];
+        if (!isfinite(x) || !isfinite(y) || !isfinite(z)) continue;
+        if (x * x + y * y + z * z < thres * thres) continue;   /* :72, all f32 */
+        kept[3 * cloudSize] = x; kept[3 * cloudSize + 1] = y; kept[3 * cloudSize + 2] = z;
+        cloudSize++;
+    }
+    if (cloudSize == 0) { free(kept); *n_out = 0; return ORC_ERR_EMPTY; }   /* reference would read points[0] of an empty cloud */
+
+    /* :114-126 */
+    float startOri = -atan2f(kept[1], kept[0]);
+    float endOri = (float)((double)(-atan2f(kept[3 * (cloudSize - 1) + 1], kept[3 * (cloudSize - 1)])) + 2 * M_PI);
+    if ((double)(endOri - startOri) > 3 * M_PI)      endOri = (float)((double)endOri - 2 * M_PI);
+    else if ((double)(endOri - startOri) < M_PI)     endOri = (float)((double)endOri + 2 * M_PI);
+
+    /* _factor = (N_SCANS-1) / (upBound - lowerBound)   (:441, int / float -> float) */
+    const float factor = (float)(N_SCANS - 1) / (P->up_bound - P->lower_bound);
+
+    int *ring = (int *)malloc((size_t)cloudSize * sizeof(int));
+    float *inten = (float *)malloc((size_t)cloudSize * sizeof(float));
+    int *cnt = (int *)calloc((size_t)N_SCANS + 1, sizeof(int));
+    int halfPassed = 0;
+    int count = cloudSize;
+    for (int i = 0; i < cloudSize; ++i) {
+        const float x = kept[3 * i], y = kept[3 * i + 1], z = kept[3 * i + 2];
+        /* float angle = atan(point.z / sqrt(point.x*point.x + point.y*point.y)) * 180 / M_PI;   (:139)
+         * float overloads of sqrt/atan (libstdc++ <math.h> wrapper is in the TU via ros/tf headers):
+         * atanf(...) * 180 is an f32 product, "/ M_PI" promotes to f64, the result is stored as f32. */
+        const float angle = (float)((double)(atanf(z / sqrtf(x * x + y * y)) * 180.0f) / M_PI);
+        int scanID;
+        if (P->ring_model == 0 && N_SCANS == 16)
+            scanID = trunc_to_int((double)((angle + 15.0f) / 2.0f) + 0.5);                  /* :144 */
+        else if (P->ring_model == 0 && N_SCANS == 32)
+            scanID = trunc_to_int(((double)angle + 92.0 / 3.0) * 3.0 / 4.0);                /* :153 */
+        else
+            scanID = trunc_to_int((double)((angle - P->lower_bound) * factor) + 0.5);       /* :162 */
+        if (scanID > (N_SCANS - 1) || scanID < 0) { ring[i] = -1; count--; continue; }      /* :145-149, :164-168 */
+
+        float ori = -atan2f(y, x);                                                            /* :177 */
+        if (!halfPassed) {
+            if ((double)ori < (double)startOri - M_PI / 2)            ori = (float)((double)ori + 2 * M_PI);
+            else if ((double)ori > (double)startOri + M_PI * 3 / 2)   ori = (float)((double)ori - 2 * M_PI);
+            if ((double)(ori - startOri) > M_PI) halfPassed = 1;
+        } else {
+            ori = (float)((double)ori + 2 * M_PI);
+            if ((double)ori < (double)endOri - M_PI * 3 / 2)          ori = (float)((double)ori + 2 * M_PI);
+            else if ((double)ori > (double)endOri + M_PI / 2)         ori = (float)((double)ori - 2 * M_PI);
+        }
+        const float relTime = (ori - startOri) / (endOri - startOri);                         /* :207 f32 */
+        inten[i] = (float)((double)scanID + 0.1 * (double)relTime);                           /* :208 scanPeriod = 0.1 (double) */
+        ring[i] = scanID;
+        cnt[scanID + 1]++;
+    }
+    /* stable bucket by ring + concat (:209, :215-221) */
+    for (int r = 0; r < N_SCANS; ++r) cnt[r + 1] += cnt[r];
+    for (int r = 0; r < N_SCANS; ++r) {
+        scan_start[r] = cnt[r] + 5;
+        scan_end[r] = cnt[r + 1] - 6;
+    }
+    int *cur = (int *)malloc((size_t)N_SCANS * sizeof(int));
+    memcpy(cur, cnt, (size_t)N_SCANS * sizeof(int));
+    for (int i = 0; i < cloudSize; ++i) {
+        if (ring[i] < 0) continue;
+        orc_point *p = &cloud[cur[ring[i]]++];
+        p->x = kept[3 * i]; p->y = kept[3 * i + 1]; p->z = kept[3 * i + 2]; p->intensity = inten[i];
+    }
+    *n_out = count;
+    free(cur); free(cnt); free(inten); free(ring); free(kept);
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a2  scanRegistration.cpp:225-235                                                            */
+/* ------------------------------------------------------------------------------------------ */
+void orc_curvature(const orc_point *c, int n, float *curv)
+{
+    for (int i = 5; i < n - 5; i++) {
+        /* strictly left-to-right f32, "10 * p.x" is int->float then f32 product (:228-230) */
+        float diffX = c[i - 5].x + c[i - 4].x + c[i - 3].x + c[i - 2].x + c[i - 1].x - 10 * c[i].x + c[i + 1].x + c[i + 2].x + c[i + 3].x + c[i + 4].x + c[i + 5].x;
+        float diffY = c[i - 5].y + c[i - 4].y + c[i - 3].y + c[i - 2].y + c[i - 1].y - 10 * c[i].y + c[i + 1].y + c[i + 2].y + c[i + 3].y + c[i + 4].y + c[i + 5].y;
+        float diffZ = c[i - 5].z + c[i - 4].z + c[i - 3].z + c[i - 2].z + c[i - 1].z - 10 * c[i].z + c[i + 1].z + c[i + 2].z + c[i + 3].z + c[i + 4].z + c[i + 5].z;
+        curv[i] = diffX * diffX + diffY * diffY + diffZ * diffZ;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a4  pcl::VoxelGrid<PointXYZI>::applyFilter (PCL 1.10 voxel_grid.hpp), restated              */
+/*     call site scanRegistration.cpp:370-376, leaf (0.2,0.2,0.2), downsample_all_data_ = true */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { unsigned int idx; int pos; } vox_key;
+static int vox_cmp(const void *a, const void *b)
+{
+    const vox_key *ka = (const vox_key *)a, *kb = (const vox_key *)b;
+    if (ka->idx != kb->idx) return ka->idx < kb->idx ? -1 : 1;
+    /* PCL uses an unstable std::sort on idx only; the order inside a voxel (hence the f32 summation
+     * order of the centroid) is unspecified there.  Oracle and HIP path define it: input order. */
+    return (ka->pos > kb->pos) - (ka->pos < kb->pos);
+}
+
+int orc_voxel_grid(const orc_point *in, int n, float leaf, orc_point *out, int *n_out)
+{
+    if (n <= 0) { *n_out = 0; return ORC_OK; }
+    const float inv = 1.0f / leaf;                       /* inverse_leaf_size_ = Array4f::Ones() / leaf_size_ */
+    float mn[3] = {in[0].x, in[0].y, in[0].z}, mx[3] = {in[0].x, in[0].y, in[0].z};
+    for (int i = 1; i < n; ++i) {                        /* getMinMax3D */
+        const float p[3] = {in[i].x, in[i].y, in[i].z};
+        for (int k = 0; k < 3; ++k) { if (p[k] < mn[k]) mn[k] = p[k]; if (p[k] > mx[k]) mx[k] = p[k]; }
+    }
+    int64_t d[3];
+    for (int k = 0; k < 3; ++k) d[k] = (int64_t)((mx[k] - mn[k]) * inv) + 1;
+    if (d[0] * d[1] * d[2] > (int64_t)INT_MAX) {         /* "Leaf size is too small": output = *input_ */
+        memcpy(out, in, (size_t)n * sizeof(orc_point)); *n_out = n; return ORC_OK;
+    }
+    int min_b[3], max_b[3], div_b[3], mul[3];
+    for (int k = 0; k < 3; ++k) {
+        min_b[k] = (int)floorf(mn[k] * inv);
+        max_b[k] = (int)floorf(mx[k] * inv);
+        div_b[k] = max_b[k] - min_b[k] + 1;
+    }
+    mul[0] = 1; mul[1] = div_b[0]; mul[2] = div_b[0] * div_b[1];
+    vox_key *keys = (vox_key *)malloc((size_t)n * sizeof(vox_key));
+    for (int i = 0; i < n; ++i) {
+        const int ijk0 = (int)(floorf(in[i].x * inv) - (float)min_b[0]);
+        const int ijk1 = (int)(floorf(in[i].y * inv) - (float)min_b[1]);
+        const int ijk2 = (int)(floorf(in[i].z * inv) - (float)min_b[2]);
+        keys[i].idx = (unsigned int)(ijk0 * mul[0] + ijk1 * mul[1] + ijk2 * mul[2]);
+        keys[i].pos = i;
+    }
+    qsort(keys, (size_t)n, sizeof(vox_key), vox_cmp);
+    int m = 0;
+    for (int first = 0; first < n;) {
+        int last = first + 1;
+        while (last < n && keys[last].idx == keys[first].idx) ++last;
+        /* CentroidPoint<PointXYZI>: AccumulatorXYZ (Vector3f sum, get = sum / n) + AccumulatorIntensity */
+        float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f;
+        for (int k = first; k < last; ++k) {
+            const orc_point *p = &in[keys[k].pos];
+            sx += p->x; sy += p->y; sz += p->z; si += p->intensity;
+        }
+        const float cnt = (float)(last - first);
+        out[m].x = sx / cnt; out[m].y = sy / cnt; out[m].z = sz / cnt; out[m].intensity = si / cnt;
+        ++m; first = last;
+    }
+    free(keys);
+    *n_out = m;
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a3  scanRegistration.cpp:42 (comp), :246-377                                                */
+/* ------------------------------------------------------------------------------------------ */
+static const float *g_curv_for_sort;
+static int curv_cmp(const void *a, const void *b)
+{
+    const int ia = *(const int *)a, ib = *(const int *)b;
+    const float ca = g_curv_for_sort[ia], cb = g_curv_for_sort[ib];
+    if (ca < cb) return -1;
+    if (ca > cb) return 1;
+    /* comp() (:42) orders by curvature only and std::sort is unstable: order of equal curvatures is
+     * unspecified in the reference.  Oracle and HIP path define it: ascending point index. */
+    return (ia > ib) - (ia < ib);
+}
+
+static float gap2(const orc_point *c, int a, int b)
+{
+    const float dx = c[a].x - c[b].x, dy = c[a].y - c[b].y, dz = c[a].z - c[b].z;
+    return dx * dx + dy * dy + dz * dz;
+}
+
+static void mark_neighbours(const orc_point *c, int ind, int *picked)
+{
+    for (int l = 1; l <= 5; l++) {                               /* :288-299 */
+        if ((double)gap2(c, ind + l, ind + l - 1) > 0.05) break;
+        picked[ind + l] = 1;
+    }
+    for (int l = -1; l >= -5; l--) {                             /* :300-311 */
+        if ((double)gap2(c, ind + l, ind + l + 1) > 0.05) break;
+        picked[ind + l] = 1;
+    }
+}
+
+int orc_pick(const orc_point *cloud, int n, const float *curv,
+             const int *scan_start, const int *scan_end, int n_scans, int *label,
+             orc_point *sharp, int *n_sharp, orc_point *less_sharp, int *n_less_sharp,
+             orc_point *flat, int *n_flat, orc_point *less_flat, int *n_less_flat, int *tie_count)
+{
+    int *sortInd = (int *)malloc((size_t)(n > 0 ? n : 1) * sizeof(int));
+    int *picked = (int *)calloc((size_t)(n > 0 ? n : 1), sizeof(int));
+    orc_point *lf_scan = (orc_point *)malloc((size_t)(n > 0 ? n : 1) * sizeof(orc_point));
+    for (int i = 0; i < n; ++i) sortInd[i] = i;
+    for (int i = 5; i < n - 5; ++i) label[i] = 0;                /* :232-234 */
+    int ns = 0, nls = 0, nf = 0, nlf = 0, ties = 0;
+
+    for (int i = 0; i < n_scans; i++) {
+        if (scan_end[i] - scan_start[i] < 6) continue;           /* :248 */
+        int n_lf_scan = 0;
+        for (int j = 0; j < 6; j++) {
+            const int sp = scan_start[i] + (scan_end[i] - scan_start[i]) * j / 6;           /* :253 */
+            const int ep = scan_start[i] + (scan_end[i] - scan_start[i]) * (j + 1) / 6 - 1; /* :254 */
+            g_curv_for_sort = curv;
+            qsort(sortInd + sp, (size_t)(ep - sp + 1), sizeof(int), curv_cmp);               /* :257 */
+            for (int k = sp; k < ep; ++k) if (curv[sortInd[k]] == curv[sortInd[k + 1]]) ties++;
+
+            int largestPickedNum = 0;
+            for (int k = ep; k >= sp; k--) {                     /* :261-313 */
+                const int ind = sortInd[k];
+                if (picked[ind] == 0 && (double)curv[ind] > 0.1) {
+                    largestPickedNum++;
+                    if (largestPickedNum <= 2) {
+                        label[ind] = 2;
+                        sharp[ns++] = cloud[ind];
+                        less_sharp[nls++] = cloud[ind];
+                    } else if (largestPickedNum <= 20) {
+                        label[ind] = 1;
+                        less_sharp[nls++] = cloud[ind];
+                    } else {
+                        break;
+                    }
+                    picked[ind] = 1;
+                    mark_neighbours(cloud, ind, picked);
+                }
+            }
+            int smallestPickedNum = 0;
+            for (int k = sp; k <= ep; k++) {                     /* :316-359 */
+                const int ind = sortInd[k];
+                if (picked[ind] == 0 && (double)curv[ind] < 0.1) {
+                    label[ind] = -1;
+                    flat[nf++] = cloud[ind];
+                    smallestPickedNum++;
+                    if (smallestPickedNum >= 4) break;           /* :328-331: breaks BEFORE marking */
+                    picked[ind] = 1;
+                    mark_neighbours(cloud, ind, picked);
+                }
+            }
+            for (int k = sp; k <= ep; k++)                       /* :361-367 */
+                if (label[k] <= 0) lf_scan[n_lf_scan++] = cloud[k];
+        }
+        int m = 0;
+        orc_voxel_grid(lf_scan, n_lf_scan, 0.2f, less_flat + nlf, &m);   /* :370-376 */
+        nlf += m;
+    }
+    *n_sharp = ns; *n_less_sharp = nls; *n_flat = nf; *n_less_flat = nlf;
+    if (tie_count) *tie_count = ties;
+    free(lf_scan); free(picked); free(sortInd);
+    return ORC_OK;
+}
+
+int orc_extract(const float *xyz, int stride, int n_in, const orc_params *P,
+                orc_point *cloud, int *n_out, int *scan_start, int *scan_end,
+                float *curv, int *label,
+                orc_point *sharp, int *n_sharp, orc_point *less_sharp, int *n_less_sharp,
+                orc_point *flat, int *n_flat, orc_point *less_flat, int *n_less_flat)
+{
+    int rc = orc_organize(xyz, stride, n_in, P, cloud, n_out, scan_start, scan_end);
+    if (rc != ORC_OK) return rc;
+    orc_curvature(cloud, *n_out, curv);
+    return orc_pick(cloud, *n_out, curv, scan_start, scan_end, P->n_scans, label,
+                    sharp, n_sharp, less_sharp, n_less_sharp, flat, n_flat, less_flat, n_less_flat, NULL);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a5  laserOdometry.cpp:77-95 with DISTORTION 0 (:23)                                         */
+/* ------------------------------------------------------------------------------------------ */
+/* Eigen::QuaternionBase::_transformVector: uv = u x v; uv += uv; v + w*uv + u x uv */
+static void quat_rotate(const double q[4], const double v[3], double out[3])
+{
+    const double ux = q[0], uy = q[1], uz = q[2], w = q[3];
+    double uvx = uy * v[2] - uz * v[1];
+    double uvy = uz * v[0] - ux * v[2];
+    double uvz = ux * v[1] - uy * v[0];
+    uvx += uvx; uvy += uvy; uvz += uvz;
+    out[0] = (v[0] + w * uvx) + (uy * uvz - uz * uvy);
+    out[1] = (v[1] + w * uvy) + (uz * uvx - ux * uvz);
+    out[2] = (v[2] + w * uvz) + (ux * uvy - uy * uvx);
+}
+
+void orc_transform_to_start(const double q[4], const double t[3], const orc_point *pi, orc_point *po)
+{
+    /* s = 1.0 (:84).  Identity.slerp(1, q) (Eigen 3.3): scale0 = 0 and scale1 = +-1 exactly in both
+     * branches (1-t = 0; sin(theta)/sin(theta) = 1), so q_point_last = +-q and the rotation formula,
+     * even in (u,w), gives bit-identical results for q and -q.  t_point_last = 1.0 * t = t. */
+    const double v[3] = {(double)pi->x, (double)pi->y, (double)pi->z};
+    double r[3];
+    quat_rotate(q, v, r);
+    po->x = (float)(r[0] + t[0]);
+    po->y = (float)(r[1] + t[1]);
+    po->z = (float)(r[2] + t[2]);
+    po->intensity = pi->intensity;
+}
+
+/* FLANN L2_Simple<float> (PCL KdTreeFLANN distance): result = 0; for d: diff = a[d]-b[d]; result += diff*diff */
+static float flann_l2(const orc_point *a, const orc_point *b)
+{
+    float result = 0.0f, diff;
+    diff = a->x - b->x; result += diff * diff;
+    diff = a->y - b->y; result += diff * diff;
+    diff = a->z - b->z; result += diff * diff;
+    return result;
+}
+
+/* exact K=1 nearest neighbour (kd-tree search is exact; equal-distance winner is traversal-dependent
+ * in FLANN, defined here and in the HIP path as the lowest index). */
+static int nn1(const orc_point *q, const orc_point *cloud, int m, float *dist)
+{
+    int best = -1; float bd = INFINITY;
+    for (int j = 0; j < m; ++j) {
+        const float d = flann_l2(q, &cloud[j]);
+        if (d < bd) { bd = d; best = j; }
+    }
+    *dist = bd;
+    return best;
+}
+
+/* (points[j].x - pointSel.x) * (...) + ... : all f32, widened to double on assignment (:514-519) */
+static double walk_d2(const orc_point *p, const orc_point *sel)
+{
+    return (double)((p->x - sel->x) * (p->x - sel->x) + (p->y - sel->y) * (p->y - sel->y) + (p->z - sel->z) * (p->z - sel->z));
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a6  laserOdometry.cpp:491-620                                                               */
+/* ------------------------------------------------------------------------------------------ */
+int orc_associate_corner(const double q[4], const double t[3], const orc_point *sharp, int ns,
+                         const orc_point *last, int mc, int *src_idx, int *idx_a, int *idx_b, int *n_e)
+{
+    int ne = 0;
+    for (int i = 0; i < ns && mc > 0; ++i) {
+        orc_point sel;
+        orc_transform_to_start(q, t, &sharp[i], &sel);
+        float d0;
+        const int nn = nn1(&sel, last, mc, &d0);
+        int closestPointInd = -1, minPointInd2 = -1;
+        if ((double)d0 < 25.0) {                                  /* DISTANCE_SQ_THRESHOLD (:29, :497) */
+            closestPointInd = nn;
+            const int closestPointScanID = (int)last[closestPointInd].intensity;
+            double minPointSqDis2 = 25.0;
+            for (int j = closestPointInd + 1; j < mc; ++j) {      /* :504-527 */
+                if ((int)last[j].intensity <= closestPointScanID) continue;
+                if ((double)(int)last[j].intensity > (closestPointScanID + 2.5)) break;
+                const double d = walk_d2(&last[j], &sel);
+                if (d < minPointSqDis2) { minPointSqDis2 = d; minPointInd2 = j; }
+            }
+            for (int j = closestPointInd - 1; j >= 0; --j) {      /* :530-553 */
+                if ((int)last[j].intensity >= closestPointScanID) continue;
+                if ((double)(int)last[j].intensity < (closestPointScanID - 2.5)) break;
+                const double d = walk_d2(&last[j], &sel);
+                if (d < minPointSqDis2) { minPointSqDis2 = d; minPointInd2 = j; }
+            }
+        }
+        if (minPointInd2 >= 0) {                                  /* :556 */
+            src_idx[ne] = i; idx_a[ne] = closestPointInd; idx_b[ne] = minPointInd2; ne++;
+        }
+    }
+    *n_e = ne;
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a7  laserOdometry.cpp:653-793                                                               */
+/* ------------------------------------------------------------------------------------------ */
+int orc_associate_plane(const double q[4], const double t[3], const orc_point *flat, int nf,
+                        const orc_point *last, int ms, int *src_idx, int *idx_a, int *idx_b, int *idx_c, int *n_p)
+{
+    int np = 0;
+    for (int i = 0; i < nf && ms > 0; ++i) {
+        orc_point sel;
+        orc_transform_to_start(q, t, &flat[i], &sel);
+        float d0;
+        const int nn = nn1(&sel, last, ms, &d0);
+        int closestPointInd = -1, minPointInd2 = -1, minPointInd3 = -1;
+        if ((double)d0 < 25.0) {
+            closestPointInd = nn;
+            const int closestPointScanID = (int)last[closestPointInd].intensity;
+            double minPointSqDis2 = 25.0, minPointSqDis3 = 25.0;
+            for (int j = closestPointInd + 1; j < ms; ++j) {      /* :668-693 */
+                if ((double)(int)last[j].intensity > (closestPointScanID + 2.5)) break;
+                const double d = walk_d2(&last[j], &sel);
+                if ((int)last[j].intensity <= closestPointScanID && d < minPointSqDis2) { minPointSqDis2 = d; minPointInd2 = j; }
+                else if ((int)last[j].intensity > closestPointScanID && d < minPointSqDis3) { minPointSqDis3 = d; minPointInd3 = j; }
+            }
+            for (int j = closestPointInd - 1; j >= 0; --j) {      /* :696-721 */
+                if ((double)(int)last[j].intensity < (closestPointScanID - 2.5)) break;
+                const double d = walk_d2(&last[j], &sel);
+                if ((int)last[j].intensity >= closestPointScanID && d < minPointSqDis2) { minPointSqDis2 = d; minPointInd2 = j; }
+                else if ((int)last[j].intensity < closestPointScanID && d < minPointSqDis3) { minPointSqDis3 = d; minPointInd3 = j; }
+            }
+            if (minPointInd2 >= 0 && minPointInd3 >= 0) {         /* :723 */
+                src_idx[np] = i; idx_a[np] = closestPointInd; idx_b[np] = minPointInd2; idx_c[np] = minPointInd3; np++;
+            }
+        }
+    }
+    *n_p = np;
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a8  laserOdometry.cpp:153-342                                                               */
+/* ------------------------------------------------------------------------------------------ */
+static float Distance(const orc_point *a, const orc_point *b)      /* :153-162 */
+{
+    const float dx = a->x - b->x, dy = a->y - b->y, dz = a->z - b->z;
+    return sqrtf(dx * dx + dy * dy + dz * dz);
+}
+
+typedef struct { int index; float score; } vertex_vote;           /* common.h:40-43 */
+static int vote_cmp_canonical(const void *a, const void *b)
+{
+    const vertex_vote *va = (const vertex_vote *)a, *vb = (const vertex_vote *)b;
+    if (va->score != vb->score) return va->score < vb->score ? -1 : 1;
+    return (va->index > vb->index) - (va->index < vb->index);
+}
+
+void orc_vote(const orc_point *src, const orc_point *tgt, int n, int corner_case,
+              int *counts, int *sel_idx, float *sel_w, int *n_sel)
+{
+    const int number_of_region = corner_case ? 5 : 10;            /* :179-188 */
+    const float score_threshold = 0.96f;
+    int nsel = 0;
+    for (int num_region = 0; num_region < number_of_region; num_region++) {
+        const int initial_pos = n / number_of_region * num_region;                        /* :202 */
+        const int end_pos = (num_region == number_of_region - 1) ? n : n / number_of_region * (num_region + 1);
+        const int cor_size = end_pos - initial_pos;
+        if (cor_size <= 0) continue;
+        vertex_vote *vote_record = (vertex_vote *)malloc((size_t)cor_size * sizeof(vertex_vote));
+        for (int i = 0; i < cor_size; ++i) { vote_record[i].index = i; vote_record[i].score = 0.0f; }
+        for (int i = 0; i < cor_size; i++) {                      /* :228-252 */
+            for (int j = i + 1; j < cor_size; j++) {
+                const float s1 = Distance(&src[initial_pos + i], &src[initial_pos + j]);
+                const float s2 = Distance(&tgt[initial_pos + i], &tgt[initial_pos + j]);
+                const float dis_gap = fabsf(s1 - s2);
+                const float score = expf(-(dis_gap * dis_gap) / (1.0f * 1.0f));          /* std::exp(float) */
+                if (score < score_threshold) { vote_record[j].score += 1; vote_record[i].score += 1; }
+            }
+        }
+        for (int i = 0; i < cor_size; ++i) counts[initial_pos + i] = (int)vote_record[i].score;
+        /* reference: std::sort descending (:255) then walk from the low-count end (:304-329).
+         * canonical order here: ascending (count, index). */
+        qsort(vote_record, (size_t)cor_size, sizeof(vertex_vote), vote_cmp_canonical);
+        const float num_selected = 0.90f * (float)cor_size;       /* :299-300 */
+        for (int i = 0; i < cor_size; ++i) {
+            if (vote_record[i].score > num_selected) break;       /* :312-316 */
+            sel_idx[nsel] = initial_pos + vote_record[i].index;
+            sel_w[nsel] = (vote_record[i].score <= 50.0f) ? 5.0f : 1.0f;                  /* :317-322 */
+            nsel++;
+        }
+        free(vote_record);
+    }
+    *n_sel = nsel;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a9  lidarFactor.hpp under ceres::AutoDiffCostFunction<., R, 4, 3>: forward Jets of width 7   */
+/* ------------------------------------------------------------------------------------------ */
+#define JN 7
+typedef struct { double a; double v[JN]; } jet;
+
+static jet J_const(double a) { jet r; r.a = a; for (int k = 0; k < JN; ++k) r.v[k] = 0.0; return r; }
+static jet J_var(double a, int k) { jet r = J_const(a); r.v[k] = 1.0; return r; }
+static jet J_add(jet f, jet g) { jet r; r.a = f.a + g.a; for (int k = 0; k < JN; ++k) r.v[k] = f.v[k] + g.v[k]; return r; }
+static jet J_sub(jet f, jet g) { jet r; r.a = f.a - g.a; for (int k = 0; k < JN; ++k) r.v[k] = f.v[k] - g.v[k]; return r; }
+static jet J_neg(jet f) { jet r; r.a = -f.a; for (int k = 0; k < JN; ++k) r.v[k] = -f.v[k]; return r; }
+/* ceres/jet.h: f*g = (f.a*g.a, f.a*g.v + f.v*g.a) */
+static jet J_mul(jet f, jet g) { jet r; r.a = f.a * g.a; for (int k = 0; k < JN; ++k) r.v[k] = f.a * g.v[k] + f.v[k] * g.a; return r; }
+/* ceres/jet.h: g_a_inverse = 1/g.a; f_a_by_g_a = f.a*g_a_inverse; (f_a_by_g_a, (f.v - f_a_by_g_a*g.v)*g_a_inverse) */
+static jet J_div(jet f, jet g)
+{
+    jet r; const double gi = 1.0 / g.a; const double fg = f.a * gi;
+    r.a = fg; for (int k = 0; k < JN; ++k) r.v[k] = (f.v[k] - fg * g.v[k]) * gi; return r;
+}
+static jet J_sqrt(jet f)
+{
+    jet r; const double tmp = sqrt(f.a); const double two_a_inverse = 1.0 / (2.0 * tmp);
+    r.a = tmp; for (int k = 0; k < JN; ++k) r.v[k] = f.v[k] * two_a_inverse; return r;
+}
+static jet J_acos(jet f)
+{
+    jet r; const double tmp = -1.0 / sqrt(1.0 - f.a * f.a);
+    r.a = acos(f.a); for (int k = 0; k < JN; ++k) r.v[k] = tmp * f.v[k]; return r;
+}
+static jet J_sin(jet f)
+{
+    jet r; const double c = cos(f.a);
+    r.a = sin(f.a); for (int k = 0; k < JN; ++k) r.v[k] = c * f.v[k]; return r;
+}
+
+typedef struct { jet x, y, z, w; } jquat;      /* Eigen coeffs order x,y,z,w */
+typedef struct { jet x, y, z; } jvec;
+
+/* Eigen 3.3 QuaternionBase::slerp(t, other) called on Identity (lidarFactor.hpp:25-26) */
+static jquat slerp_from_identity(jet t, jquat o)
+{
+    const double one = 1.0 - 2.220446049250313e-16;
+    const jet I0 = J_const(0.0), I1 = J_const(1.0);
+    /* d = coeffs().dot(other.coeffs()), 4-term novec tree: (x*ox + y*oy) + (z*oz + w*ow) */
+    jet d = J_add(J_add(J_mul(I0, o.x), J_mul(I0, o.y)), J_add(J_mul(I0, o.z), J_mul(I1, o.w)));
+    jet absD = d.a < 0.0 ? J_neg(d) : d;
+    jet scale0, scale1;
+    if (absD.a >= one) {
+        scale0 = J_sub(J_const(1.0), t);
+        scale1 = t;
+    } else {
+        jet theta = J_acos(absD);
+        jet sinTheta = J_sin(theta);
+        scale0 = J_div(J_sin(J_mul(J_sub(J_const(1.0), t), theta)), sinTheta);
+        scale1 = J_div(J_sin(J_mul(t, theta)), sinTheta);
+    }
+    if (d.a < 0.0) scale1 = J_neg(scale1);
+    jquat r;
+    r.x = J_add(J_mul(scale0, I0), J_mul(scale1, o.x));
+    r.y = J_add(J_mul(scale0, I0), J_mul(scale1, o.y));
+    r.z = J_add(J_mul(scale0, I0), J_mul(scale1, o.z));
+    r.w = J_add(J_mul(scale0, I1), J_mul(scale1, o.w));
+    return r;
+}
+
+static jvec jcross(jvec a, jvec b)
+{
+    jvec r;
+    r.x = J_sub(J_mul(a.y, b.z), J_mul(a.z, b.y));
+    r.y = J_sub(J_mul(a.z, b.x), J_mul(a.x, b.z));
+    r.z = J_sub(J_mul(a.x, b.y), J_mul(a.y, b.x));
+    return r;
+}
+static jvec jvsub(jvec a, jvec b) { jvec r = {J_sub(a.x, b.x), J_sub(a.y, b.y), J_sub(a.z, b.z)}; return r; }
+static jvec jvadd(jvec a, jvec b) { jvec r = {J_add(a.x, b.x), J_add(a.y, b.y), J_add(a.z, b.z)}; return r; }
+static jvec jvconst(const double p[3]) { jvec r = {J_const(p[0]), J_const(p[1]), J_const(p[2])}; return r; }
+/* Eigen novec redux tree for 3 terms: e0 + (e1 + e2) */
+static jet jnorm(jvec a) { return J_sqrt(J_add(J_mul(a.x, a.x), J_add(J_mul(a.y, a.y), J_mul(a.z, a.z)))); }
+static jet jdot(jvec a, jvec b) { return J_add(J_mul(a.x, b.x), J_add(J_mul(a.y, b.y), J_mul(a.z, b.z))); }
+
+/* q * v: uv = u x v; uv += uv; v + w*uv + u x uv */
+static jvec jrotate(jquat q, jvec v)
+{
+    jvec u = {q.x, q.y, q.z};
+    jvec uv = jcross(u, v);
+    uv.x = J_add(uv.x, uv.x); uv.y = J_add(uv.y, uv.y); uv.z = J_add(uv.z, uv.z);
+    jvec wuv = {J_mul(q.w, uv.x), J_mul(q.w, uv.y), J_mul(q.w, uv.z)};
+    return jvadd(jvadd(v, wuv), jcross(u, uv));
+}
+
+static jvec transformed_point(const double q[4], const double t[3], const double cp[3], double s)
+{
+    /* Quaternion<T> q_last_curr{q[3], q[0], q[1], q[2]}  (w,x,y,z ctor; lidarFactor.hpp:24) */
+    jquat ql = {J_var(q[0], 0), J_var(q[1], 1), J_var(q[2], 2), J_var(q[3], 3)};
+    ql = slerp_from_identity(J_const(s), ql);
+    jet S = J_const(s);
+    jvec tl = {J_mul(S, J_var(t[0], 4)), J_mul(S, J_var(t[1], 5)), J_mul(S, J_var(t[2], 6))};
+    return jvadd(jrotate(ql, jvconst(cp)), tl);
+}
+
+static void unpack(jet r, double *res, double *Jq, double *Jt)
+{
+    *res = r.a;
+    for (int k = 0; k < 4; ++k) Jq[k] = r.v[k];
+    for (int k = 0; k < 3; ++k) Jt[k] = r.v[4 + k];
+}
+
+void orc_edge_factor(const double q[4], const double t[3], const double cp[3], const double a[3],
+                     const double b[3], double s, double r[3], double Jq[12], double Jt[9])
+{
+    jvec lp = transformed_point(q, t, cp, s);
+    jvec lpa = jvconst(a), lpb = jvconst(b);
+    jvec nu = jcross(jvsub(lp, lpa), jvsub(lp, lpb));             /* lidarFactor.hpp:32 */
+    jvec de = jvsub(lpa, lpb);                                    /* :33 */
+    jet n = jnorm(de);
+    unpack(J_div(nu.x, n), &r[0], &Jq[0], &Jt[0]);                /* :35-37 */
+    unpack(J_div(nu.y, n), &r[1], &Jq[4], &Jt[3]);
+    unpack(J_div(nu.z, n), &r[2], &Jq[8], &Jt[6]);
+}
+
+void orc_plane_factor_modify(const double q[4], const double t[3], const double cp[3], const double j[3],
+                     const double l[3], const double m[3], double s, double weight,
+                     double r[1], double Jq[4], double Jt[3])
+{
+    /* ctor (:210-211): ljm_norm = (j - l).cross(j - m); ljm_norm.normalize();  (doubles) */
+    const double a[3] = {j[0] - l[0], j[1] - l[1], j[2] - l[2]}, b[3] = {j[0] - m[0], j[1] - m[1], j[2] - m[2]};
+    double n[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+    const double z = (n[0] * n[0] + n[1] * n[1]) + n[2] * n[2];   /* Vector3d squaredNorm, SSE2 linear-vectorised redux */
+    if (z > 0.0) { const double nn = sqrt(z); n[0] /= nn; n[1] /= nn; n[2] /= nn; }
+    jvec lp = transformed_point(q, t, cp, s);
+    jet res = J_mul(jdot(jvsub(lp, jvconst(j)), jvconst(n)), J_const(weight));               /* :233 */
+    unpack(res, r, Jq, Jt);
+}
+
+void orc_plane_norm_factor(const double q[4], const double t[3], const double cp[3], const double n[3],
+                     double negative_OA_dot_norm, double r[1], double Jq[4], double Jt[3])
+{
+    jquat qw = {J_var(q[0], 0), J_var(q[1], 1), J_var(q[2], 2), J_var(q[3], 3)};          /* :263 */
+    jvec tw = {J_var(t[0], 4), J_var(t[1], 5), J_var(t[2], 6)};
+    jvec pw = jvadd(jrotate(qw, jvconst(cp)), tw);                                          /* :267 */
+    jet res = J_add(jdot(jvconst(n), pw), J_const(negative_OA_dot_norm));                   /* :270 */
+    unpack(res, r, Jq, Jt);
+}
+
+/* ceres::EigenQuaternionManifold::PlusJacobian, 4x3 row-major, rows in storage order x,y,z,w */
+void orc_quat_plus_jacobian(const double x[4], double P[12])
+{
+    const double qx = x[0], qy = x[1], qz = x[2], qw = x[3];
+    P[0] =  qw; P[1]  =  qz; P[2]  = -qy;     /* row x */
+    P[3] = -qz; P[4]  =  qw; P[5]  =  qx;     /* row y */
+    P[6] =  qy; P[7]  = -qx; P[8]  =  qw;     /* row z */
+    P[9] = -qx; P[10] = -qy; P[11] = -qz;     /* row w */
+}
+
+/* ceres QuaternionPlus: q+ = [sin(|d|) d/|d|, cos|d|] (x) q */
+void orc_quat_plus(const double x[4], const double d[3], double out[4])
+{
+    const double n2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    double qd[4];
+    if (n2 != 0.0) {
+        const double n = sqrt(n2); const double sn = sin(n) / n;
+        qd[3] = cos(n); qd[0] = sn * d[0]; qd[1] = sn * d[1]; qd[2] = sn * d[2];
+    } else { qd[3] = 1.0; qd[0] = d[0]; qd[1] = d[1]; qd[2] = d[2]; }
+    const double ax = qd[0], ay = qd[1], az = qd[2], aw = qd[3], bx = x[0], by = x[1], bz = x[2], bw = x[3];
+    out[3] = aw * bw - ax * bx - ay * by - az * bz;
+    out[0] = aw * bx + ax * bw + ay * bz - az * by;
+    out[1] = aw * by - ax * bz + ay * bw + az * bx;
+    out[2] = aw * bz + ax * by - ay * bx + az * bw;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a10  residual blocks -> HuberLoss(0.1) corrector -> normal equations                         */
+/* ------------------------------------------------------------------------------------------ */
+static void accumulate_block(int rows, const double *r, const double *Jq, const double *Jt, const double P[12],
+                             double huber_delta, double H[36], double g[6], double *cost)
+{
+    double Jl[3][6], rr[3];
+    for (int i = 0; i < rows; ++i) {
+        for (int c = 0; c < 3; ++c) {            /* local = ambient(rows x 4) * PlusJacobian(4 x 3) */
+            double acc = 0.0;
+            for (int k = 0; k < 4; ++k) acc += Jq[i * 4 + k] * P[k * 3 + c];
+            Jl[i][c] = acc;
+        }
+        for (int c = 0; c < 3; ++c) Jl[i][3 + c] = Jt[i * 3 + c];
+        rr[i] = r[i];
+    }
+    double sq = 0.0;
+    for (int i = 0; i < rows; ++i) sq += rr[i] * rr[i];
+    double rho0 = sq, rho1 = 1.0;
+    if (huber_delta > 0.0) {
+        /* ceres::HuberLoss::Evaluate, a = delta, b = a^2 */
+        const double b = huber_delta * huber_delta;
+        if (sq > b) {
+            const double rnorm = sqrt(sq);
+            rho0 = 2.0 * huber_delta * rnorm - b;
+            rho1 = huber_delta / rnorm; if (rho1 < 2.2250738585072014e-308) rho1 = 2.2250738585072014e-308;
+        }
+        /* Corrector: rho'' <= 0 for Huber, so residual_scaling_ = sqrt(rho'), alpha_sq_norm_ = 0 */
+        const double sr = sqrt(rho1);
+        for (int i = 0; i < rows; ++i) { rr[i] *= sr; for (int c = 0; c < 6; ++c) Jl[i][c] *= sr; }
+    }
+    *cost += 0.5 * rho0;
+    for (int i = 0; i < rows; ++i)
+        for (int a = 0; a < 6; ++a) {
+            g[a] += Jl[i][a] * rr[i];
+            for (int c = 0; c < 6; ++c) H[a * 6 + c] += Jl[i][a] * Jl[i][c];
+        }
+}
+
+void orc_normal_equations(const double q[4], const double t[3],
+                          const orc_point *sharp, const int *e_src, const orc_point *corner_last,
+                          const int *e_a, const int *e_b, int n_e,
+                          const orc_point *flat, const int *p_src, const orc_point *surf_last,
+                          const int *p_a, const int *p_b, const int *p_c, const float *p_w, int n_p,
+                          double huber_delta, double H[36], double g[6], double *cost)
+{
+    double P[12];
+    orc_quat_plus_jacobian(q, P);
+    memset(H, 0, 36 * sizeof(double)); memset(g, 0, 6 * sizeof(double)); *cost = 0.0;
+    for (int i = 0; i < n_e; ++i) {
+        const orc_point *c = &sharp[e_src[i]], *a = &corner_last[e_a[i]], *b = &corner_last[e_b[i]];
+        const double cp[3] = {c->x, c->y, c->z}, pa[3] = {a->x, a->y, a->z}, pb[3] = {b->x, b->y, b->z};
+        double r[3], Jq[12], Jt[9];
+        orc_edge_factor(q, t, cp, pa, pb, 1.0, r, Jq, Jt);
+        accumulate_block(3, r, Jq, Jt, P, huber_delta, H, g, cost);
+    }
+    for (int i = 0; i < n_p; ++i) {
+        const orc_point *c = &flat[p_src[i]], *a = &surf_last[p_a[i]], *b = &surf_last[p_b[i]], *d = &surf_last[p_c[i]];
+        const double cp[3] = {c->x, c->y, c->z}, pa[3] = {a->x, a->y, a->z}, pb[3] = {b->x, b->y, b->z}, pc[3] = {d->x, d->y, d->z};
+        double r[1], Jq[4], Jt[3];
+        orc_plane_factor_modify(q, t, cp, pa, pb, pc, 1.0, p_w ? (double)p_w[i] : 1.0, r, Jq, Jt);
+        accumulate_block(1, r, Jq, Jt, P, huber_delta, H, g, cost);
+    }
+}
+
+int orc_gn_solve(const double H[36], const double g[6], double delta[6])
+{
+    double L[36];
+    memset(L, 0, sizeof(L));
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double s = H[i * 6 + j];
+            for (int k = 0; k < j; ++k) s -= L[i * 6 + k] * L[j * 6 + k];
+            if (i == j) { if (!(s > 0.0)) return -1; L[i * 6 + i] = sqrt(s); }
+            else L[i * 6 + j] = s / L[j * 6 + j];
+        }
+    double y[6];
+    for (int i = 0; i < 6; ++i) { double s = -g[i]; for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * y[k]; y[i] = s / L[i * 6 + i]; }
+    for (int i = 5; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < 6; ++k) s -= L[k * 6 + i] * delta[k]; delta[i] = s / L[i * 6 + i]; }
+    return 0;
+}
+
+void orc_pose_update(double q[4], double t[3], const double delta[6])
+{
+    double qn[4];
+    orc_quat_plus(q, delta, qn);
+    memcpy(q, qn, sizeof(qn));
+    t[0] += delta[3]; t[1] += delta[4]; t[2] += delta[5];
+}

@@ -1,0 +1,115 @@
+/*
+ * ll_oracle.h -- CPU ORACLE for the Light-LOAM per-scan hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product path (light-loam_amd/) never
+ * links, imports or calls anything in oracle/ and has no CPU fallback.
+ *
+ * PARITY UNPINNED: the reference (BrenYi/Light-LOAM) ships no tests, golden vectors or
+ * fixtures, and none of its translation units can be compiled in this image (every TU
+ * needs ROS1 + PCL, and the odometry path also Eigen + Ceres; none are installed and no
+ * stand-in headers are written for them).  This file is therefore a *restatement* of the
+ * reference algorithm, each function citing the reference file:line it follows; the
+ * third-party arithmetic on the path (PCL 1.10 VoxelGrid / KdTreeFLANN->FLANN L2_Simple,
+ * Eigen 3.3 Quaternion slerp/_transformVector/cross/normalize, Ceres 2.x Jet, HuberLoss,
+ * Corrector, EigenQuaternionManifold) is restated from their published algorithms.
+ * What IS pinned here: libm.  The oracle calls the host glibc atanf/atan2f/expf/sqrtf
+ * exactly where the reference does.
+ *
+ * All citations are relative to /root/reference/.
+ */
+#ifndef LL_ORACLE_H
+#define LL_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* pcl::PointXYZI (include/aloam_velodyne/common.h:7) packed to 16 B */
+typedef struct { float x, y, z, intensity; } orc_point;
+
+/* scanRegistration.cpp:435-441 node parameters */
+typedef struct {
+    int    n_scans;        /* "scan_line" */
+    int    ring_model;     /* 0 = reference switch (16/32/64 only); 1 = linear model of the 64 branch for any n_scans (extension) */
+    double minimum_range;  /* "minimum_range" */
+    float  lower_bound;    /* "lowerBound" (-24.9) */
+    float  up_bound;       /* "upBound" (2) */
+} orc_params;
+
+enum { ORC_OK = 0, ORC_ERR_EMPTY = -1, ORC_ERR_BAD_RINGS = -2, ORC_ERR_CAPACITY = -3 };
+
+/* ---- a1: removeNaN + removeClosedPointCloud + ring/relTime assignment + stable ring bucket ---- */
+/* scanRegistration.cpp:58-85, :105-221 */
+int orc_organize(const float *xyz, int stride_floats, int n_in, const orc_params *P,
+                 orc_point *cloud, int *n_out, int *scan_start, int *scan_end);
+
+/* ---- a2: curvature, scanRegistration.cpp:225-235 (curv[i] valid for i in [5, n-5)) ---- */
+void orc_curvature(const orc_point *cloud, int n, float *curv);
+
+/* ---- a3 + a4: segment sort, greedy pick, less-flat voxel grid, scanRegistration.cpp:246-377 ---- */
+/* label is int32 like cloudLabel[]; entries outside [5,n-5) are left untouched (caller zero-fills). */
+int orc_pick(const orc_point *cloud, int n, const float *curv,
+             const int *scan_start, const int *scan_end, int n_scans, int *label,
+             orc_point *sharp, int *n_sharp, orc_point *less_sharp, int *n_less_sharp,
+             orc_point *flat, int *n_flat, orc_point *less_flat, int *n_less_flat,
+             int *tie_count /* nullable: # of equal-curvature neighbours met in the sorted order */);
+
+/* pcl::VoxelGrid<PointXYZI>::applyFilter restated (PCL 1.10), leaf (l,l,l), downsample_all_data = true */
+int orc_voxel_grid(const orc_point *in, int n, float leaf, orc_point *out, int *n_out);
+
+/* whole laserCloudHandler, scanRegistration.cpp:87-428 (without the ROS messages) */
+int orc_extract(const float *xyz, int stride_floats, int n_in, const orc_params *P,
+                orc_point *cloud, int *n_out, int *scan_start, int *scan_end,
+                float *curv, int *label,
+                orc_point *sharp, int *n_sharp, orc_point *less_sharp, int *n_less_sharp,
+                orc_point *flat, int *n_flat, orc_point *less_flat, int *n_less_flat);
+
+/* ---- a5: TransformToStart with DISTORTION 0, laserOdometry.cpp:77-95 ---- */
+void orc_transform_to_start(const double q[4] /*x,y,z,w*/, const double t[3], const orc_point *pi, orc_point *po);
+
+/* ---- a6: corner association, laserOdometry.cpp:491-620.  One entry per accepted correspondence. ---- */
+int orc_associate_corner(const double q[4], const double t[3], const orc_point *sharp, int ns,
+                         const orc_point *corner_last, int mc,
+                         int *src_idx, int *idx_a, int *idx_b, int *n_e);
+/* ---- a7: plane association, laserOdometry.cpp:653-793 ---- */
+int orc_associate_plane(const double q[4], const double t[3], const orc_point *flat, int nf,
+                        const orc_point *surf_last, int ms,
+                        int *src_idx, int *idx_a, int *idx_b, int *idx_c, int *n_p);
+
+/* ---- a8: graph_based_correspondence_vote_simple, laserOdometry.cpp:153-342 ---- */
+/* counts[n] = incompatibility count per correspondence; selected (index, weight) in region order then
+ * ascending (count, index) -- the reference's order inside equal counts is std::sort-unspecified. */
+void orc_vote(const orc_point *src, const orc_point *tgt, int n, int corner_case,
+              int *counts, int *sel_idx, float *sel_w, int *n_sel);
+
+/* ---- a9: cost functors evaluated the way ceres::AutoDiffCostFunction does (forward Jets, width 7) ---- */
+/* Jq is row-major (rows x 4) w.r.t. q = (x,y,z,w); Jt row-major (rows x 3). */
+void orc_edge_factor(const double q[4], const double t[3], const double cp[3], const double a[3],
+                     const double b[3], double s, double r[3], double Jq[12], double Jt[9]);      /* lidarFactor.hpp:9-52 */
+void orc_plane_factor_modify(const double q[4], const double t[3], const double cp[3], const double j[3],
+                     const double l[3], const double m[3], double s, double weight,
+                     double r[1], double Jq[4], double Jt[3]);                                    /* lidarFactor.hpp:203-251 */
+void orc_plane_norm_factor(const double q[4], const double t[3], const double cp[3], const double n[3],
+                     double negative_OA_dot_norm, double r[1], double Jq[4], double Jt[3]);      /* lidarFactor.hpp:253-285 */
+/* ceres EigenQuaternionManifold::PlusJacobian (4x3 row-major) and Plus */
+void orc_quat_plus_jacobian(const double q[4], double P[12]);
+void orc_quat_plus(const double q[4], const double delta[3], double q_out[4]);
+
+/* ---- a10: HuberLoss(0.1) corrector + normal equations + one Gauss-Newton step ---- */
+/* laserOdometry.cpp:475-482, :615-616, :797-808, :820-825.  Blocks: n_e edges (3 rows each) then n_p planes.
+ * H is 6x6 row-major over (dq[3], dt[3]), g = J^T r, cost = sum 0.5*rho(s). */
+void orc_normal_equations(const double q[4], const double t[3],
+                          const orc_point *sharp, const int *e_src, const orc_point *corner_last,
+                          const int *e_a, const int *e_b, int n_e,
+                          const orc_point *flat, const int *p_src, const orc_point *surf_last,
+                          const int *p_a, const int *p_b, const int *p_c, const float *p_w, int n_p,
+                          double huber_delta /* <=0: no loss */, double H[36], double g[6], double *cost);
+int orc_gn_solve(const double H[36], const double g[6], double delta[6]);   /* H delta = -g, Cholesky */
+void orc_pose_update(double q[4], double t[3], const double delta[6]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

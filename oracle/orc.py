@@ -1,0 +1,217 @@
+"""ctypes binding of the CPU oracle (oracle/ll_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product package (light-loam_amd/) never imports this module.  PARITY UNPINNED -- see ll_oracle.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "libll_oracle.so")
+
+POINT = np.dtype([("x", "f4"), ("y", "f4"), ("z", "f4"), ("intensity", "f4")])
+
+
+class Params(C.Structure):
+    _fields_ = [("n_scans", C.c_int), ("ring_model", C.c_int), ("minimum_range", C.c_double),
+                ("lower_bound", C.c_float), ("up_bound", C.c_float)]
+
+
+def build(force=False):
+    src = [os.path.join(_HERE, f) for f in ("ll_oracle.c", "ll_oracle.h", "Makefile")]
+    if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        for name in ("orc_organize", "orc_pick", "orc_voxel_grid", "orc_extract", "orc_associate_corner",
+                     "orc_associate_plane", "orc_gn_solve"):
+            getattr(_lib, name).restype = C.c_int
+    return _lib
+
+
+def params(n_scans=64, minimum_range=None, lower_bound=-24.9, up_bound=2.0, ring_model=0):
+    if minimum_range is None:
+        minimum_range = 5.0 if n_scans == 64 else 0.3     # launch/aloam_velodyne_HDL_64.launch:8, VLP_16.launch
+    return Params(n_scans, ring_model, float(minimum_range), lower_bound, up_bound)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f4(points):
+    """(n,4) float32 view of a point array (structured POINT or plain)."""
+    a = np.ascontiguousarray(points)
+    if a.dtype == POINT:
+        a = a.view(np.float32).reshape(-1, 4)
+    return np.ascontiguousarray(a, dtype=np.float32).reshape(-1, 4)
+
+
+def organize(xyz, P):
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+    n_in, stride = xyz.shape
+    cloud = np.zeros((max(n_in, 1), 4), np.float32)
+    n = C.c_int(0)
+    ss = np.zeros(P.n_scans, np.int32)
+    se = np.zeros(P.n_scans, np.int32)
+    rc = lib().orc_organize(_p(xyz), stride, n_in, C.byref(P), _p(cloud), C.byref(n), _p(ss), _p(se))
+    return rc, cloud[:n.value].copy(), ss, se
+
+
+def curvature(cloud):
+    cloud = _f4(cloud)
+    curv = np.zeros(len(cloud), np.float32)
+    lib().orc_curvature(_p(cloud), len(cloud), _p(curv))
+    return curv
+
+
+def voxel_grid(points, leaf=0.2):
+    points = _f4(points)
+    out = np.zeros((max(len(points), 1), 4), np.float32)
+    n = C.c_int(0)
+    lib().orc_voxel_grid(_p(points), len(points), C.c_float(leaf), _p(out), C.byref(n))
+    return out[:n.value].copy()
+
+
+def extract(xyz, P):
+    """Whole laserCloudHandler.  Returns dict of arrays."""
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+    n_in, stride = xyz.shape
+    cap = max(n_in, 1)
+    cloud = np.zeros((cap, 4), np.float32)
+    curv = np.zeros(cap, np.float32)
+    label = np.zeros(cap, np.int32)
+    ss = np.zeros(P.n_scans, np.int32)
+    se = np.zeros(P.n_scans, np.int32)
+    sharp = np.zeros((cap, 4), np.float32)
+    less_sharp = np.zeros((cap, 4), np.float32)
+    flat = np.zeros((cap, 4), np.float32)
+    less_flat = np.zeros((cap, 4), np.float32)
+    n = C.c_int(0); ns = C.c_int(0); nls = C.c_int(0); nf = C.c_int(0); nlf = C.c_int(0)
+    rc = lib().orc_extract(_p(xyz), stride, n_in, C.byref(P), _p(cloud), C.byref(n), _p(ss), _p(se), _p(curv), _p(label),
+                           _p(sharp), C.byref(ns), _p(less_sharp), C.byref(nls), _p(flat), C.byref(nf),
+                           _p(less_flat), C.byref(nlf))
+    return dict(rc=rc, cloud=cloud[:n.value].copy(), curv=curv[:n.value].copy(), label=label[:n.value].copy(),
+                scan_start=ss, scan_end=se, sharp=sharp[:ns.value].copy(), less_sharp=less_sharp[:nls.value].copy(),
+                flat=flat[:nf.value].copy(), less_flat=less_flat[:nlf.value].copy())
+
+
+def transform_to_start(q, t, pts):
+    pts = _f4(pts)
+    out = np.zeros_like(pts)
+    q = np.ascontiguousarray(q, np.float64); t = np.ascontiguousarray(t, np.float64)
+    f = lib().orc_transform_to_start
+    for i in range(len(pts)):
+        f(_p(q), _p(t), C.c_void_p(pts.ctypes.data + 16 * i), C.c_void_p(out.ctypes.data + 16 * i))
+    return out
+
+
+def associate_corner(q, t, sharp, corner_last):
+    sharp = _f4(sharp); corner_last = _f4(corner_last)
+    q = np.ascontiguousarray(q, np.float64); t = np.ascontiguousarray(t, np.float64)
+    cap = max(len(sharp), 1)
+    src = np.zeros(cap, np.int32); a = np.zeros(cap, np.int32); b = np.zeros(cap, np.int32)
+    n = C.c_int(0)
+    lib().orc_associate_corner(_p(q), _p(t), _p(sharp), len(sharp), _p(corner_last), len(corner_last),
+                               _p(src), _p(a), _p(b), C.byref(n))
+    k = n.value
+    return src[:k].copy(), a[:k].copy(), b[:k].copy()
+
+
+def associate_plane(q, t, flat, surf_last):
+    flat = _f4(flat); surf_last = _f4(surf_last)
+    q = np.ascontiguousarray(q, np.float64); t = np.ascontiguousarray(t, np.float64)
+    cap = max(len(flat), 1)
+    src = np.zeros(cap, np.int32); a = np.zeros(cap, np.int32); b = np.zeros(cap, np.int32); c = np.zeros(cap, np.int32)
+    n = C.c_int(0)
+    lib().orc_associate_plane(_p(q), _p(t), _p(flat), len(flat), _p(surf_last), len(surf_last),
+                              _p(src), _p(a), _p(b), _p(c), C.byref(n))
+    k = n.value
+    return src[:k].copy(), a[:k].copy(), b[:k].copy(), c[:k].copy()
+
+
+def vote(src, tgt, corner_case=False):
+    src = _f4(src); tgt = _f4(tgt)
+    n = len(src)
+    counts = np.zeros(max(n, 1), np.int32); idx = np.zeros(max(n, 1), np.int32); w = np.zeros(max(n, 1), np.float32)
+    ns = C.c_int(0)
+    lib().orc_vote(_p(src), _p(tgt), n, int(bool(corner_case)), _p(counts), _p(idx), _p(w), C.byref(ns))
+    return counts[:n].copy(), idx[:ns.value].copy(), w[:ns.value].copy()
+
+
+def _d(a, n):
+    a = np.ascontiguousarray(a, np.float64)
+    assert a.size == n
+    return a
+
+
+def edge_factor(q, t, cp, a, b, s=1.0):
+    r = np.zeros(3); Jq = np.zeros((3, 4)); Jt = np.zeros((3, 3))
+    q = _d(q, 4); t = _d(t, 3); cp = _d(cp, 3); a = _d(a, 3); b = _d(b, 3)
+    lib().orc_edge_factor(_p(q), _p(t), _p(cp), _p(a), _p(b), C.c_double(s), _p(r), _p(Jq), _p(Jt))
+    return r, Jq, Jt
+
+
+def plane_factor_modify(q, t, cp, j, l, m, s=1.0, weight=1.0):
+    r = np.zeros(1); Jq = np.zeros((1, 4)); Jt = np.zeros((1, 3))
+    q = _d(q, 4); t = _d(t, 3); cp = _d(cp, 3); j = _d(j, 3); l = _d(l, 3); m = _d(m, 3)
+    lib().orc_plane_factor_modify(_p(q), _p(t), _p(cp), _p(j), _p(l), _p(m), C.c_double(s), C.c_double(weight),
+                                  _p(r), _p(Jq), _p(Jt))
+    return r, Jq, Jt
+
+
+def plane_norm_factor(q, t, cp, n, d):
+    r = np.zeros(1); Jq = np.zeros((1, 4)); Jt = np.zeros((1, 3))
+    q = _d(q, 4); t = _d(t, 3); cp = _d(cp, 3); n = _d(n, 3)
+    lib().orc_plane_norm_factor(_p(q), _p(t), _p(cp), _p(n), C.c_double(d), _p(r), _p(Jq), _p(Jt))
+    return r, Jq, Jt
+
+
+def quat_plus_jacobian(q):
+    P = np.zeros((4, 3)); q = _d(q, 4)
+    lib().orc_quat_plus_jacobian(_p(q), _p(P))
+    return P
+
+
+def quat_plus(q, d):
+    out = np.zeros(4); q = _d(q, 4); d = _d(d, 3)
+    lib().orc_quat_plus(_p(q), _p(d), _p(out))
+    return out
+
+
+def normal_equations(q, t, sharp, e_src, corner_last, e_a, e_b, flat, p_src, surf_last, p_a, p_b, p_c, p_w,
+                     huber_delta=0.1):
+    q = _d(q, 4); t = _d(t, 3)
+    sharp = _f4(sharp); corner_last = _f4(corner_last); flat = _f4(flat); surf_last = _f4(surf_last)
+    i32 = lambda a: np.ascontiguousarray(a, np.int32)
+    e_src, e_a, e_b, p_src, p_a, p_b, p_c = map(i32, (e_src, e_a, e_b, p_src, p_a, p_b, p_c))
+    pw = None if p_w is None else np.ascontiguousarray(p_w, np.float32)
+    H = np.zeros((6, 6)); g = np.zeros(6); cost = C.c_double(0)
+    lib().orc_normal_equations(_p(q), _p(t), _p(sharp), _p(e_src), _p(corner_last), _p(e_a), _p(e_b), len(e_src),
+                               _p(flat), _p(p_src), _p(surf_last), _p(p_a), _p(p_b), _p(p_c),
+                               None if pw is None else _p(pw), len(p_src), C.c_double(huber_delta),
+                               _p(H), _p(g), C.byref(cost))
+    return H, g, cost.value
+
+
+def gn_solve(H, g):
+    H = np.ascontiguousarray(H, np.float64); g = _d(g, 6); d = np.zeros(6)
+    rc = lib().orc_gn_solve(_p(H), _p(g), _p(d))
+    return rc, d
+
+
+def pose_update(q, t, delta):
+    q = _d(q, 4).copy(); t = _d(t, 3).copy(); delta = _d(delta, 6)
+    lib().orc_pose_update(_p(q), _p(t), _p(delta))
+    return q, t

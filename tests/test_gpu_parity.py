@@ -1,0 +1,194 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+
+Bar: integer / index results and every f32 produced by f32 arithmetic bit-exact; f64 residuals, Jacobians,
+normal equations and pose within REL_TOL (autodiff Jets vs closed-form derivatives differ by rounding only).
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-9      # f64 quantities: |hip - oracle| <= REL_TOL * max(1, |oracle|_inf)
+
+
+def close(a, b, what):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, what
+    scale = max(1.0, float(np.abs(b).max()) if b.size else 1.0)
+    err = float(np.abs(a - b).max()) if a.size else 0.0
+    assert err <= REL_TOL * scale, f"{what}: max abs err {err:g} vs scale {scale:g}"
+
+
+SHAPES = {
+    "S64": dict(rings=64),
+    "S16": dict(rings=16),
+    "S32": dict(rings=32),
+    "S64_azmajor_jitter_nan": dict(rings=64, order=1, az_jitter_deg=0.4, drop_prob=0.03, emit_nan=1),
+    "S64_ringmajor_jitter": dict(rings=64, az_jitter_deg=0.4),
+}
+
+
+@pytest.fixture(scope="module", params=list(SHAPES))
+def case(request, api, orc, synth):
+    kw = dict(SHAPES[request.param]); rings = kw.pop("rings")
+    cfg = synth.default_cfg(rings, **kw)
+    scans = [synth.scan(cfg, k) for k in range(3)]
+    P = orc.params(rings)
+    prm = api.default_params(rings, batch=3, write_curvature=1, max_points=max(len(s) for s in scans) + 7)
+    ctx = api.Context(prm)
+    for k, s in enumerate(scans):
+        ctx.upload_scan(k, s)
+    ctx.extract(0, 3)
+    ref = [orc.extract(s, P) for s in scans]
+    yield dict(name=request.param, ctx=ctx, ref=ref, scans=scans, rings=rings)
+    ctx.close()
+
+
+def test_organize_bit_exact(case):
+    """a1: laserCloud (xyz + intensity), scanStartInd/scanEndInd."""
+    for k in range(3):
+        cloud, ss, se = case["ctx"].cloud(k)
+        r = case["ref"][k]
+        assert case["ctx"].scan_info(k).status == 0 and r["rc"] == 0
+        assert len(cloud) == len(r["cloud"])
+        assert_bit_equal(cloud, r["cloud"], f"{case['name']} scan {k} laserCloud")
+        assert (ss == r["scan_start"]).all() and (se == r["scan_end"]).all()
+
+
+def test_curvature_and_labels_bit_exact(case):
+    """a2 + a3: cloudCurvature on [5, n-5) and cloudLabel."""
+    for k in range(3):
+        lab, cv = case["ctx"].labels(k, curvature=True)
+        r = case["ref"][k]
+        n = len(lab)
+        assert_bit_equal(cv[5:n - 5], r["curv"][5:n - 5], f"{case['name']} scan {k} curvature")
+        assert (lab[5:n - 5].astype(np.int32) == r["label"][5:n - 5]).all()
+        assert (lab[:5] == 0).all() and (lab[n - 5:] == 0).all()
+
+
+def test_feature_clouds_bit_exact(case):
+    """a3 + a4: the four published clouds, same points in the same order."""
+    for k in range(3):
+        f = case["ctx"].features(k)
+        r = case["ref"][k]
+        for name in ("sharp", "less_sharp", "flat", "less_flat"):
+            assert_bit_equal(f[name], r[name], f"{case['name']} scan {k} {name}")
+        assert len(r["sharp"]) > 0 and len(r["less_flat"]) > 100
+
+
+@pytest.fixture(scope="module")
+def odo(case, orc):
+    """scan 1 and 2 against their predecessors at a non-trivial pose guess."""
+    ctx = case["ctx"]
+    q = np.array([0.001, -0.002, 0.004, 1.0]); q /= np.linalg.norm(q)
+    t = np.array([0.8, 0.02, -0.01])
+    pose = np.concatenate([q, t])
+    ctx.set_target_from_slot(0)
+    ctx.associate(1, 2, pose)
+    ctx.vote(1, 2, True)
+    ctx.normal_equations(1, 2)
+    ctx.synchronize()
+    out = []
+    for k in (1, 2):
+        cur, prev = case["ref"][k], case["ref"][k - 1]
+        es, ea, eb = orc.associate_corner(q, t, cur["sharp"], prev["less_sharp"])
+        ps, pa, pb, pc = orc.associate_plane(q, t, cur["flat"], prev["less_flat"])
+        cnt, sidx, sw = orc.vote(cur["flat"][ps], prev["less_flat"][pa])
+        out.append(dict(es=es, ea=ea, eb=eb, ps=ps, pa=pa, pb=pb, pc=pc, cnt=cnt, sidx=sidx, sw=sw, cur=cur, prev=prev))
+    return dict(q=q, t=t, pose=pose, ref=out)
+
+
+def test_association_indices_exact(case, odo):
+    """a5-a7: (src, a, b[, c]) index tuples in correspondence order."""
+    for i, k in enumerate((1, 2)):
+        r = odo["ref"][i]
+        es, ea, eb = case["ctx"].edge_corr(k)
+        ps, pa, pb, pc = case["ctx"].plane_corr(k)
+        assert len(r["es"]) > 10 and len(r["ps"]) > 10
+        for got, want, nm in ((es, r["es"], "e_src"), (ea, r["ea"], "e_a"), (eb, r["eb"], "e_b"),
+                              (ps, r["ps"], "p_src"), (pa, r["pa"], "p_a"), (pb, r["pb"], "p_b"), (pc, r["pc"], "p_c")):
+            assert len(got) == len(want) and (got == want).all(), f"{case['name']} scan {k} {nm}"
+
+
+def test_vote_exact(case, odo):
+    """a8: incompatibility counts, selected set and weights."""
+    for i, k in enumerate((1, 2)):
+        r = odo["ref"][i]
+        cnt, sel, w = case["ctx"].vote_result(k)
+        assert (cnt == r["cnt"]).all()
+        want_sel = np.zeros(len(cnt), bool); want_sel[r["sidx"]] = True
+        assert (sel == want_sel).all()
+        want_w = np.ones(len(cnt), np.float32); want_w[r["sidx"]] = r["sw"]
+        assert (w[sel] == want_w[sel]).all()
+        assert case["ctx"].pair_info(k).n_plane_selected == len(r["sidx"])
+
+
+def _oracle_neq(orc, odo, r):
+    order = np.sort(r["sidx"])                        # HIP accumulates selected planes in correspondence order
+    wmap = np.ones(len(r["ps"]), np.float32); wmap[r["sidx"]] = r["sw"]
+    return orc.normal_equations(odo["q"], odo["t"], r["cur"]["sharp"], r["es"], r["prev"]["less_sharp"], r["ea"], r["eb"],
+                                r["cur"]["flat"], r["ps"][order], r["prev"]["less_flat"], r["pa"][order], r["pb"][order],
+                                r["pc"][order], wmap[order], 0.1)
+
+
+def test_normal_equations(case, odo, orc):
+    """a9 + a10: H, g, cost (Huber 0.1) against Jet-autodiff blocks."""
+    for i, k in enumerate((1, 2)):
+        H, g, cost = case["ctx"].normal_equations_result(k)
+        Ho, go, co = _oracle_neq(orc, odo, odo["ref"][i])
+        close(H, Ho, "H"); close(g, go, "g"); close(cost, co, "cost")
+        assert np.allclose(H, H.T)
+
+
+def test_residual_jacobian_rows(case, odo, orc):
+    """What ceres::CostFunction::Evaluate would return per block: r, d r/d q (ambient xyzw), d r/d t."""
+    k, r = 1, odo["ref"][0]
+    rr, Jq, Jt = case["ctx"].residual_jacobian(k, odo["pose"])
+    ne = len(r["es"])
+    assert len(rr) == 3 * ne + len(r["sidx"])
+    for i in range(0, ne, max(1, ne // 40)):
+        cp = r["cur"]["sharp"][r["es"][i], :3]; a = r["prev"]["less_sharp"][r["ea"][i], :3]; b = r["prev"]["less_sharp"][r["eb"][i], :3]
+        ro, Jqo, Jto = orc.edge_factor(odo["q"], odo["t"], cp, a, b)
+        close(rr[3 * i:3 * i + 3], ro, "edge r"); close(Jq[3 * i:3 * i + 3], Jqo, "edge Jq"); close(Jt[3 * i:3 * i + 3], Jto, "edge Jt")
+    order = np.sort(r["sidx"]); wmap = np.ones(len(r["ps"]), np.float32); wmap[r["sidx"]] = r["sw"]
+    for i in order[::max(1, len(order) // 40)]:
+        row = 3 * ne + int(np.searchsorted(order, i))
+        cp = r["cur"]["flat"][r["ps"][i], :3]; pj = r["prev"]["less_flat"][r["pa"][i], :3]
+        pl = r["prev"]["less_flat"][r["pb"][i], :3]; pm = r["prev"]["less_flat"][r["pc"][i], :3]
+        ro, Jqo, Jto = orc.plane_factor_modify(odo["q"], odo["t"], cp, pj, pl, pm, 1.0, float(wmap[i]))
+        close(rr[row], ro[0], "plane r"); close(Jq[row], Jqo[0], "plane Jq"); close(Jt[row], Jto[0], "plane Jt")
+
+
+def test_gn_step_pose(case, odo, orc):
+    """one Gauss-Newton iteration: Cholesky solve + EigenQuaternionManifold::Plus."""
+    ctx = case["ctx"]
+    ctx.gn_step(1, 2)
+    for i, k in enumerate((1, 2)):
+        Ho, go, _ = _oracle_neq(orc, odo, odo["ref"][i])
+        rc, d = orc.gn_solve(Ho, go)
+        assert rc == 0
+        qo, to = orc.pose_update(odo["q"], odo["t"], d)
+        p = ctx.pose(k)
+        close(p[:4], qo, "q"); close(p[4:], to, "t")
+
+
+def test_hot_path_matches_staged(case, odo):
+    """ll_hot_path_batch (one launch sequence, no host sync) == the staged calls."""
+    ctx = case["ctx"]
+    staged = [ctx.pose(k) for k in (1, 2)]
+    ctx.set_target_from_slot(0)
+    ctx.hot_path(1, 2, odo["pose"], vote=True)
+    ctx.synchronize()
+    for i, k in enumerate((1, 2)):
+        assert (ctx.pose(k) == staged[i]).all()
+
+
+def test_vote_disabled_keeps_all(case, odo):
+    """now_frame <= 5 branch (laserOdometry.cpp:781-787): every plane correspondence, weight 1."""
+    ctx = case["ctx"]
+    ctx.vote(1, 2, False)
+    cnt, sel, w = ctx.vote_result(1)
+    assert sel.all() and (w == 1.0).all()
+    ctx.vote(1, 2, True)
