@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- scans/s of the Light-LOAM per-scan hot path on MI355X.
+
+One STEP = one pass of the hot path (extract + associate + vote + normal equations + one GN step,
+BASELINE.json's metric unit) over a batch of synthetic KITTI-shape 64-ring scans that is already resident in
+HBM when the timed region starts.  `value` = scans processed by all ranks per second.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Scans shard across GPUs with no data-path collective (scan-parallel): every rank owns
+`--batch` scans, so scaling is weak.  torch is used for the process group (RCCL), the barrier and the device
+synchronisation only; the work is the HIP library behind include/lightloam_hip.h.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md chip table: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def build_workload(synth, rings, batch, distinct, seed):
+    """batch+1 scans: slot i (and the carry target, index -1) follow a ping-pong walk over `distinct`+1 consecutive
+    poses, so every (slot k-1, slot k) pair is a pair of ADJACENT poses (one step forward or backward)."""
+    cfg = synth.default_cfg(rings, seed=seed)
+    base = [synth.scan(cfg, k) for k in range(distinct + 1)]
+    poses = [synth.pose(cfg, k) for k in range(distinct + 1)]
+
+    def tri(i):
+        period = 2 * distinct
+        j = i % period
+        return j if j <= distinct else period - j
+
+    order = [tri(i) for i in range(batch + 1)]          # order[0] is the carry, order[i+1] is slot i
+    guesses = np.zeros((batch, 7))
+    for i in range(batch):
+        a, b = poses[order[i]], poses[order[i + 1]]      # previous, current
+        dyaw = b[2] - a[2]
+        c, s = np.cos(a[2]), np.sin(a[2])
+        dx, dy = b[0] - a[0], b[1] - a[1]
+        # current -> previous frame transform, perturbed: the warm start the reference carries between frames
+        t = np.array([c * dx + s * dy, -s * dx + c * dy, 0.0]) * 0.9
+        yaw = dyaw * 0.9
+        guesses[i] = [0.0, 0.0, np.sin(yaw / 2), np.cos(yaw / 2), t[0], t[1], t[2]]
+    return base, order, guesses
+
+
+def cpu_baseline(orc, rings, base, order, guesses, budget_s=15.0):
+    """The oracle (kind 'port': our CPU restatement, 1 thread, grid-accelerated exact NN) over a bounded sample
+    of the same units of work."""
+    P = orc.params(rings)
+    orc.set_nn_mode(1)
+    units = 0
+    t0 = time.perf_counter()
+    prev = orc.extract(base[order[0]], P)                 # the carry is not counted
+    t0 = time.perf_counter()
+    while True:
+        i = units % (len(order) - 1)
+        cur = orc.extract(base[order[i + 1]], P)
+        if i == 0:
+            prev_use = orc.extract(base[order[0]], P) if units else prev
+        q, t = guesses[i][:4], guesses[i][4:]
+        es, ea, eb = orc.associate_corner(q, t, cur["sharp"], prev_use["less_sharp"])
+        ps, pa, pb, pc = orc.associate_plane(q, t, cur["flat"], prev_use["less_flat"])
+        cnt, sidx, sw = orc.vote(cur["flat"][ps], prev_use["less_flat"][pa])
+        H, g, cost = orc.normal_equations(q, t, cur["sharp"], es, prev_use["less_sharp"], ea, eb, cur["flat"], ps[sidx],
+                                          prev_use["less_flat"], pa[sidx], pb[sidx], pc[sidx], sw, 0.1)
+        rc, d = orc.gn_solve(H, g)
+        prev_use = cur
+        units += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or units >= 4096:
+            break
+    orc.set_nn_mode(0)
+    return units / el, units, el
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="scans resident per GPU and processed per step")
+    ap.add_argument("--chunk", type=int, default=0, help="scans per launch sequence inside a step (0 = whole batch)")
+    ap.add_argument("--rings", type=int, default=64)
+    ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic poses the batch cycles through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+
+    import lightloam_amd  # noqa: F401
+    from lightloam_amd import api, synth
+
+    # every rank owns its own scans (different seed => different noise), same shape
+    base, order, guesses = build_workload(synth, args.rings, args.batch, args.distinct, 0x5EED0000 + rank)
+    max_pts = max(len(s) for s in base)
+    prm = api.default_params(args.rings, batch=args.batch + 1, max_points=max_pts, chunk=args.chunk)
+    ctx = api.Context(prm, device=local_rank)
+    # slot B holds the carry scan: extract it once, make it the carry target, then load the batch
+    ctx.upload_scan(args.batch, base[order[0]])
+    ctx.extract(args.batch, 1)
+    ctx.set_target_from_slot(args.batch)
+    for i in range(args.batch):
+        ctx.upload_scan(i, base[order[i + 1]])
+    ctx.set_pose_guess(0, args.batch, guesses)
+    ctx.synchronize()
+
+    def step():
+        ctx.hot_path(0, args.batch, None, vote=True)     # pose restarts from the stored guess, device-to-device
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.profile_enable(True)
+    ctx.profile_read(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_read(reset=True)
+    ctx.profile_enable(False)
+
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    # sanity on the result of the timed work (not timed): every slot converged to a finite pose, counts are sane
+    info = ctx.scan_info(0); pair = ctx.pair_info(0); pose = ctx.pose(0)
+    assert info.status == 0 and pair.n_edge > 0 and pair.n_plane_selected > 0 and np.isfinite(pose).all()
+    ab = ctx.algorithmic_bytes(0, args.batch)
+
+    if rank == 0:
+        total_scans = args.batch * world * args.steps
+        value = total_scans / elapsed
+        # dominant kernel by summed HIP-event time; algorithmic bytes of the stage it belongs to, per launch
+        dom = max(prof, key=lambda k: prof[k][0])
+        dom_ms, dom_launches = prof[dom]
+        stage_bytes = {"k_classify": ab["ext"], "k_offsets": ab["ext"], "k_scatter": ab["ext"], "k_ring_features": ab["ext"],
+                       "k_compact": ab["ext"], "k_associate": ab["assoc"], "k_vote": ab["vote"],
+                       "k_normal_equations": ab["rj"], "k_gn_step": ab["rj"]}[dom]
+        launches_per_step = max(1, dom_launches // max(1, args.steps))
+        bytes_per_launch = stage_bytes / launches_per_step
+        avg_ms = dom_ms / max(1, dom_launches)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "scans/sec (feature-extract+match+one GN iter), 64-ring cloud",
+            "value": value, "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 (features, association, vote) + f64 (residuals, Jacobians, normal equations)",
+            "data": "synthetic",
+            "config": {"workload": "HDL-64E / KITTI-shape scan (64 rings x 2048 azimuths, min_range 5 m), feature extraction "
+                                   "+ graph-match + one GN iteration per scan pair, inputs resident in HBM",
+                       "scans_per_gpu_per_step": args.batch, "chunk": args.chunk or args.batch,
+                       "points_per_scan_in": int(info.n_in), "points_per_scan_kept": int(info.n),
+                       "parallelism": f"scan-parallel x{world}, no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "whole_path_algorithmic_GBps": (ab["ext"] + ab["assoc"] + ab["vote"] + ab["rj"]) * args.steps / elapsed / 1e9,
+                         "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1]}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import orc
+            v, units, el = cpu_baseline(orc, args.rings, base, order, guesses, args.cpu_budget)
+            out["cpu_baseline"] = {"value": v, "unit": "scans/s", "cores": 1, "kind": "port",
+                                   "sample": f"{units} scan pairs of the same synthetic stream in {el:.1f} s, oracle/ll_oracle.c "
+                                             "single thread (extract + grid-NN associate + vote + autodiff normal equations + solve)"}
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -65,6 +65,8 @@ typedef struct {
     float nearby_scan;        /* NEARBY_SCAN 2.5 (laserOdometry.cpp:30) */
     float huber_delta;        /* HuberLoss(0.1) (laserOdometry.cpp:475); <= 0 disables the loss */
     int   write_curvature;    /* also store cloudCurvature[] to HBM (debug / parity output; off on the hot path) */
+    int   chunk;              /* ll_hot_path_batch processes the slot range in chunks of this many scans so that a chunk's
+                                 intermediates stay in the 256 MiB Infinity Cache between kernels; 0 = whole range */
 } ll_params;
 
 /* Per-scan sizes produced by the extract stage. */
@@ -123,6 +125,8 @@ int ll_download_features(ll_ctx *ctx, int slot,
 int ll_set_target(ll_ctx *ctx, const ll_point *host_corner_last, int m_c, const ll_point *host_surf_last, int m_s);
 int ll_set_target_from_slot(ll_ctx *ctx, int slot);   /* device-to-device: slot's less-sharp/less-flat become the carry */
 int ll_associate_batch(ll_ctx *ctx, int first, int count, const double *host_pose_guess);
+/* Store the guess in HBM; ll_hot_path_batch(..., NULL, ...) then restarts every slot from it without touching the host. */
+int ll_set_pose_guess(ll_ctx *ctx, int first, int count, const double *host_pose_guess);
 int ll_get_pair_info(ll_ctx *ctx, int slot, ll_pair_info *info);
 /* edge: (src index into sharp, a, b into corner_last); plane: (src into flat, a, b, c into surf_last).  */
 int ll_download_edge_corr(ll_ctx *ctx, int slot, int *src, int *a, int *b, int cap);
@@ -155,6 +159,13 @@ int ll_residual_jacobian(ll_ctx *ctx, int slot, const double *pose7, double *r, 
  * One pass: extract + associate + vote + normal equations + one GN step for slots [first, first+count),
  * everything device-resident, no host synchronisation inside.  `vote_enable` as above.                   */
 int ll_hot_path_batch(ll_ctx *ctx, int first, int count, const double *host_pose_guess, int vote_enable);
+
+/* ---------------------------------------------------------------- measurement
+ * With profiling on, every kernel launched by the stage calls is bracketed by HIP events on the ctx stream.
+ * ll_profile_read synchronises the stream and returns, per kernel, the summed duration and the launch count
+ * since the last reset.  names[i] points to a static string.  n is in: capacity / out: kernels returned.    */
+int ll_profile_enable(ll_ctx *ctx, int on);
+int ll_profile_read(ll_ctx *ctx, int *n, const char **names, double *total_ms, int *launches, int reset);
 
 /* Algorithmic HBM bytes of the last ll_hot_path_batch / stage calls, summed over the slots they covered,
  * by SURVEY.md section 8d's formula (B_ext, B_assoc, B_vote, B_rj).                                      */

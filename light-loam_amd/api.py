@@ -21,7 +21,7 @@ EXPORTS = [
     "ll_download_features", "ll_set_target", "ll_set_target_from_slot", "ll_associate_batch", "ll_get_pair_info",
     "ll_download_edge_corr", "ll_download_plane_corr", "ll_vote_batch", "ll_download_vote",
     "ll_normal_equations_batch", "ll_download_normal_equations", "ll_gn_step_batch", "ll_download_pose",
-    "ll_residual_jacobian", "ll_hot_path_batch", "ll_algorithmic_bytes",
+    "ll_residual_jacobian", "ll_hot_path_batch", "ll_algorithmic_bytes", "ll_profile_enable", "ll_profile_read", "ll_set_pose_guess",
 ]
 
 
@@ -30,7 +30,8 @@ class Params(C.Structure):
                 ("lower_bound", C.c_float), ("up_bound", C.c_float), ("max_points", C.c_int),
                 ("max_ring_points", C.c_int), ("batch", C.c_int), ("curv_threshold", C.c_float),
                 ("gap_sq_threshold", C.c_float), ("leaf_size", C.c_float), ("nn_dist_sq_max", C.c_float),
-                ("nearby_scan", C.c_float), ("huber_delta", C.c_float), ("write_curvature", C.c_int)]
+                ("nearby_scan", C.c_float), ("huber_delta", C.c_float), ("write_curvature", C.c_int),
+                ("chunk", C.c_int)]
 
 
 class ScanInfo(C.Structure):
@@ -175,6 +176,10 @@ class Context:
         p = self._poses(pose, count)
         self._ck(self.lib.ll_associate_batch(self.h, first, count, _ptr(p)))
 
+    def set_pose_guess(self, first, count, pose):
+        p = self._poses(pose, count)
+        self._ck(self.lib.ll_set_pose_guess(self.h, first, count, _ptr(p)))
+
     def vote(self, first=0, count=1, enable=True):
         self._ck(self.lib.ll_vote_batch(self.h, first, count, int(bool(enable))))
 
@@ -229,6 +234,16 @@ class Context:
     def hot_path(self, first=0, count=1, pose=None, vote=True):
         p = self._poses(pose, count)
         self._ck(self.lib.ll_hot_path_batch(self.h, first, count, _ptr(p), int(bool(vote))))
+
+    def profile_enable(self, on=True):
+        self._ck(self.lib.ll_profile_enable(self.h, int(bool(on))))
+
+    def profile_read(self, reset=True):
+        """{kernel name: (total_ms, launches)} measured with HIP events on the ctx stream."""
+        n = C.c_int(16)
+        names = (C.c_char_p * 16)(); ms = (C.c_double * 16)(); launches = (C.c_int * 16)()
+        self._ck(self.lib.ll_profile_read(self.h, C.byref(n), names, ms, launches, int(bool(reset))))
+        return {names[i].decode(): (ms[i], launches[i]) for i in range(n.value)}
 
     def algorithmic_bytes(self, first=0, count=1):
         b = [C.c_double(0) for _ in range(4)]

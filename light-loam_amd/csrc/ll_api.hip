@@ -11,7 +11,33 @@
 #include <cstdio>
 #include <cmath>
 
+#define LL_PROF_EVENTS 8192
+struct LLProfiler {
+    bool on = false;
+    std::vector<hipEvent_t> ev;
+    std::vector<int> id;          /* kernel that STARTS at event i, LL_K_END for a closing mark */
+    int n = 0;
+    double total_ms[LL_K_COUNT] = {0};
+    int launches[LL_K_COUNT] = {0};
+};
+static const char *const kKernelNames[LL_K_COUNT] = {"k_classify", "k_offsets", "k_scatter", "k_ring_features", "k_compact",
+                                                     "k_associate", "k_vote", "k_normal_equations", "k_gn_step"};
+
+void ll_prof_mark(LLProfiler *p, int kernel_id, hipStream_t st)
+{
+    if (!p || !p->on || p->n >= (int)p->ev.size()) return;
+    /* a closing mark directly followed by an opening mark would cost two events; merge them */
+    if (p->n > 0 && p->id[p->n - 1] == LL_K_END && kernel_id != LL_K_END) { /* keep the END event as the start */
+        p->id[p->n - 1] = kernel_id | 0x100;   /* 0x100: this event also closed the previous kernel */
+        return;
+    }
+    (void)hipEventRecord(p->ev[p->n], st);
+    p->id[p->n] = kernel_id;
+    p->n++;
+}
+
 struct ll_ctx {
+    LLProfiler prof;
     ll_params p;
     LLView V;
     hipStream_t stream = nullptr;
@@ -81,6 +107,7 @@ extern "C" void ll_destroy(ll_ctx *ctx)
     for (void *p : ctx->allocs) (void)hipFree(p);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->ev_ok) for (auto &e : ctx->ev) (void)hipEventDestroy(e);
+    for (auto &e : ctx->prof.ev) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -151,7 +178,7 @@ extern "C" int ll_create(int device, const ll_params *p, ll_ctx **out)
     ok = ok && dev_alloc(ctx, V.e_src, (size_t)B * V.cap_sharp) && dev_alloc(ctx, V.e_a, (size_t)B * V.cap_sharp) && dev_alloc(ctx, V.e_b, (size_t)B * V.cap_sharp);
     ok = ok && dev_alloc(ctx, V.p_src, (size_t)B * V.cap_flat) && dev_alloc(ctx, V.p_a, (size_t)B * V.cap_flat) && dev_alloc(ctx, V.p_b, (size_t)B * V.cap_flat) && dev_alloc(ctx, V.p_c, (size_t)B * V.cap_flat);
     ok = ok && dev_alloc(ctx, V.v_count, (size_t)B * V.cap_flat) && dev_alloc(ctx, V.v_sel, (size_t)B * V.cap_flat) && dev_alloc(ctx, V.v_w, (size_t)B * V.cap_flat);
-    ok = ok && dev_alloc(ctx, V.pair, B) && dev_alloc(ctx, V.pose, (size_t)B * 7) && dev_alloc(ctx, V.neq, (size_t)B * LL_NEQ_STRIDE);
+    ok = ok && dev_alloc(ctx, V.pair, B) && dev_alloc(ctx, V.pose, (size_t)B * 7) && dev_alloc(ctx, V.pose_guess, (size_t)B * 7) && dev_alloc(ctx, V.neq, (size_t)B * LL_NEQ_STRIDE);
     ok = ok && dev_alloc(ctx, ctx->d_tmp_pose, 7);
     if (!ok) { ll_destroy(ctx); return LL_ERR_HIP; }
     ctx->feat_lds = ll_features_lds_bytes(p->max_ring_points);
@@ -160,6 +187,7 @@ extern "C" int ll_create(int device, const ll_params *p, ll_ctx **out)
     std::vector<double> ident((size_t)B * 7, 0.0);
     for (int b = 0; b < B; ++b) ident[(size_t)b * 7 + 3] = 1.0;
     if (hipMemcpyAsync(V.pose, ident.data(), ident.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(V.pose_guess, ident.data(), ident.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess) { g_create_err = "initial upload failed"; ll_destroy(ctx); return LL_ERR_HIP; }
     ctx->h_stage_pts = NP;
     if (hipHostMalloc((void **)&ctx->h_stage, (size_t)NP * sizeof(float4), hipHostMallocDefault) != hipSuccess) { g_create_err = "hipHostMalloc failed"; ll_destroy(ctx); return LL_ERR_HIP; }
@@ -204,8 +232,8 @@ extern "C" int ll_upload_scan(ll_ctx *ctx, int slot, const float *xyz, int strid
 extern "C" int ll_extract_batch(ll_ctx *ctx, int first, int count)
 {
     int rc = check_range(ctx, first, count); if (rc) return rc;
-    ll_launch_organize(ctx->V, first, count, ctx->stream);
-    ll_launch_features(ctx->V, first, count, ctx->feat_lds, ctx->stream);
+    ll_launch_organize(ctx->V, first, count, ctx->stream, &ctx->prof);
+    ll_launch_features(ctx->V, first, count, ctx->feat_lds, ctx->stream, &ctx->prof);
     LL_HIP(hipGetLastError());
     return LL_OK;
 }
@@ -214,9 +242,17 @@ static int upload_poses(ll_ctx *ctx, int first, int count, const double *host_po
 {
     if (host_pose) {
         LL_HIP(hipMemcpyAsync(ctx->V.pose + (size_t)first * 7, host_pose, (size_t)count * 7 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        LL_HIP(hipMemcpyAsync(ctx->V.pose_guess + (size_t)first * 7, host_pose, (size_t)count * 7 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         LL_HIP(hipStreamSynchronize(ctx->stream));    /* host buffer may be reused by the caller */
     }
     return LL_OK;
+}
+
+extern "C" int ll_set_pose_guess(ll_ctx *ctx, int first, int count, const double *host_pose)
+{
+    int rc = check_range(ctx, first, count); if (rc) return rc;
+    if (!host_pose) return LL_ERR_ARG;
+    return upload_poses(ctx, first, count, host_pose);
 }
 
 extern "C" int ll_set_target(ll_ctx *ctx, const ll_point *corner, int m_c, const ll_point *surf, int m_s)
@@ -255,7 +291,7 @@ extern "C" int ll_associate_batch(ll_ctx *ctx, int first, int count, const doubl
     int rc = check_range(ctx, first, count); if (rc) return rc;
     rc = upload_poses(ctx, first, count, host_pose_guess); if (rc) return rc;
     ctx->V.carry_slot = first;
-    ll_launch_associate(ctx->V, first, count, ctx->stream);
+    ll_launch_associate(ctx->V, first, count, ctx->stream, &ctx->prof);
     LL_HIP(hipGetLastError());
     return LL_OK;
 }
@@ -264,7 +300,7 @@ extern "C" int ll_vote_batch(ll_ctx *ctx, int first, int count, int enable)
 {
     int rc = check_range(ctx, first, count); if (rc) return rc;
     ctx->V.carry_slot = first;
-    ll_launch_vote(ctx->V, first, count, enable, ctx->stream);
+    ll_launch_vote(ctx->V, first, count, enable, ctx->stream, &ctx->prof);
     LL_HIP(hipGetLastError());
     return LL_OK;
 }
@@ -274,7 +310,7 @@ extern "C" int ll_normal_equations_batch(ll_ctx *ctx, int first, int count, cons
     int rc = check_range(ctx, first, count); if (rc) return rc;
     rc = upload_poses(ctx, first, count, host_pose); if (rc) return rc;
     ctx->V.carry_slot = first;
-    ll_launch_normal_equations(ctx->V, first, count, 0, ctx->stream);
+    ll_launch_normal_equations(ctx->V, first, count, 0, ctx->stream, &ctx->prof);
     LL_HIP(hipGetLastError());
     return LL_OK;
 }
@@ -282,7 +318,7 @@ extern "C" int ll_normal_equations_batch(ll_ctx *ctx, int first, int count, cons
 extern "C" int ll_gn_step_batch(ll_ctx *ctx, int first, int count)
 {
     int rc = check_range(ctx, first, count); if (rc) return rc;
-    ll_launch_gn_step(ctx->V, first, count, ctx->stream);
+    ll_launch_gn_step(ctx->V, first, count, ctx->stream, &ctx->prof);
     LL_HIP(hipGetLastError());
     return LL_OK;
 }
@@ -291,12 +327,22 @@ extern "C" int ll_hot_path_batch(ll_ctx *ctx, int first, int count, const double
 {
     int rc = check_range(ctx, first, count); if (rc) return rc;
     rc = upload_poses(ctx, first, count, host_pose_guess); if (rc) return rc;
+    /* NULL guess: restart from the stored guess (device-to-device, no host synchronisation) */
+    if (!host_pose_guess)
+        LL_HIP(hipMemcpyAsync(ctx->V.pose + (size_t)first * 7, ctx->V.pose_guess + (size_t)first * 7, (size_t)count * 7 * sizeof(double),
+                              hipMemcpyDeviceToDevice, ctx->stream));
     ctx->V.carry_slot = first;
-    ll_launch_organize(ctx->V, first, count, ctx->stream);
-    ll_launch_features(ctx->V, first, count, ctx->feat_lds, ctx->stream);
-    ll_launch_associate(ctx->V, first, count, ctx->stream);
-    ll_launch_vote(ctx->V, first, count, vote_enable, ctx->stream);
-    ll_launch_normal_equations(ctx->V, first, count, 1, ctx->stream);
+    /* chunks keep a chunk's intermediates (ori/ring, laserCloud, feature slots) inside the Infinity Cache between
+     * the producing and the consuming kernel; the target of a chunk's first slot is the previous chunk's last slot */
+    const int chunk = (ctx->p.chunk > 0) ? ctx->p.chunk : count;
+    for (int c0 = 0; c0 < count; c0 += chunk) {
+        const int f = first + c0, n = (count - c0 < chunk) ? count - c0 : chunk;
+        ll_launch_organize(ctx->V, f, n, ctx->stream, &ctx->prof);
+        ll_launch_features(ctx->V, f, n, ctx->feat_lds, ctx->stream, &ctx->prof);
+        ll_launch_associate(ctx->V, f, n, ctx->stream, &ctx->prof);
+        ll_launch_vote(ctx->V, f, n, vote_enable, ctx->stream, &ctx->prof);
+        ll_launch_normal_equations(ctx->V, f, n, 1, ctx->stream, &ctx->prof);
+    }
     LL_HIP(hipGetLastError());
     return LL_OK;
 }
@@ -476,6 +522,41 @@ extern "C" int ll_residual_jacobian(ll_ctx *ctx, int slot, const double *pose7, 
     rc = dl(ctx, Jq, dJq, rows * 4 * sizeof(double)); if (rc) return rc;
     rc = dl(ctx, Jt, dJt, rows * 3 * sizeof(double)); if (rc) return rc;
     LL_HIP(hipStreamSynchronize(ctx->stream));
+    return LL_OK;
+}
+
+extern "C" int ll_profile_enable(ll_ctx *ctx, int on)
+{
+    if (!ctx) return LL_ERR_ARG;
+    LLProfiler &P = ctx->prof;
+    if (on && P.ev.empty()) {
+        P.ev.resize(LL_PROF_EVENTS); P.id.assign(LL_PROF_EVENTS, LL_K_END);
+        for (auto &e : P.ev) LL_HIP(hipEventCreate(&e));
+    }
+    P.on = on != 0;
+    return LL_OK;
+}
+
+extern "C" int ll_profile_read(ll_ctx *ctx, int *n, const char **names, double *total_ms, int *launches, int reset)
+{
+    if (!ctx || !n) return LL_ERR_ARG;
+    LLProfiler &P = ctx->prof;
+    LL_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i + 1 < P.n; ++i) {
+        const int k = P.id[i] & 0xff;
+        if (P.id[i] == LL_K_END || k >= LL_K_COUNT) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, P.ev[i], P.ev[i + 1]) == hipSuccess) { P.total_ms[k] += ms; P.launches[k]++; }
+    }
+    P.n = 0;
+    const int m = (*n < LL_K_COUNT) ? *n : LL_K_COUNT;
+    for (int k = 0; k < m; ++k) {
+        if (names) names[k] = kKernelNames[k];
+        if (total_ms) total_ms[k] = P.total_ms[k];
+        if (launches) launches[k] = P.launches[k];
+    }
+    *n = m;
+    if (reset) for (int k = 0; k < LL_K_COUNT; ++k) { P.total_ms[k] = 0; P.launches[k] = 0; }
     return LL_OK;
 }
 

@@ -167,8 +167,10 @@ __global__ __launch_bounds__(LL_BLOCK) void k_associate(LLView V, int first, int
     }
 }
 
-void ll_launch_associate(const LLView &V, int first, int count, hipStream_t st)
+void ll_launch_associate(const LLView &V, int first, int count, hipStream_t st, LLProfiler *prof)
 {
     const int qbc = (V.cap_sharp + LL_BLOCK - 1) / LL_BLOCK, qbp = (V.cap_flat + LL_BLOCK - 1) / LL_BLOCK;
+    ll_prof_mark(prof, LL_K_ASSOCIATE, st);
     hipLaunchKernelGGL(k_associate, dim3(count * (qbc + qbp)), dim3(LL_BLOCK), 0, st, V, first, count, qbc, qbp);
+    ll_prof_mark(prof, LL_K_END, st);
 }

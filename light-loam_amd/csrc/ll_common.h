@@ -76,6 +76,7 @@ struct LLView {
     int *v_count; uint8_t *v_sel; float *v_w;
     PairHdr *pair;
     double *pose;                  /* [B][7] qx qy qz qw tx ty tz */
+    double *pose_guess;            /* [B][7] para_q/para_t at entry of the hot path (laserOdometry.cpp:61-62) */
     double *neq;                   /* [B][44]: H[36] row-major, g[6], cost, rows */
     int carry_slot;                /* the slot whose target is the carry (first slot of the batch) */
 };
@@ -102,12 +103,18 @@ __device__ __forceinline__ void ll_targets(const LLView &V, int s, const float4 
     }
 }
 
+/* per-kernel HIP-event profiler (ll_api.hip); mark(id) = "kernel id starts here, the previous one ended" */
+enum { LL_K_CLASSIFY = 0, LL_K_OFFSETS, LL_K_SCATTER, LL_K_RING_FEATURES, LL_K_COMPACT, LL_K_ASSOCIATE, LL_K_VOTE,
+       LL_K_NORMAL_EQ, LL_K_GN_STEP, LL_K_COUNT, LL_K_END = -1 };
+struct LLProfiler;
+void ll_prof_mark(LLProfiler *p, int kernel_id, hipStream_t st);
+
 /* launchers implemented in the per-stage .hip files */
-void ll_launch_organize(const LLView &V, int first, int count, hipStream_t st);
-void ll_launch_features(const LLView &V, int first, int count, size_t lds_bytes, hipStream_t st);
-void ll_launch_associate(const LLView &V, int first, int count, hipStream_t st);
-void ll_launch_vote(const LLView &V, int first, int count, int enable, hipStream_t st);
-void ll_launch_normal_equations(const LLView &V, int first, int count, int do_step, hipStream_t st);
-void ll_launch_gn_step(const LLView &V, int first, int count, hipStream_t st);
+void ll_launch_organize(const LLView &V, int first, int count, hipStream_t st, LLProfiler *prof);
+void ll_launch_features(const LLView &V, int first, int count, size_t lds_bytes, hipStream_t st, LLProfiler *prof);
+void ll_launch_associate(const LLView &V, int first, int count, hipStream_t st, LLProfiler *prof);
+void ll_launch_vote(const LLView &V, int first, int count, int enable, hipStream_t st, LLProfiler *prof);
+void ll_launch_normal_equations(const LLView &V, int first, int count, int do_step, hipStream_t st, LLProfiler *prof);
+void ll_launch_gn_step(const LLView &V, int first, int count, hipStream_t st, LLProfiler *prof);
 void ll_launch_rows(const LLView &V, int slot, const double *pose7_dev, double *r, double *Jq, double *Jt, hipStream_t st);
 size_t ll_features_lds_bytes(int max_ring);

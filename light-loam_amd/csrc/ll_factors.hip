@@ -263,13 +263,17 @@ __global__ __launch_bounds__(LL_BLOCK) void k_rows(LLView V, int s, const double
     }
 }
 
-void ll_launch_normal_equations(const LLView &V, int first, int count, int do_step, hipStream_t st)
+void ll_launch_normal_equations(const LLView &V, int first, int count, int do_step, hipStream_t st, LLProfiler *prof)
 {
+    ll_prof_mark(prof, LL_K_NORMAL_EQ, st);
     hipLaunchKernelGGL(k_normal_equations, dim3(count), dim3(LL_BLOCK), 0, st, V, first, count, do_step);
+    ll_prof_mark(prof, LL_K_END, st);
 }
-void ll_launch_gn_step(const LLView &V, int first, int count, hipStream_t st)
+void ll_launch_gn_step(const LLView &V, int first, int count, hipStream_t st, LLProfiler *prof)
 {
+    ll_prof_mark(prof, LL_K_GN_STEP, st);
     hipLaunchKernelGGL(k_gn_step, dim3((count + 63) / 64), dim3(64), 0, st, V, first, count);
+    ll_prof_mark(prof, LL_K_END, st);
 }
 void ll_launch_rows(const LLView &V, int slot, const double *pose7_dev, double *r, double *Jq, double *Jt, hipStream_t st)
 {

@@ -386,10 +386,13 @@ __global__ __launch_bounds__(128) void k_compact(LLView V, int first, int count)
     }
 }
 
-void ll_launch_features(const LLView &V, int first, int count, size_t lds_bytes, hipStream_t st)
+void ll_launch_features(const LLView &V, int first, int count, size_t lds_bytes, hipStream_t st, LLProfiler *prof)
 {
     const int groups = (count + 7) / 8;
     const int grid = 8 * V.R * groups;
+    ll_prof_mark(prof, LL_K_RING_FEATURES, st);
     hipLaunchKernelGGL(k_ring_features, dim3(grid), dim3(LL_BLOCK), lds_bytes, st, V, first, count);
+    ll_prof_mark(prof, LL_K_COMPACT, st);
     hipLaunchKernelGGL(k_compact, dim3(grid), dim3(128), 0, st, V, first, count);
+    ll_prof_mark(prof, LL_K_END, st);
 }

@@ -234,11 +234,15 @@ __global__ __launch_bounds__(LL_BLOCK) void k_scatter(LLView V, int first, int c
     }
 }
 
-void ll_launch_organize(const LLView &V, int first, int count, hipStream_t st)
+void ll_launch_organize(const LLView &V, int first, int count, hipStream_t st, LLProfiler *prof)
 {
     const int groups = (count + 7) / 8;
     const int grid = 8 * V.T * groups;
+    ll_prof_mark(prof, LL_K_CLASSIFY, st);
     hipLaunchKernelGGL(k_classify, dim3(grid), dim3(LL_BLOCK), 0, st, V, first, count);
+    ll_prof_mark(prof, LL_K_OFFSETS, st);
     hipLaunchKernelGGL(k_offsets, dim3(count), dim3(LL_BLOCK), 0, st, V, first, count);
+    ll_prof_mark(prof, LL_K_SCATTER, st);
     hipLaunchKernelGGL(k_scatter, dim3(grid), dim3(LL_BLOCK), 0, st, V, first, count);
+    ll_prof_mark(prof, LL_K_END, st);
 }

@@ -108,8 +108,10 @@ __global__ __launch_bounds__(LL_BLOCK) void k_vote(LLView V, int first, int coun
     }
 }
 
-void ll_launch_vote(const LLView &V, int first, int count, int enable, hipStream_t st)
+void ll_launch_vote(const LLView &V, int first, int count, int enable, hipStream_t st, LLProfiler *prof)
 {
     const size_t lds = (size_t)V.cap_flat * 24;
+    ll_prof_mark(prof, LL_K_VOTE, st);
     hipLaunchKernelGGL(k_vote, dim3(count), dim3(LL_BLOCK), lds, st, V, first, count, enable);
+    ll_prof_mark(prof, LL_K_END, st);
 }

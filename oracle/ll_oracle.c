@@ -343,7 +343,7 @@ static float flann_l2(const orc_point *a, const orc_point *b)
 
 /* exact K=1 nearest neighbour (kd-tree search is exact; equal-distance winner is traversal-dependent
  * in FLANN, defined here and in the HIP path as the lowest index). */
-static int nn1(const orc_point *q, const orc_point *cloud, int m, float *dist)
+static int nn1_brute(const orc_point *q, const orc_point *cloud, int m, float *dist)
 {
     int best = -1; float bd = INFINITY;
     for (int j = 0; j < m; ++j) {
@@ -352,6 +352,100 @@ static int nn1(const orc_point *q, const orc_point *cloud, int m, float *dist)
     }
     *dist = bd;
     return best;
+}
+
+/* Same answer for every query whose nearest neighbour is closer than sqrt(r2max) -- the only case the
+ * callers use (:497 / :659 reject d >= 25) -- from a uniform grid instead of a linear scan, so that the timed
+ * CPU baseline has kd-tree-class cost like the reference (PCL KdTreeFLANN).  Candidates are compared with the
+ * same f32 flann_l2 value and the same lowest-index tie rule; cells are pruned only when every point in them
+ * is provably farther (in double, with margin) than the current best. */
+typedef struct { float cell; float mn[3]; int dim[3]; int *start; int *idx; int m; const orc_point *cloud; } nn_grid;
+static int g_nn_mode = 0;               /* 0 = linear scan, 1 = grid */
+void orc_set_nn_mode(int mode) { g_nn_mode = mode; }
+
+static void grid_cell_of(const nn_grid *g, const orc_point *p, int c[3])
+{
+    const float v[3] = {p->x, p->y, p->z};
+    for (int k = 0; k < 3; ++k) {
+        int i = (int)floorf((v[k] - g->mn[k]) / g->cell);
+        if (i < 0) i = 0; if (i >= g->dim[k]) i = g->dim[k] - 1;
+        c[k] = i;
+    }
+}
+
+static nn_grid *grid_build(const orc_point *cloud, int m, float cell)
+{
+    nn_grid *g = (nn_grid *)calloc(1, sizeof(nn_grid));
+    g->cell = cell; g->m = m; g->cloud = cloud;
+    float mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    g->mn[0] = g->mn[1] = g->mn[2] = INFINITY;
+    for (int i = 0; i < m; ++i) {
+        const float v[3] = {cloud[i].x, cloud[i].y, cloud[i].z};
+        for (int k = 0; k < 3; ++k) { if (v[k] < g->mn[k]) g->mn[k] = v[k]; if (v[k] > mx[k]) mx[k] = v[k]; }
+    }
+    for (int k = 0; k < 3; ++k) {
+        g->dim[k] = (m > 0) ? (int)floorf((mx[k] - g->mn[k]) / cell) + 1 : 1;
+        if (g->dim[k] > 512) { g->dim[k] = 512; }
+    }
+    /* if an axis was clamped the cell index saturates; correctness is kept by the bounds-based pruning below */
+    const size_t nc = (size_t)g->dim[0] * g->dim[1] * g->dim[2];
+    g->start = (int *)calloc(nc + 1, sizeof(int));
+    g->idx = (int *)malloc((size_t)(m > 0 ? m : 1) * sizeof(int));
+    int *cellof = (int *)malloc((size_t)(m > 0 ? m : 1) * sizeof(int));
+    for (int i = 0; i < m; ++i) {
+        int c[3]; grid_cell_of(g, &cloud[i], c);
+        cellof[i] = (c[2] * g->dim[1] + c[1]) * g->dim[0] + c[0];
+        g->start[cellof[i] + 1]++;
+    }
+    for (size_t c = 0; c < nc; ++c) g->start[c + 1] += g->start[c];
+    int *cur = (int *)malloc(nc * sizeof(int));
+    memcpy(cur, g->start, nc * sizeof(int));
+    for (int i = 0; i < m; ++i) g->idx[cur[cellof[i]]++] = i;      /* ascending index inside a cell */
+    free(cur); free(cellof);
+    return g;
+}
+
+static void grid_free(nn_grid *g) { if (g) { free(g->start); free(g->idx); free(g); } }
+
+static int nn1_grid(const nn_grid *g, const orc_point *q, float r2max, float *dist)
+{
+    int best = -1; float bd = INFINITY;
+    if (g->m == 0) { *dist = bd; return -1; }
+    int c0[3]; grid_cell_of(g, q, c0);
+    const int rad = (int)ceilf(sqrtf(r2max) / g->cell) + 1;
+    const double qv[3] = {q->x, q->y, q->z};
+    for (int ring = 0; ring <= rad; ++ring) {
+        /* every cell of Chebyshev ring `ring` is at least (ring-1)*cell away; stop once that exceeds the best */
+        if (ring >= 2) { const double lb = (double)(ring - 1) * g->cell; if (lb * lb * 0.999 > (double)(bd < r2max ? bd : r2max)) break; }
+        for (int dz = -ring; dz <= ring; ++dz) for (int dy = -ring; dy <= ring; ++dy) for (int dx = -ring; dx <= ring; ++dx) {
+            const int ad = (abs(dx) > abs(dy) ? abs(dx) : abs(dy)); const int cheb = ad > abs(dz) ? ad : abs(dz);
+            if (cheb != ring) continue;
+            const int cx = c0[0] + dx, cy = c0[1] + dy, cz = c0[2] + dz;
+            if (cx < 0 || cy < 0 || cz < 0 || cx >= g->dim[0] || cy >= g->dim[1] || cz >= g->dim[2]) continue;
+            const size_t c = ((size_t)cz * g->dim[1] + cy) * g->dim[0] + cx;
+            for (int k = g->start[c]; k < g->start[c + 1]; ++k) {
+                const int j = g->idx[k];
+                const float d = flann_l2(q, &g->cloud[j]);
+                if (d < bd || (d == bd && j < best)) { bd = d; best = j; }
+            }
+        }
+    }
+    (void)qv;
+    /* saturated (clamped) border cells can hold far points only; a query outside the grid by more than the
+     * search radius simply finds nothing closer than r2max, which the callers treat as "no match" */
+    *dist = bd;
+    return best;
+}
+
+static int nn1(const orc_point *q, const orc_point *cloud, int m, const nn_grid *g, float *dist)
+{
+    if (g) {
+        int j = nn1_grid(g, q, 25.0f, dist);
+        if (j >= 0 && *dist < 25.0f) return j;
+        *dist = INFINITY;            /* nothing within the acceptance radius: callers reject either way */
+        return -1;
+    }
+    return nn1_brute(q, cloud, m, dist);
 }
 
 /* (points[j].x - pointSel.x) * (...) + ... : all f32, widened to double on assignment (:514-519) */
@@ -367,11 +461,12 @@ int orc_associate_corner(const double q[4], const double t[3], const orc_point *
                          const orc_point *last, int mc, int *src_idx, int *idx_a, int *idx_b, int *n_e)
 {
     int ne = 0;
+    nn_grid *grid = (g_nn_mode && mc > 0) ? grid_build(last, mc, 1.0f) : NULL;
     for (int i = 0; i < ns && mc > 0; ++i) {
         orc_point sel;
         orc_transform_to_start(q, t, &sharp[i], &sel);
         float d0;
-        const int nn = nn1(&sel, last, mc, &d0);
+        const int nn = nn1(&sel, last, mc, grid, &d0);
         int closestPointInd = -1, minPointInd2 = -1;
         if ((double)d0 < 25.0) {                                  /* DISTANCE_SQ_THRESHOLD (:29, :497) */
             closestPointInd = nn;
@@ -395,6 +490,7 @@ int orc_associate_corner(const double q[4], const double t[3], const orc_point *
         }
     }
     *n_e = ne;
+    grid_free(grid);
     return ORC_OK;
 }
 
@@ -405,11 +501,12 @@ int orc_associate_plane(const double q[4], const double t[3], const orc_point *f
                         const orc_point *last, int ms, int *src_idx, int *idx_a, int *idx_b, int *idx_c, int *n_p)
 {
     int np = 0;
+    nn_grid *grid = (g_nn_mode && ms > 0) ? grid_build(last, ms, 1.0f) : NULL;
     for (int i = 0; i < nf && ms > 0; ++i) {
         orc_point sel;
         orc_transform_to_start(q, t, &flat[i], &sel);
         float d0;
-        const int nn = nn1(&sel, last, ms, &d0);
+        const int nn = nn1(&sel, last, ms, grid, &d0);
         int closestPointInd = -1, minPointInd2 = -1, minPointInd3 = -1;
         if ((double)d0 < 25.0) {
             closestPointInd = nn;
@@ -433,6 +530,7 @@ int orc_associate_plane(const double q[4], const double t[3], const orc_point *f
         }
     }
     *n_p = np;
+    grid_free(grid);
     return ORC_OK;
 }
 

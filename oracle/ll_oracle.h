@@ -69,6 +69,11 @@ int orc_extract(const float *xyz, int stride_floats, int n_in, const orc_params 
 /* ---- a5: TransformToStart with DISTORTION 0, laserOdometry.cpp:77-95 ---- */
 void orc_transform_to_start(const double q[4] /*x,y,z,w*/, const double t[3], const orc_point *pi, orc_point *po);
 
+/* K=1 search strategy of a6/a7: 0 = linear scan (default; the plainest statement of "exact NN"),
+ * 1 = uniform grid with exact pruning (same results; used when the oracle is TIMED as the CPU baseline so
+ * it has kd-tree-class cost like the reference's PCL KdTreeFLANN). */
+void orc_set_nn_mode(int mode);
+
 /* ---- a6: corner association, laserOdometry.cpp:491-620.  One entry per accepted correspondence. ---- */
 int orc_associate_corner(const double q[4], const double t[3], const orc_point *sharp, int ns,
                          const orc_point *corner_last, int mc,

@@ -107,6 +107,10 @@ def extract(xyz, P):
                 flat=flat[:nf.value].copy(), less_flat=less_flat[:nlf.value].copy())
 
 
+def set_nn_mode(mode):
+    lib().orc_set_nn_mode(int(mode))
+
+
 def transform_to_start(q, t, pts):
     pts = _f4(pts)
     out = np.zeros_like(pts)
