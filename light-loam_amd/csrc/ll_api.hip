@@ -21,7 +21,7 @@ struct LLProfiler {
     int launches[LL_K_COUNT] = {0};
 };
 static const char *const kKernelNames[LL_K_COUNT] = {"k_classify", "k_offsets", "k_scatter", "k_ring_features", "k_compact",
-                                                     "k_associate", "k_vote", "k_normal_equations", "k_gn_step"};
+                                                     "k_associate", "k_vote", "k_normal_equations", "k_gn_step", "k_build_grid"};
 
 void ll_prof_mark(LLProfiler *p, int kernel_id, hipStream_t st)
 {
@@ -173,6 +173,8 @@ extern "C" int ll_create(int device, const ll_params *p, ll_ctx **out)
     ok = ok && dev_alloc(ctx, V.sharp, (size_t)B * V.cap_sharp, false) && dev_alloc(ctx, V.lsharp, (size_t)B * V.cap_lsharp, false) &&
          dev_alloc(ctx, V.flat, (size_t)B * V.cap_flat, false) && dev_alloc(ctx, V.lflat, BN, false);
     ok = ok && dev_alloc(ctx, V.carry_corner, V.cap_lsharp) && dev_alloc(ctx, V.carry_surf, NP) && dev_alloc(ctx, V.carry_cnt, 2);
+    ok = ok && dev_alloc(ctx, V.gstart, (size_t)B * 2 * LL_GSTRIDE) && dev_alloc(ctx, V.gpts_c, (size_t)B * V.cap_lsharp, false) && dev_alloc(ctx, V.gpts_s, BN, false);
+    ok = ok && dev_alloc(ctx, V.carry_gstart, (size_t)2 * LL_GSTRIDE) && dev_alloc(ctx, V.carry_gpts_c, V.cap_lsharp, false) && dev_alloc(ctx, V.carry_gpts_s, NP, false);
     ok = ok && dev_alloc(ctx, V.eq_a, (size_t)B * V.cap_sharp) && dev_alloc(ctx, V.eq_b, (size_t)B * V.cap_sharp);
     ok = ok && dev_alloc(ctx, V.pq_a, (size_t)B * V.cap_flat) && dev_alloc(ctx, V.pq_b, (size_t)B * V.cap_flat) && dev_alloc(ctx, V.pq_c, (size_t)B * V.cap_flat);
     ok = ok && dev_alloc(ctx, V.e_src, (size_t)B * V.cap_sharp) && dev_alloc(ctx, V.e_a, (size_t)B * V.cap_sharp) && dev_alloc(ctx, V.e_b, (size_t)B * V.cap_sharp);
@@ -234,6 +236,7 @@ extern "C" int ll_extract_batch(ll_ctx *ctx, int first, int count)
     int rc = check_range(ctx, first, count); if (rc) return rc;
     ll_launch_organize(ctx->V, first, count, ctx->stream, &ctx->prof);
     ll_launch_features(ctx->V, first, count, ctx->feat_lds, ctx->stream, &ctx->prof);
+    ll_launch_build_grid(ctx->V, first, count, 0, ctx->stream, &ctx->prof);
     LL_HIP(hipGetLastError());
     return LL_OK;
 }
@@ -264,6 +267,7 @@ extern "C" int ll_set_target(ll_ctx *ctx, const ll_point *corner, int m_c, const
     if (m_s) LL_HIP(hipMemcpyAsync(V.carry_surf, surf, (size_t)m_s * 16, hipMemcpyHostToDevice, ctx->stream));
     const int cnt[2] = {m_c, m_s};
     LL_HIP(hipMemcpyAsync(V.carry_cnt, cnt, sizeof(cnt), hipMemcpyHostToDevice, ctx->stream));
+    ll_launch_build_grid(V, 0, 1, 1, ctx->stream, nullptr);
     LL_HIP(hipStreamSynchronize(ctx->stream));
     return LL_OK;
 }
@@ -282,6 +286,7 @@ extern "C" int ll_set_target_from_slot(ll_ctx *ctx, int slot)
 {
     int rc = check_range(ctx, slot, 1); if (rc) return rc;
     hipLaunchKernelGGL(k_copy_carry, dim3(64), dim3(256), 0, ctx->stream, ctx->V, slot);
+    ll_launch_build_grid(ctx->V, 0, 1, 1, ctx->stream, nullptr);
     LL_HIP(hipGetLastError());
     return LL_OK;
 }
@@ -339,6 +344,7 @@ extern "C" int ll_hot_path_batch(ll_ctx *ctx, int first, int count, const double
         const int f = first + c0, n = (count - c0 < chunk) ? count - c0 : chunk;
         ll_launch_organize(ctx->V, f, n, ctx->stream, &ctx->prof);
         ll_launch_features(ctx->V, f, n, ctx->feat_lds, ctx->stream, &ctx->prof);
+        ll_launch_build_grid(ctx->V, f, n, 0, ctx->stream, &ctx->prof);
         ll_launch_associate(ctx->V, f, n, ctx->stream, &ctx->prof);
         ll_launch_vote(ctx->V, f, n, vote_enable, ctx->stream, &ctx->prof);
         ll_launch_normal_equations(ctx->V, f, n, 1, ctx->stream, &ctx->prof);

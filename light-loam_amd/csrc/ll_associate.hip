@@ -4,18 +4,191 @@
  * of /root/reference.
  *
  * Targets of slot s are the less-sharp / less-flat clouds of slot s-1, still resident in HBM from the
- * extract stage (no publish -> subscribe -> fromROSMsg -> kd-tree build).  The kd-tree's exact K=1 search
- * is restated as an exact scan: 256 queries per workgroup (one per lane), target tiles of 1024 points staged
- * in LDS and broadcast-read, FLANN's L2_Simple accumulation order ((dx*dx + dy*dy) + dz*dz, f32, no FMA),
- * equal distances resolved to the lowest index.  The ring walks (:504-553, :668-721) are sequential loops
- * with early breaks in the reference; here a wave scans the window 64 targets at a time for one query,
- * the break becomes a ballot ("first lane whose ring is out of the +-2.5 window"), and the running
- * minimum with strict '<' becomes a lexicographic (distance, visiting order) min-reduction.
+ * extract stage (no publish -> subscribe -> fromROSMsg -> kd-tree build).
+ *
+ * k_build_grid (one workgroup per (scan, cloud)) builds what replaces the kd-tree:
+ *   - a uniform 2-D (x, y) cell grid: LDS histogram over 128 x 128 cells of 2 m, exclusive scan, scatter of
+ *     (x, y, z, ring << 24 | original index) into cell order.  Points outside +-128 m saturate into the border
+ *     cells, whose rectangles are treated as unbounded outwards;
+ *   - ring tables first_ge[v] = min{j : ring_j >= v}, last_le[v] = max{j : ring_j <= v} (ring_j = int(intensity_j))
+ *     and a flag saying whether they reproduce the reference's sequential walk bounds for EVERY start index
+ *     (true whenever ring ids never run more than NEARBY_SCAN ahead/behind of their position, as in any cloud
+ *     the extract stage produces; arbitrary user targets may clear it).
+ * k_associate, 8 lanes per query (one 128-byte line of cell-ordered points per step):
+ *   K=1 search   cells visited in Chebyshev rings around the query's cell, a cell skipped only when its rectangle
+ *                is provably farther than the best so far, the ring loop stopped when the whole next ring is.
+ *                Distance = FLANN L2_Simple in f32 ((dx*dx + dy*dy) + dz*dz, no FMA); equal distances -> lowest
+ *                original index (traversal-dependent in the kd-tree; defined here and in the oracle).  Only
+ *                neighbours closer than DISTANCE_SQ_THRESHOLD are ever used (:497 / :659): at most 4 rings.
+ *   ring walks   (:504-553, :668-721) are sequential loops over a contiguous index window with early breaks and a
+ *                running minimum under strict '<'.  With valid tables the window is (last_le[..], first_ge[..]),
+ *                and the result is the lexicographic minimum of (distance, visiting order) over the window points
+ *                of the right ring class -- found with the same pruned cell search instead of scanning ~2500
+ *                points per query.  Without valid tables the wave-cooperative sequential scan below is used
+ *                (break = ballot of "first lane whose ring leaves the +-2.5 window").  Both are exact.
  */
 #include "ll_common.h"
 #include <limits.h>
 
-#define LL_NN_TILE 1024
+__device__ __forceinline__ int ll_cell_coord(float v)
+{
+    const int c = (int)floorf((v + LL_GRID_ORG) * (1.0f / LL_GRID_CELL));
+    return min(max(c, 0), LL_GRID_G - 1);
+}
+
+/* squared distance from (qx, qy) to the rectangle of cell (cx, cy), shrunk by a 1 mm margin so that float rounding
+ * in ll_cell_coord can never make it an over-estimate; border cells are unbounded outwards */
+__device__ __forceinline__ float ll_cell_lb2(float qx, float qy, int cx, int cy)
+{
+    const float lox = (float)cx * LL_GRID_CELL - LL_GRID_ORG, loy = (float)cy * LL_GRID_CELL - LL_GRID_ORG;
+    float dx = 0.0f, dy = 0.0f;
+    if (qx < lox && cx > 0) dx = lox - qx;
+    else if (qx > lox + LL_GRID_CELL && cx < LL_GRID_G - 1) dx = qx - (lox + LL_GRID_CELL);
+    if (qy < loy && cy > 0) dy = loy - qy;
+    else if (qy > loy + LL_GRID_CELL && cy < LL_GRID_G - 1) dy = qy - (loy + LL_GRID_CELL);
+    dx = fmaxf(dx - 1e-3f, 0.0f); dy = fmaxf(dy - 1e-3f, 0.0f);
+    return dx * dx + dy * dy;
+}
+
+/* walk bounds of a start ring rc: the up-walk stops at the first ring > rc + NEARBY_SCAN, the down-walk at the
+ * first ring < rc - NEARBY_SCAN (compared in double like the reference); for integer rings that is > hi / < lo */
+__device__ __forceinline__ int ll_ring_hi(int rc, double nearby) { return (int)floor((double)rc + nearby); }
+__device__ __forceinline__ int ll_ring_lo(int rc, double nearby) { return (int)ceil((double)rc - nearby); }
+
+/* block-wide exclusive scans with max / min (256 threads) */
+__device__ __forceinline__ int ll_block_exscan_max(int v, int *sc)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc = max(inc, t); }
+    if (lane == 63) sc[wave] = inc;
+    __syncthreads();
+    int base = INT_MIN;
+    for (int w = 0; w < wave; ++w) base = max(base, sc[w]);
+    int ex = __shfl_up(inc, 1); if (lane == 0) ex = INT_MIN;
+    __syncthreads();
+    return max(base, ex);
+}
+__device__ __forceinline__ int ll_block_exscan_min_rev(int v, int *sc)      /* exclusive SUFFIX min */
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_down(inc, o); if (lane + o < 64) inc = min(inc, t); }
+    if (lane == 0) sc[wave] = inc;
+    __syncthreads();
+    int base = INT_MAX;
+    for (int w = wave + 1; w < LL_BLOCK / 64; ++w) base = min(base, sc[w]);
+    int ex = __shfl_down(inc, 1); if (lane == 63) ex = INT_MAX;
+    __syncthreads();
+    return min(base, ex);
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char ll_gsm[];
+
+/* grid + ring tables of a target cloud; carry != 0: the carry clouds, else slot first + blockIdx/2 */
+__global__ __launch_bounds__(LL_BLOCK) void k_build_grid(LLView V, int first, int count, int carry)
+{
+    const int which = blockIdx.x & 1, sl = blockIdx.x >> 1;
+    if (sl >= count) return;
+    const int tid = threadIdx.x;
+    const float4 *pts; int m; int *gstart; float4 *gpts;
+    if (carry) {
+        pts = which ? V.carry_surf : V.carry_corner; m = V.carry_cnt[which];
+        gstart = V.carry_gstart + (size_t)which * LL_GSTRIDE;
+        gpts = which ? V.carry_gpts_s : V.carry_gpts_c;
+    } else {
+        const int s = first + sl;
+        const ScanHdr h = V.hdr[s];
+        pts = which ? V.lflat + (size_t)s * V.NP : V.lsharp + (size_t)s * V.cap_lsharp;
+        m = (h.status != 0) ? 0 : (which ? h.n_less_flat : h.n_less_sharp);
+        gstart = V.gstart + ((size_t)s * 2 + which) * LL_GSTRIDE;
+        gpts = which ? V.gpts_s + (size_t)s * V.NP : V.gpts_c + (size_t)s * V.cap_lsharp;
+    }
+    int *hist = (int *)ll_gsm;                      /* [LL_GRID_NC] */
+    __shared__ int sc[8];
+    __shared__ int feq[LL_TAB + 1], leq[LL_TAB + 1];
+    __shared__ int okflag;
+    for (int i = tid; i < LL_GRID_NC; i += LL_BLOCK) hist[i] = 0;
+    for (int i = tid; i <= LL_TAB; i += LL_BLOCK) { feq[i] = INT_MAX; leq[i] = -1; }
+    if (tid == 0) okflag = (V.nearby >= 0.0) ? 1 : 0;
+    __syncthreads();
+    for (int i = tid; i < m; i += LL_BLOCK) {
+        const float4 p = pts[i];
+        atomicAdd(&hist[ll_cell_coord(p.y) * LL_GRID_G + ll_cell_coord(p.x)], 1);
+    }
+    __syncthreads();
+    constexpr int PER = LL_GRID_NC / LL_BLOCK;
+    int sum = 0;
+    for (int k = 0; k < PER; ++k) sum += hist[tid * PER + k];
+    int total = 0;
+    int run = ll_block_exscan(sum, sc, total);
+    for (int k = 0; k < PER; ++k) { const int c = hist[tid * PER + k]; hist[tid * PER + k] = run; gstart[tid * PER + k] = run; run += c; }
+    if (tid == LL_BLOCK - 1) gstart[LL_GRID_NC] = total;
+    __syncthreads();
+    for (int i = tid; i < m; i += LL_BLOCK) {
+        const float4 p = pts[i];
+        const int pos = atomicAdd(&hist[ll_cell_coord(p.y) * LL_GRID_G + ll_cell_coord(p.x)], 1);
+        const int r = (int)p.w;                                              /* int(intensity): the walk's scan id */
+        gpts[pos] = make_float4(p.x, p.y, p.z, __int_as_float((i & 0xFFFFFF) | ((r & 0xFF) << 24)));
+    }
+
+    /* ---- ring tables + validity ---- */
+    const int per = (m + LL_BLOCK - 1) / LL_BLOCK;
+    const int a0 = min(m, tid * per), a1 = min(m, a0 + per);
+    int cmax = INT_MIN, cmin = INT_MAX; bool bad = false;
+    for (int j = a0; j < a1; ++j) {
+        const int r = (int)pts[j].w;
+        if (r < 0 || r >= LL_TAB) { bad = true; continue; }
+        atomicMin(&feq[r], j); atomicMax(&leq[r], j);
+        cmax = max(cmax, r); cmin = min(cmin, r);
+    }
+    int pm = ll_block_exscan_max(cmax, sc);          /* max ring over all j before this thread's chunk */
+    int sm = ll_block_exscan_min_rev(cmin, sc);      /* min ring over all j after this thread's chunk */
+    if (!bad) {
+        for (int j = a0; j < a1; ++j) {              /* no earlier point may already be beyond this point's up-window */
+            const int r = (int)pts[j].w;
+            if (pm > ll_ring_hi(r, V.nearby)) bad = true;
+            pm = max(pm, r);
+        }
+        for (int j = a1 - 1; j >= a0; --j) {         /* no later point may be below this point's down-window */
+            const int r = (int)pts[j].w;
+            if (sm < ll_ring_lo(r, V.nearby)) bad = true;
+            sm = min(sm, r);
+        }
+    }
+    if (bad) okflag = 0;
+    __syncthreads();
+    int *tab = gstart + LL_GRID_NC + 1;              /* first_ge[LL_TAB+1], last_le[LL_TAB+1], ok, m */
+    if (tid == 0) {
+        int run_min = m;
+        for (int v = LL_TAB; v >= 0; --v) { if (feq[v] != INT_MAX) run_min = min(run_min, feq[v]); tab[v] = run_min; }
+        int run_max = -1;
+        for (int v = 0; v <= LL_TAB; ++v) { run_max = max(run_max, leq[v]); tab[LL_TAB + 1 + v] = run_max; }
+        tab[2 * (LL_TAB + 1)] = okflag;
+        tab[2 * (LL_TAB + 1) + 1] = m;
+    }
+}
+
+struct TargetRef { const float4 *pts; int m; const int *gstart; const float4 *gpts; const int *tab; };
+
+__device__ __forceinline__ TargetRef ll_target(const LLView &V, int s, int which)
+{
+    TargetRef T;
+    if (s == V.carry_slot) {
+        T.pts = which ? V.carry_surf : V.carry_corner; T.m = V.carry_cnt[which];
+        T.gstart = V.carry_gstart + (size_t)which * LL_GSTRIDE;
+        T.gpts = which ? V.carry_gpts_s : V.carry_gpts_c;
+    } else {
+        const int t = s - 1;
+        const ScanHdr h = V.hdr[t];
+        T.pts = which ? V.lflat + (size_t)t * V.NP : V.lsharp + (size_t)t * V.cap_lsharp;
+        T.m = (h.status != 0) ? 0 : (which ? h.n_less_flat : h.n_less_sharp);
+        T.gstart = V.gstart + ((size_t)t * 2 + which) * LL_GSTRIDE;
+        T.gpts = which ? V.gpts_s + (size_t)t * V.NP : V.gpts_c + (size_t)t * V.cap_lsharp;
+    }
+    T.tab = T.gstart + LL_GRID_NC + 1;
+    return T;
+}
 
 __device__ __forceinline__ void ll_rotate(const double q[4], const double v[3], double out[3])
 {
@@ -30,9 +203,16 @@ __device__ __forceinline__ void ll_rotate(const double q[4], const double v[3], 
 
 struct Best { float d; int ord; int j; };
 
+__device__ __forceinline__ void ll_best_take(Best &b, float d, int ord, int j, float dmax)
+{
+    /* sequential semantics "if (d < min) take" over the visiting order == lexicographic min of (d, ord), d < dmax */
+    if (d < dmax && (d < b.d || (d == b.d && ord < b.ord))) { b.d = d; b.ord = ord; b.j = j; }
+}
+
+template <int WIDTH>
 __device__ __forceinline__ void ll_best_reduce(Best &b)
 {
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = WIDTH / 2; o > 0; o >>= 1) {
         const float d2 = __shfl_xor(b.d, o); const int o2 = __shfl_xor(b.ord, o); const int j2 = __shfl_xor(b.j, o);
         if (d2 < b.d || (d2 == b.d && o2 < b.ord)) { b.d = d2; b.ord = o2; b.j = j2; }
     }
@@ -44,10 +224,34 @@ __device__ __forceinline__ float ll_walk_d2(const float4 p, float sx, float sy, 
     return (p.x - sx) * (p.x - sx) + (p.y - sy) * (p.y - sy) + (p.z - sz) * (p.z - sz);
 }
 
+/* visit the cells around (qx, qy) in Chebyshev rings; f(cell_start, cell_end) scans one cell, bound() is the current
+ * pruning radius^2 (shrinks as candidates are found), sync() shares the best inside the 8-lane group */
+template <typename Scan, typename Bound, typename Sync>
+__device__ __forceinline__ void ll_grid_search(const int *gstart, float qx, float qy, int rmax, Scan scan, Bound bound, Sync sync)
+{
+    const int cx = ll_cell_coord(qx), cy = ll_cell_coord(qy);
+    for (int ring = 0; ring <= rmax; ++ring) {
+        if (ring >= 2) { const float lbr = (float)(ring - 1) * LL_GRID_CELL - 1e-3f; if (lbr * lbr > bound()) break; }
+        for (int dy = -ring; dy <= ring; ++dy) {
+            const int yy = cy + dy;
+            if (yy < 0 || yy >= LL_GRID_G) continue;
+            const int step = (dy == -ring || dy == ring || ring == 0) ? 1 : 2 * ring;
+            for (int dx = -ring; dx <= ring; dx += step) {
+                const int xx = cx + dx;
+                if (xx < 0 || xx >= LL_GRID_G) continue;
+                if (ll_cell_lb2(qx, qy, xx, yy) > bound()) continue;
+                const int c = yy * LL_GRID_G + xx;
+                scan(gstart[c], gstart[c + 1]);
+            }
+        }
+        sync();
+    }
+}
+
 template <bool PLANE>
 __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int qblock,
-                                                   const float4 *queries, int nq, const float4 *tgt, int M,
-                                                   int *out_a, int *out_b, int *out_c, float4 *tile)
+                                                   const float4 *queries, int nq, const TargetRef T,
+                                                   int *out_a, int *out_b, int *out_c, float4 *qs, int *nn, int *rb, int *rcl)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const int qi = qblock * LL_BLOCK + tid;
@@ -62,76 +266,125 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
         ll_rotate(pose, v, rr);
         sx = (float)(rr[0] + pose[4]); sy = (float)(rr[1] + pose[5]); sz = (float)(rr[2] + pose[6]);
     }
-    /* exact K=1 NN */
-    float bestd = INFINITY; int besti = -1;
-    for (int t0 = 0; t0 < M; t0 += LL_NN_TILE) {
-        __syncthreads();
-        for (int k = tid; k < LL_NN_TILE; k += LL_BLOCK) if (t0 + k < M) tile[k] = tgt[t0 + k];
-        __syncthreads();
-        const int cnt = min(LL_NN_TILE, M - t0);
-        for (int j = 0; j < cnt; ++j) {
-            const float4 p = tile[j];
-            float diff = sx - p.x; float d = diff * diff;
-            diff = sy - p.y; d += diff * diff;
-            diff = sz - p.z; d += diff * diff;
-            if (d < bestd) { bestd = d; besti = t0 + j; }
-        }
-    }
-    int closest = (have && besti >= 0 && bestd < V.nn_max) ? besti : -1;      /* :497 / :659 */
+    qs[tid] = make_float4(sx, sy, sz, have ? 1.0f : 0.0f);
+    __syncthreads();
 
-    /* ring-window walks, one query at a time per wave */
-    int res_b = -1, res_c = -1;
-    for (int qq = 0; qq < 64; ++qq) {
-        const int c = __shfl(closest, qq);
-        if (c < 0) continue;
-        const float qx = __shfl(sx, qq), qy = __shfl(sy, qq), qz = __shfl(sz, qq);
-        const int rc = (int)tgt[c].w;                                           /* closestPointScanID (:500, :664) */
-        Best b2 = {V.nn_max, INT_MAX, -1}, b3 = {V.nn_max, INT_MAX, -1};
-        /* increasing scan line (:504-527 / :668-693) */
-        for (int j0 = c + 1; j0 < M; j0 += 64) {
-            const int j = j0 + lane;
-            const bool in = j < M;
-            const float4 p = in ? tgt[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-            const int rj = (int)p.w;
-            const bool stop = in && ((double)rj > (double)rc + V.nearby);
-            const unsigned long long sm = __ballot(stop);
-            const bool ok = in && (sm == 0ull || lane < __ffsll((long long)sm) - 1);
-            if (ok) {
-                const float d = ll_walk_d2(p, qx, qy, qz);
-                const int ord = j - c - 1;
-                if (PLANE) {
-                    if (rj <= rc) { if (d < b2.d) { b2.d = d; b2.ord = ord; b2.j = j; } }
-                    else          { if (d < b3.d) { b3.d = d; b3.ord = ord; b3.j = j; } }
-                } else {
-                    if (rj > rc && d < b2.d) { b2.d = d; b2.ord = ord; b2.j = j; }
-                }
+    const int g = tid >> 3, sub = tid & 7;
+    const int rmax = (int)ceilf(sqrtf(V.nn_max) / LL_GRID_CELL) + 1;
+    const float4 *gpts = T.gpts; const int *gstart = T.gstart;
+    const float4 *tgt = T.pts; const int M = T.m;
+    const bool tab_ok = T.tab[2 * (LL_TAB + 1)] != 0 && T.tab[2 * (LL_TAB + 1) + 1] == M;
+    const float dmax = V.nn_max;
+    for (int pass = 0; pass < LL_BLOCK / 32; ++pass) {
+        const int ql = pass * 32 + g;
+        const float4 q = qs[ql];
+        int closest = -1, res_b = -1, res_c = -1;
+        if (q.w != 0.0f && M > 0) {
+            /* ---- exact K=1 NN within nn_max ---- */
+            float bd = dmax; int bi = INT_MAX;
+            ll_grid_search(gstart, q.x, q.y, rmax,
+                [&](int st, int en) {
+                    for (int k = st + sub; k < en; k += 8) {
+                        const float4 p = gpts[k];
+                        float diff = q.x - p.x; float d = diff * diff;        /* FLANN L2_Simple: a = query, b = data */
+                        diff = q.y - p.y; d += diff * diff;
+                        diff = q.z - p.z; d += diff * diff;
+                        const int idx = __float_as_int(p.w) & 0xFFFFFF;
+                        if (d < dmax && (d < bd || (d == bd && idx < bi))) { bd = d; bi = idx; }
+                    }
+                },
+                [&]() { return bd; },
+                [&]() {
+                    for (int o = 1; o < 8; o <<= 1) {
+                        const float d2 = __shfl_xor(bd, o); const int i2 = __shfl_xor(bi, o);
+                        if (d2 < bd || (d2 == bd && i2 < bi)) { bd = d2; bi = i2; }
+                    }
+                });
+            if (bi != INT_MAX) closest = bi;                                     /* :497 / :659: d < DISTANCE_SQ_THRESHOLD */
+
+            /* ---- second / third point inside the ring window, table-bounded cell search ---- */
+            if (closest >= 0 && tab_ok) {
+                const int c = closest;
+                const int rc = (int)tgt[c].w;                                    /* closestPointScanID (:500, :664) */
+                const int hi = ll_ring_hi(rc, V.nearby), lo = ll_ring_lo(rc, V.nearby);
+                const int jhi = (hi + 1 > LL_TAB) ? M : T.tab[max(hi + 1, 0)];                 /* first j with ring > hi */
+                const int jlo = (lo - 1 < 0) ? -1 : T.tab[LL_TAB + 1 + min(lo - 1, LL_TAB)];   /* last j with ring < lo */
+                Best b2 = {dmax, INT_MAX, -1}, b3 = {dmax, INT_MAX, -1};
+                ll_grid_search(gstart, q.x, q.y, rmax,
+                    [&](int st, int en) {
+                        for (int k = st + sub; k < en; k += 8) {
+                            const float4 p = gpts[k];
+                            const int w = __float_as_int(p.w);
+                            const int j = w & 0xFFFFFF, rj = (w >> 24) & 0xFF;
+                            if (j <= jlo || j >= jhi || j == c) continue;
+                            const float d = ll_walk_d2(p, q.x, q.y, q.z);
+                            if (j > c) {                                          /* increasing scan line (:504-527 / :668-693) */
+                                const int ord = j - c - 1;
+                                if (PLANE) { if (rj <= rc) ll_best_take(b2, d, ord, j, dmax); else ll_best_take(b3, d, ord, j, dmax); }
+                                else if (rj > rc) ll_best_take(b2, d, ord, j, dmax);
+                            } else {                                              /* decreasing scan line (:530-553 / :696-721) */
+                                const int ord = M + (c - 1 - j);
+                                if (PLANE) { if (rj >= rc) ll_best_take(b2, d, ord, j, dmax); else ll_best_take(b3, d, ord, j, dmax); }
+                                else if (rj < rc) ll_best_take(b2, d, ord, j, dmax);
+                            }
+                        }
+                    },
+                    [&]() { return PLANE ? fmaxf(b2.d, b3.d) : b2.d; },
+                    [&]() { ll_best_reduce<8>(b2); if (PLANE) ll_best_reduce<8>(b3); });
+                res_b = b2.j; res_c = b3.j;
             }
-            if (sm) break;
         }
-        /* decreasing scan line (:530-553 / :696-721) */
-        for (int j0 = c - 1; j0 >= 0; j0 -= 64) {
-            const int j = j0 - lane;
-            const bool in = j >= 0;
-            const float4 p = in ? tgt[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-            const int rj = (int)p.w;
-            const bool stop = in && ((double)rj < (double)rc - V.nearby);
-            const unsigned long long sm = __ballot(stop);
-            const bool ok = in && (sm == 0ull || lane < __ffsll((long long)sm) - 1);
-            if (ok) {
-                const float d = ll_walk_d2(p, qx, qy, qz);
-                const int ord = M + (c - 1 - j);
-                if (PLANE) {
-                    if (rj >= rc) { if (d < b2.d) { b2.d = d; b2.ord = ord; b2.j = j; } }
-                    else          { if (d < b3.d) { b3.d = d; b3.ord = ord; b3.j = j; } }
-                } else {
-                    if (rj < rc && d < b2.d) { b2.d = d; b2.ord = ord; b2.j = j; }
+        if (sub == 0) { nn[ql] = closest; rb[ql] = res_b; rcl[ql] = res_c; }
+    }
+    __syncthreads();
+    const int closest = have ? nn[tid] : -1;
+    int res_b = rb[tid], res_c = rcl[tid];
+
+    if (!tab_ok) {
+        /* fallback: the reference's sequential walks, one query at a time per wave */
+        res_b = -1; res_c = -1;
+        for (int qq = 0; qq < 64; ++qq) {
+            const int c = __shfl(closest, qq);
+            if (c < 0) continue;
+            const float qx = __shfl(sx, qq), qy = __shfl(sy, qq), qz = __shfl(sz, qq);
+            const int rc = (int)tgt[c].w;
+            Best b2 = {dmax, INT_MAX, -1}, b3 = {dmax, INT_MAX, -1};
+            for (int j0 = c + 1; j0 < M; j0 += 64) {
+                const int j = j0 + lane;
+                const bool in = j < M;
+                const float4 p = in ? tgt[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int rj = (int)p.w;
+                const bool stop = in && ((double)rj > (double)rc + V.nearby);
+                const unsigned long long sm = __ballot(stop);
+                const bool ok = in && (sm == 0ull || lane < __ffsll((long long)sm) - 1);
+                if (ok) {
+                    const float d = ll_walk_d2(p, qx, qy, qz);
+                    const int ord = j - c - 1;
+                    if (PLANE) { if (rj <= rc) ll_best_take(b2, d, ord, j, dmax); else ll_best_take(b3, d, ord, j, dmax); }
+                    else if (rj > rc) ll_best_take(b2, d, ord, j, dmax);
                 }
+                if (sm) break;
             }
-            if (sm) break;
+            for (int j0 = c - 1; j0 >= 0; j0 -= 64) {
+                const int j = j0 - lane;
+                const bool in = j >= 0;
+                const float4 p = in ? tgt[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int rj = (int)p.w;
+                const bool stop = in && ((double)rj < (double)rc - V.nearby);
+                const unsigned long long sm = __ballot(stop);
+                const bool ok = in && (sm == 0ull || lane < __ffsll((long long)sm) - 1);
+                if (ok) {
+                    const float d = ll_walk_d2(p, qx, qy, qz);
+                    const int ord = M + (c - 1 - j);
+                    if (PLANE) { if (rj >= rc) ll_best_take(b2, d, ord, j, dmax); else ll_best_take(b3, d, ord, j, dmax); }
+                    else if (rj < rc) ll_best_take(b2, d, ord, j, dmax);
+                }
+                if (sm) break;
+            }
+            ll_best_reduce<64>(b2);
+            if (PLANE) ll_best_reduce<64>(b3);
+            if (lane == qq) { res_b = b2.j; res_c = b3.j; }
         }
-        ll_best_reduce(b2);
-        if (PLANE) ll_best_reduce(b3);
-        if (lane == qq) { res_b = b2.j; res_c = b3.j; }
     }
     if (have) {
         bool valid = closest >= 0 && res_b >= 0 && (!PLANE || res_c >= 0);       /* :556 / :723 */
@@ -147,24 +400,35 @@ __global__ __launch_bounds__(LL_BLOCK) void k_associate(LLView V, int first, int
     const int sl = blockIdx.x / per, item = blockIdx.x % per;
     if (sl >= count) return;
     const int s = first + sl;
-    __shared__ float4 tile[LL_NN_TILE];
+    __shared__ float4 qs[LL_BLOCK];
+    __shared__ int nn[LL_BLOCK], rb[LL_BLOCK], rcl[LL_BLOCK];
     const ScanHdr h = V.hdr[s];
-    const float4 *corner, *surf; int mc, ms;
-    ll_targets(V, s, corner, mc, surf, ms);
     const bool ok = h.status == 0;
     if (item < qb_corner) {
         const int nq = ok ? h.n_sharp : 0;
         if (item * LL_BLOCK >= nq) return;
-        ll_associate_block<false>(V, s, item, V.sharp + (size_t)s * V.cap_sharp, nq, corner, mc,
-                                  V.eq_a + (size_t)s * V.cap_sharp, V.eq_b + (size_t)s * V.cap_sharp, nullptr, tile);
+        ll_associate_block<false>(V, s, item, V.sharp + (size_t)s * V.cap_sharp, nq, ll_target(V, s, 0),
+                                  V.eq_a + (size_t)s * V.cap_sharp, V.eq_b + (size_t)s * V.cap_sharp, nullptr, qs, nn, rb, rcl);
     } else {
         const int qb = item - qb_corner;
         const int nq = ok ? h.n_flat : 0;
         if (qb * LL_BLOCK >= nq) return;
-        ll_associate_block<true>(V, s, qb, V.flat + (size_t)s * V.cap_flat, nq, surf, ms,
+        ll_associate_block<true>(V, s, qb, V.flat + (size_t)s * V.cap_flat, nq, ll_target(V, s, 1),
                                  V.pq_a + (size_t)s * V.cap_flat, V.pq_b + (size_t)s * V.cap_flat,
-                                 V.pq_c + (size_t)s * V.cap_flat, tile);
+                                 V.pq_c + (size_t)s * V.cap_flat, qs, nn, rb, rcl);
     }
+}
+
+void ll_launch_build_grid(const LLView &V, int first, int count, int carry, hipStream_t st, LLProfiler *prof)
+{
+    static bool attr_set = false;
+    if (!attr_set) {   /* 64 KiB histogram + static LDS exceeds the default dynamic-LDS limit */
+        (void)hipFuncSetAttribute((const void *)k_build_grid, hipFuncAttributeMaxDynamicSharedMemorySize, LL_GRID_NC * sizeof(int));
+        attr_set = true;
+    }
+    ll_prof_mark(prof, LL_K_GRID, st);
+    hipLaunchKernelGGL(k_build_grid, dim3(2 * (carry ? 1 : count)), dim3(LL_BLOCK), LL_GRID_NC * sizeof(int), st, V, first, carry ? 1 : count, carry);
+    ll_prof_mark(prof, LL_K_END, st);
 }
 
 void ll_launch_associate(const LLView &V, int first, int count, hipStream_t st, LLProfiler *prof)

@@ -27,6 +27,14 @@
 #define LL_LSHARP_PER_SEG 20
 #define LL_FLAT_PER_SEG 4
 #define LL_SEGS 6
+/* nearest-neighbour cell grid over (x, y): 128 x 128 cells of 2 m centred on the sensor */
+#define LL_GRID_G 128
+#define LL_GRID_CELL 2.0f
+#define LL_GRID_ORG 128.0f
+#define LL_GRID_NC (LL_GRID_G * LL_GRID_G)
+/* ring tables stored behind the cell starts: first_ge[LL_TAB+1], last_le[LL_TAB+1], ok flag, cloud size */
+#define LL_TAB 160
+#define LL_GSTRIDE (LL_GRID_NC + 1 + 2 * (LL_TAB + 1) + 2)
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -68,6 +76,9 @@ struct LLView {
     float4 *sharp, *lsharp, *flat, *lflat;
     /* targets */
     float4 *carry_corner, *carry_surf; int *carry_cnt;    /* carry_cnt[2] */
+    /* NN grids of every slot's less-sharp (0) / less-flat (1) cloud and of the carry: cell starts + cell-ordered (x,y,z,index) */
+    int *gstart; float4 *gpts_c, *gpts_s;                 /* [B][2][NC+1], [B][cap_lsharp], [B][NP] */
+    int *carry_gstart; float4 *carry_gpts_c, *carry_gpts_s;
     /* association (per query, then compacted) */
     int *eq_a, *eq_b;              /* [B][cap_sharp]  -1 = no correspondence */
     int *pq_a, *pq_b, *pq_c;       /* [B][cap_flat] */
@@ -90,6 +101,24 @@ __device__ __forceinline__ int ll_trunc_to_int(double v)
     return (int)v;
 }
 
+/* exclusive prefix sum of one int per thread over a 256-thread workgroup: 64-lane shuffle scan + 4 wave totals
+ * through LDS (sc: >= 4 ints).  Returns the exclusive prefix; total = workgroup sum.  Ends with a barrier. */
+__device__ __forceinline__ int ll_block_exscan(int v, int *sc, int &total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) sc[wave] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < LL_BLOCK / 64; ++w) { const int t = sc[w]; if (w < wave) base += t; tot += t; }
+    total = tot;
+    __syncthreads();
+    return base + inc - v;
+}
+
 /* target clouds of slot s: features of slot s-1, or the carry for the batch's first slot */
 __device__ __forceinline__ void ll_targets(const LLView &V, int s, const float4 *&corner, int &mc, const float4 *&surf, int &ms)
 {
@@ -105,7 +134,7 @@ __device__ __forceinline__ void ll_targets(const LLView &V, int s, const float4 
 
 /* per-kernel HIP-event profiler (ll_api.hip); mark(id) = "kernel id starts here, the previous one ended" */
 enum { LL_K_CLASSIFY = 0, LL_K_OFFSETS, LL_K_SCATTER, LL_K_RING_FEATURES, LL_K_COMPACT, LL_K_ASSOCIATE, LL_K_VOTE,
-       LL_K_NORMAL_EQ, LL_K_GN_STEP, LL_K_COUNT, LL_K_END = -1 };
+       LL_K_NORMAL_EQ, LL_K_GN_STEP, LL_K_GRID, LL_K_COUNT, LL_K_END = -1 };
 struct LLProfiler;
 void ll_prof_mark(LLProfiler *p, int kernel_id, hipStream_t st);
 
@@ -113,6 +142,7 @@ void ll_prof_mark(LLProfiler *p, int kernel_id, hipStream_t st);
 void ll_launch_organize(const LLView &V, int first, int count, hipStream_t st, LLProfiler *prof);
 void ll_launch_features(const LLView &V, int first, int count, size_t lds_bytes, hipStream_t st, LLProfiler *prof);
 void ll_launch_associate(const LLView &V, int first, int count, hipStream_t st, LLProfiler *prof);
+void ll_launch_build_grid(const LLView &V, int first, int count, int carry, hipStream_t st, LLProfiler *prof);
 void ll_launch_vote(const LLView &V, int first, int count, int enable, hipStream_t st, LLProfiler *prof);
 void ll_launch_normal_equations(const LLView &V, int first, int count, int do_step, hipStream_t st, LLProfiler *prof);
 void ll_launch_gn_step(const LLView &V, int first, int count, hipStream_t st, LLProfiler *prof);

@@ -82,28 +82,30 @@ __device__ __forceinline__ void ll_ce(u64 *k, int i, int l)
 /* Sort nseg independent key ranges [b(j), b(j+1)) ascending.  seg_begin(j) = L*j/nseg for the six curvature
  * segments (scanRegistration.cpp:253-254) or the single voxel range.  All comparators are ascending, so
  * positions >= the segment length behave as +inf padding that never has to move. */
-__device__ __forceinline__ void ll_bitonic_segments(u64 *keys, int L, int nseg, int tid)
+/* segb[0..nseg] (LDS) holds the segment bounds; all index math is shifts and masks (p2, k, j are powers of two). */
+__device__ __forceinline__ void ll_bitonic_segments(u64 *keys, const int *segb, int nseg, int tid)
 {
     int lmax = 0;
-    for (int j = 0; j < nseg; ++j) lmax = max(lmax, (int)((long long)L * (j + 1) / nseg - (long long)L * j / nseg));
+    for (int j = 0; j < nseg; ++j) lmax = max(lmax, segb[j + 1] - segb[j]);
     if (lmax < 2) return;
-    int p2 = 2; while (p2 < lmax) p2 <<= 1;
-    const int half = p2 >> 1;
-    for (int k = 2; k <= p2; k <<= 1) {
-        const int hk = k >> 1;
-        for (int p = tid; p < nseg * half; p += LL_BLOCK) {           /* flip: i <-> block_start + (k-1-t) */
-            const int sg = p / half, q = p - sg * half;
-            const int b0 = (int)((long long)L * sg / nseg), len = (int)((long long)L * (sg + 1) / nseg) - b0;
-            const int blk = q / hk, t = q - blk * hk;
-            const int i = blk * k + t, l = blk * k + (k - 1 - t);
+    int lg = 1; while ((1 << lg) < lmax) ++lg;             /* p2 = 1 << lg */
+    const int lgh = lg - 1, half = 1 << lgh, npairs = nseg << lgh;
+    for (int lk = 1; lk <= lg; ++lk) {                     /* k = 1 << lk */
+        const int lhk = lk - 1, hk = 1 << lhk;
+        for (int p = tid; p < npairs; p += LL_BLOCK) {     /* flip: i <-> block_start + (k-1-t) */
+            const int sg = p >> lgh, q = p & (half - 1);
+            const int b0 = segb[sg], len = segb[sg + 1] - b0;
+            const int blk = q >> lhk, t = q & (hk - 1);
+            const int i = (blk << lk) + t, l = (blk << lk) + ((1 << lk) - 1 - t);
             if (l < len) ll_ce(keys + b0, i, l);
         }
         __syncthreads();
-        for (int j = hk >> 1; j > 0; j >>= 1) {
-            for (int p = tid; p < nseg * half; p += LL_BLOCK) {
-                const int sg = p / half, q = p - sg * half;
-                const int b0 = (int)((long long)L * sg / nseg), len = (int)((long long)L * (sg + 1) / nseg) - b0;
-                const int i = ((q / j) * 2 * j) + (q % j), l = i + j;
+        for (int lj = lhk - 1; lj >= 0; --lj) {            /* j = 1 << lj */
+            const int j = 1 << lj;
+            for (int p = tid; p < npairs; p += LL_BLOCK) {
+                const int sg = p >> lgh, q = p & (half - 1);
+                const int b0 = segb[sg], len = segb[sg + 1] - b0;
+                const int i = ((q >> lj) << (lj + 1)) + (q & (j - 1)), l = i + j;
                 if (l < len) ll_ce(keys + b0, i, l);
             }
             __syncthreads();
@@ -186,7 +188,10 @@ __global__ __launch_bounds__(LL_BLOCK) void k_ring_features(LLView V, int first,
     }
 
     /* ---------------- phase 2: sort the six segments (:251-257) ---------------- */
-    if (active) ll_bitonic_segments(L.keys, Lseg, LL_SEGS, tid);
+    int *segb = L.scratch + 320;                                       /* segment bounds for the sort network */
+    if (tid <= LL_SEGS) segb[tid] = Lseg * tid / LL_SEGS;              /* sp_j - S, int math of :253-254 */
+    __syncthreads();
+    if (active) ll_bitonic_segments(L.keys, segb, LL_SEGS, tid);
     __syncthreads();
 
     /* ---------------- phase 3: greedy pick, wave 0 ---------------- */
@@ -265,7 +270,6 @@ __global__ __launch_bounds__(LL_BLOCK) void k_ring_features(LLView V, int first,
             }
         }
         int *sc = L.scratch;
-        sc[tid] = cntl;
         float *fs = (float *)(L.scratch + LL_BLOCK + 16);
         /* wave reduce min/max, then across the 4 waves through LDS */
         for (int o = 32; o > 0; o >>= 1) {
@@ -273,21 +277,12 @@ __global__ __launch_bounds__(LL_BLOCK) void k_ring_features(LLView V, int first,
             mxx = fmaxf(mxx, __shfl_xor(mxx, o)); mxy = fmaxf(mxy, __shfl_xor(mxy, o)); mxz = fmaxf(mxz, __shfl_xor(mxz, o));
         }
         if (lane == 0) { float *w = fs + (tid >> 6) * 6; w[0] = mnx; w[1] = mny; w[2] = mnz; w[3] = mxx; w[4] = mxy; w[5] = mxz; }
-        __syncthreads();
-        if (tid == 0) {
-            int run = 0;
-            for (int i = 0; i < LL_BLOCK; ++i) { const int c = sc[i]; sc[i] = run; run += c; }
-            sc[LL_BLOCK] = run;
-            for (int w = 1; w < LL_BLOCK / 64; ++w)
-                for (int c = 0; c < 3; ++c) { fs[c] = fminf(fs[c], fs[w * 6 + c]); fs[3 + c] = fmaxf(fs[3 + c], fs[w * 6 + 3 + c]); }
-        }
-        __syncthreads();
-        const int m = sc[LL_BLOCK];
-        {
-            int pos = sc[tid];
-            for (int q = a0; q < a1; ++q) if (L.lab[q + 5] <= 0) L.lf_list[pos++] = (unsigned short)(q + 5);
-        }
-        const float mn[3] = {fs[0], fs[1], fs[2]}, mx[3] = {fs[3], fs[4], fs[5]};
+        int m = 0;
+        int pos = ll_block_exscan(cntl, sc, m);                      /* barriers inside also publish fs[] */
+        for (int q = a0; q < a1; ++q) if (L.lab[q + 5] <= 0) L.lf_list[pos++] = (unsigned short)(q + 5);
+        float mn[3] = {fs[0], fs[1], fs[2]}, mx[3] = {fs[3], fs[4], fs[5]};
+        for (int w = 1; w < LL_BLOCK / 64; ++w)
+            for (int c = 0; c < 3; ++c) { mn[c] = fminf(mn[c], fs[w * 6 + c]); mx[c] = fmaxf(mx[c], fs[w * 6 + 3 + c]); }
         __syncthreads();
         if (m > 0) {
             /* pcl::VoxelGrid::applyFilter (PCL 1.10), restated */
@@ -312,8 +307,9 @@ __global__ __launch_bounds__(LL_BLOCK) void k_ring_features(LLView V, int first,
                 }
                 L.keys[jx] = ((u64)idx << 32) | (unsigned)jx;
             }
+            if (tid == 0) { segb[0] = 0; segb[1] = m; }
             __syncthreads();
-            ll_bitonic_segments(L.keys, m, 1, tid);
+            ll_bitonic_segments(L.keys, segb, 1, tid);
             __syncthreads();
             /* run heads -> output rank */
             const int perm = (m + LL_BLOCK - 1) / LL_BLOCK;
@@ -321,17 +317,8 @@ __global__ __launch_bounds__(LL_BLOCK) void k_ring_features(LLView V, int first,
             int heads = 0;
             for (int p = b0; p < b1; ++p)
                 if (p == 0 || (unsigned)(L.keys[p] >> 32) != (unsigned)(L.keys[p - 1] >> 32)) heads++;
-            sc[tid] = heads;
-            __syncthreads();
-            if (tid == 0) {
-                int run = 0;
-                for (int i = 0; i < LL_BLOCK; ++i) { const int c = sc[i]; sc[i] = run; run += c; }
-                sc[LL_BLOCK] = run;
-            }
-            __syncthreads();
-            n_lf_out = sc[LL_BLOCK];
+            int o = ll_block_exscan(heads, sc, n_lf_out);
             float4 *out = V.lflat_slot + (size_t)s * V.NP + off;
-            int o = sc[tid];
             for (int p = b0; p < b1; ++p) {
                 const unsigned vid = (unsigned)(L.keys[p] >> 32);
                 if (p != 0 && vid == (unsigned)(L.keys[p - 1] >> 32)) continue;
@@ -390,6 +377,11 @@ void ll_launch_features(const LLView &V, int first, int count, size_t lds_bytes,
 {
     const int groups = (count + 7) / 8;
     const int grid = 8 * V.R * groups;
+    static size_t attr_bytes = 0;
+    if (lds_bytes > attr_bytes) {
+        (void)hipFuncSetAttribute((const void *)k_ring_features, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        attr_bytes = lds_bytes;
+    }
     ll_prof_mark(prof, LL_K_RING_FEATURES, st);
     hipLaunchKernelGGL(k_ring_features, dim3(grid), dim3(LL_BLOCK), lds_bytes, st, V, first, count);
     ll_prof_mark(prof, LL_K_COMPACT, st);

@@ -76,27 +76,47 @@ __global__ __launch_bounds__(LL_BLOCK) void k_classify(LLView V, int first, int 
 
     float *ori = V.ori + (size_t)s * V.NP;
     int8_t *ring = V.ring + (size_t)s * V.NP;
+    const int lane = tid & 63;
+    int bits = 0; while ((1 << bits) < V.R) ++bits;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    /* the constants of the halfPassed predicate, hoisted (f64) */
+    const double so_lo = (double)start_ori - M_PI / 2, so_hi = (double)start_ori + M_PI * 3 / 2;
 #pragma unroll
     for (int k = 0; k < LL_TILE / LL_BLOCK; ++k) {
         const int i = base + k * LL_BLOCK + tid;
-        if (i >= n_in) continue;
-        const float4 p = raw[i];
-        int id = -1; float o = 0.0f;
-        if (ll_keep(p, V.thres)) {
-            atomicMin(&sh_fk, i); atomicMax(&sh_lk, i);
+        const bool in = i < n_in;
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in) p = raw[i];
+        const bool kept = in && ll_keep(p, V.thres);
+        int id = -1; float o = 0.0f; bool firstp = false;
+        if (kept) {
             o = -ll_atan2f(p.y, p.x);                                                 /* :177 (also start/endOri source) */
             id = ll_scan_id(V, p);
             if (id >= 0) {
-                atomicAdd(&hist[id], 1);
                 /* the !halfPassed branch (:180-192) evaluated as if the flag were still false */
                 float a = o;
-                if ((double)a < (double)start_ori - M_PI / 2)            a = (float)((double)a + 2 * M_PI);
-                else if ((double)a > (double)start_ori + M_PI * 3 / 2)   a = (float)((double)a - 2 * M_PI);
-                if ((double)(a - start_ori) > M_PI) atomicMin(&sh_first_p, i);
+                if ((double)a < so_lo)        a = (float)((double)a + 2 * M_PI);
+                else if ((double)a > so_hi)   a = (float)((double)a - 2 * M_PI);
+                firstp = (double)(a - start_ori) > M_PI;
             }
         }
-        ori[i] = o;
-        ring[i] = (int8_t)id;
+        if (in) { ori[i] = o; ring[i] = (int8_t)id; }
+        /* wave-level reductions by ballot: lanes hold consecutive indices, so first/last set lane = min/max index.
+         * (per-lane LDS atomics on one address serialise 64-way; ring-major input puts a whole wave on one bin) */
+        const int i0 = base + k * LL_BLOCK + (tid & ~63);
+        const unsigned long long km = __ballot(kept);
+        if (km && lane == 0) { atomicMin(&sh_fk, i0 + __ffsll((long long)km) - 1); atomicMax(&sh_lk, i0 + 63 - __clzll((long long)km)); }
+        const unsigned long long pm = __ballot(firstp);
+        if (pm && lane == 0) atomicMin(&sh_first_p, i0 + __ffsll((long long)pm) - 1);
+        unsigned long long m = __ballot(id >= 0);
+        if (m) {
+            for (int b = 0; b < bits; ++b) {
+                const bool bit = (id >> b) & 1;
+                const unsigned long long bal = __ballot(bit);
+                m &= bit ? bal : ~bal;
+            }
+            if (id >= 0 && (m & lt) == 0ull) atomicAdd(&hist[id], __popcll(m));       /* one add per distinct ring in the wave */
+        }
     }
     __syncthreads();
     const size_t tb = ((size_t)s * V.T + tile);

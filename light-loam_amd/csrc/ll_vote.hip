@@ -25,13 +25,9 @@ __device__ __forceinline__ int ll_block_compact(int n, int *sc, F emit, const in
     const int a0 = min(n, tid * per), a1 = min(n, a0 + per);
     int c = 0;
     for (int i = a0; i < a1; ++i) c += valid_src[i] >= 0;
-    sc[tid] = c;
-    __syncthreads();
-    if (tid == 0) { int run = 0; for (int i = 0; i < LL_BLOCK; ++i) { const int t = sc[i]; sc[i] = run; run += t; } sc[LL_BLOCK] = run; }
-    __syncthreads();
-    int pos = sc[tid];
+    int total = 0;
+    int pos = ll_block_exscan(c, sc, total);
     for (int i = a0; i < a1; ++i) if (valid_src[i] >= 0) emit(i, pos++);
-    const int total = sc[LL_BLOCK];
     __syncthreads();
     return total;
 }
