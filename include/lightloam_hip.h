@@ -166,6 +166,8 @@ int ll_hot_path_batch(ll_ctx *ctx, int first, int count, const double *host_pose
  * since the last reset.  names[i] points to a static string.  n is in: capacity / out: kernels returned.    */
 int ll_profile_enable(ll_ctx *ctx, int on);
 int ll_profile_read(ll_ctx *ctx, int *n, const char **names, double *total_ms, int *launches, int reset);
+/* 16 in-kernel phase counters (shader cycles); zero unless the library was built with -DLL_PHASE_TIMING (tools/phase_timing.py) */
+int ll_debug_counters(ll_ctx *ctx, unsigned long long *out16, int reset);
 
 /* Algorithmic HBM bytes of the last ll_hot_path_batch / stage calls, summed over the slots they covered,
  * by SURVEY.md section 8d's formula (B_ext, B_assoc, B_vote, B_rj).                                      */

@@ -15,7 +15,8 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
 
 
 def lib_path():
-    return os.path.join(_HERE, "liblightloam_hip.so")
+    # LIGHTLOAM_HIP_LIB lets a profiling tool load an instrumented build of the same sources
+    return os.environ.get("LIGHTLOAM_HIP_LIB") or os.path.join(_HERE, "liblightloam_hip.so")
 
 
 def synth_lib_path():

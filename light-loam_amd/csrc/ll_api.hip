@@ -181,7 +181,7 @@ extern "C" int ll_create(int device, const ll_params *p, ll_ctx **out)
     ok = ok && dev_alloc(ctx, V.p_src, (size_t)B * V.cap_flat) && dev_alloc(ctx, V.p_a, (size_t)B * V.cap_flat) && dev_alloc(ctx, V.p_b, (size_t)B * V.cap_flat) && dev_alloc(ctx, V.p_c, (size_t)B * V.cap_flat);
     ok = ok && dev_alloc(ctx, V.v_count, (size_t)B * V.cap_flat) && dev_alloc(ctx, V.v_sel, (size_t)B * V.cap_flat) && dev_alloc(ctx, V.v_w, (size_t)B * V.cap_flat);
     ok = ok && dev_alloc(ctx, V.pair, B) && dev_alloc(ctx, V.pose, (size_t)B * 7) && dev_alloc(ctx, V.pose_guess, (size_t)B * 7) && dev_alloc(ctx, V.neq, (size_t)B * LL_NEQ_STRIDE);
-    ok = ok && dev_alloc(ctx, ctx->d_tmp_pose, 7);
+    ok = ok && dev_alloc(ctx, ctx->d_tmp_pose, 7) && dev_alloc(ctx, V.dbg, 16);
     if (!ok) { ll_destroy(ctx); return LL_ERR_HIP; }
     ctx->feat_lds = ll_features_lds_bytes(p->max_ring_points);
     if (ctx->feat_lds > 160 * 1024) { g_create_err = "max_ring_points needs more than 160 KiB of LDS"; ll_destroy(ctx); return LL_ERR_ARG; }
@@ -527,6 +527,16 @@ extern "C" int ll_residual_jacobian(ll_ctx *ctx, int slot, const double *pose7, 
     rc = dl(ctx, r, dr, rows * sizeof(double)); if (rc) return rc;
     rc = dl(ctx, Jq, dJq, rows * 4 * sizeof(double)); if (rc) return rc;
     rc = dl(ctx, Jt, dJt, rows * 3 * sizeof(double)); if (rc) return rc;
+    LL_HIP(hipStreamSynchronize(ctx->stream));
+    return LL_OK;
+}
+
+/* debug: the 16 phase-timing counters (all zero unless built with -DLL_PHASE_TIMING); reset = zero them afterwards */
+extern "C" int ll_debug_counters(ll_ctx *ctx, unsigned long long *out16, int reset)
+{
+    if (!ctx || !out16) return LL_ERR_ARG;
+    LL_HIP(hipMemcpyAsync(out16, ctx->V.dbg, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    if (reset) LL_HIP(hipMemsetAsync(ctx->V.dbg, 0, 16 * sizeof(unsigned long long), ctx->stream));
     LL_HIP(hipStreamSynchronize(ctx->stream));
     return LL_OK;
 }

@@ -90,6 +90,7 @@ struct LLView {
     double *pose_guess;            /* [B][7] para_q/para_t at entry of the hot path (laserOdometry.cpp:61-62) */
     double *neq;                   /* [B][44]: H[36] row-major, g[6], cost, rows */
     int carry_slot;                /* the slot whose target is the carry (first slot of the batch) */
+    unsigned long long *dbg;       /* [16] phase-timing counters (only written by -DLL_PHASE_TIMING builds) */
 };
 
 #define LL_NEQ_STRIDE 44

@@ -83,32 +83,138 @@ __device__ __forceinline__ void ll_ce(u64 *k, int i, int l)
  * segments (scanRegistration.cpp:253-254) or the single voxel range.  All comparators are ascending, so
  * positions >= the segment length behave as +inf padding that never has to move. */
 /* segb[0..nseg] (LDS) holds the segment bounds; all index math is shifts and masks (p2, k, j are powers of two). */
+#define LL_SORT_MAXP 8      /* compare-exchanges a thread keeps in flight per batch */
+
+/* one step of the network: FLIP ? (i <-> block mirror, block = 1 << lx) : (i <-> i + (1 << lx)).
+ * Each thread first computes all its pairs, then issues every LDS load, then compares and stores: the loads of a
+ * thread's pairs overlap instead of forming one dependent round trip per pair. */
+template <bool FLIP>
+__device__ __forceinline__ void ll_sort_step(u64 *keys, const int (&sb)[LL_SEGS + 1], int lgh, int npairs, int lx, int tid)
+{
+    const int half = 1 << lgh;
+    for (int p0 = 0; p0 < npairs; p0 += LL_BLOCK * LL_SORT_MAXP) {
+        int ia[LL_SORT_MAXP], ib[LL_SORT_MAXP];
+        u64 a[LL_SORT_MAXP], b[LL_SORT_MAXP];
+#pragma unroll
+        for (int u = 0; u < LL_SORT_MAXP; ++u) {
+            const int p = p0 + u * LL_BLOCK + tid;
+            ia[u] = -1; ib[u] = 0;
+            if (p < npairs) {
+                const int sg = p >> lgh, q = p & (half - 1);
+                int b0 = sb[0], b1 = sb[1];
+#pragma unroll
+                for (int t = 1; t < LL_SEGS; ++t) if (sg == t) { b0 = sb[t]; b1 = sb[t + 1]; }
+                int i, l;
+                if (FLIP) { const int blk = q >> (lx - 1), t = q & ((1 << (lx - 1)) - 1); i = (blk << lx) + t; l = (blk << lx) + ((1 << lx) - 1 - t); }
+                else      { i = ((q >> lx) << (lx + 1)) + (q & ((1 << lx) - 1)); l = i + (1 << lx); }
+                if (l < b1 - b0) { ia[u] = b0 + i; ib[u] = b0 + l; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < LL_SORT_MAXP; ++u) if (ia[u] >= 0) { a[u] = keys[ia[u]]; b[u] = keys[ib[u]]; }
+#pragma unroll
+        for (int u = 0; u < LL_SORT_MAXP; ++u) if (ia[u] >= 0 && a[u] > b[u]) { keys[ia[u]] = b[u]; keys[ib[u]] = a[u]; }
+    }
+}
+
+/* segb[0..nseg] (LDS) holds the segment bounds (nseg <= LL_SEGS); index math is shifts and masks only. */
 __device__ __forceinline__ void ll_bitonic_segments(u64 *keys, const int *segb, int nseg, int tid)
 {
+    int sb[LL_SEGS + 1];
+#pragma unroll
+    for (int j = 0; j <= LL_SEGS; ++j) sb[j] = segb[min(j, nseg)];
     int lmax = 0;
-    for (int j = 0; j < nseg; ++j) lmax = max(lmax, segb[j + 1] - segb[j]);
+#pragma unroll
+    for (int j = 0; j < LL_SEGS; ++j) lmax = max(lmax, sb[j + 1] - sb[j]);
     if (lmax < 2) return;
     int lg = 1; while ((1 << lg) < lmax) ++lg;             /* p2 = 1 << lg */
-    const int lgh = lg - 1, half = 1 << lgh, npairs = nseg << lgh;
-    for (int lk = 1; lk <= lg; ++lk) {                     /* k = 1 << lk */
-        const int lhk = lk - 1, hk = 1 << lhk;
-        for (int p = tid; p < npairs; p += LL_BLOCK) {     /* flip: i <-> block_start + (k-1-t) */
-            const int sg = p >> lgh, q = p & (half - 1);
-            const int b0 = segb[sg], len = segb[sg + 1] - b0;
-            const int blk = q >> lhk, t = q & (hk - 1);
-            const int i = (blk << lk) + t, l = (blk << lk) + ((1 << lk) - 1 - t);
-            if (l < len) ll_ce(keys + b0, i, l);
+    const int lgh = lg - 1, npairs = nseg << lgh;
+    for (int lk = 1; lk <= lg; ++lk) {                     /* merge size k = 1 << lk */
+        ll_sort_step<true>(keys, sb, lgh, npairs, lk, tid);
+        __syncthreads();
+        for (int lj = lk - 2; lj >= 0; --lj) {             /* j = 1 << lj */
+            ll_sort_step<false>(keys, sb, lgh, npairs, lj, tid);
+            __syncthreads();
+        }
+    }
+}
+
+/* Stable least-significant-digit radix sort of keys[0..n) by their HIGH 32 bits, one 256-thread workgroup, n <= 256*LL_RS_E.
+ * 4-bit digits.  Element g lives in row g / 256, lane g % 256 (registers); its destination is
+ *   #(elements with a smaller digit) + #(same digit, earlier (row, wave)) + rank inside its wave,
+ * the first two from one workgroup exclusive scan over the digit-major table cnt[digit][row*4 + wave], the last from a
+ * ballot match (5 ballots).  Digits that are equal for every key are skipped (their pass would be the identity).
+ * Stability makes the result ordered by (high 32 bits, original position): exactly the (curvature, index) /
+ * (voxel, input order) orders the oracle defines.  SEG_PASS appends a pass on the segment of the key's low-32 local
+ * index, so the six curvature segments end up sorted in place in their own ranges. */
+#define LL_RS_E 9
+template <bool SEG_PASS>
+__device__ __forceinline__ void ll_radix_sort_hi32(u64 *keys, int n, int *cnt, int *sc, const int *segb, int tid)
+{
+    constexpr int SLOTS = LL_RS_E * (LL_BLOCK / 64);            /* (row, wave) pairs */
+    constexpr int NCNT = 16 * SLOTS;
+    const int lane = tid & 63, wave = tid >> 6;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    u64 e[LL_RS_E];
+    unsigned vary = 0;
+    const unsigned hi0 = (n > 0) ? (unsigned)(keys[0] >> 32) : 0u;
+#pragma unroll
+    for (int k = 0; k < LL_RS_E; ++k) {
+        const int g = k * LL_BLOCK + tid;
+        e[k] = (g < n) ? keys[g] : ~0ull;
+        if (g < n) vary |= (unsigned)(e[k] >> 32) ^ hi0;
+    }
+    for (int o = 32; o > 0; o >>= 1) vary |= __shfl_xor(vary, o);
+    if (tid == 0) cnt[NCNT] = 0;
+    __syncthreads();
+    if (lane == 0 && vary) atomicOr((unsigned *)&cnt[NCNT], vary);
+    __syncthreads();
+    vary = (unsigned)cnt[NCNT];
+    int sb1 = 0, sb2 = 0, sb3 = 0, sb4 = 0, sb5 = 0;
+    if (SEG_PASS) { sb1 = segb[1]; sb2 = segb[2]; sb3 = segb[3]; sb4 = segb[4]; sb5 = segb[5]; }
+    for (int sh = 0; sh < (SEG_PASS ? 36 : 32); sh += 4) {
+        const bool segpass = sh >= 32;
+        if (!segpass && ((vary >> sh) & 15u) == 0u) continue;
+        for (int i = tid; i < NCNT; i += LL_BLOCK) cnt[i] = 0;
+        __syncthreads();
+        int dig[LL_RS_E], rnk[LL_RS_E];
+#pragma unroll
+        for (int k = 0; k < LL_RS_E; ++k) {
+            const int g = k * LL_BLOCK + tid;
+            const bool valid = g < n;
+            int d;
+            if (segpass) { const int q = (int)(unsigned)e[k] - 5; d = (q >= sb1) + (q >= sb2) + (q >= sb3) + (q >= sb4) + (q >= sb5); }
+            else d = (int)(((unsigned)(e[k] >> 32) >> sh) & 15u);
+            unsigned long long m = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const bool bit = (d >> b) & 1;
+                const unsigned long long bal = __ballot(bit);
+                m &= bit ? bal : ~bal;
+            }
+            dig[k] = d; rnk[k] = __popcll(m & lt);
+            if (valid && rnk[k] == 0) cnt[d * SLOTS + k * (LL_BLOCK / 64) + wave] = __popcll(m);
         }
         __syncthreads();
-        for (int lj = lhk - 1; lj >= 0; --lj) {            /* j = 1 << lj */
-            const int j = 1 << lj;
-            for (int p = tid; p < npairs; p += LL_BLOCK) {
-                const int sg = p >> lgh, q = p & (half - 1);
-                const int b0 = segb[sg], len = segb[sg + 1] - b0;
-                const int i = ((q >> lj) << (lj + 1)) + (q & (j - 1)), l = i + j;
-                if (l < len) ll_ce(keys + b0, i, l);
-            }
-            __syncthreads();
+        {   /* exclusive scan of the digit-major table: 3 consecutive counters per thread */
+            const int i0 = tid * 3;
+            int v0 = 0, v1 = 0, v2 = 0;
+            if (i0 < NCNT) { v0 = cnt[i0]; v1 = cnt[i0 + 1]; v2 = cnt[i0 + 2]; }
+            int total;
+            const int base = ll_block_exscan(v0 + v1 + v2, sc, total);
+            if (i0 < NCNT) { cnt[i0] = base; cnt[i0 + 1] = base + v0; cnt[i0 + 2] = base + v0 + v1; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < LL_RS_E; ++k) {
+            const int g = k * LL_BLOCK + tid;
+            if (g < n) keys[cnt[dig[k] * SLOTS + k * (LL_BLOCK / 64) + wave] + rnk[k]] = e[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < LL_RS_E; ++k) {
+            const int g = k * LL_BLOCK + tid;
+            e[k] = (g < n) ? keys[g] : ~0ull;
         }
     }
 }
@@ -131,6 +237,17 @@ __device__ __forceinline__ void ll_mark(const FeatLds &L, int sel, int lane)
 }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char ll_smem[];
+
+/* opt-in phase timing (tools/phase_timing.py builds with -DLL_PHASE_TIMING): thread 0 of every workgroup adds the
+ * s_memtime cycles spent in each phase to V.dbg[phase]; V.dbg[15] counts workgroups */
+#ifdef LL_PHASE_TIMING
+#define LL_PHASE_BEGIN() long long ll_t0 = (tid == 0) ? (long long)__builtin_amdgcn_s_memtime() : 0
+#define LL_PHASE(i) do { __syncthreads(); if (tid == 0) { const long long t1 = (long long)__builtin_amdgcn_s_memtime(); \
+    atomicAdd(&V.dbg[i], (unsigned long long)(t1 - ll_t0)); ll_t0 = t1; } } while (0)
+#else
+#define LL_PHASE_BEGIN() do {} while (0)
+#define LL_PHASE(i) do {} while (0)
+#endif
 
 __global__ __launch_bounds__(LL_BLOCK) void k_ring_features(LLView V, int first, int count)
 {
@@ -157,6 +274,7 @@ __global__ __launch_bounds__(LL_BLOCK) void k_ring_features(LLView V, int first,
     if (tid < 3) L.lists[156 + tid] = 0;                              /* n_sharp, n_lsharp, n_flat */
     __syncthreads();
 
+    LL_PHASE_BEGIN();
     /* ---------------- phase 1: curvature + gap flags + keys ---------------- */
     for (int c0 = 0; c0 < nr; c0 += LL_TILE) {
         const int g0 = off + c0;                                      /* global index of tile slot 5 */
@@ -187,73 +305,87 @@ __global__ __launch_bounds__(LL_BLOCK) void k_ring_features(LLView V, int first,
         __syncthreads();
     }
 
+    LL_PHASE(0);
     /* ---------------- phase 2: sort the six segments (:251-257) ---------------- */
     int *segb = L.scratch + 320;                                       /* segment bounds for the sort network */
     if (tid <= LL_SEGS) segb[tid] = Lseg * tid / LL_SEGS;              /* sp_j - S, int math of :253-254 */
     __syncthreads();
-    if (active) ll_bitonic_segments(L.keys, segb, LL_SEGS, tid);
+    const bool use_radix = V.max_ring <= LL_RS_E * LL_BLOCK;          /* longer rings: bitonic network (any length) */
+    int *rs_cnt = (int *)L.tx;                                         /* the curvature tile is free after phase 1 */
+    if (active) {
+        if (use_radix) ll_radix_sort_hi32<true>(L.keys, Lseg, rs_cnt, L.scratch, segb, tid);
+        else ll_bitonic_segments(L.keys, segb, LL_SEGS, tid);
+    }
     __syncthreads();
 
+    LL_PHASE(1);
     /* ---------------- phase 3: greedy pick, wave 0 ---------------- */
     if (active && tid < 64) {
         int ns = 0, nls = 0, nf = 0;
         for (int j = 0; j < LL_SEGS; ++j) {
             const int sp = Lseg * j / 6, ep = Lseg * (j + 1) / 6 - 1;     /* key slots; = (:253-254) - S */
             const int len = ep - sp + 1;
-            /* corners: descending curvature (:261-313) */
-            int largest = 0; bool done = false;
-            for (int c0 = 0; c0 < len && !done; c0 += 64) {
-                const bool have = c0 + lane < len;
-                const u64 key = have ? L.keys[ep - (c0 + lane)] : 0ull;
-                const int li = (int)(unsigned)key;
-                const bool cand = have && ((double)ll_u2f((unsigned)(key >> 32)) > V.curv_thr);
-                if (__ballot(cand) == 0ull) break;
-                for (;;) {
-                    const bool elig = cand && !ll_bit(L.picked, li);
-                    const unsigned long long m = __ballot(elig);
-                    if (!m) break;
-                    const int f = __ffsll((long long)m) - 1;
-                    const int sel = __shfl(li, f);
-                    largest++;
-                    if (largest > LL_LSHARP_PER_SEG) { done = true; break; }      /* :281-284 */
-                    if (lane == 0) {
-                        if (largest <= LL_SHARP_PER_SEG) { L.lab[sel] = 2; L.lists[ns] = sel; }
-                        else L.lab[sel] = 1;
-                        L.lists[12 + nls] = sel;
+            /* pass 0: corners, descending curvature (:261-313); pass 1: flats, ascending (:316-359) */
+            for (int pass = 0; pass < 2; ++pass) {
+                int npick = 0; bool done = false;
+                for (int c0 = 0; c0 < len && !done; c0 += 64) {
+                    const bool have = c0 + lane < len;
+                    const u64 key = have ? L.keys[pass == 0 ? ep - (c0 + lane) : sp + c0 + lane] : 0ull;
+                    const int li = (int)(unsigned)key;
+                    const double cv = (double)ll_u2f((unsigned)(key >> 32));
+                    const bool cand = have && (pass == 0 ? cv > V.curv_thr : cv < V.curv_thr);
+                    if (__ballot(cand) == 0ull) break;
+                    /* per candidate, once per chunk: is it already suppressed, and which index range [lo, hi] would its
+                     * own pick suppress (:288-311): bits gapf[li-4 .. li+5] straight from the LDS bitmap */
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");          /* marks of earlier chunks / segments */
+                    bool elig = false; int lo = 0, hi = 0;
+                    if (cand) {
+                        elig = !ll_bit(L.picked, li);
+                        const int b0 = li - 4;
+                        const u64 w = ((u64)L.gapf[(b0 >> 5) + 1] << 32) | L.gapf[b0 >> 5];
+                        const unsigned bits = (unsigned)(w >> (b0 & 31)) & 0x3ffu;   /* bit t = gapf[li - 4 + t] */
+                        const unsigned fwd = bits >> 5;                              /* l = 1..5  -> gapf[li + l] */
+                        const int fn = fwd ? (__ffs(fwd) - 1) : 5;
+                        int bn = 5;                                                  /* l = -1..-5 -> gapf[li + l + 1] */
+#pragma unroll
+                        for (int mm = 4; mm >= 0; --mm) if ((bits >> (4 - mm)) & 1u) bn = mm;
+                        lo = li - bn; hi = li + fn;
                     }
-                    if (largest <= LL_SHARP_PER_SEG) ns++;
-                    nls++;
-                    ll_mark(L, sel, lane);
+                    for (;;) {
+                        const unsigned long long m = __ballot(elig);
+                        if (!m) break;
+                        const int f = __ffsll((long long)m) - 1;
+                        const int sel = __builtin_amdgcn_readlane(li, f);
+                        const int slo = __builtin_amdgcn_readlane(lo, f), shi = __builtin_amdgcn_readlane(hi, f);
+                        npick++;
+                        if (pass == 0) {
+                            if (npick > LL_LSHARP_PER_SEG) { done = true; break; }          /* :281-284 */
+                            if (lane == 0) {
+                                if (npick <= LL_SHARP_PER_SEG) { L.lab[sel] = 2; L.lists[ns] = sel; }
+                                else L.lab[sel] = 1;
+                                L.lists[12 + nls] = sel;
+                            }
+                            if (npick <= LL_SHARP_PER_SEG) ns++;
+                            nls++;
+                        } else {
+                            if (lane == 0) { L.lab[sel] = -1; L.lists[132 + nf] = sel; }
+                            nf++;
+                            if (npick >= LL_FLAT_PER_SEG) { done = true; break; }           /* :328-331: before marking */
+                        }
+                        /* cloudNeighborPicked[slo..shi] = 1: registers for this chunk, LDS bitmap for later ones */
+                        const int idx = slo + lane;
+                        if (idx <= shi) atomicOr(&L.picked[idx >> 5], 1u << (idx & 31));
+                        if (li >= slo && li <= shi) elig = false;
+                    }
+                    if (__ballot(have && !cand) != 0ull) break;                         /* the rest is beyond the threshold */
                 }
-                if (__ballot(have && !cand) != 0ull) break;                         /* rest is <= threshold */
-            }
-            /* flats: ascending curvature (:316-359) */
-            int smallest = 0; done = false;
-            for (int c0 = 0; c0 < len && !done; c0 += 64) {
-                const bool have = c0 + lane < len;
-                const u64 key = have ? L.keys[sp + c0 + lane] : 0ull;
-                const int li = (int)(unsigned)key;
-                const bool cand = have && ((double)ll_u2f((unsigned)(key >> 32)) < V.curv_thr);
-                if (__ballot(cand) == 0ull) break;
-                for (;;) {
-                    const bool elig = cand && !ll_bit(L.picked, li);
-                    const unsigned long long m = __ballot(elig);
-                    if (!m) break;
-                    const int f = __ffsll((long long)m) - 1;
-                    const int sel = __shfl(li, f);
-                    if (lane == 0) { L.lab[sel] = -1; L.lists[132 + nf] = sel; }
-                    nf++;
-                    smallest++;
-                    if (smallest >= LL_FLAT_PER_SEG) { done = true; break; }         /* :328-331: before marking */
-                    ll_mark(L, sel, lane);
-                }
-                if (__ballot(have && !cand) != 0ull) break;
             }
         }
         if (lane == 0) { L.lists[156] = ns; L.lists[157] = nls; L.lists[158] = nf; }
     }
     __syncthreads();
 
+    LL_PHASE(2);
     /* ---------------- phase 4: less-flat compaction + VoxelGrid (:361-376) ---------------- */
     int n_lf_out = 0;
     if (active) {
@@ -309,7 +441,10 @@ __global__ __launch_bounds__(LL_BLOCK) void k_ring_features(LLView V, int first,
             }
             if (tid == 0) { segb[0] = 0; segb[1] = m; }
             __syncthreads();
-            ll_bitonic_segments(L.keys, segb, 1, tid);
+            LL_PHASE(3);
+            if (use_radix) ll_radix_sort_hi32<false>(L.keys, m, rs_cnt, L.scratch, segb, tid);
+            else ll_bitonic_segments(L.keys, segb, 1, tid);
+            LL_PHASE(4);
             __syncthreads();
             /* run heads -> output rank */
             const int perm = (m + LL_BLOCK - 1) / LL_BLOCK;
@@ -323,17 +458,23 @@ __global__ __launch_bounds__(LL_BLOCK) void k_ring_features(LLView V, int first,
                 const unsigned vid = (unsigned)(L.keys[p] >> 32);
                 if (p != 0 && vid == (unsigned)(L.keys[p - 1] >> 32)) continue;
                 /* CentroidPoint<PointXYZI>: f32 sums in input order, divided by float(n) */
-                float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f; int cn = 0;
-                for (int q = p; q < m && (unsigned)(L.keys[q] >> 32) == vid; ++q) {
-                    const float4 pt = cloud[off + L.lf_list[(unsigned)L.keys[q]]];
-                    sx += pt.x; sy += pt.y; sz += pt.z; si += pt.w; cn++;
+                float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f;
+                int e = p + 1;
+                while (e < m && (unsigned)(L.keys[e] >> 32) == vid) ++e;             /* run = [p, e) */
+                for (int q = p; q < e; q += 4) {                                     /* 4 independent gathers in flight, */
+                    float4 pt[4];                                                    /* then the adds in input order     */
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (q + u < e) pt[u] = cloud[off + L.lf_list[(unsigned)L.keys[q + u]]];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (q + u < e) { sx += pt[u].x; sy += pt[u].y; sz += pt[u].z; si += pt[u].w; }
                 }
-                const float fn = (float)cn;
+                const float fn = (float)(e - p);
                 out[o++] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
             }
         }
     }
 
+    LL_PHASE(5);
     /* ---------------- phase 5: labels + feature slots ---------------- */
     int8_t *label = V.label + (size_t)s * V.NP + off;
     for (int i = tid; i < nr; i += LL_BLOCK) label[i] = L.lab[i];
@@ -343,6 +484,10 @@ __global__ __launch_bounds__(LL_BLOCK) void k_ring_features(LLView V, int first,
     if (tid < nls) V.lsharp_slot[ring_id * 120 + tid] = cloud[off + L.lists[12 + tid]];
     if (tid < nf) V.flat_slot[ring_id * 24 + tid] = cloud[off + L.lists[132 + tid]];
     if (tid == 0) { fcnt[0] = ns; fcnt[1] = nls; fcnt[2] = nf; fcnt[3] = n_lf_out; }
+    LL_PHASE(6);
+#ifdef LL_PHASE_TIMING
+    if (tid == 0) atomicAdd(&V.dbg[15], 1ull);
+#endif
 }
 
 /* per-ring slots -> clouds in publication order (ring, segment, pick order; :273-279, :325, :376) */

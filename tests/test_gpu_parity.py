@@ -185,6 +185,21 @@ def test_hot_path_matches_staged(case, odo):
         assert (ctx.pose(k) == staged[i]).all()
 
 
+def test_long_ring_capacity_path(api, orc, synth):
+    """max_ring_points above the radix-sort capacity (2304) switches the feature kernel to its any-length bitonic
+    network; the published clouds must not change."""
+    cfg = synth.default_cfg(64)
+    scan = synth.scan(cfg, 3)
+    ref = orc.extract(scan, orc.params(64))
+    ctx = api.Context(api.default_params(64, batch=1, max_points=len(scan), max_ring_points=4608))
+    ctx.upload_scan(0, scan)
+    ctx.extract(0, 1)
+    f = ctx.features(0)
+    for name in ("sharp", "less_sharp", "flat", "less_flat"):
+        assert_bit_equal(f[name], ref[name], f"long-ring path {name}")
+    ctx.close()
+
+
 def test_vote_disabled_keeps_all(case, odo):
     """now_frame <= 5 branch (laserOdometry.cpp:781-787): every plane correspondence, weight 1."""
     ctx = case["ctx"]

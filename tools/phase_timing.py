@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Per-phase shader cycles inside k_ring_features: builds an instrumented copy of the library (-DLL_PHASE_TIMING)
+under gpurun_out/, runs a batch of S64 scans through it and prints the average cycles per workgroup per phase."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+out = os.path.join(ROOT, "gpurun_out", "liblightloam_hip_phase.so")
+os.makedirs(os.path.dirname(out), exist_ok=True)
+os.environ["LIGHTLOAM_HIP_LIB"] = out
+import lightloam_amd  # noqa: E402,F401
+from lightloam_amd import build, api, synth  # noqa: E402
+
+build.build_hip(force=True, extra_flags=["-DLL_PHASE_TIMING"])
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+cfg = synth.default_cfg(64)
+scans = [synth.scan(cfg, k) for k in range(4)]
+ctx = api.Context(api.default_params(64, batch=B, max_points=max(map(len, scans))))
+for i in range(B):
+    ctx.upload_scan(i, scans[i % 4])
+ctx.extract(0, B)
+buf = (C.c_ulonglong * 16)()
+ctx._ck(ctx.lib.ll_debug_counters(ctx.h, buf, 1))
+ctx.extract(0, B)
+ctx._ck(ctx.lib.ll_debug_counters(ctx.h, buf, 1))
+names = ["p1 curvature+keys", "p2 segment sort", "p3 greedy pick", "p4a compact+bounds+voxel keys", "p4b voxel sort",
+         "p4c heads+centroids", "p5 outputs"]
+n = max(1, buf[15])
+tot = sum(buf[i] for i in range(7))
+print(f"k_ring_features phase timing over {buf[15]} workgroups (s_memtime cycles per workgroup, thread 0 wall):")
+for i, nm in enumerate(names):
+    print(f"  {nm:32s} {buf[i] / n:10.0f}  {100.0 * buf[i] / max(1, tot):5.1f}%")
+print(f"  {'total':32s} {tot / n:10.0f}")
