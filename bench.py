@@ -168,7 +168,7 @@ def main():
         # dominant kernel by summed HIP-event time; algorithmic bytes of the stage it belongs to, per launch
         dom = max(prof, key=lambda k: prof[k][0])
         dom_ms, dom_launches = prof[dom]
-        stage_bytes = {"k_classify": ab["ext"], "k_offsets": ab["ext"], "k_scatter": ab["ext"], "k_ring_features": ab["ext"],
+        stage_bytes = {"k_first_kept": ab["ext"], "k_classify": ab["ext"], "k_offsets": ab["ext"], "k_scatter": ab["ext"], "k_ring_features": ab["ext"],
                        "k_compact": ab["ext"], "k_associate": ab["assoc"], "k_build_grid": ab["assoc"], "k_vote": ab["vote"],
                        "k_normal_equations": ab["rj"], "k_gn_step": ab["rj"]}[dom]
         launches_per_step = max(1, dom_launches // max(1, args.steps))

@@ -21,7 +21,7 @@ struct LLProfiler {
     int launches[LL_K_COUNT] = {0};
 };
 static const char *const kKernelNames[LL_K_COUNT] = {"k_classify", "k_offsets", "k_scatter", "k_ring_features", "k_compact",
-                                                     "k_associate", "k_vote", "k_normal_equations", "k_gn_step", "k_build_grid"};
+                                                     "k_associate", "k_vote", "k_normal_equations", "k_gn_step", "k_build_grid", "k_first_kept"};
 
 void ll_prof_mark(LLProfiler *p, int kernel_id, hipStream_t st)
 {

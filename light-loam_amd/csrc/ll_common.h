@@ -135,7 +135,7 @@ __device__ __forceinline__ void ll_targets(const LLView &V, int s, const float4 
 
 /* per-kernel HIP-event profiler (ll_api.hip); mark(id) = "kernel id starts here, the previous one ended" */
 enum { LL_K_CLASSIFY = 0, LL_K_OFFSETS, LL_K_SCATTER, LL_K_RING_FEATURES, LL_K_COMPACT, LL_K_ASSOCIATE, LL_K_VOTE,
-       LL_K_NORMAL_EQ, LL_K_GN_STEP, LL_K_GRID, LL_K_COUNT, LL_K_END = -1 };
+       LL_K_NORMAL_EQ, LL_K_GN_STEP, LL_K_GRID, LL_K_FIRST, LL_K_COUNT, LL_K_END = -1 };
 struct LLProfiler;
 void ll_prof_mark(LLProfiler *p, int kernel_id, hipStream_t st);
 

@@ -43,6 +43,40 @@ __device__ __forceinline__ int ll_scan_id(const LLView &V, const float4 p)
     return (id > V.R - 1 || id < 0) ? -1 : id;
 }
 
+/* first kept point of each scan -> startOri (:114).  One workgroup per scan, 4 points per thread per round, stops at
+ * the first round that keeps anything.  (With minimum_range 5 the first rings of a ring-major scan are dropped
+ * entirely: the first kept point can be tens of thousands of points in.) */
+__global__ __launch_bounds__(LL_BLOCK) void k_first_kept(LLView V, int first, int count)
+{
+    if ((int)blockIdx.x >= count) return;
+    const int s = first + blockIdx.x;
+    const int n_in = V.n_in[s];
+    const int tid = threadIdx.x;
+    const float4 *raw = V.raw + (size_t)s * V.NP;
+    __shared__ int sh_first;
+    if (tid == 0) sh_first = INT_MAX;
+    __syncthreads();
+    for (int c = 0; c < n_in; c += LL_TILE) {
+        int mine = INT_MAX;
+#pragma unroll
+        for (int k = LL_TILE / LL_BLOCK - 1; k >= 0; --k) {
+            const int i = c + k * LL_BLOCK + tid;
+            if (i < n_in && ll_keep(raw[i], V.thres)) mine = i;
+        }
+        if (__syncthreads_or(mine != INT_MAX ? 1 : 0)) {
+            if (mine != INT_MAX) atomicMin(&sh_first, mine);
+            break;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int fk = sh_first;
+        float start_ori = 0.0f;
+        if (fk != INT_MAX) { const float4 p0 = raw[fk]; start_ori = -ll_atan2f(p0.y, p0.x); }
+        V.hdr[s].start_ori = start_ori; V.hdr[s].first_kept = fk;
+    }
+}
+
 __global__ __launch_bounds__(LL_BLOCK) void k_classify(LLView V, int first, int count)
 {
     int sl, tile;
@@ -50,29 +84,16 @@ __global__ __launch_bounds__(LL_BLOCK) void k_classify(LLView V, int first, int 
     const int s = first + sl;
     const int n_in = V.n_in[s];
     const int base = tile * LL_TILE;
-    if (base >= n_in && !(tile == 0)) return;
+    if (base >= n_in) return;
     const int tid = threadIdx.x;
     const float4 *raw = V.raw + (size_t)s * V.NP;
 
-    __shared__ int sh_first, sh_first_p, sh_fk, sh_lk;
+    __shared__ int sh_first_p, sh_fk, sh_lk;
     __shared__ int hist[LL_MAX_RINGS];
-    if (tid == 0) { sh_first = INT_MAX; sh_first_p = INT_MAX; sh_fk = INT_MAX; sh_lk = -1; }
+    if (tid == 0) { sh_first_p = INT_MAX; sh_fk = INT_MAX; sh_lk = -1; }
     if (tid < LL_MAX_RINGS) hist[tid] = 0;
     __syncthreads();
-
-    /* first kept point of the scan -> startOri (:114).  Usually index 0: one iteration. */
-    for (int c = 0; c < n_in; c += LL_BLOCK) {
-        const int i = c + tid;
-        const bool kept = i < n_in && ll_keep(raw[i], V.thres);
-        if (__syncthreads_or(kept ? 1 : 0)) {
-            if (kept) atomicMin(&sh_first, i);
-            break;
-        }
-    }
-    __syncthreads();
-    const int fk = sh_first;
-    float start_ori = 0.0f;
-    if (fk != INT_MAX) { const float4 p0 = raw[fk]; start_ori = -ll_atan2f(p0.y, p0.x); }
+    const float start_ori = V.hdr[s].start_ori;                      /* k_first_kept */
 
     float *ori = V.ori + (size_t)s * V.NP;
     int8_t *ring = V.ring + (size_t)s * V.NP;
@@ -125,7 +146,6 @@ __global__ __launch_bounds__(LL_BLOCK) void k_classify(LLView V, int first, int 
         V.tile_first_p[tb] = sh_first_p;
         V.tile_first_kept[tb] = sh_fk;
         V.tile_last_kept[tb] = sh_lk;
-        if (tile == 0) { V.hdr[s].start_ori = start_ori; V.hdr[s].first_kept = fk; }
     }
 }
 
@@ -258,6 +278,8 @@ void ll_launch_organize(const LLView &V, int first, int count, hipStream_t st, L
 {
     const int groups = (count + 7) / 8;
     const int grid = 8 * V.T * groups;
+    ll_prof_mark(prof, LL_K_FIRST, st);
+    hipLaunchKernelGGL(k_first_kept, dim3(count), dim3(LL_BLOCK), 0, st, V, first, count);
     ll_prof_mark(prof, LL_K_CLASSIFY, st);
     hipLaunchKernelGGL(k_classify, dim3(grid), dim3(LL_BLOCK), 0, st, V, first, count);
     ll_prof_mark(prof, LL_K_OFFSETS, st);
