@@ -1,0 +1,55 @@
+"""The bit-exact libm restatements the HIP path uses for ring / azimuth assignment and the vote predicate
+(light-loam_amd/csrc/ll_exact_math.h) against the HOST libm the reference calls.  The header is compiled for the
+host with g++ -ffp-contract=off (same source the device compiles), so this pins the device arithmetic to glibc."""
+import ctypes as C
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "native", "exact_math_host.cpp")
+OUT = os.path.join(ROOT, "tests", "native", "_build", "libexact_math_host.so")
+
+
+@pytest.fixture(scope="module")
+def em():
+    hdr = os.path.join(ROOT, "light-loam_amd", "csrc", "ll_exact_math.h")
+    if not os.path.exists(OUT) or max(os.path.getmtime(SRC), os.path.getmtime(hdr)) > os.path.getmtime(OUT):
+        os.makedirs(os.path.dirname(OUT), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-fno-fast-math",
+                               "-I", os.path.dirname(hdr), "-o", OUT, SRC, "-lm"])
+    lib = C.CDLL(OUT)
+    lib.em_check_atanf.restype = C.c_longlong
+    lib.em_check_atanf.argtypes = [C.c_ulonglong, C.c_ulonglong, C.POINTER(C.c_uint)]
+    lib.em_check_atan2f.restype = C.c_longlong
+    lib.em_check_atan2f.argtypes = [C.c_longlong, C.c_ulonglong]
+    lib.em_check_atan2f_specials.restype = C.c_longlong
+    lib.em_check_vote.restype = C.c_longlong
+    lib.em_check_vote.argtypes = [C.c_ulonglong, C.c_ulonglong]
+    return lib
+
+
+def test_atanf_stratified(em):
+    """every 61st bit pattern of all 2^32 floats (7e7 inputs, every exponent and both signs)."""
+    bad = C.c_uint(0xffffffff)
+    assert em.em_check_atanf(17, 61, C.byref(bad)) == 0, hex(bad.value)
+
+
+@pytest.mark.slow
+def test_atanf_exhaustive(em):
+    bad = C.c_uint(0xffffffff)
+    assert em.em_check_atanf(0, 1, C.byref(bad)) == 0, hex(bad.value)
+
+
+def test_atan2f_special_values(em):
+    assert em.em_check_atan2f_specials() == 0
+
+
+def test_atan2f_random_pairs(em):
+    assert em.em_check_atan2f(80_000_000, 0x1234567) == 0
+
+
+def test_vote_predicate_threshold_all_non_negative_floats(em):
+    """std::exp(-gap2) < 0.96f  <=>  gap2 >= 0x3d273506, for EVERY non-negative f32 (2^31 inputs, ~7 s on 8 cores)."""
+    assert em.em_check_vote(0, 1) == 0

@@ -1,0 +1,461 @@
+"""CPU tests of the oracle (oracle/ll_oracle.c): known-answer cases derived by hand from the reference source,
+independent cross-checks of the restated third-party arithmetic (finite differences, a second derivation in
+torch float64 autograd), and the edge cases the reference code paths contain.
+
+The reference ships no tests or golden vectors and cannot be built in this image, so these do
+NOT pin the oracle to the reference ("parity unpinned", see oracle/ll_oracle.h); they pin it to the behaviour we
+read out of the cited lines.
+"""
+import numpy as np
+import pytest
+
+
+def ring_point(ring, az_deg, rng_m, lower=-24.9, upper=2.0, n=64):
+    el = np.deg2rad(lower + (upper - lower) * ring / (n - 1))
+    az = np.deg2rad(az_deg)
+    return [rng_m * np.cos(el) * np.cos(az), rng_m * np.cos(el) * np.sin(az), rng_m * np.sin(el)]
+
+
+# ----------------------------------------------------------------------------- a1
+def test_ring_assignment_bin_centres(orc):
+    """scanRegistration.cpp:162: scanID = int((angle - lowerBound) * factor + 0.5) at exact bin centres."""
+    pts = np.array([ring_point(r, -10.0 * k - 1, 20.0) for r in range(64) for k in range(20)], np.float32)
+    rc, cloud, ss, se = orc.organize(pts, orc.params(64))
+    assert rc == 0 and len(cloud) == len(pts)
+    assert (cloud[:, 3].astype(int) == np.repeat(np.arange(64), 20)).all()
+    assert (ss == np.arange(64) * 20 + 5).all() and (se == (np.arange(64) + 1) * 20 - 6).all()
+
+
+def test_vlp16_and_hdl32_formulas(orc):
+    for n, formula in ((16, lambda a: int((a + 15) / 2 + 0.5)), (32, lambda a: int((a + 92.0 / 3.0) * 3.0 / 4.0))):
+        angs = np.linspace(-14.9, 14.9, 41) if n == 16 else np.linspace(-30.3, 10.2, 41)
+        # y decreasing = clockwise sweep, so relTime >= 0 and int(intensity) is the ring itself
+        pts = np.array([[10 * np.cos(np.deg2rad(a)), -0.1 * i, 10 * np.sin(np.deg2rad(a))] for i, a in enumerate(angs)], np.float32)
+        rc, cloud, ss, se = orc.organize(pts, orc.params(n, minimum_range=0.3))
+        got = np.sort(cloud[:, 3].astype(int))
+        want = np.sort([formula(np.float32(np.rad2deg(np.arctan(p[2] / np.hypot(p[0], p[1]))))) for p in pts])
+        assert (got == want).all()
+
+
+def test_filters_nan_min_range_and_ring_rejection(orc):
+    P = orc.params(64)                                   # minimum_range 5
+    pts = np.array([ring_point(10, 0, 20), [np.nan, 1, 1], ring_point(10, -1, 4.9), ring_point(10, -2, 5.1),
+                    [10, 0, 10],                        # elevation 45 deg -> scanID out of range -> dropped (:164-168)
+                    [np.inf, 0, 0], ring_point(11, -3, 30)], np.float32)
+    rc, cloud, _, _ = orc.organize(pts, P)
+    assert rc == 0 and len(cloud) == 3
+    assert np.allclose(cloud[:, :3], pts[[0, 3, 6]], atol=0)
+
+
+def test_empty_after_filtering_is_an_error(orc):
+    rc, cloud, _, _ = orc.organize(np.array([[1, 1, 1], [np.nan, 0, 0]], np.float32), orc.params(64))
+    assert rc == -1 and len(cloud) == 0                  # the reference would dereference points[0]
+    assert orc.organize(np.zeros((0, 3), np.float32), orc.params(64))[0] == -1
+
+
+def test_bad_scan_line_count(orc):
+    assert orc.organize(np.ones((4, 3), np.float32), orc.params(48))[0] == -2       # :447-451
+    assert orc.organize(np.array([ring_point(3, 0, 10, n=48)], np.float32), orc.params(48, ring_model=1))[0] == 0
+
+
+def test_rel_time_azimuth_major_sweep(orc):
+    """Clockwise sweep in firing order: relTime grows 0 -> 1 (:177-208); intensity = ring + 0.1 * relTime."""
+    az = -np.arange(0, 360, 2.0)
+    pts = np.array([ring_point(20, a, 15.0) for a in az], np.float32)
+    rc, cloud, _, _ = orc.organize(pts, orc.params(64))
+    frac = cloud[:, 3] - 20
+    assert rc == 0 and (np.diff(frac) > 0).all() and frac[0] == 0 and 0.099 < frac[-1] < 0.1001
+
+
+def test_negative_rel_time_lowers_the_integer_part(orc):
+    """A point just BEFORE the start azimuth gets relTime < 0, so int(intensity) reads ring-1: the reference's walks
+    use int(intensity) as the scan id (laserOdometry.cpp:500); the restatement must keep that quirk."""
+    pts = np.array([ring_point(20, 0.0, 15.0), ring_point(21, +0.5, 15.0), ring_point(21, -90, 15.0),
+                    ring_point(21, -200, 15.0), ring_point(21, -359, 15.0)], np.float32)
+    rc, cloud, _, _ = orc.organize(pts, orc.params(64))
+    first21 = cloud[1]
+    assert first21[3] < 21 and int(first21[3]) == 20
+
+
+def test_half_passed_is_sticky(orc):
+    """Once (ori - startOri) > pi was seen, later points use the endOri branch (:194-205) even at small azimuth."""
+    pts = np.array([ring_point(5, 0, 12), ring_point(5, -190, 12), ring_point(6, -10, 12), ring_point(6, -350, 12)], np.float32)
+    rc, cloud, _, _ = orc.organize(pts, orc.params(64))
+    ring6 = cloud[cloud[:, 3].astype(int) >= 6]
+    # -10 deg after halfPassed is read as 370 deg: relTime > 1
+    assert (ring6[0, 3] - 6) > 0.1
+
+
+# ----------------------------------------------------------------------------- a2 / a3
+def line_ring(n, step=0.05, rng_m=10.0, ring=30, bump=None):
+    """n points of one ring on a straight wall x = rng_m (y advancing by step), optional lateral bumps."""
+    el = np.deg2rad(-24.9 + 26.9 * ring / 63)
+    y = (np.arange(n) - n / 2) * step
+    x = np.full(n, rng_m)
+    if bump:
+        for i, d in bump.items():
+            x[i] += d
+    z = np.hypot(x, y) * np.tan(el)
+    return np.stack([x, y, z], 1).astype(np.float32)
+
+
+def test_curvature_of_a_straight_line_is_tiny_and_labels_are_flat(orc):
+    pts = line_ring(200)
+    ex = orc.extract(pts, orc.params(64))
+    assert ex["rc"] == 0 and len(ex["sharp"]) == 0 and len(ex["less_sharp"]) == 0
+    assert len(ex["flat"]) == 6 * 4                     # 4 flats per segment (:328-331)
+    assert ex["curv"][5:-5].max() < 1e-3
+
+
+def py_extract_labels(cloud, scan_start, scan_end):
+    """Independent restatement of scanRegistration.cpp:225-368 in plain Python/numpy-f32 (labels + pick lists)."""
+    f = np.float32
+    n = len(cloud)
+    X = cloud[:, :3].astype(np.float32)
+    curv = np.zeros(n, np.float32)
+    for i in range(5, n - 5):
+        d = np.zeros(3, np.float32)
+        for c in range(3):
+            acc = X[i - 5, c]
+            for k in (-4, -3, -2, -1):
+                acc = f(acc + X[i + k, c])
+            acc = f(acc - f(f(10) * X[i, c]))
+            for k in (1, 2, 3, 4, 5):
+                acc = f(acc + X[i + k, c])
+            d[c] = acc
+        curv[i] = f(f(f(d[0] * d[0]) + f(d[1] * d[1])) + f(d[2] * d[2]))
+    label = np.zeros(n, np.int32); picked = np.zeros(n + 8, np.int32)
+    sharp, less_sharp, flat = [], [], []
+
+    def gap2(a, b):
+        e = X[a] - X[b]
+        return f(f(f(e[0] * e[0]) + f(e[1] * e[1])) + f(e[2] * e[2]))
+
+    def mark(ind):
+        for l in range(1, 6):
+            if float(gap2(ind + l, ind + l - 1)) > 0.05:
+                break
+            picked[ind + l] = 1
+        for l in range(-1, -6, -1):
+            if float(gap2(ind + l, ind + l + 1)) > 0.05:
+                break
+            picked[ind + l] = 1
+
+    for S, E in zip(scan_start, scan_end):
+        if E - S < 6:
+            continue
+        for j in range(6):
+            sp = S + (E - S) * j // 6; ep = S + (E - S) * (j + 1) // 6 - 1
+            order = sorted(range(sp, ep + 1), key=lambda i: (curv[i], i))
+            big = 0
+            for ind in reversed(order):
+                if picked[ind] == 0 and float(curv[ind]) > 0.1:
+                    big += 1
+                    if big <= 2:
+                        label[ind] = 2; sharp.append(ind); less_sharp.append(ind)
+                    elif big <= 20:
+                        label[ind] = 1; less_sharp.append(ind)
+                    else:
+                        break
+                    picked[ind] = 1; mark(ind)
+            small = 0
+            for ind in order:
+                if picked[ind] == 0 and float(curv[ind]) < 0.1:
+                    label[ind] = -1; flat.append(ind); small += 1
+                    if small >= 4:
+                        break
+                    picked[ind] = 1; mark(ind)
+    return curv, label, sharp, less_sharp, flat
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_pick_against_independent_python_restatement(orc, seed):
+    """Random rough rings (many corners, small gaps so that suppression crosses segment boundaries, short rings)."""
+    rng = np.random.default_rng(100 + seed)
+    rings = []
+    for ring, n in zip((10, 11, 12, 13, 14), (rng.integers(17, 60), 16, rng.integers(60, 200), 5, rng.integers(30, 90))):
+        el = np.deg2rad(-24.9 + 26.9 * ring / 63)
+        y = -(np.arange(n) - n / 2) * rng.choice([0.02, 0.05, 0.3])
+        x = 10 + rng.normal(0, rng.choice([0.001, 0.02, 0.2]), n)
+        rings.append(np.stack([x, y, np.hypot(x, y) * np.tan(el)], 1))
+    pts = np.concatenate(rings).astype(np.float32)
+    ex = orc.extract(pts, orc.params(64))
+    assert ex["rc"] == 0 and len(ex["cloud"]) == len(pts)
+    curv, label, sharp, less_sharp, flat = py_extract_labels(ex["cloud"], ex["scan_start"], ex["scan_end"])
+    n = len(pts)
+    assert (curv[5:n - 5] == ex["curv"][5:n - 5]).all()
+    assert (label[5:n - 5] == ex["label"][5:n - 5]).all()
+    for name, idx in (("sharp", sharp), ("less_sharp", less_sharp), ("flat", flat)):
+        assert len(ex[name]) == len(idx) and (ex[name] == ex["cloud"][idx]).all(), name
+
+
+def test_single_bump_is_picked_sharp(orc):
+    pts = line_ring(200, bump={100: 0.5})
+    ex = orc.extract(pts, orc.params(64))
+    assert ex["label"][100] == 2 and len(ex["sharp"]) >= 1
+    assert any((ex["cloud"][100] == s).all() for s in ex["sharp"])
+
+
+def test_more_than_twenty_corners_in_a_segment(orc):
+    """Every 12th point bumped (suppression reaches +-5 only when gaps are small; bumps of 1 m break the gap test)."""
+    bump = {i: 1.0 for i in range(6, 600, 2)}
+    pts = line_ring(600, bump=bump)
+    ex = orc.extract(pts, orc.params(64))
+    lab = ex["label"]
+    seg = (len(pts) - 11) // 6
+    assert (lab == 2).sum() == 12 and (lab == 1).sum() == 6 * 18   # 2 sharp + 18 less-sharp per segment, 21st breaks
+    assert len(ex["less_sharp"]) == 6 * 20
+
+
+def test_short_ring_is_skipped(orc):
+    """scanEndInd - scanStartInd < 6 (:248): a ring with 16 points produces nothing.  17 points: six one-point
+    segments; the first flat pick suppresses the other five (+-5 neighbours, small gaps), so exactly one flat."""
+    for n, expect in ((16, 0), (17, 1)):
+        ex = orc.extract(line_ring(n), orc.params(64))
+        assert len(ex["flat"]) == expect
+
+
+# ----------------------------------------------------------------------------- a4
+def test_voxel_grid_is_the_per_voxel_mean(orc):
+    rng = np.random.default_rng(1)
+    pts = np.concatenate([rng.uniform(-3, 3, (500, 3)), rng.uniform(0, 1, (500, 1))], 1).astype(np.float32)
+    out = orc.voxel_grid(pts, 0.2)
+    inv = np.float32(1.0) / np.float32(0.2)
+    mn = np.floor(pts[:, :3].min(0) * inv).astype(int)
+    ijk = np.floor(pts[:, :3] * inv).astype(int) - mn
+    div = ijk.max(0) + 1
+    vid = ijk[:, 0] + ijk[:, 1] * div[0] + ijk[:, 2] * div[0] * div[1]
+    uniq = np.unique(vid)
+    assert len(out) == len(uniq)
+    for k, v in enumerate(uniq):                         # output is ordered by voxel index
+        sel = pts[vid == v]
+        acc = np.zeros(4, np.float32)
+        for p in sel:                                    # f32 sums in input order, then / float(n)
+            acc = acc + p
+        assert (out[k] == acc / np.float32(len(sel))).all()
+
+
+def test_voxel_grid_empty_and_single(orc):
+    assert len(orc.voxel_grid(np.zeros((0, 4), np.float32))) == 0
+    p = np.array([[1.23, -4.5, 0.7, 12.05]], np.float32)
+    assert (orc.voxel_grid(p) == p).all()
+
+
+# ----------------------------------------------------------------------------- a5-a7
+def test_transform_to_start_is_a_rigid_transform(orc):
+    q = np.array([0.1, -0.2, 0.3, 0.9]); q /= np.linalg.norm(q)
+    t = np.array([1.0, 2.0, -0.5])
+    pts = np.array([[1, 2, 3, 7.1], [-4, 0.5, 2, 3.05]], np.float32)
+    out = orc.transform_to_start(q, t, pts)
+    x, y, z, w = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    assert np.allclose(out[:, :3], pts[:, :3].astype(np.float64) @ R.T + t, atol=1e-5)
+    assert (out[:, 3] == pts[:, 3]).all()
+
+
+def test_corner_association_picks_a_different_ring_within_two(orc):
+    """NN + walk (:491-553): second point must be on another ring, at most 2 rings away, nearest to the query."""
+    tgt = []
+    for ring in range(10, 16):
+        for k in range(5):
+            tgt.append([10 + 0.3 * k, 0.1 * (ring - 10), 0.0, ring + 0.01 * k])
+    tgt = np.array(tgt, np.float32)
+    q = np.array([[10.31, 0.21, 0.0, 0.0]], np.float32)         # nearest: ring 12, k = 1
+    src, a, b = orc.associate_corner([0, 0, 0, 1], [0, 0, 0], q, tgt)
+    assert len(src) == 1 and int(tgt[a[0], 3]) == 12
+    assert int(tgt[b[0], 3]) in (11, 13) and abs(tgt[b[0], 0] - 10.3) < 1e-5
+    # nothing within 5 m -> no correspondence
+    src, a, b = orc.associate_corner([0, 0, 0, 1], [0, 0, 50.0], q, tgt)
+    assert len(src) == 0
+
+
+def test_plane_association_needs_same_or_lower_and_other_ring(orc):
+    tgt = np.array([[10, 0, 0, 5.0], [10.2, 0, 0, 5.02], [10.4, 0, 0, 5.04], [10, 0.3, 0, 6.0], [10.2, 0.3, 0, 6.02]], np.float32)
+    q = np.array([[10.05, 0.02, 0, 0]], np.float32)
+    src, a, b, c = orc.associate_plane([0, 0, 0, 1], [0, 0, 0], q, tgt)
+    assert (a[0], b[0], c[0]) == (0, 1, 3)
+    # remove the other ring -> no third point -> no correspondence (:723)
+    src, a, b, c = orc.associate_plane([0, 0, 0, 1], [0, 0, 0], q, tgt[:3])
+    assert len(src) == 0
+
+
+def test_grid_nn_equals_linear_scan(orc, synth):
+    cfg = synth.default_cfg(16)
+    e0 = orc.extract(synth.scan(cfg, 0), orc.params(16)); e1 = orc.extract(synth.scan(cfg, 1), orc.params(16))
+    for pose in ([0, 0, 0, 1, 0, 0, 0], [0.01, 0, 0.05, 1, 2.0, -1.0, 0.1], [0, 0, 0, 1, 40, 0, 0]):
+        q = np.array(pose[:4], float); q /= np.linalg.norm(q); t = np.array(pose[4:], float)
+        orc.set_nn_mode(0)
+        a = orc.associate_corner(q, t, e1["sharp"], e0["less_sharp"]) + orc.associate_plane(q, t, e1["flat"], e0["less_flat"])
+        orc.set_nn_mode(1)
+        b = orc.associate_corner(q, t, e1["sharp"], e0["less_sharp"]) + orc.associate_plane(q, t, e1["flat"], e0["less_flat"])
+        orc.set_nn_mode(0)
+        assert all(len(x) == len(y) and (x == y).all() for x, y in zip(a, b))
+
+
+# ----------------------------------------------------------------------------- a8
+def test_vote_small_inputs_use_one_region(orc):
+    """n < number_of_region: cor_size_all / 10 == 0, every region but the last is empty (:202-215)."""
+    rng = np.random.default_rng(2)
+    src = rng.uniform(-5, 5, (7, 4)).astype(np.float32)
+    tgt = src.copy(); tgt[3, :3] += 3.0                 # one outlier correspondence
+    cnt, idx, w = orc.vote(src, tgt)
+    assert cnt[3] == 6 and (np.delete(cnt, 3) == 1).all()
+    # 6 > 0.9f * 7 = 6.3 is false: even the outlier is kept (:312), and every count is <= 50 -> weight 5
+    assert sorted(idx.tolist()) == list(range(7)) and (w == 5.0).all()
+    assert idx[-1] == 3                                            # ascending count: the outlier comes last
+
+
+def test_vote_weight_switch_at_fifty(orc):
+    """count <= 50 -> weight 5, else 1 (:317-322); count > 0.9 * m -> dropped."""
+    rng = np.random.default_rng(3)
+    n = 1500                                            # 10 regions of 150
+    src = rng.uniform(-20, 20, (n, 4)).astype(np.float32)
+    tgt = src.copy()
+    bad = np.arange(0, 150, 2)[:60]                     # 60 inconsistent correspondences in region 0
+    tgt[bad, :3] += rng.uniform(900, 1100, (60, 3)).astype(np.float32)   # far beyond any pairwise distance
+    cnt, idx, w = orc.vote(src, tgt)
+    good0 = np.setdiff1d(np.arange(150), bad)
+    assert (cnt[good0] == 60).all()                     # each good one disagrees with the 60 bad ones only
+    wmap = dict(zip(idx.tolist(), w.tolist()))
+    assert all(wmap[i] == 1.0 for i in good0)           # 60 > 50 -> weight 1
+    assert all(wmap[i] == 5.0 for i in range(150, n))
+    assert all(b not in wmap for b in bad if cnt[b] > 0.9 * 150)
+
+
+def test_vote_counts_are_symmetric_pair_counts(orc):
+    rng = np.random.default_rng(4)
+    src = rng.uniform(-5, 5, (40, 4)).astype(np.float32); tgt = rng.uniform(-5, 5, (40, 4)).astype(np.float32)
+    cnt, _, _ = orc.vote(src, tgt)
+    total = 0
+    for r in range(10):
+        b0, b1 = 4 * r, (40 if r == 9 else 4 * (r + 1))
+        for i in range(b0, b1):
+            for j in range(i + 1, b1):
+                s1 = np.sqrt(np.float32(((src[i, :3] - src[j, :3]) ** 2).sum(dtype=np.float32)))
+                s2 = np.sqrt(np.float32(((tgt[i, :3] - tgt[j, :3]) ** 2).sum(dtype=np.float32)))
+                total += 2 * int(np.exp(-np.float32(abs(s1 - s2)) ** 2) < np.float32(0.96))
+    assert abs(int(cnt.sum()) - total) <= 2             # numpy's f32 summation order may flip a borderline pair
+
+
+# ----------------------------------------------------------------------------- a9 / a10
+def rand_pose(rng, small=True):
+    q = np.concatenate([rng.normal(0, 0.05 if small else 0.5, 3), [1.0]]); q /= np.linalg.norm(q)
+    return q, rng.normal(0, 1.0, 3)
+
+
+def fd_jacobian(f, q, t, eps=1e-6):
+    r0 = f(q, t)
+    Jq = np.zeros((len(r0), 4)); Jt = np.zeros((len(r0), 3))
+    for k in range(4):
+        d = np.zeros(4); d[k] = eps
+        Jq[:, k] = (f(q + d, t) - f(q - d, t)) / (2 * eps)
+    for k in range(3):
+        d = np.zeros(3); d[k] = eps
+        Jt[:, k] = (f(q, t + d) - f(q, t - d)) / (2 * eps)
+    return Jq, Jt
+
+
+def test_factor_jacobians_match_finite_differences(orc):
+    rng = np.random.default_rng(5)
+    for trial in range(10):
+        q, t = rand_pose(rng, small=trial < 5)
+        cp, a, b, c = (rng.normal(0, 5, 3) for _ in range(4))
+        r, Jq, Jt = orc.edge_factor(q, t, cp, a, b)
+        fJq, fJt = fd_jacobian(lambda qq, tt: orc.edge_factor(qq, tt, cp, a, b)[0], q, t)
+        assert np.allclose(Jq, fJq, atol=1e-6 * max(1, np.abs(Jq).max())) and np.allclose(Jt, fJt, atol=1e-6)
+        r, Jq, Jt = orc.plane_factor_modify(q, t, cp, a, b, c, 1.0, 5.0)
+        fJq, fJt = fd_jacobian(lambda qq, tt: orc.plane_factor_modify(qq, tt, cp, a, b, c, 1.0, 5.0)[0], q, t)
+        assert np.allclose(Jq, fJq, atol=1e-6 * max(1, np.abs(Jq).max())) and np.allclose(Jt, fJt, atol=1e-6)
+        n = rng.normal(0, 1, 3); n /= np.linalg.norm(n)
+        r, Jq, Jt = orc.plane_norm_factor(q, t, cp, n, 0.7)
+        fJq, fJt = fd_jacobian(lambda qq, tt: orc.plane_norm_factor(qq, tt, cp, n, 0.7)[0], q, t)
+        assert np.allclose(Jq, fJq, atol=1e-6 * max(1, np.abs(Jq).max())) and np.allclose(Jt, fJt, atol=1e-6)
+
+
+def test_factors_against_torch_autograd(orc):
+    """Second, independent derivation: lidarFactor.hpp's formulas written in torch float64, differentiated by autograd."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(6)
+
+    def rot(q, v):
+        u, w = q[:3], q[3]
+        uv = 2 * torch.linalg.cross(u, v)
+        return v + w * uv + torch.linalg.cross(u, uv)
+
+    for _ in range(5):
+        qn, tn = rand_pose(rng)
+        cp, a, b, c = (torch.tensor(rng.normal(0, 5, 3)) for _ in range(4))
+        q = torch.tensor(qn, requires_grad=True); t = torch.tensor(tn, requires_grad=True)
+
+        def edge(q, t):
+            lp = rot(q, cp) + t
+            return torch.linalg.cross(lp - a, lp - b) / torch.linalg.norm(a - b)
+
+        def plane(q, t):
+            n = torch.linalg.cross(a - b, a - c); n = n / torch.linalg.norm(n)
+            return ((rot(q, cp) + t - a) @ n * 5.0).reshape(1)
+
+        for fn, ofn in ((edge, lambda: orc.edge_factor(qn, tn, cp.numpy(), a.numpy(), b.numpy())),
+                        (plane, lambda: orc.plane_factor_modify(qn, tn, cp.numpy(), a.numpy(), b.numpy(), c.numpy(), 1.0, 5.0))):
+            r, Jq, Jt = ofn()
+            Jq_t, Jt_t = torch.autograd.functional.jacobian(fn, (q, t))
+            assert np.allclose(r, fn(q, t).detach().numpy(), rtol=1e-12, atol=1e-12)
+            assert np.allclose(Jq, Jq_t.numpy(), rtol=1e-10, atol=1e-10) and np.allclose(Jt, Jt_t.numpy(), rtol=1e-10, atol=1e-10)
+
+
+def test_quaternion_manifold(orc):
+    rng = np.random.default_rng(7)
+    q, _ = rand_pose(rng, small=False)
+    P = orc.quat_plus_jacobian(q)
+    eps = 1e-7
+    fd = np.stack([(orc.quat_plus(q, eps * np.eye(3)[k]) - orc.quat_plus(q, -eps * np.eye(3)[k])) / (2 * eps) for k in range(3)], 1)
+    assert np.allclose(P, fd, atol=1e-7)
+    assert np.allclose(orc.quat_plus(q, np.zeros(3)), q)
+    d = np.array([0.1, -0.2, 0.05])
+    assert abs(np.linalg.norm(orc.quat_plus(q, d)) - 1) < 1e-12
+
+
+def test_huber_scaling_and_cost(orc):
+    """One edge block: s = |r|^2 > 0.01 -> rows scaled by sqrt(0.1/|r|), cost = 0.5*(2*0.1*|r| - 0.01)."""
+    sharp = np.array([[1, 0, 0, 0]], np.float32)
+    corner = np.array([[0, 0, 1, 0], [0, 0, -1, 0]], np.float32)         # line = z axis; distance of (1,0,0) is 1
+    z = np.zeros((0, 4), np.float32); zi = np.zeros(0, np.int32)
+    q = [0, 0, 0, 1]; t = [0, 0, 0]
+    H, g, cost = orc.normal_equations(q, t, sharp, [0], corner, [0], [1], z, zi, z, zi, zi, zi, None, 0.1)
+    assert abs(cost - 0.5 * (2 * 0.1 * 1.0 - 0.01)) < 1e-12
+    H0, g0, cost0 = orc.normal_equations(q, t, sharp, [0], corner, [0], [1], z, zi, z, zi, zi, zi, None, 0.0)
+    assert abs(cost0 - 0.5) < 1e-12 and np.allclose(H, 0.1 * H0) and np.allclose(g, 0.1 * g0)
+
+
+def test_gauss_newton_recovers_a_known_motion(orc, synth):
+    """Noise-free geometry: points on 3 orthogonal planes + 3 lines, moved by a known small transform."""
+    rng = np.random.default_rng(8)
+    qt, tt = rand_pose(rng); tt *= 0.05
+    # target structures (previous frame)
+    planes = [(np.array([1.0, 0, 0]), 10.0), (np.array([0, 1.0, 0]), -8.0), (np.array([0, 0, 1.0]), -1.7)]
+    surf, flat = [], []
+    for nrm, d in planes:
+        basis = np.linalg.svd(nrm.reshape(1, 3))[2][1:]
+        for ring in range(20, 26):
+            for k in range(30):
+                p = nrm * d + basis[0] * (k - 15) * 0.4 + basis[1] * (ring - 23) * 0.5
+                surf.append([*p, ring + 0.001 * k])
+    surf = np.array(surf, np.float32)
+    # current-frame points: x_cur with R x_cur + t = x_prev
+    x, y, z, w = qt
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    sel = rng.choice(len(surf), 200, replace=False)
+    flat = np.concatenate([((surf[sel, :3].astype(np.float64) - tt) @ R), surf[sel, 3:4]], 1).astype(np.float32)
+    q = np.array([0, 0, 0, 1.0]); t = np.zeros(3)
+    z4 = np.zeros((0, 4), np.float32); zi = np.zeros(0, np.int32)
+    for _ in range(5):
+        ps, pa, pb, pc = orc.associate_plane(q, t, flat, surf)
+        H, g, cost = orc.normal_equations(q, t, z4, zi, z4, zi, zi, flat, ps, surf, pa, pb, pc, None, 0.1)
+        rc, d = orc.gn_solve(H, g)
+        assert rc == 0
+        q, t = orc.pose_update(q, t, d)
+    assert np.allclose(t, tt, atol=2e-3) and min(np.abs(q - qt).max(), np.abs(q + qt).max()) < 1e-3
