@@ -136,6 +136,10 @@ int ll_download_plane_corr(ll_ctx *ctx, int slot, int *src, int *a, int *b, int 
  * graph_based_correspondence_vote_simple (laserOdometry.cpp:165-342, call :796) on the plane
  * correspondences of each pair.  enable = 0 reproduces the now_frame <= 5 branch (:781-787): all kept, weight 1. */
 int ll_vote_batch(ll_ctx *ctx, int first, int count, int enable);
+/* The free function itself, on caller-supplied host correspondences (Corre_Match.src / .tgt, laserOdometry.cpp:165-172):
+ * corner_case selects 5 regions instead of 10 (:179-188).  Outputs are per correspondence, in input order.          */
+int ll_vote_host(ll_ctx *ctx, const ll_point *host_src, const ll_point *host_tgt, int n, int corner_case,
+                 int *count, uint8_t *selected, float *weight);
 /* per plane correspondence (in correspondence order): incompatibility count, selected flag, weight      */
 int ll_download_vote(ll_ctx *ctx, int slot, int *count, uint8_t *selected, float *weight, int cap);
 

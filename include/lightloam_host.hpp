@@ -1,0 +1,193 @@
+/*
+ * lightloam_host.hpp -- C++ host-side mirror of the reference's own seams over the C ABI (lightloam_hip.h).
+ *
+ * The reference (BrenYi/Light-LOAM, paths relative to /root/reference/) is three ROS1 nodes; a maintainer replaces
+ * the BODY of the functions below and keeps names, argument meaning, output order and error behaviour:
+ *   laserCloudHandler                           src/scanRegistration.cpp:87-428
+ *   graph_based_correspondence_vote_simple      src/laserOdometry.cpp:165-342 (call :796)
+ *   the correspondence loops + ceres::Solve     src/laserOdometry.cpp:439-832  -> OdometryFrame below
+ *   Corre_Match / Vertex_Vote / compare_score   include/aloam_velodyne/common.h:20-52
+ * Header-only, C++14, no ROS / PCL / Eigen / Ceres needed (this image has none): clouds are std::vector<PointXYZI>
+ * with the PCL field names; templates convert from any point type that has x, y, z (and intensity).
+ * The optional Ceres adapter at the end compiles only when <ceres/ceres.h> is available and is NOT compiled or
+ * tested in this image.
+ */
+#ifndef LIGHTLOAM_HOST_HPP
+#define LIGHTLOAM_HOST_HPP
+
+#include <algorithm>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "lightloam_hip.h"
+
+namespace lightloam {
+
+struct PointXYZI { float x, y, z, intensity; };                      /* pcl::PointXYZI without the SSE padding */
+static_assert(sizeof(PointXYZI) == sizeof(ll_point), "layout");
+typedef PointXYZI PointType;                                          /* common.h:7 */
+
+typedef struct {                                                      /* common.h:20-31 */
+    int index;
+    PointXYZI src;
+    PointXYZI tgt;
+    float score;
+    float s;
+} Corre_Match;
+
+typedef struct { int index; float score; } Vertex_Vote;               /* common.h:40-43 */
+struct compare_score { bool operator()(Vertex_Vote const &a, Vertex_Vote const &b) { return a.score > b.score; } };   /* :50-52 */
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+/* RAII ll_ctx; one per node thread (the reference nodes are single-threaded spinners, scanRegistration.cpp:475) */
+class Context {
+public:
+    explicit Context(int scan_line, int batch = 2, int device = 0, double minimum_range = -1.0) {
+        ll_default_params(&p_, scan_line);
+        p_.batch = batch;
+        if (minimum_range >= 0) p_.minimum_range = (float)minimum_range;       /* nh.param("minimum_range") :438 */
+        const int rc = ll_create(device, &p_, &ctx_);
+        if (rc != LL_OK) throw Error(rc, ll_last_error(nullptr));               /* LL_ERR_BAD_RINGS == "only support velodyne with 16, 32 or 64 scan line" :447-451 */
+    }
+    ~Context() { ll_destroy(ctx_); }
+    Context(const Context &) = delete;
+    Context &operator=(const Context &) = delete;
+    ll_ctx *get() const { return ctx_; }
+    const ll_params &params() const { return p_; }
+    void check(int rc) const { if (rc != LL_OK) throw Error(rc, ll_last_error(ctx_)); }
+private:
+    ll_params p_;
+    ll_ctx *ctx_ = nullptr;
+};
+
+/* ---- scanRegistration.cpp:87-428.  Input: the points of the PointCloud2 message (x,y,z[,.]) with `stride` floats
+ * per point; outputs: what the node publishes on /velodyne_cloud_2, /laser_cloud_sharp, /laser_cloud_less_sharp,
+ * /laser_cloud_flat, /laser_cloud_less_flat (:382-410), same point order.  Returns false where the reference would
+ * have dereferenced an empty cloud (no point survives the filters). */
+inline bool laserCloudHandler(Context &c, int slot, const float *xyz, int stride, int n,
+                              std::vector<PointXYZI> &laserCloud, std::vector<PointXYZI> &cornerPointsSharp,
+                              std::vector<PointXYZI> &cornerPointsLessSharp, std::vector<PointXYZI> &surfPointsFlat,
+                              std::vector<PointXYZI> &surfPointsLessFlat)
+{
+    c.check(ll_upload_scan(c.get(), slot, xyz, stride, n));
+    c.check(ll_extract_batch(c.get(), slot, 1));
+    ll_scan_info info;
+    c.check(ll_get_scan_info(c.get(), slot, &info));
+    if (info.status == LL_ERR_EMPTY) return false;
+    if (info.status != LL_OK) throw Error(info.status, "scan registration failed (capacity)");
+    laserCloud.resize(info.n); cornerPointsSharp.resize(info.n_sharp); cornerPointsLessSharp.resize(info.n_less_sharp);
+    surfPointsFlat.resize(info.n_flat); surfPointsLessFlat.resize(info.n_less_flat);
+    c.check(ll_download_cloud(c.get(), slot, (ll_point *)laserCloud.data(), info.n, nullptr, nullptr));
+    c.check(ll_download_features(c.get(), slot, (ll_point *)cornerPointsSharp.data(), info.n_sharp,
+                                 (ll_point *)cornerPointsLessSharp.data(), info.n_less_sharp,
+                                 (ll_point *)surfPointsFlat.data(), info.n_flat, (ll_point *)surfPointsLessFlat.data(), info.n_less_flat));
+    return true;
+}
+
+/* ---- laserOdometry.cpp:165-342, same signature minus the six unused arguments.  Appends to selected_idx in the
+ * reference's order: per region, the vote records sorted with the SAME std::sort / compare_score call on the same
+ * initial sequence, then walked from the low-count end (:255, :304-329). */
+inline void graph_based_correspondence_vote_simple(Context &c, std::vector<Corre_Match> &correspondences, bool corner_case,
+                                                   std::vector<Vertex_Vote> &selected_idx)
+{
+    const int n = (int)correspondences.size();
+    if (n == 0) return;
+    std::vector<ll_point> src(n), tgt(n);
+    for (int i = 0; i < n; ++i) {
+        src[i] = {correspondences[i].src.x, correspondences[i].src.y, correspondences[i].src.z, correspondences[i].src.intensity};
+        tgt[i] = {correspondences[i].tgt.x, correspondences[i].tgt.y, correspondences[i].tgt.z, correspondences[i].tgt.intensity};
+    }
+    std::vector<int> count(n);
+    c.check(ll_vote_host(c.get(), src.data(), tgt.data(), n, corner_case ? 1 : 0, count.data(), nullptr, nullptr));
+    const int number_of_region = corner_case ? 5 : 10;                                  /* :179-188 */
+    for (int num_region = 0; num_region < number_of_region; num_region++) {
+        const int initial_pos = n / number_of_region * num_region;                      /* :202 */
+        const int end_pos = (num_region == number_of_region - 1) ? n : n / number_of_region * (num_region + 1);
+        const int cor_size = end_pos - initial_pos;
+        std::vector<Vertex_Vote> vote_record((size_t)std::max(cor_size, 0));
+        for (int i = 0; i < cor_size; ++i) { vote_record[i].index = i; vote_record[i].score = (float)count[initial_pos + i]; }
+        std::sort(vote_record.begin(), vote_record.end(), compare_score());             /* :255 */
+        const float num_selected = 0.90f * cor_size;                                    /* :299-300 */
+        for (int i = cor_size - 1; i >= 0; i--) {                                       /* :304-329 */
+            Vertex_Vote obj;
+            obj.index = correspondences[initial_pos + vote_record[i].index].index;
+            if (vote_record[i].score > num_selected) break;
+            obj.score = (vote_record[i].score <= 50) ? 5.0f : 1.0f;
+            selected_idx.push_back(obj);
+        }
+    }
+}
+
+/* ---- the per-frame body of laserOdometry.cpp:439-832, one outer iteration at a time.
+ * slot_curr holds the current scan's features (after laserCloudHandler), the target is what set_last() stored
+ * (laserCloudCornerLast / laserCloudSurfLast, :882-896).  q = para_q (x,y,z,w), t = para_t (:61-62). */
+class OdometryFrame {
+public:
+    explicit OdometryFrame(Context &c) : c_(c) {}
+    /* kdtreeCornerLast->setInputCloud / kdtreeSurfLast->setInputCloud (:895-896) from host clouds ... */
+    void set_last(const std::vector<PointXYZI> &cornerLast, const std::vector<PointXYZI> &surfLast) {
+        c_.check(ll_set_target(c_.get(), (const ll_point *)cornerLast.data(), (int)cornerLast.size(),
+                               (const ll_point *)surfLast.data(), (int)surfLast.size()));
+    }
+    /* ... or device-to-device from the slot that was just registered (the pointer swap of :882-888) */
+    void set_last_from_slot(int slot) { c_.check(ll_set_target_from_slot(c_.get(), slot)); }
+
+    /* correspondence search (:491-620, :653-793) + vote when now_frame > 5 (:794-810) + residual blocks + one
+     * Gauss-Newton iteration of the problem Ceres would be handed (:820-825).  Updates q, t in place. */
+    void iterate(int slot_curr, double q[4], double t[3], bool vote, ll_pair_info *info = nullptr) {
+        const double pose[7] = {q[0], q[1], q[2], q[3], t[0], t[1], t[2]};
+        c_.check(ll_associate_batch(c_.get(), slot_curr, 1, pose));
+        c_.check(ll_vote_batch(c_.get(), slot_curr, 1, vote ? 1 : 0));
+        c_.check(ll_normal_equations_batch(c_.get(), slot_curr, 1, nullptr));
+        c_.check(ll_gn_step_batch(c_.get(), slot_curr, 1));
+        double out[7];
+        c_.check(ll_download_pose(c_.get(), slot_curr, out));
+        for (int k = 0; k < 4; ++k) q[k] = out[k];
+        for (int k = 0; k < 3; ++k) t[k] = out[4 + k];
+        if (info) c_.check(ll_get_pair_info(c_.get(), slot_curr, info));
+    }
+private:
+    Context &c_;
+};
+
+}  // namespace lightloam
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Optional Ceres adapter (NOT compiled in this image: Ceres is absent).  Keeps the parameter-block layout (4, 3) of
+ * lidarFactor.hpp and lets ceres::Solve drive the device evaluation: ONE cost function for all residual blocks of the
+ * frame, whose Evaluate() is ll_residual_jacobian (rows = 3 * edges + selected planes, jacobians[0] rows x 4 over
+ * (x,y,z,w), jacobians[1] rows x 3, row-major).  HuberLoss(0.1) is applied per reference residual block, so the batched
+ * function must be wrapped with LL huber off and a ceres::LossFunction cannot be used as is -- see INTEGRATION.md.   */
+#if defined(LIGHTLOAM_WITH_CERES) && __has_include(<ceres/ceres.h>)
+#include <ceres/ceres.h>
+namespace lightloam {
+class BatchedLidarCost : public ceres::CostFunction {
+public:
+    BatchedLidarCost(Context &c, int slot, int rows) : c_(c), slot_(slot) {
+        set_num_residuals(rows);
+        mutable_parameter_block_sizes()->push_back(4);
+        mutable_parameter_block_sizes()->push_back(3);
+        jq_.resize((size_t)rows * 4); jt_.resize((size_t)rows * 3);
+    }
+    bool Evaluate(double const *const *parameters, double *residuals, double **jacobians) const override {
+        const double pose[7] = {parameters[0][0], parameters[0][1], parameters[0][2], parameters[0][3],
+                                parameters[1][0], parameters[1][1], parameters[1][2]};
+        if (ll_residual_jacobian(c_.get(), slot_, pose, residuals, jq_.data(), jt_.data(), num_residuals()) != LL_OK) return false;
+        if (jacobians && jacobians[0]) std::copy(jq_.begin(), jq_.end(), jacobians[0]);
+        if (jacobians && jacobians[1]) std::copy(jt_.begin(), jt_.end(), jacobians[1]);
+        return true;
+    }
+private:
+    Context &c_; int slot_;
+    mutable std::vector<double> jq_, jt_;
+};
+}  // namespace lightloam
+#endif
+
+#endif /* LIGHTLOAM_HOST_HPP */

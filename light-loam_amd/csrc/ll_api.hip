@@ -310,6 +310,35 @@ extern "C" int ll_vote_batch(ll_ctx *ctx, int first, int count, int enable)
     return LL_OK;
 }
 
+/* graph_based_correspondence_vote_simple on caller-supplied correspondences (laserOdometry.cpp:165-172) */
+extern "C" int ll_vote_host(ll_ctx *ctx, const ll_point *src, const ll_point *tgt, int n, int corner_case,
+                            int *count, uint8_t *selected, float *weight)
+{
+    if (!ctx || n < 0 || (n > 0 && (!src || !tgt))) return LL_ERR_ARG;
+    if (n == 0) return LL_OK;
+    if ((size_t)n * 24 + 16 > 160 * 1024) { ctx->err = "ll_vote_host: more than 6826 correspondences do not fit one workgroup's LDS"; return LL_ERR_CAPACITY; }
+    /* scratch: src, tgt (float4), count (int), weight (float), selected (u8) */
+    const size_t bytes = (size_t)n * (16 + 16 + 4 + 4 + 1) + 64;
+    void *d = nullptr;
+    LL_HIP(hipMallocAsync(&d, bytes, ctx->stream));
+    float4 *dsrc = (float4 *)d, *dtgt = dsrc + n;
+    int *dcnt = (int *)(dtgt + n); float *dw = (float *)(dcnt + n); uint8_t *dsel = (uint8_t *)(dw + n);
+    int rc = LL_OK;
+    do {
+        if (hipMemcpyAsync(dsrc, src, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(dtgt, tgt, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = LL_ERR_HIP; break; }
+        ll_launch_vote_points(dsrc, dtgt, n, corner_case ? 5 : 10, dcnt, dsel, dw, ctx->stream);   /* :179-188 */
+        if (hipGetLastError() != hipSuccess) { rc = LL_ERR_HIP; break; }
+        if (count && hipMemcpyAsync(count, dcnt, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { rc = LL_ERR_HIP; break; }
+        if (weight && hipMemcpyAsync(weight, dw, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { rc = LL_ERR_HIP; break; }
+        if (selected && hipMemcpyAsync(selected, dsel, (size_t)n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { rc = LL_ERR_HIP; break; }
+    } while (0);
+    (void)hipFreeAsync(d, ctx->stream);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = LL_ERR_HIP;
+    if (rc != LL_OK) ctx->err = "ll_vote_host: HIP runtime call failed";
+    return rc;
+}
+
 extern "C" int ll_normal_equations_batch(ll_ctx *ctx, int first, int count, const double *host_pose)
 {
     int rc = check_range(ctx, first, count); if (rc) return rc;

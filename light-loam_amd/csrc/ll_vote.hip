@@ -4,19 +4,19 @@
  * correspondence lists (:574-585, :745-757).
  *
  * One workgroup per scan pair.  Per-query association results are compacted in query order (the order the
- * reference appends them).  The vote is the reference's dense all-pairs test inside each of 10 contiguous
- * regions: thread i counts the j of its region with | |src_i-src_j| - |tgt_i-tgt_j| |^2 >= T, where
- * "std::exp(-gap^2) < 0.96f" is replaced by the bit-exact threshold of ll_exact_math.h.  src/tgt points of
- * the region are staged once in LDS and broadcast-read.  Selection: count <= 0.9f*m, weight 5 if count <= 50
- * else 1 (:299-322).  Output is per correspondence (count, selected, weight); the reference's output ORDER
- * (ascending count, std::sort ties unspecified) only permutes residual blocks and is reproduced on the host
- * side where needed (include/lightloam_host.hpp).
+ * reference appends them).  The vote is the reference's dense all-pairs test inside each of 10 (planes) or 5
+ * (corners) contiguous regions: thread i counts the j of its region with | |src_i-src_j| - |tgt_i-tgt_j| |^2 >= T,
+ * where "std::exp(-gap^2) < 0.96f" is replaced by the bit-exact threshold of ll_exact_math.h.  src/tgt points are
+ * staged once in LDS and broadcast-read.  Selection: count <= 0.9f*m, weight 5 if count <= 50 else 1 (:299-322).
+ * Output is per correspondence (count, selected, weight); the reference's output ORDER (ascending count, std::sort
+ * ties unspecified) only permutes residual blocks and is reproduced on the host side where a caller needs it
+ * (include/lightloam_host.hpp runs the same std::sort on the counts).
  */
 #include "ll_common.h"
 
 extern __shared__ __attribute__((aligned(16))) unsigned char ll_vsm[];
 
-/* stable compaction of flags[0..n) by one workgroup; returns total, writes exclusive positions through cb */
+/* stable compaction of valid_src[0..n) >= 0 by one workgroup; emit(i, pos) for every kept i; returns the total */
 template <typename F>
 __device__ __forceinline__ int ll_block_compact(int n, int *sc, F emit, const int *valid_src)
 {
@@ -30,6 +30,40 @@ __device__ __forceinline__ int ll_block_compact(int n, int *sc, F emit, const in
     for (int i = a0; i < a1; ++i) if (valid_src[i] >= 0) emit(i, pos++);
     __syncthreads();
     return total;
+}
+
+/* the vote proper on LDS-staged src (S3) / tgt (T3) xyz triples; returns this thread's number of selected entries */
+__device__ __forceinline__ int ll_vote_core(const float *S3, const float *T3, int n_p, int number_of_region, int enable,
+                                            int *vc, uint8_t *vs, float *vw)
+{
+    const int chunk = n_p / number_of_region;                     /* cor_size_all / number_of_region (:202) */
+    int my_sel = 0;
+    for (int i = threadIdx.x; i < n_p; i += LL_BLOCK) {
+        int cnt = 0, sel = 1; float w = 1.0f;
+        if (enable) {
+            const int rg = (chunk > 0) ? min(i / chunk, number_of_region - 1) : number_of_region - 1;
+            const int b0 = chunk * rg, b1 = (rg == number_of_region - 1) ? n_p : chunk * (rg + 1);
+            const float ax = S3[3 * i], ay = S3[3 * i + 1], az = S3[3 * i + 2];
+            const float bx = T3[3 * i], by = T3[3 * i + 1], bz = T3[3 * i + 2];
+            for (int j = b0; j < b1; ++j) {
+                if (j == i) continue;
+                /* Distance() (:153-162): f32 sqrt of dx*dx + dy*dy + dz*dz; the reference evaluates (i, j) with i < j
+                 * only -- the squares make the operand order irrelevant bit-for-bit */
+                float dx = ax - S3[3 * j], dy = ay - S3[3 * j + 1], dz = az - S3[3 * j + 2];
+                const float s1 = sqrtf(dx * dx + dy * dy + dz * dz);
+                dx = bx - T3[3 * j]; dy = by - T3[3 * j + 1]; dz = bz - T3[3 * j + 2];
+                const float s2 = sqrtf(dx * dx + dy * dy + dz * dz);
+                const float gap = fabsf(s1 - s2);
+                cnt += ll_vote_incompatible(gap * gap) ? 1 : 0;
+            }
+            const float num_selected = 0.90f * (float)(b1 - b0);                 /* :299-300 */
+            sel = !((float)cnt > num_selected);                                   /* :312 */
+            w = ((float)cnt <= 50.0f) ? 5.0f : 1.0f;                              /* :317-322 */
+        }
+        vc[i] = cnt; vs[i] = (uint8_t)sel; vw[i] = w;
+        my_sel += sel;
+    }
+    return my_sel;
 }
 
 __global__ __launch_bounds__(LL_BLOCK) void k_vote(LLView V, int first, int count, int enable)
@@ -59,43 +93,15 @@ __global__ __launch_bounds__(LL_BLOCK) void k_vote(LLView V, int first, int coun
     float *T3 = S3 + 3 * (size_t)V.cap_flat;     /* [n_p][3] */
     const float4 *flat = V.flat + (size_t)s * V.cap_flat;
     if (tid == 0) nsel_sh = 0;
-    __syncthreads();                              /* p_src / p_a written above are visible after the barrier in ll_block_compact */
+    __syncthreads();
     for (int i = tid; i < n_p; i += LL_BLOCK) {
         const float4 a = flat[ps[i]], b = surf[pa[i]];
         S3[3 * i] = a.x; S3[3 * i + 1] = a.y; S3[3 * i + 2] = a.z;
         T3[3 * i] = b.x; T3[3 * i + 1] = b.y; T3[3 * i + 2] = b.z;
     }
     __syncthreads();
-
-    int *vc = V.v_count + (size_t)s * V.cap_flat; uint8_t *vs = V.v_sel + (size_t)s * V.cap_flat; float *vw = V.v_w + (size_t)s * V.cap_flat;
-    const int number_of_region = 10;             /* plane case (:186-187) */
-    const int chunk = n_p / number_of_region;    /* cor_size_all / number_of_region (:202) */
-    int my_sel = 0;
-    for (int i = tid; i < n_p; i += LL_BLOCK) {
-        int cnt = 0, sel = 1; float w = 1.0f;
-        if (enable) {
-            int rg = (chunk > 0) ? min(i / chunk, number_of_region - 1) : number_of_region - 1;
-            const int b0 = chunk * rg, b1 = (rg == number_of_region - 1) ? n_p : chunk * (rg + 1);
-            const float ax = S3[3 * i], ay = S3[3 * i + 1], az = S3[3 * i + 2];
-            const float bx = T3[3 * i], by = T3[3 * i + 1], bz = T3[3 * i + 2];
-            for (int j = b0; j < b1; ++j) {
-                if (j == i) continue;
-                /* Distance() (:153-162): f32 sqrt of dx*dx + dy*dy + dz*dz; operand order (i, j) with i < j in the
-                 * reference -- squares make the order irrelevant bit-for-bit */
-                float dx = ax - S3[3 * j], dy = ay - S3[3 * j + 1], dz = az - S3[3 * j + 2];
-                const float s1 = sqrtf(dx * dx + dy * dy + dz * dz);
-                dx = bx - T3[3 * j]; dy = by - T3[3 * j + 1]; dz = bz - T3[3 * j + 2];
-                const float s2 = sqrtf(dx * dx + dy * dy + dz * dz);
-                const float gap = fabsf(s1 - s2);
-                cnt += ll_vote_incompatible(gap * gap) ? 1 : 0;
-            }
-            const float num_selected = 0.90f * (float)(b1 - b0);                 /* :299-300 */
-            sel = !((float)cnt > num_selected);                                   /* :312 */
-            w = ((float)cnt <= 50.0f) ? 5.0f : 1.0f;                              /* :317-322 */
-        }
-        vc[i] = cnt; vs[i] = (uint8_t)sel; vw[i] = w;
-        my_sel += sel;
-    }
+    const int my_sel = ll_vote_core(S3, T3, n_p, 10 /* plane case (:186-187) */, enable,
+                                    V.v_count + (size_t)s * V.cap_flat, V.v_sel + (size_t)s * V.cap_flat, V.v_w + (size_t)s * V.cap_flat);
     if (my_sel) atomicAdd(&nsel_sh, my_sel);
     __syncthreads();
     if (tid == 0) {
@@ -104,10 +110,34 @@ __global__ __launch_bounds__(LL_BLOCK) void k_vote(LLView V, int first, int coun
     }
 }
 
+/* the free function's own signature: caller-supplied correspondences (src / tgt points), 5 or 10 regions */
+__global__ __launch_bounds__(LL_BLOCK) void k_vote_points(const float4 *src, const float4 *tgt, int n, int regions,
+                                                          int *vc, uint8_t *vs, float *vw)
+{
+    float *S3 = (float *)ll_vsm, *T3 = S3 + 3 * (size_t)n;
+    for (int i = threadIdx.x; i < n; i += LL_BLOCK) {
+        const float4 a = src[i], b = tgt[i];
+        S3[3 * i] = a.x; S3[3 * i + 1] = a.y; S3[3 * i + 2] = a.z;
+        T3[3 * i] = b.x; T3[3 * i + 1] = b.y; T3[3 * i + 2] = b.z;
+    }
+    __syncthreads();
+    (void)ll_vote_core(S3, T3, n, regions, 1, vc, vs, vw);
+}
+
 void ll_launch_vote(const LLView &V, int first, int count, int enable, hipStream_t st, LLProfiler *prof)
 {
     const size_t lds = (size_t)V.cap_flat * 24;
+    static size_t attr_bytes = 0;
+    if (lds > attr_bytes) { (void)hipFuncSetAttribute((const void *)k_vote, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_bytes = lds; }
     ll_prof_mark(prof, LL_K_VOTE, st);
     hipLaunchKernelGGL(k_vote, dim3(count), dim3(LL_BLOCK), lds, st, V, first, count, enable);
     ll_prof_mark(prof, LL_K_END, st);
+}
+
+void ll_launch_vote_points(const float4 *src, const float4 *tgt, int n, int regions, int *vc, uint8_t *vs, float *vw, hipStream_t st)
+{
+    const size_t lds = (size_t)n * 24 + 16;
+    static size_t attr_bytes = 0;
+    if (lds > attr_bytes) { (void)hipFuncSetAttribute((const void *)k_vote_points, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_bytes = lds; }
+    hipLaunchKernelGGL(k_vote_points, dim3(1), dim3(LL_BLOCK), lds, st, src, tgt, n, regions, vc, vs, vw);
 }

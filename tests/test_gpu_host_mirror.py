@@ -1,0 +1,54 @@
+"""The C++ host mirror (include/lightloam_host.hpp) driven like the reference nodes would: a g++-built program links
+the HIP library, reads two KITTI-format .bin scans, and its outputs are checked against the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_host_mirror_pipeline(tmp_path, orc, synth, api):
+    from lightloam_amd import build
+    lib_dir = os.path.dirname(build.lib_path())
+    exe = str(tmp_path / "host_pipeline")
+    subprocess.check_call(["g++", "-O2", "-std=c++14", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "native", "host_pipeline.cpp"), "-o", exe,
+                           "-L", lib_dir, "-llightloam_hip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
+    cfg = synth.default_cfg(16)
+    scans = [synth.scan(cfg, k) for k in range(2)]
+    for k, s in enumerate(scans):
+        s.astype("<f4").tofile(tmp_path / f"scan{k}.bin")
+    out = subprocess.run([exe, str(tmp_path / "scan0.bin"), str(tmp_path / "scan1.bin"), str(tmp_path / "o"), "16"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    P = orc.params(16)
+    e0, e1 = orc.extract(scans[0], P), orc.extract(scans[1], P)
+    rd = lambda name, dt=np.float32: np.fromfile(tmp_path / f"o_{name}.bin", dtype=dt)
+    for name, key in (("cloud1", "cloud"), ("sharp1", "sharp"), ("lsharp1", "less_sharp"), ("flat1", "flat"), ("lflat1", "less_flat")):
+        assert rd(name).tobytes() == e1[key].tobytes(), name
+    q = np.array([0, 0, 0, 1.0]); t = np.array([0.9, 0, 0])
+    es, ea, eb = orc.associate_corner(q, t, e1["sharp"], e0["less_sharp"])
+    ps, pa, pb, pc = orc.associate_plane(q, t, e1["flat"], e0["less_flat"])
+    cnt, sidx, sw = orc.vote(e1["flat"][ps], e0["less_flat"][pa])
+    order = np.sort(sidx); wmap = np.ones(len(ps), np.float32); wmap[sidx] = sw
+    H, g, _ = orc.normal_equations(q, t, e1["sharp"], es, e0["less_sharp"], ea, eb, e1["flat"], ps[order], e0["less_flat"],
+                                   pa[order], pb[order], pc[order], wmap[order], 0.1)
+    rc, d = orc.gn_solve(H, g)
+    qo, to = orc.pose_update(q, t, d)
+    pose = rd("pose", np.float64)
+    assert np.allclose(pose[:4], qo, atol=1e-9) and np.allclose(pose[4:], to, atol=1e-9)
+    # the free function: same selected set and weights as the oracle, in the reference's low-count-first order per region
+    sel = rd("selected").reshape(-1, 2)
+    got_idx = sel[:, 0].astype(int)
+    assert sorted(got_idx.tolist()) == sorted(sidx.tolist())
+    assert all(wmap[i] == w for i, w in zip(got_idx, sel[:, 1]))
+    n = len(ps); chunk = n // 10
+    region = np.minimum(got_idx // chunk, 9) if chunk else np.full(len(got_idx), 9)
+    assert (np.diff(region) >= 0).all()
+    for r in range(10):
+        c = cnt[got_idx[region == r]]
+        assert (np.diff(c) >= 0).all()
