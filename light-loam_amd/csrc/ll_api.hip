@@ -117,7 +117,7 @@ extern "C" int ll_create(int device, const ll_params *p, ll_ctx **out)
     if (!p || !out) return LL_ERR_ARG;
     *out = nullptr;
     if (p->n_scans < 1 || p->n_scans > LL_MAX_RINGS || p->batch < 1 || p->max_points < 32 || p->max_points > 400000 ||
-        p->max_ring_points < 32 || p->max_ring_points > 16384) { g_create_err = "bad parameter"; return LL_ERR_ARG; }
+        p->max_ring_points < 32 || p->max_ring_points > 9216) { g_create_err = "bad parameter"; return LL_ERR_ARG; }
     if (p->ring_model == 0 && p->n_scans != 16 && p->n_scans != 32 && p->n_scans != 64) {
         g_create_err = "only support velodyne with 16, 32 or 64 scan line (scanRegistration.cpp:447-451); use ring_model 1 for the linear model";
         return LL_ERR_BAD_RINGS;

@@ -6,17 +6,19 @@
  * (cloudNeighborPicked marks leak from segment j into segment j+1 of the same ring, never across rings,
  * because scanStartInd/EndInd keep a 5-point margin).  Everything between reading laserCloud and writing
  * labels + feature points stays on chip:
- *   phase 1  1024-point tiles of x/y/z (+5 halo, the flat array is used like the reference: curvature
+ *   phase 1  512-point tiles of x/y/z (+5 halo, the flat array is used like the reference: curvature
  *            crosses ring boundaries) staged in LDS -> 11-tap curvature (strict left-to-right f32, no FMA),
- *            consecutive-point gap flags (1 bit/point) and 64-bit sort keys (curvature bits << 32 | local index)
- *   phase 2  bitonic network (all comparators ascending, so virtual +inf padding never moves) over the six
- *            segments in place; key order = (curvature, index): std::sort leaves equal curvatures
+ *            consecutive-point gap flags (1 bit/point) and sort records (u32 curvature bits, u16 local index)
+ *   phase 2  stable LSD radix sort (4-bit digits, ballot ranking) by curvature, then by segment: the six
+ *            segments end up sorted in place by (curvature, index) -- std::sort leaves equal curvatures
  *            unspecified, this path and the oracle define ascending index
- *   phase 3  wave 0 replays the greedy pick: 64 candidates per step, ballot -> first eligible lane ->
- *            neighbour suppression from the gap bits with one ballot
- *   phase 4  less-flat points (label <= 0) compacted in index order, voxel index per PCL's formula, sorted by
- *            (voxel, input order) with the same network, one thread per voxel run sums in input order
+ *   phase 3  wave 0 replays the greedy pick: 64 candidates per step, eligibility and each candidate's suppression
+ *            range in registers, a pick = ballot -> readlane -> range compare
+ *   phase 4  less-flat points (label <= 0) compacted in index order, voxel index per PCL's formula, radix-sorted by
+ *            (voxel, input order), one thread per voxel run sums in input order
  *   phase 5  labels + feature slots out; k_compact turns per-ring slots into the published clouds.
+ * The kernel is latency-bound (dependent LDS round trips, one serial phase), so LDS is kept at ~26 KB for a
+ * 2304-point ring capacity: six workgroups per CU.  ROWS = sort records per thread (capacity 256 * ROWS).
  * HBM traffic per ring point: 16 B read (+ L2-hot re-reads for the centroid gather), 1 B label, features.
  */
 #include "ll_common.h"
@@ -30,139 +32,83 @@ __device__ __forceinline__ bool ll_xcd_map2(int id, int per_scan, int count, int
     return scan < count;
 }
 
-typedef unsigned long long u64;
+#define LL_FTILE 512      /* points per curvature tile */
+#define LL_NLIST 160      /* sharp[12] lsharp[120] flat[24] + 3 counters */
 
 struct FeatLds {
-    u64 *keys;            /* [max_ring] */
-    float *tx, *ty, *tz;  /* [LL_TILE + 10] */
+    unsigned *k32;             /* [mr] sort key: curvature bits / voxel index */
+    unsigned short *k16;       /* [mr] payload: local index / input order */
+    float *tx, *ty, *tz;       /* [LL_FTILE + 16] phase 1; afterwards tx.. is reused as lf_list (u16 [mr]) */
+    unsigned short *lf_list;   /* aliases the tile */
     unsigned *picked, *gapf;   /* bitmaps over local index */
-    int8_t *lab;          /* [max_ring] */
-    unsigned short *lf_list;   /* [max_ring] */
-    int *lists;           /* sharp[12] lsharp[120] flat[24] */
-    int *scratch;         /* [LL_BLOCK + 16] */
+    int8_t *lab;               /* [mr] */
+    int *lists;                /* [LL_NLIST] */
+    int *cnt;                  /* [16 * ROWS * 4 + 1] radix counters */
+    int *sc;                   /* [64] scan scratch, bounds, segment table */
 };
+
+static size_t ll_feat_tile_bytes(size_t mr) { const size_t t = 3 * 4 * (size_t)(LL_FTILE + 16); return t > 2 * mr ? t : 2 * mr; }
 
 size_t ll_features_lds_bytes(int max_ring)
 {
-    const size_t mr = (size_t)((max_ring + 63) / 64 * 64);
-    size_t b = 8 * mr;                       /* keys */
-    b += 3 * 4 * (size_t)(LL_TILE + 16);     /* tile x,y,z */
+    const size_t mr = (size_t)((max_ring + 255) / 256 * 256);
+    const size_t rows = (mr / 256 <= 9) ? 9 : (mr / 256 <= 18) ? 18 : 36;     /* the ROWS instantiation that will run */
+    size_t b = 4 * mr + 2 * mr;              /* k32 + k16 */
+    b += ll_feat_tile_bytes(mr);             /* tile / lf_list */
     b += 2 * 4 * (mr / 32 + 2);              /* bitmaps */
     b += mr;                                 /* labels */
-    b += 2 * mr;                             /* less-flat list */
-    b += 4 * 160;                            /* lists */
-    b += 4 * (LL_BLOCK + 16) * 2;            /* scratch */
+    b += 4 * LL_NLIST;
+    b += 4 * (16 * rows * 4 + 4);            /* radix counters */
+    b += 4 * 64;
     return (b + 15) / 16 * 16 + 64;
 }
 
 __device__ __forceinline__ FeatLds ll_carve(unsigned char *base, int max_ring)
 {
-    const size_t mr = (size_t)((max_ring + 63) / 64 * 64);
+    const size_t mr = (size_t)((max_ring + 255) / 256 * 256);
+    const size_t rows = (mr / 256 <= 9) ? 9 : (mr / 256 <= 18) ? 18 : 36;     /* the ROWS instantiation that will run */
+    const size_t tile = 3 * 4 * (size_t)(LL_FTILE + 16);
+    const size_t tile_bytes = tile > 2 * mr ? tile : 2 * mr;
     FeatLds L;
     unsigned char *p = base;
-    L.keys = (u64 *)p; p += 8 * mr;
-    L.tx = (float *)p; p += 4 * (LL_TILE + 16);
-    L.ty = (float *)p; p += 4 * (LL_TILE + 16);
-    L.tz = (float *)p; p += 4 * (LL_TILE + 16);
+    L.k32 = (unsigned *)p; p += 4 * mr;
+    L.tx = (float *)p; L.ty = L.tx + (LL_FTILE + 16); L.tz = L.ty + (LL_FTILE + 16);
+    L.lf_list = (unsigned short *)p; p += tile_bytes;
     L.picked = (unsigned *)p; p += 4 * (mr / 32 + 2);
     L.gapf = (unsigned *)p; p += 4 * (mr / 32 + 2);
-    L.lists = (int *)p; p += 4 * 160;
-    L.scratch = (int *)p; p += 4 * (LL_BLOCK + 16) * 2;
-    L.lf_list = (unsigned short *)p; p += 2 * mr;
+    L.lists = (int *)p; p += 4 * LL_NLIST;
+    L.cnt = (int *)p; p += 4 * (16 * rows * 4 + 4);
+    L.sc = (int *)p; p += 4 * 64;
+    L.k16 = (unsigned short *)p; p += 2 * mr;
     L.lab = (int8_t *)p;
     return L;
 }
 
-__device__ __forceinline__ void ll_ce(u64 *k, int i, int l)
-{
-    const u64 a = k[i], b = k[l];
-    if (a > b) { k[i] = b; k[l] = a; }
-}
-
-/* Sort nseg independent key ranges [b(j), b(j+1)) ascending.  seg_begin(j) = L*j/nseg for the six curvature
- * segments (scanRegistration.cpp:253-254) or the single voxel range.  All comparators are ascending, so
- * positions >= the segment length behave as +inf padding that never has to move. */
-/* segb[0..nseg] (LDS) holds the segment bounds; all index math is shifts and masks (p2, k, j are powers of two). */
-#define LL_SORT_MAXP 8      /* compare-exchanges a thread keeps in flight per batch */
-
-/* one step of the network: FLIP ? (i <-> block mirror, block = 1 << lx) : (i <-> i + (1 << lx)).
- * Each thread first computes all its pairs, then issues every LDS load, then compares and stores: the loads of a
- * thread's pairs overlap instead of forming one dependent round trip per pair. */
-template <bool FLIP>
-__device__ __forceinline__ void ll_sort_step(u64 *keys, const int (&sb)[LL_SEGS + 1], int lgh, int npairs, int lx, int tid)
-{
-    const int half = 1 << lgh;
-    for (int p0 = 0; p0 < npairs; p0 += LL_BLOCK * LL_SORT_MAXP) {
-        int ia[LL_SORT_MAXP], ib[LL_SORT_MAXP];
-        u64 a[LL_SORT_MAXP], b[LL_SORT_MAXP];
-#pragma unroll
-        for (int u = 0; u < LL_SORT_MAXP; ++u) {
-            const int p = p0 + u * LL_BLOCK + tid;
-            ia[u] = -1; ib[u] = 0;
-            if (p < npairs) {
-                const int sg = p >> lgh, q = p & (half - 1);
-                int b0 = sb[0], b1 = sb[1];
-#pragma unroll
-                for (int t = 1; t < LL_SEGS; ++t) if (sg == t) { b0 = sb[t]; b1 = sb[t + 1]; }
-                int i, l;
-                if (FLIP) { const int blk = q >> (lx - 1), t = q & ((1 << (lx - 1)) - 1); i = (blk << lx) + t; l = (blk << lx) + ((1 << lx) - 1 - t); }
-                else      { i = ((q >> lx) << (lx + 1)) + (q & ((1 << lx) - 1)); l = i + (1 << lx); }
-                if (l < b1 - b0) { ia[u] = b0 + i; ib[u] = b0 + l; }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < LL_SORT_MAXP; ++u) if (ia[u] >= 0) { a[u] = keys[ia[u]]; b[u] = keys[ib[u]]; }
-#pragma unroll
-        for (int u = 0; u < LL_SORT_MAXP; ++u) if (ia[u] >= 0 && a[u] > b[u]) { keys[ia[u]] = b[u]; keys[ib[u]] = a[u]; }
-    }
-}
-
-/* segb[0..nseg] (LDS) holds the segment bounds (nseg <= LL_SEGS); index math is shifts and masks only. */
-__device__ __forceinline__ void ll_bitonic_segments(u64 *keys, const int *segb, int nseg, int tid)
-{
-    int sb[LL_SEGS + 1];
-#pragma unroll
-    for (int j = 0; j <= LL_SEGS; ++j) sb[j] = segb[min(j, nseg)];
-    int lmax = 0;
-#pragma unroll
-    for (int j = 0; j < LL_SEGS; ++j) lmax = max(lmax, sb[j + 1] - sb[j]);
-    if (lmax < 2) return;
-    int lg = 1; while ((1 << lg) < lmax) ++lg;             /* p2 = 1 << lg */
-    const int lgh = lg - 1, npairs = nseg << lgh;
-    for (int lk = 1; lk <= lg; ++lk) {                     /* merge size k = 1 << lk */
-        ll_sort_step<true>(keys, sb, lgh, npairs, lk, tid);
-        __syncthreads();
-        for (int lj = lk - 2; lj >= 0; --lj) {             /* j = 1 << lj */
-            ll_sort_step<false>(keys, sb, lgh, npairs, lj, tid);
-            __syncthreads();
-        }
-    }
-}
-
-/* Stable least-significant-digit radix sort of keys[0..n) by their HIGH 32 bits, one 256-thread workgroup, n <= 256*LL_RS_E.
- * 4-bit digits.  Element g lives in row g / 256, lane g % 256 (registers); its destination is
- *   #(elements with a smaller digit) + #(same digit, earlier (row, wave)) + rank inside its wave,
+/* Stable least-significant-digit radix sort of the records (k32[g], k16[g]), g < n <= 256*ROWS, by k32; one workgroup.
+ * 4-bit digits.  Record g lives in row g / 256 of thread g % 256 (registers); its destination is
+ *   #(records with a smaller digit) + #(same digit, earlier (row, wave)) + rank inside its wave,
  * the first two from one workgroup exclusive scan over the digit-major table cnt[digit][row*4 + wave], the last from a
  * ballot match (5 ballots).  Digits that are equal for every key are skipped (their pass would be the identity).
- * Stability makes the result ordered by (high 32 bits, original position): exactly the (curvature, index) /
- * (voxel, input order) orders the oracle defines.  SEG_PASS appends a pass on the segment of the key's low-32 local
- * index, so the six curvature segments end up sorted in place in their own ranges. */
-#define LL_RS_E 9
-template <bool SEG_PASS>
-__device__ __forceinline__ void ll_radix_sort_hi32(u64 *keys, int n, int *cnt, int *sc, const int *segb, int tid)
+ * Stability makes the result ordered by (k32, original position): exactly the (curvature, index) / (voxel, input
+ * order) orders the oracle defines.  SEG_PASS appends a pass on the segment of the local index in k16, so the six
+ * curvature segments end up sorted in place in their own ranges. */
+template <int ROWS, bool SEG_PASS>
+__device__ __forceinline__ void ll_radix_sort(unsigned *k32, unsigned short *k16, int n, int *cnt, int *sc, const int *segb, int tid)
 {
-    constexpr int SLOTS = LL_RS_E * (LL_BLOCK / 64);            /* (row, wave) pairs */
+    constexpr int SLOTS = ROWS * (LL_BLOCK / 64);               /* (row, wave) pairs */
     constexpr int NCNT = 16 * SLOTS;
+    constexpr int PER = (NCNT + LL_BLOCK - 1) / LL_BLOCK;       /* counters per thread in the scan */
     const int lane = tid & 63, wave = tid >> 6;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    u64 e[LL_RS_E];
+    unsigned e32[ROWS]; unsigned short e16[ROWS];
     unsigned vary = 0;
-    const unsigned hi0 = (n > 0) ? (unsigned)(keys[0] >> 32) : 0u;
+    const unsigned hi0 = (n > 0) ? k32[0] : 0u;
 #pragma unroll
-    for (int k = 0; k < LL_RS_E; ++k) {
+    for (int k = 0; k < ROWS; ++k) {
         const int g = k * LL_BLOCK + tid;
-        e[k] = (g < n) ? keys[g] : ~0ull;
-        if (g < n) vary |= (unsigned)(e[k] >> 32) ^ hi0;
+        e32[k] = (g < n) ? k32[g] : 0xffffffffu;
+        e16[k] = (g < n) ? k16[g] : (unsigned short)0;
+        if (g < n) vary |= e32[k] ^ hi0;
     }
     for (int o = 32; o > 0; o >>= 1) vary |= __shfl_xor(vary, o);
     if (tid == 0) cnt[NCNT] = 0;
@@ -177,14 +123,14 @@ __device__ __forceinline__ void ll_radix_sort_hi32(u64 *keys, int n, int *cnt, i
         if (!segpass && ((vary >> sh) & 15u) == 0u) continue;
         for (int i = tid; i < NCNT; i += LL_BLOCK) cnt[i] = 0;
         __syncthreads();
-        int dig[LL_RS_E], rnk[LL_RS_E];
+        int dig[ROWS], rnk[ROWS];
 #pragma unroll
-        for (int k = 0; k < LL_RS_E; ++k) {
+        for (int k = 0; k < ROWS; ++k) {
             const int g = k * LL_BLOCK + tid;
             const bool valid = g < n;
             int d;
-            if (segpass) { const int q = (int)(unsigned)e[k] - 5; d = (q >= sb1) + (q >= sb2) + (q >= sb3) + (q >= sb4) + (q >= sb5); }
-            else d = (int)(((unsigned)(e[k] >> 32) >> sh) & 15u);
+            if (segpass) { const int q = (int)e16[k] - 5; d = (q >= sb1) + (q >= sb2) + (q >= sb3) + (q >= sb4) + (q >= sb5); }
+            else d = (int)((e32[k] >> sh) & 15u);
             unsigned long long m = __ballot(valid);
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
@@ -196,45 +142,33 @@ __device__ __forceinline__ void ll_radix_sort_hi32(u64 *keys, int n, int *cnt, i
             if (valid && rnk[k] == 0) cnt[d * SLOTS + k * (LL_BLOCK / 64) + wave] = __popcll(m);
         }
         __syncthreads();
-        {   /* exclusive scan of the digit-major table: 3 consecutive counters per thread */
-            const int i0 = tid * 3;
-            int v0 = 0, v1 = 0, v2 = 0;
-            if (i0 < NCNT) { v0 = cnt[i0]; v1 = cnt[i0 + 1]; v2 = cnt[i0 + 2]; }
+        {   /* exclusive scan of the digit-major table: PER consecutive counters per thread */
+            const int i0 = tid * PER;
+            int v[PER]; int s = 0;
+#pragma unroll
+            for (int u = 0; u < PER; ++u) { v[u] = (i0 + u < NCNT) ? cnt[i0 + u] : 0; s += v[u]; }
             int total;
-            const int base = ll_block_exscan(v0 + v1 + v2, sc, total);
-            if (i0 < NCNT) { cnt[i0] = base; cnt[i0 + 1] = base + v0; cnt[i0 + 2] = base + v0 + v1; }
+            int run = ll_block_exscan(s, sc, total);
+#pragma unroll
+            for (int u = 0; u < PER; ++u) { if (i0 + u < NCNT) cnt[i0 + u] = run; run += v[u]; }
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < LL_RS_E; ++k) {
+        for (int k = 0; k < ROWS; ++k) {
             const int g = k * LL_BLOCK + tid;
-            if (g < n) keys[cnt[dig[k] * SLOTS + k * (LL_BLOCK / 64) + wave] + rnk[k]] = e[k];
+            if (g < n) { const int pos = cnt[dig[k] * SLOTS + k * (LL_BLOCK / 64) + wave] + rnk[k]; k32[pos] = e32[k]; k16[pos] = e16[k]; }
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < LL_RS_E; ++k) {
+        for (int k = 0; k < ROWS; ++k) {
             const int g = k * LL_BLOCK + tid;
-            e[k] = (g < n) ? keys[g] : ~0ull;
+            e32[k] = (g < n) ? k32[g] : 0xffffffffu;
+            e16[k] = (g < n) ? k16[g] : (unsigned short)0;
         }
     }
 }
 
 __device__ __forceinline__ bool ll_bit(const unsigned *bm, int i) { return (bm[i >> 5] >> (i & 31)) & 1u; }
-
-/* neighbour suppression (:288-311 / :334-357) for the pick at local index sel; whole wave participates */
-__device__ __forceinline__ void ll_mark(const FeatLds &L, int sel, int lane)
-{
-    bool g = false;
-    if (lane < 5) g = ll_bit(L.gapf, sel + lane + 1);              /* forward l = lane+1: gap(sel+l, sel+l-1) */
-    else if (lane < 10) g = ll_bit(L.gapf, sel - (lane - 5));      /* backward l = -(m+1): gap(sel+l, sel+l+1) = gapf[sel-m] */
-    const unsigned long long b = __ballot(g);
-    const unsigned fm = (unsigned)(b & 0x1f), bm = (unsigned)((b >> 5) & 0x1f);
-    const int fn = fm ? (__ffs(fm) - 1) : 5, bn = bm ? (__ffs(bm) - 1) : 5;
-    const int lo = sel - bn, hi = sel + fn;
-    const int idx = lo + lane;
-    if (idx <= hi) atomicOr(&L.picked[idx >> 5], 1u << (idx & 31));
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-}
 
 extern __shared__ __attribute__((aligned(16))) unsigned char ll_smem[];
 
@@ -249,7 +183,9 @@ extern __shared__ __attribute__((aligned(16))) unsigned char ll_smem[];
 #define LL_PHASE(i) do {} while (0)
 #endif
 
-__global__ __launch_bounds__(LL_BLOCK) void k_ring_features(LLView V, int first, int count)
+/* 2nd launch bound = waves per SIMD: six 256-thread workgroups per CU for the common 2304-point capacity (<= 80 VGPRs) */
+template <int ROWS>
+__global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features(LLView V, int first, int count)
 {
     int sl, r;
     if (!ll_xcd_map2(blockIdx.x, V.R, count, sl, r)) return;
@@ -267,24 +203,27 @@ __global__ __launch_bounds__(LL_BLOCK) void k_ring_features(LLView V, int first,
     const int Lseg = active ? (E - S) : 0;                            /* indices S .. E-1 are in segments */
     const float4 *cloud = V.cloud + (size_t)s * V.NP;
     FeatLds L = ll_carve(ll_smem, V.max_ring);
+    int *segb = L.sc + 16;                                            /* segment bounds (slots) for sort + pick */
+    float *fs = (float *)(L.sc + 32);                                 /* 24 floats: per-wave bounds */
 
     const int nwords = (nr + 31) / 32 + 1;
     for (int i = tid; i < nwords; i += LL_BLOCK) { L.picked[i] = 0; L.gapf[i] = 0; }
     for (int i = tid; i < nr; i += LL_BLOCK) L.lab[i] = 0;
     if (tid < 3) L.lists[156 + tid] = 0;                              /* n_sharp, n_lsharp, n_flat */
+    if (tid <= LL_SEGS) segb[tid] = Lseg * tid / LL_SEGS;             /* sp_j - S, int math of :253-254 */
     __syncthreads();
 
     LL_PHASE_BEGIN();
-    /* ---------------- phase 1: curvature + gap flags + keys ---------------- */
-    for (int c0 = 0; c0 < nr; c0 += LL_TILE) {
+    /* ---------------- phase 1: curvature + gap flags + sort records ---------------- */
+    for (int c0 = 0; c0 < nr; c0 += LL_FTILE) {
         const int g0 = off + c0;                                      /* global index of tile slot 5 */
-        for (int t = tid; t < LL_TILE + 10; t += LL_BLOCK) {
+        for (int t = tid; t < LL_FTILE + 10; t += LL_BLOCK) {
             const int g = g0 - 5 + t;
             if (g >= 0 && g < N) { const float4 p = cloud[g]; L.tx[t] = p.x; L.ty[t] = p.y; L.tz[t] = p.z; }
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < LL_TILE / LL_BLOCK; ++k) {
+        for (int k = 0; k < LL_FTILE / LL_BLOCK; ++k) {
             const int li = c0 + k * LL_BLOCK + tid;
             if (li >= nr) continue;
             const int g = off + li, t = li - c0 + 5;
@@ -299,7 +238,7 @@ __global__ __launch_bounds__(LL_BLOCK) void k_ring_features(LLView V, int first,
                 const float dZ = Z[-5] + Z[-4] + Z[-3] + Z[-2] + Z[-1] - 10 * Z[0] + Z[1] + Z[2] + Z[3] + Z[4] + Z[5];
                 const float cv = dX * dX + dY * dY + dZ * dZ;
                 if (V.write_curv) V.curv[(size_t)s * V.NP + g] = cv;
-                if (active && g >= S && g < E) L.keys[g - S] = ((u64)ll_f2u(cv) << 32) | (unsigned)li;
+                if (active && g >= S && g < E) { L.k32[g - S] = ll_f2u(cv); L.k16[g - S] = (unsigned short)li; }
             }
         }
         __syncthreads();
@@ -307,32 +246,27 @@ __global__ __launch_bounds__(LL_BLOCK) void k_ring_features(LLView V, int first,
 
     LL_PHASE(0);
     /* ---------------- phase 2: sort the six segments (:251-257) ---------------- */
-    int *segb = L.scratch + 320;                                       /* segment bounds for the sort network */
-    if (tid <= LL_SEGS) segb[tid] = Lseg * tid / LL_SEGS;              /* sp_j - S, int math of :253-254 */
-    __syncthreads();
-    const bool use_radix = V.max_ring <= LL_RS_E * LL_BLOCK;          /* longer rings: bitonic network (any length) */
-    int *rs_cnt = (int *)L.tx;                                         /* the curvature tile is free after phase 1 */
-    if (active) {
-        if (use_radix) ll_radix_sort_hi32<true>(L.keys, Lseg, rs_cnt, L.scratch, segb, tid);
-        else ll_bitonic_segments(L.keys, segb, LL_SEGS, tid);
-    }
+    if (active) ll_radix_sort<ROWS, true>(L.k32, L.k16, Lseg, L.cnt, L.sc, segb, tid);
     __syncthreads();
 
     LL_PHASE(1);
     /* ---------------- phase 3: greedy pick, wave 0 ---------------- */
     if (active && tid < 64) {
+        /* the pick is one long dependent instruction chain on a single wave while the other waves of the workgroup
+         * wait at the barrier: let it win issue arbitration against the co-resident workgroups' bulk phases */
+        __builtin_amdgcn_s_setprio(3);
         int ns = 0, nls = 0, nf = 0;
         for (int j = 0; j < LL_SEGS; ++j) {
-            const int sp = Lseg * j / 6, ep = Lseg * (j + 1) / 6 - 1;     /* key slots; = (:253-254) - S */
+            const int sp = Lseg * j / 6, ep = Lseg * (j + 1) / 6 - 1;     /* record slots; = (:253-254) - S */
             const int len = ep - sp + 1;
             /* pass 0: corners, descending curvature (:261-313); pass 1: flats, ascending (:316-359) */
             for (int pass = 0; pass < 2; ++pass) {
                 int npick = 0; bool done = false;
                 for (int c0 = 0; c0 < len && !done; c0 += 64) {
                     const bool have = c0 + lane < len;
-                    const u64 key = have ? L.keys[pass == 0 ? ep - (c0 + lane) : sp + c0 + lane] : 0ull;
-                    const int li = (int)(unsigned)key;
-                    const double cv = (double)ll_u2f((unsigned)(key >> 32));
+                    const int slot = pass == 0 ? ep - (c0 + lane) : sp + c0 + lane;
+                    const int li = have ? (int)L.k16[slot] : 0;
+                    const double cv = have ? (double)ll_u2f(L.k32[slot]) : 0.0;
                     const bool cand = have && (pass == 0 ? cv > V.curv_thr : cv < V.curv_thr);
                     if (__ballot(cand) == 0ull) break;
                     /* per candidate, once per chunk: is it already suppressed, and which index range [lo, hi] would its
@@ -342,7 +276,7 @@ __global__ __launch_bounds__(LL_BLOCK) void k_ring_features(LLView V, int first,
                     if (cand) {
                         elig = !ll_bit(L.picked, li);
                         const int b0 = li - 4;
-                        const u64 w = ((u64)L.gapf[(b0 >> 5) + 1] << 32) | L.gapf[b0 >> 5];
+                        const unsigned long long w = ((unsigned long long)L.gapf[(b0 >> 5) + 1] << 32) | L.gapf[b0 >> 5];
                         const unsigned bits = (unsigned)(w >> (b0 & 31)) & 0x3ffu;   /* bit t = gapf[li - 4 + t] */
                         const unsigned fwd = bits >> 5;                              /* l = 1..5  -> gapf[li + l] */
                         const int fn = fwd ? (__ffs(fwd) - 1) : 5;
@@ -382,6 +316,7 @@ __global__ __launch_bounds__(LL_BLOCK) void k_ring_features(LLView V, int first,
             }
         }
         if (lane == 0) { L.lists[156] = ns; L.lists[157] = nls; L.lists[158] = nf; }
+        __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
 
@@ -401,8 +336,6 @@ __global__ __launch_bounds__(LL_BLOCK) void k_ring_features(LLView V, int first,
                 mxx = fmaxf(mxx, p.x); mxy = fmaxf(mxy, p.y); mxz = fmaxf(mxz, p.z);
             }
         }
-        int *sc = L.scratch;
-        float *fs = (float *)(L.scratch + LL_BLOCK + 16);
         /* wave reduce min/max, then across the 4 waves through LDS */
         for (int o = 32; o > 0; o >>= 1) {
             mnx = fminf(mnx, __shfl_xor(mnx, o)); mny = fminf(mny, __shfl_xor(mny, o)); mnz = fminf(mnz, __shfl_xor(mnz, o));
@@ -410,7 +343,7 @@ __global__ __launch_bounds__(LL_BLOCK) void k_ring_features(LLView V, int first,
         }
         if (lane == 0) { float *w = fs + (tid >> 6) * 6; w[0] = mnx; w[1] = mny; w[2] = mnz; w[3] = mxx; w[4] = mxy; w[5] = mxz; }
         int m = 0;
-        int pos = ll_block_exscan(cntl, sc, m);                      /* barriers inside also publish fs[] */
+        int pos = ll_block_exscan(cntl, L.sc, m);                    /* barriers inside also publish fs[] */
         for (int q = a0; q < a1; ++q) if (L.lab[q + 5] <= 0) L.lf_list[pos++] = (unsigned short)(q + 5);
         float mn[3] = {fs[0], fs[1], fs[2]}, mx[3] = {fs[3], fs[4], fs[5]};
         for (int w = 1; w < LL_BLOCK / 64; ++w)
@@ -437,13 +370,11 @@ __global__ __launch_bounds__(LL_BLOCK) void k_ring_features(LLView V, int first,
                     const int i2 = (int)(floorf(p.z * inv) - (float)min_b[2]);
                     idx = (unsigned)(i0 + i1 * mul1 + i2 * mul2);
                 }
-                L.keys[jx] = ((u64)idx << 32) | (unsigned)jx;
+                L.k32[jx] = idx; L.k16[jx] = (unsigned short)jx;
             }
-            if (tid == 0) { segb[0] = 0; segb[1] = m; }
             __syncthreads();
             LL_PHASE(3);
-            if (use_radix) ll_radix_sort_hi32<false>(L.keys, m, rs_cnt, L.scratch, segb, tid);
-            else ll_bitonic_segments(L.keys, segb, 1, tid);
+            ll_radix_sort<ROWS, false>(L.k32, L.k16, m, L.cnt, L.sc, segb, tid);
             LL_PHASE(4);
             __syncthreads();
             /* run heads -> output rank */
@@ -451,20 +382,20 @@ __global__ __launch_bounds__(LL_BLOCK) void k_ring_features(LLView V, int first,
             const int b0 = min(m, tid * perm), b1 = min(m, b0 + perm);
             int heads = 0;
             for (int p = b0; p < b1; ++p)
-                if (p == 0 || (unsigned)(L.keys[p] >> 32) != (unsigned)(L.keys[p - 1] >> 32)) heads++;
-            int o = ll_block_exscan(heads, sc, n_lf_out);
+                if (p == 0 || L.k32[p] != L.k32[p - 1]) heads++;
+            int o = ll_block_exscan(heads, L.sc, n_lf_out);
             float4 *out = V.lflat_slot + (size_t)s * V.NP + off;
             for (int p = b0; p < b1; ++p) {
-                const unsigned vid = (unsigned)(L.keys[p] >> 32);
-                if (p != 0 && vid == (unsigned)(L.keys[p - 1] >> 32)) continue;
+                const unsigned vid = L.k32[p];
+                if (p != 0 && vid == L.k32[p - 1]) continue;
                 /* CentroidPoint<PointXYZI>: f32 sums in input order, divided by float(n) */
                 float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f;
                 int e = p + 1;
-                while (e < m && (unsigned)(L.keys[e] >> 32) == vid) ++e;             /* run = [p, e) */
+                while (e < m && L.k32[e] == vid) ++e;                                /* run = [p, e) */
                 for (int q = p; q < e; q += 4) {                                     /* 4 independent gathers in flight, */
                     float4 pt[4];                                                    /* then the adds in input order     */
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) if (q + u < e) pt[u] = cloud[off + L.lf_list[(unsigned)L.keys[q + u]]];
+                    for (int u = 0; u < 4; ++u) if (q + u < e) pt[u] = cloud[off + L.lf_list[L.k16[q + u]]];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) if (q + u < e) { sx += pt[u].x; sy += pt[u].y; sz += pt[u].z; si += pt[u].w; }
                 }
@@ -518,17 +449,26 @@ __global__ __launch_bounds__(128) void k_compact(LLView V, int first, int count)
     }
 }
 
+template <int ROWS>
+static void ll_launch_ring_features(const LLView &V, int first, int count, int grid, size_t lds_bytes, hipStream_t st)
+{
+    static size_t attr_bytes = 0;
+    if (lds_bytes > attr_bytes) {
+        (void)hipFuncSetAttribute((const void *)k_ring_features<ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        attr_bytes = lds_bytes;
+    }
+    hipLaunchKernelGGL(k_ring_features<ROWS>, dim3(grid), dim3(LL_BLOCK), lds_bytes, st, V, first, count);
+}
+
 void ll_launch_features(const LLView &V, int first, int count, size_t lds_bytes, hipStream_t st, LLProfiler *prof)
 {
     const int groups = (count + 7) / 8;
     const int grid = 8 * V.R * groups;
-    static size_t attr_bytes = 0;
-    if (lds_bytes > attr_bytes) {
-        (void)hipFuncSetAttribute((const void *)k_ring_features, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        attr_bytes = lds_bytes;
-    }
     ll_prof_mark(prof, LL_K_RING_FEATURES, st);
-    hipLaunchKernelGGL(k_ring_features, dim3(grid), dim3(LL_BLOCK), lds_bytes, st, V, first, count);
+    const int rows = (V.max_ring + 255) / 256;                 /* sort records per thread */
+    if (rows <= 9) ll_launch_ring_features<9>(V, first, count, grid, lds_bytes, st);
+    else if (rows <= 18) ll_launch_ring_features<18>(V, first, count, grid, lds_bytes, st);
+    else ll_launch_ring_features<36>(V, first, count, grid, lds_bytes, st);
     ll_prof_mark(prof, LL_K_COMPACT, st);
     hipLaunchKernelGGL(k_compact, dim3(grid), dim3(128), 0, st, V, first, count);
     ll_prof_mark(prof, LL_K_END, st);
