@@ -55,35 +55,16 @@ __device__ __forceinline__ float ll_cell_lb2(float qx, float qy, int cx, int cy)
 __device__ __forceinline__ int ll_ring_hi(int rc, double nearby) { return (int)floor((double)rc + nearby); }
 __device__ __forceinline__ int ll_ring_lo(int rc, double nearby) { return (int)ceil((double)rc - nearby); }
 
-/* block-wide exclusive scans with max / min (256 threads) */
-__device__ __forceinline__ int ll_block_exscan_max(int v, int *sc)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int inc = v;
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc = max(inc, t); }
-    if (lane == 63) sc[wave] = inc;
-    __syncthreads();
-    int base = INT_MIN;
-    for (int w = 0; w < wave; ++w) base = max(base, sc[w]);
-    int ex = __shfl_up(inc, 1); if (lane == 0) ex = INT_MIN;
-    __syncthreads();
-    return max(base, ex);
-}
-__device__ __forceinline__ int ll_block_exscan_min_rev(int v, int *sc)      /* exclusive SUFFIX min */
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int inc = v;
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_down(inc, o); if (lane + o < 64) inc = min(inc, t); }
-    if (lane == 0) sc[wave] = inc;
-    __syncthreads();
-    int base = INT_MAX;
-    for (int w = wave + 1; w < LL_BLOCK / 64; ++w) base = min(base, sc[w]);
-    int ex = __shfl_down(inc, 1); if (lane == 63) ex = INT_MAX;
-    __syncthreads();
-    return min(base, ex);
-}
-
 extern __shared__ __attribute__((aligned(16))) unsigned char ll_gsm[];
+
+#ifdef LL_PHASE_TIMING   /* tools/phase_timing.py: V.dbg[8..11] = k_build_grid phases, V.dbg[14] = its workgroups */
+#define LL_GPHASE_BEGIN() long long ll_t0 = (tid == 0) ? (long long)__builtin_amdgcn_s_memtime() : 0
+#define LL_GPHASE(i) do { __syncthreads(); if (tid == 0) { const long long t1 = (long long)__builtin_amdgcn_s_memtime(); \
+    atomicAdd(&V.dbg[i], (unsigned long long)(t1 - ll_t0)); ll_t0 = t1; if ((i) == 11) atomicAdd(&V.dbg[14], 1ull); } } while (0)
+#else
+#define LL_GPHASE_BEGIN() do {} while (0)
+#define LL_GPHASE(i) do {} while (0)
+#endif
 
 /* grid + ring tables of a target cloud; carry != 0: the carry clouds, else slot first + blockIdx/2 */
 __global__ __launch_bounds__(LL_BLOCK) void k_build_grid(LLView V, int first, int count, int carry)
@@ -104,58 +85,88 @@ __global__ __launch_bounds__(LL_BLOCK) void k_build_grid(LLView V, int first, in
         gstart = V.gstart + ((size_t)s * 2 + which) * LL_GSTRIDE;
         gpts = which ? V.gpts_s + (size_t)s * V.NP : V.gpts_c + (size_t)s * V.cap_lsharp;
     }
-    int *hist = (int *)ll_gsm;                      /* [LL_GRID_NC] */
+    /* cell c lives at hist[c + (c >> 6)]: the per-thread scan below walks 64 consecutive cells per lane, and the
+     * one-word skew per 64 cells spreads the lanes over all LDS banks instead of putting them on one */
+#define LL_HI(c) ((c) + ((c) >> 6))
+    int *hist = (int *)ll_gsm;                      /* [LL_GRID_NC + LL_GRID_NC / 64] */
     __shared__ int sc[8];
     __shared__ int feq[LL_TAB + 1], leq[LL_TAB + 1];
     __shared__ int okflag;
-    for (int i = tid; i < LL_GRID_NC; i += LL_BLOCK) hist[i] = 0;
+    for (int i = tid; i < LL_GRID_NC + LL_GRID_NC / 64; i += LL_BLOCK) hist[i] = 0;
     for (int i = tid; i <= LL_TAB; i += LL_BLOCK) { feq[i] = INT_MAX; leq[i] = -1; }
     if (tid == 0) okflag = (V.nearby >= 0.0) ? 1 : 0;
     __syncthreads();
-    for (int i = tid; i < m; i += LL_BLOCK) {
-        const float4 p = pts[i];
-        atomicAdd(&hist[ll_cell_coord(p.y) * LL_GRID_G + ll_cell_coord(p.x)], 1);
+    LL_GPHASE_BEGIN();
+    constexpr int UN = 8;                            /* independent loads in flight per thread: the kernel is latency-bound */
+    for (int i0 = tid; i0 < m; i0 += LL_BLOCK * UN) {
+        float4 p[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) { const int i = i0 + u * LL_BLOCK; if (i < m) p[u] = pts[i]; }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int i = i0 + u * LL_BLOCK;
+            if (i < m) { const int c = ll_cell_coord(p[u].y) * LL_GRID_G + ll_cell_coord(p[u].x); atomicAdd(&hist[LL_HI(c)], 1); }
+        }
     }
     __syncthreads();
-    constexpr int PER = LL_GRID_NC / LL_BLOCK;
+    LL_GPHASE(8);
+    constexpr int PER = LL_GRID_NC / LL_BLOCK;      /* 64 */
     int sum = 0;
-    for (int k = 0; k < PER; ++k) sum += hist[tid * PER + k];
+    for (int k = 0; k < PER; ++k) sum += hist[tid * (PER + 1) + k];
     int total = 0;
     int run = ll_block_exscan(sum, sc, total);
-    for (int k = 0; k < PER; ++k) { const int c = hist[tid * PER + k]; hist[tid * PER + k] = run; gstart[tid * PER + k] = run; run += c; }
+    for (int k = 0; k < PER; ++k) { const int c = hist[tid * (PER + 1) + k]; hist[tid * (PER + 1) + k] = run; gstart[tid * PER + k] = run; run += c; }
     if (tid == LL_BLOCK - 1) gstart[LL_GRID_NC] = total;
     __syncthreads();
-    for (int i = tid; i < m; i += LL_BLOCK) {
-        const float4 p = pts[i];
-        const int pos = atomicAdd(&hist[ll_cell_coord(p.y) * LL_GRID_G + ll_cell_coord(p.x)], 1);
-        const int r = (int)p.w;                                              /* int(intensity): the walk's scan id */
-        gpts[pos] = make_float4(p.x, p.y, p.z, __int_as_float((i & 0xFFFFFF) | ((r & 0xFF) << 24)));
+    LL_GPHASE(9);
+    for (int i0 = tid; i0 < m; i0 += LL_BLOCK * UN) {
+        float4 p[UN]; int pos[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) { const int i = i0 + u * LL_BLOCK; if (i < m) p[u] = pts[i]; }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int i = i0 + u * LL_BLOCK;
+            if (i < m) { const int c = ll_cell_coord(p[u].y) * LL_GRID_G + ll_cell_coord(p[u].x); pos[u] = atomicAdd(&hist[LL_HI(c)], 1); }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int i = i0 + u * LL_BLOCK;
+            if (i < m) {
+                const int r = (int)p[u].w;                                   /* int(intensity): the walk's scan id */
+                gpts[pos[u]] = make_float4(p[u].x, p[u].y, p[u].z, __int_as_float((i & 0xFFFFFF) | ((r & 0xFF) << 24)));
+            }
+        }
     }
+#undef LL_HI
 
-    /* ---- ring tables + validity ---- */
-    const int per = (m + LL_BLOCK - 1) / LL_BLOCK;
-    const int a0 = min(m, tid * per), a1 = min(m, a0 + per);
-    int cmax = INT_MIN, cmin = INT_MAX; bool bad = false;
-    for (int j = a0; j < a1; ++j) {
-        const int r = (int)pts[j].w;
-        if (r < 0 || r >= LL_TAB) { bad = true; continue; }
-        atomicMin(&feq[r], j); atomicMax(&leq[r], j);
-        cmax = max(cmax, r); cmin = min(cmin, r);
-    }
-    int pm = ll_block_exscan_max(cmax, sc);          /* max ring over all j before this thread's chunk */
-    int sm = ll_block_exscan_min_rev(cmin, sc);      /* min ring over all j after this thread's chunk */
-    if (!bad) {
-        for (int j = a0; j < a1; ++j) {              /* no earlier point may already be beyond this point's up-window */
-            const int r = (int)pts[j].w;
-            if (pm > ll_ring_hi(r, V.nearby)) bad = true;
-            pm = max(pm, r);
+    LL_GPHASE(10);
+    /* ---- ring tables + validity.  One sweep records the first / last index of every ring value (only run boundaries
+     * touch LDS).  The tables first_ge / last_le reproduce the reference's sequential walk bounds for EVERY start index
+     * iff no point lies before a point whose up-window it exceeds and none after a point whose down-window it undercuts:
+     *   exists j < c with ring_j > hi(ring_c)   <=>   exists value b:  first_ge[hi(b) + 1] < last_eq[b]
+     *   exists j > c with ring_j < lo(ring_c)   <=>   exists value b:  last_le[lo(b) - 1]  > first_eq[b]
+     * so validity is a check on the two 160-entry tables, no per-point scan. ---- */
+    const int lane = tid & 63;
+    bool bad = false;
+    for (int i0 = tid; i0 < m; i0 += LL_BLOCK * UN) {
+        float rw[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) { const int j = i0 + u * LL_BLOCK; rw[u] = (j < m) ? pts[j].w : 0.0f; }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int j = i0 + u * LL_BLOCK;
+            const bool in = j < m;
+            const int r = (int)rw[u];
+            const bool oob = in && (r < 0 || r >= LL_TAB);
+            if (oob) bad = true;
+            const int rprev = __shfl_up(r, 1), rnext = __shfl_down(r, 1);
+            if (in && !oob) {
+                if (lane == 0 || r != rprev) atomicMin(&feq[r], j);
+                if (lane == 63 || j == m - 1 || r != rnext) atomicMax(&leq[r], j);
+            }
         }
-        for (int j = a1 - 1; j >= a0; --j) {         /* no later point may be below this point's down-window */
-            const int r = (int)pts[j].w;
-            if (sm < ll_ring_lo(r, V.nearby)) bad = true;
-            sm = min(sm, r);
-        }
     }
+    LL_GPHASE(11);
     if (bad) okflag = 0;
     __syncthreads();
     int *tab = gstart + LL_GRID_NC + 1;              /* first_ge[LL_TAB+1], last_le[LL_TAB+1], ok, m */
@@ -164,7 +175,15 @@ __global__ __launch_bounds__(LL_BLOCK) void k_build_grid(LLView V, int first, in
         for (int v = LL_TAB; v >= 0; --v) { if (feq[v] != INT_MAX) run_min = min(run_min, feq[v]); tab[v] = run_min; }
         int run_max = -1;
         for (int v = 0; v <= LL_TAB; ++v) { run_max = max(run_max, leq[v]); tab[LL_TAB + 1 + v] = run_max; }
-        tab[2 * (LL_TAB + 1)] = okflag;
+        int ok = okflag;
+        for (int bv = 0; bv < LL_TAB && ok; ++bv) {
+            if (feq[bv] == INT_MAX) continue;
+            const int hi = ll_ring_hi(bv, V.nearby), lo = ll_ring_lo(bv, V.nearby);
+            const int fg = (hi + 1 > LL_TAB) ? m : tab[max(hi + 1, 0)];
+            const int ll = (lo - 1 < 0) ? -1 : tab[LL_TAB + 1 + min(lo - 1, LL_TAB)];
+            if (fg < leq[bv] || ll > feq[bv]) ok = 0;
+        }
+        tab[2 * (LL_TAB + 1)] = ok;
         tab[2 * (LL_TAB + 1) + 1] = m;
     }
 }
@@ -423,11 +442,11 @@ void ll_launch_build_grid(const LLView &V, int first, int count, int carry, hipS
 {
     static bool attr_set = false;
     if (!attr_set) {   /* 64 KiB histogram + static LDS exceeds the default dynamic-LDS limit */
-        (void)hipFuncSetAttribute((const void *)k_build_grid, hipFuncAttributeMaxDynamicSharedMemorySize, LL_GRID_NC * sizeof(int));
+        (void)hipFuncSetAttribute((const void *)k_build_grid, hipFuncAttributeMaxDynamicSharedMemorySize, (LL_GRID_NC + LL_GRID_NC / 64) * sizeof(int));
         attr_set = true;
     }
     ll_prof_mark(prof, LL_K_GRID, st);
-    hipLaunchKernelGGL(k_build_grid, dim3(2 * (carry ? 1 : count)), dim3(LL_BLOCK), LL_GRID_NC * sizeof(int), st, V, first, carry ? 1 : count, carry);
+    hipLaunchKernelGGL(k_build_grid, dim3(2 * (carry ? 1 : count)), dim3(LL_BLOCK), (LL_GRID_NC + LL_GRID_NC / 64) * sizeof(int), st, V, first, carry ? 1 : count, carry);
     ll_prof_mark(prof, LL_K_END, st);
 }
 
