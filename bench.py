@@ -87,12 +87,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="scans resident per GPU and processed per step")
+    ap.add_argument("--batch", type=int, default=1024, help="scans resident per GPU and processed per step")
     ap.add_argument("--chunk", type=int, default=0, help="scans per launch sequence inside a step (0 = whole batch)")
     ap.add_argument("--rings", type=int, default=64)
-    ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic poses the batch cycles through")
+    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic poses the batch cycles through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--calibrate", action="store_true",
+                    help="also launch k_calib_copy (1 GiB in + 1 GiB out) once: the known-byte launch tools/pmc_traffic.py "
+                         "uses to calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -129,6 +132,8 @@ def main():
         ctx.upload_scan(i, base[order[i + 1]])
     ctx.set_pose_guess(0, args.batch, guesses)
     ctx.synchronize()
+    if args.calibrate:
+        ctx._ck(ctx.lib.ll_debug_calibration_copy(ctx.h, C.c_ulonglong(1 << 30)))
 
     def step():
         ctx.hot_path(0, args.batch, None, vote=True)     # pose restarts from the stored guess, device-to-device
@@ -161,20 +166,46 @@ def main():
     info = ctx.scan_info(0); pair = ctx.pair_info(0); pose = ctx.pose(0)
     assert info.status == 0 and pair.n_edge > 0 and pair.n_plane_selected > 0 and np.isfinite(pose).all()
     ab = ctx.algorithmic_bytes(0, args.batch)
+    # per-kernel share of SURVEY.md section 8d's algorithmic bytes (every array counted once, at the kernel that must touch
+    # it), summed over the batch from the run's actual counts
+    tot = dict(n_in=0, n=0, feat=0, lsharp=0, lflat=0, q=0, ne=0, np_=0, nsel=0)
+    for i in range(args.batch):
+        si = ctx.scan_info(i); pi = ctx.pair_info(i)
+        tot["n_in"] += si.n_in; tot["n"] += si.n
+        tot["feat"] += si.n_sharp + si.n_less_sharp + si.n_flat + si.n_less_flat
+        tot["lsharp"] += si.n_less_sharp; tot["lflat"] += si.n_less_flat; tot["q"] += si.n_sharp + si.n_flat
+        tot["ne"] += pi.n_edge; tot["np_"] += pi.n_plane; tot["nsel"] += pi.n_plane_selected
+    kernel_bytes = {
+        "k_first_kept": 0.0, "k_offsets": 0.0, "k_compact": 0.0, "k_gn_step": 0.0,
+        "k_classify": 16.0 * tot["n_in"],                            # read the raw scan
+        "k_scatter": 16.0 * tot["n"],                                # write laserCloud
+        "k_ring_features": 17.0 * tot["n"] + 16.0 * tot["feat"],     # read laserCloud, write labels + the four feature clouds
+        "k_build_grid": 16.0 * (tot["lsharp"] + tot["lflat"]),       # read the target clouds once
+        "k_associate": 16.0 * tot["q"] + 8.0 * tot["ne"] + 12.0 * tot["np_"],
+        "k_vote": 32.0 * tot["np_"] + 8.0 * tot["nsel"],
+        "k_normal_equations": 48.0 * tot["ne"] + 64.0 * tot["nsel"] + 216.0 * args.batch,
+    }
 
     if rank == 0:
         total_scans = args.batch * world * args.steps
         value = total_scans / elapsed
-        # dominant kernel by summed HIP-event time; algorithmic bytes of the stage it belongs to, per launch
+        # dominant kernel by summed HIP-event time (events on the library's own stream)
         dom = max(prof, key=lambda k: prof[k][0])
         dom_ms, dom_launches = prof[dom]
-        stage_bytes = {"k_first_kept": ab["ext"], "k_classify": ab["ext"], "k_offsets": ab["ext"], "k_scatter": ab["ext"], "k_ring_features": ab["ext"],
-                       "k_compact": ab["ext"], "k_associate": ab["assoc"], "k_build_grid": ab["assoc"], "k_vote": ab["vote"],
-                       "k_normal_equations": ab["rj"], "k_gn_step": ab["rj"]}[dom]
         launches_per_step = max(1, dom_launches // max(1, args.steps))
-        bytes_per_launch = stage_bytes / launches_per_step
+        bytes_per_launch = kernel_bytes[dom] / launches_per_step
         avg_ms = dom_ms / max(1, dom_launches)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM traffic of that kernel from the separate rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                T = json.load(open(tpath))
+                if dom in T.get("kernels", {}) and T.get("rings") == args.rings:
+                    traffic = T["kernels"][dom]["hbm_bytes_per_scan"] * args.batch / launches_per_step
+            except Exception:
+                traffic = None
         out = {
             "metric": "scans/sec (feature-extract+match+one GN iter), 64-ring cloud",
             "value": value, "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -187,10 +218,12 @@ def main():
                        "points_per_scan_in": int(info.n_in), "points_per_scan_kept": int(info.n),
                        "parallelism": f"scan-parallel x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "whole_path_algorithmic_GBps": (ab["ext"] + ab["assoc"] + ab["vote"] + ab["rj"]) * args.steps / elapsed / 1e9,
-                         "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1]}},
+                         "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1]},
+                         "kernel_algorithmic_GBps": {k: kernel_bytes[k] / (v[0] / args.steps * 1e-3) / 1e9
+                                                     for k, v in prof.items() if v[1] and kernel_bytes.get(k)}},
         }
         if world == 1 and not args.no_cpu_baseline:
             from oracle import orc

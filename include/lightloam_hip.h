@@ -172,6 +172,9 @@ int ll_profile_enable(ll_ctx *ctx, int on);
 int ll_profile_read(ll_ctx *ctx, int *n, const char **names, double *total_ms, int *launches, int reset);
 /* 16 in-kernel phase counters (shader cycles); zero unless the library was built with -DLL_PHASE_TIMING (tools/phase_timing.py) */
 int ll_debug_counters(ll_ctx *ctx, unsigned long long *out16, int reset);
+/* one float4 streaming copy of `bytes` in + `bytes` out ("k_calib_copy"): the known-byte-count launch that calibrates
+ * rocprofv3's FETCH_SIZE / WRITE_SIZE counters (tools/pmc_traffic.py) */
+int ll_debug_calibration_copy(ll_ctx *ctx, unsigned long long bytes);
 
 /* Algorithmic HBM bytes of the last ll_hot_path_batch / stage calls, summed over the slots they covered,
  * by SURVEY.md section 8d's formula (B_ext, B_assoc, B_vote, B_rj).                                      */

@@ -21,7 +21,7 @@ EXPORTS = [
     "ll_download_features", "ll_set_target", "ll_set_target_from_slot", "ll_associate_batch", "ll_get_pair_info",
     "ll_download_edge_corr", "ll_download_plane_corr", "ll_vote_batch", "ll_download_vote",
     "ll_normal_equations_batch", "ll_download_normal_equations", "ll_gn_step_batch", "ll_download_pose",
-    "ll_residual_jacobian", "ll_hot_path_batch", "ll_algorithmic_bytes", "ll_profile_enable", "ll_profile_read", "ll_set_pose_guess", "ll_debug_counters", "ll_vote_host",
+    "ll_residual_jacobian", "ll_hot_path_batch", "ll_algorithmic_bytes", "ll_profile_enable", "ll_profile_read", "ll_set_pose_guess", "ll_debug_counters", "ll_vote_host", "ll_debug_calibration_copy",
 ]
 
 

@@ -118,6 +118,11 @@ extern "C" int ll_create(int device, const ll_params *p, ll_ctx **out)
     *out = nullptr;
     if (p->n_scans < 1 || p->n_scans > LL_MAX_RINGS || p->batch < 1 || p->max_points < 32 || p->max_points > 400000 ||
         p->max_ring_points < 32 || p->max_ring_points > 9216) { g_create_err = "bad parameter"; return LL_ERR_ARG; }
+    if (!(p->nn_dist_sq_max > 0.0f) || p->nn_dist_sq_max > 36.0f) {
+        /* the cell search visits Chebyshev rings 0..3 of 2 m cells: exact for every neighbour closer than 6 m */
+        g_create_err = "nn_dist_sq_max must be in (0, 36] (reference: DISTANCE_SQ_THRESHOLD = 25)";
+        return LL_ERR_ARG;
+    }
     if (p->ring_model == 0 && p->n_scans != 16 && p->n_scans != 32 && p->n_scans != 64) {
         g_create_err = "only support velodyne with 16, 32 or 64 scan line (scanRegistration.cpp:447-451); use ring_model 1 for the linear model";
         return LL_ERR_BAD_RINGS;
@@ -561,6 +566,28 @@ extern "C" int ll_residual_jacobian(ll_ctx *ctx, int slot, const double *pose7, 
 }
 
 /* debug: the 16 phase-timing counters (all zero unless built with -DLL_PHASE_TIMING); reset = zero them afterwards */
+/* PMC calibration: a float4 streaming copy of exactly `bytes` read + `bytes` written (k_calib_copy in the kernel trace).
+ * rocprofv3's FETCH_SIZE on gfx950 reports half the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM section);
+ * tools/pmc_traffic.py divides the known byte count by the counter value of this launch to get the correction. */
+__global__ void k_calib_copy(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+extern "C" int ll_debug_calibration_copy(ll_ctx *ctx, unsigned long long bytes)
+{
+    if (!ctx) return LL_ERR_ARG;
+    const size_t n = (size_t)(bytes / 16);
+    void *a = nullptr, *b = nullptr;
+    LL_HIP(hipMalloc(&a, n * 16)); LL_HIP(hipMalloc(&b, n * 16));
+    LL_HIP(hipMemsetAsync(a, 1, n * 16, ctx->stream));
+    hipLaunchKernelGGL(k_calib_copy, dim3(2048), dim3(256), 0, ctx->stream, (const float4 *)a, (float4 *)b, n);
+    LL_HIP(hipGetLastError());
+    LL_HIP(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(a); (void)hipFree(b);
+    return LL_OK;
+}
+
 extern "C" int ll_debug_counters(ll_ctx *ctx, unsigned long long *out16, int reset)
 {
     if (!ctx || !out16) return LL_ERR_ARG;

@@ -243,26 +243,51 @@ __device__ __forceinline__ float ll_walk_d2(const float4 p, float sx, float sy, 
     return (p.x - sx) * (p.x - sx) + (p.y - sy) * (p.y - sy) + (p.z - sz) * (p.z - sz);
 }
 
-/* visit the cells around (qx, qy) in Chebyshev rings; f(cell_start, cell_end) scans one cell, bound() is the current
- * pruning radius^2 (shrinks as candidates are found), sync() shares the best inside the 8-lane group */
+/* e-th cell (0 <= e < 8*ring, or the centre for ring 0) of the Chebyshev ring `ring`: top row, bottom row, then the
+ * two side cells of every inner row */
+__device__ __forceinline__ void ll_ring_cell(int ring, int e, int &dx, int &dy)
+{
+    if (ring == 0) { dx = 0; dy = 0; return; }
+    const int w = 2 * ring + 1;
+    if (e < w) { dx = e - ring; dy = -ring; }
+    else if (e < 2 * w) { dx = e - w - ring; dy = ring; }
+    else { const int t = e - 2 * w; dy = -ring + 1 + (t >> 1); dx = (t & 1) ? ring : -ring; }
+}
+
+#define LL_RING_CELLS 24          /* 8 * 3: the widest ring ever searched (nn_max 25, cell 2 m -> rings 0..3) */
+
+/* visit the cells around (qx, qy) in Chebyshev rings; scan(cell_start, cell_end) scans one cell, bound() is the current
+ * pruning radius^2 (shrinks as candidates are found), sync() shares the best inside the 8-lane group.
+ * The bounds of ALL cells of a ring are fetched at once -- lane `sub` of the group takes cells sub, sub+8, sub+16 -- and
+ * exchanged through a per-group LDS table: one parallel round of loads per ring instead of one dependent load per cell. */
 template <typename Scan, typename Bound, typename Sync>
-__device__ __forceinline__ void ll_grid_search(const int *gstart, float qx, float qy, int rmax, Scan scan, Bound bound, Sync sync)
+__device__ __forceinline__ void ll_grid_search(const int *gstart, float qx, float qy, int rmax, int *cellb, int sub,
+                                               Scan scan, Bound bound, Sync sync)
 {
     const int cx = ll_cell_coord(qx), cy = ll_cell_coord(qy);
+    if (rmax > 3) rmax = 3;                                   /* table capacity; larger radii would need more cells */
     for (int ring = 0; ring <= rmax; ++ring) {
         if (ring >= 2) { const float lbr = (float)(ring - 1) * LL_GRID_CELL - 1e-3f; if (lbr * lbr > bound()) break; }
-        for (int dy = -ring; dy <= ring; ++dy) {
-            const int yy = cy + dy;
-            if (yy < 0 || yy >= LL_GRID_G) continue;
-            const int step = (dy == -ring || dy == ring || ring == 0) ? 1 : 2 * ring;
-            for (int dx = -ring; dx <= ring; dx += step) {
-                const int xx = cx + dx;
-                if (xx < 0 || xx >= LL_GRID_G) continue;
-                if (ll_cell_lb2(qx, qy, xx, yy) > bound()) continue;
-                const int c = yy * LL_GRID_G + xx;
-                scan(gstart[c], gstart[c + 1]);
+        const int ncell = ring == 0 ? 1 : 8 * ring;
+        const float bnd = bound();
+        for (int e = sub; e < ncell; e += 8) {
+            int dx, dy; ll_ring_cell(ring, e, dx, dy);
+            const int xx = cx + dx, yy = cy + dy;
+            int st = 0, en = 0; float lb = 0.0f;
+            if (xx >= 0 && xx < LL_GRID_G && yy >= 0 && yy < LL_GRID_G) {
+                lb = ll_cell_lb2(qx, qy, xx, yy);
+                if (!(lb > bnd)) { const int c = yy * LL_GRID_G + xx; st = gstart[c]; en = gstart[c + 1]; }
             }
+            cellb[3 * e] = st; cellb[3 * e + 1] = en; cellb[3 * e + 2] = __float_as_int(lb);
         }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        for (int e = 0; e < ncell; ++e) {
+            const int st = cellb[3 * e], en = cellb[3 * e + 1];
+            if (st >= en) continue;
+            if (__int_as_float(cellb[3 * e + 2]) > bound()) continue;       /* the bound may have shrunk since the fetch */
+            scan(st, en);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         sync();
     }
 }
@@ -270,7 +295,7 @@ __device__ __forceinline__ void ll_grid_search(const int *gstart, float qx, floa
 template <bool PLANE>
 __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int qblock,
                                                    const float4 *queries, int nq, const TargetRef T,
-                                                   int *out_a, int *out_b, int *out_c, float4 *qs, int *nn, int *rb, int *rcl)
+                                                   int *out_a, int *out_b, int *out_c, float4 *qs, int *nn, int *rb, int *rcl, int *cellb_all)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const int qi = qblock * LL_BLOCK + tid;
@@ -289,6 +314,7 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
     __syncthreads();
 
     const int g = tid >> 3, sub = tid & 7;
+    int *cellb = cellb_all + g * (3 * LL_RING_CELLS);
     const int rmax = (int)ceilf(sqrtf(V.nn_max) / LL_GRID_CELL) + 1;
     const float4 *gpts = T.gpts; const int *gstart = T.gstart;
     const float4 *tgt = T.pts; const int M = T.m;
@@ -301,7 +327,7 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
         if (q.w != 0.0f && M > 0) {
             /* ---- exact K=1 NN within nn_max ---- */
             float bd = dmax; int bi = INT_MAX;
-            ll_grid_search(gstart, q.x, q.y, rmax,
+            ll_grid_search(gstart, q.x, q.y, rmax, cellb, sub,
                 [&](int st, int en) {
                     for (int k = st + sub; k < en; k += 8) {
                         const float4 p = gpts[k];
@@ -329,7 +355,7 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
                 const int jhi = (hi + 1 > LL_TAB) ? M : T.tab[max(hi + 1, 0)];                 /* first j with ring > hi */
                 const int jlo = (lo - 1 < 0) ? -1 : T.tab[LL_TAB + 1 + min(lo - 1, LL_TAB)];   /* last j with ring < lo */
                 Best b2 = {dmax, INT_MAX, -1}, b3 = {dmax, INT_MAX, -1};
-                ll_grid_search(gstart, q.x, q.y, rmax,
+                ll_grid_search(gstart, q.x, q.y, rmax, cellb, sub,
                     [&](int st, int en) {
                         for (int k = st + sub; k < en; k += 8) {
                             const float4 p = gpts[k];
@@ -421,20 +447,21 @@ __global__ __launch_bounds__(LL_BLOCK) void k_associate(LLView V, int first, int
     const int s = first + sl;
     __shared__ float4 qs[LL_BLOCK];
     __shared__ int nn[LL_BLOCK], rb[LL_BLOCK], rcl[LL_BLOCK];
+    __shared__ int cellb[(LL_BLOCK / 8) * 3 * LL_RING_CELLS];
     const ScanHdr h = V.hdr[s];
     const bool ok = h.status == 0;
     if (item < qb_corner) {
         const int nq = ok ? h.n_sharp : 0;
         if (item * LL_BLOCK >= nq) return;
         ll_associate_block<false>(V, s, item, V.sharp + (size_t)s * V.cap_sharp, nq, ll_target(V, s, 0),
-                                  V.eq_a + (size_t)s * V.cap_sharp, V.eq_b + (size_t)s * V.cap_sharp, nullptr, qs, nn, rb, rcl);
+                                  V.eq_a + (size_t)s * V.cap_sharp, V.eq_b + (size_t)s * V.cap_sharp, nullptr, qs, nn, rb, rcl, cellb);
     } else {
         const int qb = item - qb_corner;
         const int nq = ok ? h.n_flat : 0;
         if (qb * LL_BLOCK >= nq) return;
         ll_associate_block<true>(V, s, qb, V.flat + (size_t)s * V.cap_flat, nq, ll_target(V, s, 1),
                                  V.pq_a + (size_t)s * V.cap_flat, V.pq_b + (size_t)s * V.cap_flat,
-                                 V.pq_c + (size_t)s * V.cap_flat, qs, nn, rb, rcl);
+                                 V.pq_c + (size_t)s * V.cap_flat, qs, nn, rb, rcl, cellb);
     }
 }
 
