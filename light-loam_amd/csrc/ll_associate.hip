@@ -254,6 +254,7 @@ __device__ __forceinline__ void ll_ring_cell(int ring, int e, int &dx, int &dy)
     else { const int t = e - 2 * w; dy = -ring + 1 + (t >> 1); dx = (t & 1) ? ring : -ring; }
 }
 
+#define LL_SCAN_UN 4              /* point loads a lane keeps in flight while scanning a cell */
 #define LL_RING_CELLS 24          /* 8 * 3: the widest ring ever searched (nn_max 25, cell 2 m -> rings 0..3) */
 
 /* visit the cells around (qx, qy) in Chebyshev rings; scan(cell_start, cell_end) scans one cell, bound() is the current
@@ -329,13 +330,20 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
             float bd = dmax; int bi = INT_MAX;
             ll_grid_search(gstart, q.x, q.y, rmax, cellb, sub,
                 [&](int st, int en) {
-                    for (int k = st + sub; k < en; k += 8) {
-                        const float4 p = gpts[k];
-                        float diff = q.x - p.x; float d = diff * diff;        /* FLANN L2_Simple: a = query, b = data */
-                        diff = q.y - p.y; d += diff * diff;
-                        diff = q.z - p.z; d += diff * diff;
-                        const int idx = __float_as_int(p.w) & 0xFFFFFF;
-                        if (d < dmax && (d < bd || (d == bd && idx < bi))) { bd = d; bi = idx; }
+                    for (int k0 = st + sub; k0 < en; k0 += 8 * LL_SCAN_UN) {      /* LL_SCAN_UN loads in flight per lane */
+                        float4 pp[LL_SCAN_UN];
+#pragma unroll
+                        for (int u = 0; u < LL_SCAN_UN; ++u) if (k0 + 8 * u < en) pp[u] = gpts[k0 + 8 * u];
+#pragma unroll
+                        for (int u = 0; u < LL_SCAN_UN; ++u) {
+                            if (k0 + 8 * u >= en) break;
+                            const float4 p = pp[u];
+                            float diff = q.x - p.x; float d = diff * diff;    /* FLANN L2_Simple: a = query, b = data */
+                            diff = q.y - p.y; d += diff * diff;
+                            diff = q.z - p.z; d += diff * diff;
+                            const int idx = __float_as_int(p.w) & 0xFFFFFF;
+                            if (d < dmax && (d < bd || (d == bd && idx < bi))) { bd = d; bi = idx; }
+                        }
                     }
                 },
                 [&]() { return bd; },
@@ -357,8 +365,14 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
                 Best b2 = {dmax, INT_MAX, -1}, b3 = {dmax, INT_MAX, -1};
                 ll_grid_search(gstart, q.x, q.y, rmax, cellb, sub,
                     [&](int st, int en) {
-                        for (int k = st + sub; k < en; k += 8) {
-                            const float4 p = gpts[k];
+                        for (int k0 = st + sub; k0 < en; k0 += 8 * LL_SCAN_UN) {
+                          float4 pp[LL_SCAN_UN];
+#pragma unroll
+                          for (int u = 0; u < LL_SCAN_UN; ++u) if (k0 + 8 * u < en) pp[u] = gpts[k0 + 8 * u];
+#pragma unroll
+                          for (int u = 0; u < LL_SCAN_UN; ++u) {
+                            if (k0 + 8 * u >= en) break;
+                            const float4 p = pp[u];
                             const int w = __float_as_int(p.w);
                             const int j = w & 0xFFFFFF, rj = (w >> 24) & 0xFF;
                             if (j <= jlo || j >= jhi || j == c) continue;
@@ -372,6 +386,7 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
                                 if (PLANE) { if (rj >= rc) ll_best_take(b2, d, ord, j, dmax); else ll_best_take(b3, d, ord, j, dmax); }
                                 else if (rj < rc) ll_best_take(b2, d, ord, j, dmax);
                             }
+                          }
                         }
                     },
                     [&]() { return PLANE ? fmaxf(b2.d, b3.d) : b2.d; },
