@@ -55,7 +55,7 @@ def build_workload(synth, rings, batch, distinct, seed):
 def cpu_baseline(orc, rings, base, order, guesses, budget_s=15.0):
     """The oracle (kind 'port': our CPU restatement, 1 thread, grid-accelerated exact NN) over a bounded sample
     of the same units of work."""
-    P = orc.params(rings)
+    P = orc.params(rings) if rings in (16, 32, 64) else orc.params(rings, minimum_range=0.3, lower_bound=-25.0, up_bound=15.0, ring_model=1)
     orc.set_nn_mode(1)
     units = 0
     t0 = time.perf_counter()
@@ -122,7 +122,8 @@ def main():
     # every rank owns its own scans (different seed => different noise), same shape
     base, order, guesses = build_workload(synth, args.rings, args.batch, args.distinct, 0x5EED0000 + rank)
     max_pts = max(len(s) for s in base)
-    prm = api.default_params(args.rings, batch=args.batch + 1, max_points=max_pts, chunk=args.chunk)
+    extra = dict(ring_model=1, lower_bound=-25.0, up_bound=15.0, minimum_range=0.3) if args.rings not in (16, 32, 64) else {}
+    prm = api.default_params(args.rings, batch=args.batch + 1, max_points=max_pts, chunk=args.chunk, **extra)
     ctx = api.Context(prm, device=local_rank)
     # slot B holds the carry scan: extract it once, make it the carry target, then load the batch
     ctx.upload_scan(args.batch, base[order[0]])

@@ -27,7 +27,12 @@ SHAPES = {
     "S32": dict(rings=32),
     "S64_azmajor_jitter_nan": dict(rings=64, order=1, az_jitter_deg=0.4, drop_prob=0.03, emit_nan=1),
     "S64_ringmajor_jitter": dict(rings=64, az_jitter_deg=0.4),
+    # BASELINE config 5: 128 rings over [-25, +15] deg -- the reference aborts on scan_line 128 (scanRegistration.cpp:170-174);
+    # ring_model 1 applies the 64-ring linear formula (:162) with these bounds
+    "S128_linear_model": dict(rings=128),
 }
+
+RING_MODEL = {128: dict(ring_model=1, lower_bound=-25.0, up_bound=15.0, minimum_range=0.3)}
 
 
 @pytest.fixture(scope="module", params=list(SHAPES))
@@ -35,8 +40,9 @@ def case(request, api, orc, synth):
     kw = dict(SHAPES[request.param]); rings = kw.pop("rings")
     cfg = synth.default_cfg(rings, **kw)
     scans = [synth.scan(cfg, k) for k in range(3)]
-    P = orc.params(rings)
-    prm = api.default_params(rings, batch=3, write_curvature=1, max_points=max(len(s) for s in scans) + 7)
+    extra = RING_MODEL.get(rings, {})
+    P = orc.params(rings, **extra)
+    prm = api.default_params(rings, batch=3, write_curvature=1, max_points=max(len(s) for s in scans) + 7, **extra)
     ctx = api.Context(prm)
     for k, s in enumerate(scans):
         ctx.upload_scan(k, s)
