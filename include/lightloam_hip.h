@@ -159,6 +159,27 @@ int ll_download_pose(ll_ctx *ctx, int slot, double *pose7);
  * (Ceres applies it outside Evaluate).  rows = 3*n_edge + n_plane_selected.                             */
 int ll_residual_jacobian(ll_ctx *ctx, int slot, const double *pose7, double *r, double *Jq, double *Jt, int cap_rows);
 
+/* ---------------------------------------------------------------- the reference's solver and frame loop
+ * ceres::Solve as laserOdometry.cpp:820-825 configures it: trust-region / Levenberg-Marquardt, DENSE_QR,
+ * max_num_iterations = 4, every other option at its Ceres default.  ll_lm_default_options fills exactly those.       */
+typedef struct {
+    int    max_num_iterations;
+    double initial_radius, max_radius, min_radius, min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
+    double function_tolerance, gradient_tolerance, parameter_tolerance;
+    int    jacobi_scaling;
+} ll_lm_options;
+void ll_lm_default_options(ll_lm_options *o);
+/* LM solve of the residual blocks the slot currently holds (after associate + vote), starting from the slot's pose;
+ * the pose is replaced by the solution.  Device-resident, no host synchronisation; opt NULL = defaults.              */
+int ll_lm_solve_batch(ll_ctx *ctx, int first, int count, const ll_lm_options *opt);
+/* laserOdometry's per-frame body (:439-832) for the scans in slots [first, first+count), IN SEQUENCE: slot k's target
+ * is slot k-1 (the carry for slot `first`), its initial para_q/para_t is the previous slot's result (host_pose0 for the
+ * first; NULL = identity) -- the warm start of :61-65.  Per frame: n_outer (3, :439) x { associate, vote when the
+ * frame's sequence index first_frame_index + k is > 5 (:794), LM solve }.  host_poses_out: count x 7, may be NULL.
+ * The slots must have been extracted (ll_extract_batch).                                                             */
+int ll_odometry_frames(ll_ctx *ctx, int first, int count, const double *host_pose0, int n_outer, int first_frame_index,
+                       const ll_lm_options *opt, double *host_poses_out);
+
 /* ---------------------------------------------------------------- whole hot path
  * One pass: extract + associate + vote + normal equations + one GN step for slots [first, first+count),
  * everything device-resident, no host synchronisation inside.  `vote_enable` as above.                   */

@@ -22,6 +22,7 @@ EXPORTS = [
     "ll_download_edge_corr", "ll_download_plane_corr", "ll_vote_batch", "ll_download_vote",
     "ll_normal_equations_batch", "ll_download_normal_equations", "ll_gn_step_batch", "ll_download_pose",
     "ll_residual_jacobian", "ll_hot_path_batch", "ll_algorithmic_bytes", "ll_profile_enable", "ll_profile_read", "ll_set_pose_guess", "ll_debug_counters", "ll_vote_host", "ll_debug_calibration_copy",
+    "ll_lm_default_options", "ll_lm_solve_batch", "ll_odometry_frames",
 ]
 
 
@@ -37,6 +38,13 @@ class Params(C.Structure):
 class ScanInfo(C.Structure):
     _fields_ = [("status", C.c_int), ("n_in", C.c_int), ("n", C.c_int), ("n_sharp", C.c_int),
                 ("n_less_sharp", C.c_int), ("n_flat", C.c_int), ("n_less_flat", C.c_int), ("max_ring", C.c_int)]
+
+
+class LmOptions(C.Structure):
+    _fields_ = [("max_num_iterations", C.c_int), ("initial_radius", C.c_double), ("max_radius", C.c_double),
+                ("min_radius", C.c_double), ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double),
+                ("max_lm_diagonal", C.c_double), ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
+                ("parameter_tolerance", C.c_double), ("jacobi_scaling", C.c_int)]
 
 
 class PairInfo(C.Structure):
@@ -230,6 +238,18 @@ class Context:
         p = None if pose is None else np.ascontiguousarray(pose, np.float64)
         self._ck(self.lib.ll_residual_jacobian(self.h, slot, _ptr(p), _ptr(r), _ptr(Jq), _ptr(Jt), len(r)))
         return r[:rows], Jq[:rows], Jt[:rows]
+
+    def lm_solve(self, first=0, count=1, opt=None):
+        """ceres::Solve (LM, max 4 iterations) on the slot's current residual blocks, from the slot's current pose."""
+        self._ck(self.lib.ll_lm_solve_batch(self.h, first, count, None if opt is None else C.byref(opt)))
+
+    def odometry_frames(self, first, count, pose0=None, n_outer=3, first_frame_index=1, opt=None):
+        """laserOdometry's frame loop over consecutive slots; returns the (count, 7) relative poses (q_last_curr, t_last_curr)."""
+        out = np.zeros((count, 7))
+        p0 = None if pose0 is None else np.ascontiguousarray(pose0, np.float64)
+        self._ck(self.lib.ll_odometry_frames(self.h, first, count, _ptr(p0), n_outer, first_frame_index,
+                                             None if opt is None else C.byref(opt), _ptr(out)))
+        return out
 
     def hot_path(self, first=0, count=1, pose=None, vote=True):
         p = self._poses(pose, count)

@@ -186,7 +186,7 @@ extern "C" int ll_create(int device, const ll_params *p, ll_ctx **out)
     ok = ok && dev_alloc(ctx, V.p_src, (size_t)B * V.cap_flat) && dev_alloc(ctx, V.p_a, (size_t)B * V.cap_flat) && dev_alloc(ctx, V.p_b, (size_t)B * V.cap_flat) && dev_alloc(ctx, V.p_c, (size_t)B * V.cap_flat);
     ok = ok && dev_alloc(ctx, V.v_count, (size_t)B * V.cap_flat) && dev_alloc(ctx, V.v_sel, (size_t)B * V.cap_flat) && dev_alloc(ctx, V.v_w, (size_t)B * V.cap_flat);
     ok = ok && dev_alloc(ctx, V.pair, B) && dev_alloc(ctx, V.pose, (size_t)B * 7) && dev_alloc(ctx, V.pose_guess, (size_t)B * 7) && dev_alloc(ctx, V.neq, (size_t)B * LL_NEQ_STRIDE);
-    ok = ok && dev_alloc(ctx, ctx->d_tmp_pose, 7) && dev_alloc(ctx, V.dbg, 16);
+    ok = ok && dev_alloc(ctx, ctx->d_tmp_pose, 7) && dev_alloc(ctx, V.dbg, 16) && dev_alloc(ctx, V.lm, (size_t)B * LL_LM_STRIDE);
     if (!ok) { ll_destroy(ctx); return LL_ERR_HIP; }
     ctx->feat_lds = ll_features_lds_bytes(p->max_ring_points);
     if (ctx->feat_lds > 160 * 1024) { g_create_err = "max_ring_points needs more than 160 KiB of LDS"; ll_destroy(ctx); return LL_ERR_ARG; }
@@ -359,6 +359,78 @@ extern "C" int ll_gn_step_batch(ll_ctx *ctx, int first, int count)
     int rc = check_range(ctx, first, count); if (rc) return rc;
     ll_launch_gn_step(ctx->V, first, count, ctx->stream, &ctx->prof);
     LL_HIP(hipGetLastError());
+    return LL_OK;
+}
+
+extern "C" void ll_lm_default_options(ll_lm_options *o)
+{
+    o->max_num_iterations = 4;                       /* laserOdometry.cpp:822 */
+    o->initial_radius = 1e4; o->max_radius = 1e16; o->min_radius = 1e-32;
+    o->min_relative_decrease = 1e-3; o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32;
+    o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;
+    o->jacobi_scaling = 1;
+}
+
+static LLLmOpt to_dev_opt(const ll_lm_options *opt)
+{
+    ll_lm_options d; ll_lm_default_options(&d);
+    if (opt) d = *opt;
+    LLLmOpt o;
+    o.max_num_iterations = d.max_num_iterations; o.initial_radius = d.initial_radius; o.max_radius = d.max_radius;
+    o.min_radius = d.min_radius; o.min_relative_decrease = d.min_relative_decrease; o.min_lm_diagonal = d.min_lm_diagonal;
+    o.max_lm_diagonal = d.max_lm_diagonal; o.function_tolerance = d.function_tolerance; o.gradient_tolerance = d.gradient_tolerance;
+    o.parameter_tolerance = d.parameter_tolerance; o.jacobi_scaling = d.jacobi_scaling;
+    return o;
+}
+
+/* enqueue one LM solve for a slot range (carry_slot must already be set by the caller) */
+static void enqueue_lm(ll_ctx *ctx, int first, int count, const LLLmOpt &o)
+{
+    ll_launch_normal_equations(ctx->V, first, count, 0, ctx->stream, &ctx->prof);
+    ll_launch_lm_begin(ctx->V, first, count, o, ctx->stream);
+    for (int it = 0; it < o.max_num_iterations; ++it) {
+        ll_launch_lm_propose(ctx->V, first, count, o, ctx->stream);
+        ll_launch_normal_equations(ctx->V, first, count, 0, ctx->stream, &ctx->prof);
+        ll_launch_lm_accept(ctx->V, first, count, o, ctx->stream);
+    }
+}
+
+extern "C" int ll_lm_solve_batch(ll_ctx *ctx, int first, int count, const ll_lm_options *opt)
+{
+    int rc = check_range(ctx, first, count); if (rc) return rc;
+    const LLLmOpt o = to_dev_opt(opt);
+    if (o.max_num_iterations < 0 || o.max_num_iterations > 64) { ctx->err = "max_num_iterations out of range"; return LL_ERR_ARG; }
+    ctx->V.carry_slot = first;
+    enqueue_lm(ctx, first, count, o);
+    LL_HIP(hipGetLastError());
+    return LL_OK;
+}
+
+extern "C" int ll_odometry_frames(ll_ctx *ctx, int first, int count, const double *host_pose0, int n_outer, int first_frame_index,
+                                  const ll_lm_options *opt, double *host_poses_out)
+{
+    int rc = check_range(ctx, first, count); if (rc) return rc;
+    if (n_outer < 1 || n_outer > 16) { ctx->err = "n_outer out of range"; return LL_ERR_ARG; }
+    const LLLmOpt o = to_dev_opt(opt);
+    double ident[7] = {0, 0, 0, 1, 0, 0, 0};
+    LL_HIP(hipMemcpyAsync(ctx->V.pose + (size_t)first * 7, host_pose0 ? host_pose0 : ident, 7 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    LL_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->V.carry_slot = first;
+    for (int k = first; k < first + count; ++k) {
+        if (k > first)      /* para_q / para_t persist from the previous frame (:61-65) */
+            LL_HIP(hipMemcpyAsync(ctx->V.pose + (size_t)k * 7, ctx->V.pose + (size_t)(k - 1) * 7, 7 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        const int vote = (first_frame_index + (k - first)) > 5;          /* now_frame > 5 (:794) */
+        for (int outer = 0; outer < n_outer; ++outer) {                   /* :439 */
+            ll_launch_associate(ctx->V, k, 1, ctx->stream, &ctx->prof);
+            ll_launch_vote(ctx->V, k, 1, vote, ctx->stream, &ctx->prof);
+            enqueue_lm(ctx, k, 1, o);
+        }
+    }
+    LL_HIP(hipGetLastError());
+    if (host_poses_out) {
+        LL_HIP(hipMemcpyAsync(host_poses_out, ctx->V.pose + (size_t)first * 7, (size_t)count * 7 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        LL_HIP(hipStreamSynchronize(ctx->stream));
+    }
     return LL_OK;
 }
 

@@ -89,11 +89,24 @@ struct LLView {
     double *pose;                  /* [B][7] qx qy qz qw tx ty tz */
     double *pose_guess;            /* [B][7] para_q/para_t at entry of the hot path (laserOdometry.cpp:61-62) */
     double *neq;                   /* [B][44]: H[36] row-major, g[6], cost, rows */
+    double *lm;                    /* [B][LL_LM_STRIDE] Levenberg-Marquardt state of the slot's current solve */
     int carry_slot;                /* the slot whose target is the carry (first slot of the batch) */
     unsigned long long *dbg;       /* [16] phase-timing counters (only written by -DLL_PHASE_TIMING builds) */
 };
 
 #define LL_NEQ_STRIDE 44
+#define LL_LM_STRIDE 80
+
+/* ceres::Solver::Options fields the trust-region loop reads (laserOdometry.cpp:820-825 sets two, the rest are defaults) */
+struct LLLmOpt {
+    int max_num_iterations;
+    double initial_radius, max_radius, min_radius, min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
+    double function_tolerance, gradient_tolerance, parameter_tolerance;
+    int jacobi_scaling;
+};
+void ll_launch_lm_begin(const LLView &V, int first, int count, const LLLmOpt &o, hipStream_t st);
+void ll_launch_lm_propose(const LLView &V, int first, int count, const LLLmOpt &o, hipStream_t st);
+void ll_launch_lm_accept(const LLView &V, int first, int count, const LLLmOpt &o, hipStream_t st);
 
 __device__ __forceinline__ int ll_trunc_to_int(double v)
 {

@@ -848,3 +848,138 @@ void orc_pose_update(double q[4], double t[3], const double delta[6])
     memcpy(q, qn, sizeof(qn));
     t[0] += delta[3]; t[1] += delta[4]; t[2] += delta[5];
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* f1  ceres::Solve as the reference configures it (laserOdometry.cpp:820-825), restated        */
+/* ------------------------------------------------------------------------------------------ */
+void orc_lm_default(orc_lm_options *o)
+{
+    o->max_num_iterations = 4;            /* :822 */
+    o->initial_radius = 1e4; o->max_radius = 1e16; o->min_radius = 1e-32;
+    o->min_relative_decrease = 1e-3;
+    o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32;
+    o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;
+    o->jacobi_scaling = 1;
+}
+
+/* (S H S + D^2) y = -(S g) by Cholesky; DENSE_QR solves the same augmented least-squares problem */
+static int lm_step(const double H[36], const double g[6], const double scale[6], double radius,
+                   double min_diag, double max_diag, double step_scaled[6])
+{
+    double A[36], b[6];
+    for (int i = 0; i < 6; ++i) {
+        for (int j = 0; j < 6; ++j) A[i * 6 + j] = H[i * 6 + j] * scale[i] * scale[j];
+        b[i] = g[i] * scale[i];
+    }
+    for (int i = 0; i < 6; ++i) {
+        double d = A[i * 6 + i];                         /* diag(J^T J) of the SCALED Jacobian */
+        if (d < min_diag) d = min_diag; if (d > max_diag) d = max_diag;
+        A[i * 6 + i] += d / radius;                      /* lm_diagonal^2 = clamp(diag) / radius */
+    }
+    return orc_gn_solve(A, b, step_scaled);
+}
+
+void orc_lm_solve(double q[4], double t[3],
+                  const orc_point *sharp, const int *e_src, const orc_point *corner_last, const int *e_a, const int *e_b, int n_e,
+                  const orc_point *flat, const int *p_src, const orc_point *surf_last,
+                  const int *p_a, const int *p_b, const int *p_c, const float *p_w, int n_p,
+                  double huber_delta, const orc_lm_options *opt, double summary[4])
+{
+#define EVAL(qq, tt, HH, gg, cc) orc_normal_equations(qq, tt, sharp, e_src, corner_last, e_a, e_b, n_e, flat, p_src, surf_last, \
+                                                      p_a, p_b, p_c, p_w, n_p, huber_delta, HH, gg, cc)
+    double H[36], g[6], cost;
+    EVAL(q, t, H, g, &cost);
+    summary[0] = cost; summary[1] = cost; summary[2] = 0; summary[3] = 0;
+    double scale[6];
+    for (int i = 0; i < 6; ++i) scale[i] = opt->jacobi_scaling ? 1.0 / (1.0 + sqrt(H[i * 6 + i])) : 1.0;
+    double radius = opt->initial_radius, decrease_factor = 2.0;
+    int iter = 0;
+    for (;;) {
+        /* FinalizeIterationAndCheckIfMinimizerCanContinue */
+        if (iter >= opt->max_num_iterations) break;
+        {   /* gradient tolerance: max-norm of Plus(x, -gradient) - x in the ambient space */
+            double q2[4], t2[3], ng[6];
+            for (int i = 0; i < 6; ++i) ng[i] = -g[i];
+            memcpy(q2, q, sizeof(q2)); memcpy(t2, t, sizeof(t2));
+            orc_pose_update(q2, t2, ng);
+            double m = 0.0;
+            for (int i = 0; i < 4; ++i) m = fmax(m, fabs(q2[i] - q[i]));
+            for (int i = 0; i < 3; ++i) m = fmax(m, fabs(t2[i] - t[i]));
+            if (m <= opt->gradient_tolerance) break;
+        }
+        if (radius < opt->min_radius) break;
+        iter++;
+        double ys[6], delta[6];
+        int ok = lm_step(H, g, scale, radius, opt->min_lm_diagonal, opt->max_lm_diagonal, ys) == 0;
+        double model_cost_change = 0.0;
+        if (ok) {
+            /* -(g_s . y + y^T H_s y / 2) in the scaled space == -(g . d + d^T H d / 2) with d = S y */
+            for (int i = 0; i < 6; ++i) delta[i] = ys[i] * scale[i];
+            double gd = 0.0, dHd = 0.0;
+            for (int i = 0; i < 6; ++i) { gd += g[i] * delta[i]; for (int j = 0; j < 6; ++j) dHd += delta[i] * H[i * 6 + j] * delta[j]; }
+            model_cost_change = -(gd + 0.5 * dHd);
+        }
+        if (!ok || !(model_cost_change > 0.0)) { radius *= 0.5; continue; }     /* invalid step: LM StepIsInvalid */
+        double qc[4], tc[3], Hc[36], gc[6], cc;
+        memcpy(qc, q, sizeof(qc)); memcpy(tc, t, sizeof(tc));
+        orc_pose_update(qc, tc, delta);
+        EVAL(qc, tc, Hc, gc, &cc);
+        /* ParameterToleranceReached / FunctionToleranceReached: both return BEFORE the candidate is taken */
+        double step_norm = 0.0, x_norm = 0.0;
+        for (int i = 0; i < 4; ++i) { step_norm += (qc[i] - q[i]) * (qc[i] - q[i]); x_norm += q[i] * q[i]; }
+        for (int i = 0; i < 3; ++i) { step_norm += (tc[i] - t[i]) * (tc[i] - t[i]); x_norm += t[i] * t[i]; }
+        step_norm = sqrt(step_norm); x_norm = sqrt(x_norm);
+        if (step_norm <= opt->parameter_tolerance * (x_norm + opt->parameter_tolerance)) break;
+        if (fabs(cost - cc) <= opt->function_tolerance * cost) break;
+        const double relative_decrease = (cost - cc) / model_cost_change;
+        if (relative_decrease > opt->min_relative_decrease) {               /* HandleSuccessfulStep + StepAccepted */
+            memcpy(q, qc, sizeof(qc)); memcpy(t, tc, sizeof(tc));
+            memcpy(H, Hc, sizeof(Hc)); memcpy(g, gc, sizeof(gc)); cost = cc;
+            const double f = 1.0 - pow(2.0 * relative_decrease - 1.0, 3.0);
+            radius = radius / fmax(1.0 / 3.0, f);
+            if (radius > opt->max_radius) radius = opt->max_radius;
+            decrease_factor = 2.0;
+            summary[3] += 1;
+        } else {                                                             /* StepRejected */
+            radius = radius / decrease_factor;
+            decrease_factor *= 2.0;
+        }
+    }
+    summary[1] = cost; summary[2] = iter;
+#undef EVAL
+}
+
+void orc_odometry_frame(double q[4], double t[3], const orc_point *sharp, int ns, const orc_point *flat, int nf,
+                        const orc_point *corner_last, int mc, const orc_point *surf_last, int ms,
+                        int vote, int n_outer, double huber_delta, const orc_lm_options *opt)
+{
+    int *es = (int *)malloc(sizeof(int) * (size_t)(ns + 1) * 3), *ps = (int *)malloc(sizeof(int) * (size_t)(nf + 1) * 4);
+    int *ea = es + ns + 1, *eb = ea + ns + 1, *pa = ps + nf + 1, *pb = pa + nf + 1, *pc = pb + nf + 1;
+    int *cnt = (int *)malloc(sizeof(int) * (size_t)(nf + 1) * 2), *sidx = cnt + nf + 1;
+    float *sw = (float *)malloc(sizeof(float) * (size_t)(nf + 1) * 2), *w = sw + nf + 1;
+    orc_point *src = (orc_point *)malloc(sizeof(orc_point) * (size_t)(nf + 1) * 2), *tgt = src + nf + 1;
+    int *qs = (int *)malloc(sizeof(int) * (size_t)(nf + 1) * 4), *qa = qs + nf + 1, *qb = qa + nf + 1, *qc = qb + nf + 1;
+    for (int outer = 0; outer < n_outer; ++outer) {                          /* :439 */
+        int ne = 0, np = 0;
+        orc_associate_corner(q, t, sharp, ns, corner_last, mc, es, ea, eb, &ne);
+        orc_associate_plane(q, t, flat, nf, surf_last, ms, ps, pa, pb, pc, &np);
+        int nsel = np;
+        if (vote) {                                                          /* :794-810 */
+            for (int i = 0; i < np; ++i) { src[i] = flat[ps[i]]; tgt[i] = surf_last[pa[i]]; }
+            orc_vote(src, tgt, np, 0, cnt, sidx, sw, &nsel);
+            /* residual blocks in correspondence order (the order only permutes the blocks) */
+            char *keep = (char *)calloc((size_t)np + 1, 1);
+            for (int i = 0; i < np; ++i) w[i] = 1.0f;
+            for (int i = 0; i < nsel; ++i) { keep[sidx[i]] = 1; w[sidx[i]] = sw[i]; }
+            int m = 0;
+            for (int i = 0; i < np; ++i) if (keep[i]) { qs[m] = ps[i]; qa[m] = pa[i]; qb[m] = pb[i]; qc[m] = pc[i]; w[m] = w[i]; m++; }
+            free(keep);
+            nsel = m;
+        } else {
+            for (int i = 0; i < np; ++i) { qs[i] = ps[i]; qa[i] = pa[i]; qb[i] = pb[i]; qc[i] = pc[i]; w[i] = 1.0f; }   /* :781-787 */
+        }
+        double summary[4];
+        orc_lm_solve(q, t, sharp, es, corner_last, ea, eb, ne, flat, qs, surf_last, qa, qb, qc, w, nsel, huber_delta, opt, summary);
+    }
+    free(qs); free(src); free(sw); free(cnt); free(ps); free(es);
+}

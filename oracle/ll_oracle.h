@@ -114,6 +114,33 @@ void orc_normal_equations(const double q[4], const double t[3],
 int orc_gn_solve(const double H[36], const double g[6], double delta[6]);   /* H delta = -g, Cholesky */
 void orc_pose_update(double q[4], double t[3], const double delta[6]);
 
+/* ---- f1: the solver the reference actually runs, ceres::Solve with DENSE_QR, max_num_iterations = 4 and otherwise
+ * default options (laserOdometry.cpp:820-825): trust-region minimizer + Levenberg-Marquardt strategy, restated from
+ * Ceres 2.x (trust_region_minimizer.cc, levenberg_marquardt_strategy.cc) -- PARITY UNPINNED like the rest.
+ * The residual blocks are fixed (one outer iteration's correspondences); q, t are updated in place.
+ * summary[0] = initial cost, [1] = final cost, [2] = iterations run, [3] = successful steps. */
+typedef struct {
+    int    max_num_iterations;        /* 4 (:822) */
+    double initial_radius;            /* 1e4  */
+    double max_radius, min_radius;    /* 1e16, 1e-32 */
+    double min_relative_decrease;     /* 1e-3 */
+    double min_lm_diagonal, max_lm_diagonal;   /* 1e-6, 1e32 */
+    double function_tolerance, gradient_tolerance, parameter_tolerance;   /* 1e-6, 1e-10, 1e-8 */
+    int    jacobi_scaling;            /* 1 */
+} orc_lm_options;
+void orc_lm_default(orc_lm_options *o);
+void orc_lm_solve(double q[4], double t[3],
+                  const orc_point *sharp, const int *e_src, const orc_point *corner_last, const int *e_a, const int *e_b, int n_e,
+                  const orc_point *flat, const int *p_src, const orc_point *surf_last,
+                  const int *p_a, const int *p_b, const int *p_c, const float *p_w, int n_p,
+                  double huber_delta, const orc_lm_options *opt, double summary[4]);
+
+/* One frame of laserOdometry (:439-832): n_outer (3) x { correspondence search, vote when `vote`, LM solve }.
+ * q, t = para_q / para_t, warm-started by the caller (they persist between frames, :61-65). */
+void orc_odometry_frame(double q[4], double t[3], const orc_point *sharp, int ns, const orc_point *flat, int nf,
+                        const orc_point *corner_last, int mc, const orc_point *surf_last, int ms,
+                        int vote, int n_outer, double huber_delta, const orc_lm_options *opt);
+
 #ifdef __cplusplus
 }
 #endif

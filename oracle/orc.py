@@ -219,3 +219,40 @@ def pose_update(q, t, delta):
     q = _d(q, 4).copy(); t = _d(t, 3).copy(); delta = _d(delta, 6)
     lib().orc_pose_update(_p(q), _p(t), _p(delta))
     return q, t
+
+
+class LmOptions(C.Structure):
+    _fields_ = [("max_num_iterations", C.c_int), ("initial_radius", C.c_double), ("max_radius", C.c_double),
+                ("min_radius", C.c_double), ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double),
+                ("max_lm_diagonal", C.c_double), ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
+                ("parameter_tolerance", C.c_double), ("jacobi_scaling", C.c_int)]
+
+
+def lm_options():
+    o = LmOptions()
+    lib().orc_lm_default(C.byref(o))
+    return o
+
+
+def lm_solve(q, t, sharp, e_src, corner_last, e_a, e_b, flat, p_src, surf_last, p_a, p_b, p_c, p_w, huber_delta=0.1, opt=None):
+    q = _d(q, 4).copy(); t = _d(t, 3).copy()
+    sharp = _f4(sharp); corner_last = _f4(corner_last); flat = _f4(flat); surf_last = _f4(surf_last)
+    i32 = lambda a: np.ascontiguousarray(a, np.int32)
+    e_src, e_a, e_b, p_src, p_a, p_b, p_c = map(i32, (e_src, e_a, e_b, p_src, p_a, p_b, p_c))
+    pw = None if p_w is None else np.ascontiguousarray(p_w, np.float32)
+    opt = opt or lm_options()
+    summary = np.zeros(4)
+    lib().orc_lm_solve(_p(q), _p(t), _p(sharp), _p(e_src), _p(corner_last), _p(e_a), _p(e_b), len(e_src),
+                       _p(flat), _p(p_src), _p(surf_last), _p(p_a), _p(p_b), _p(p_c), None if pw is None else _p(pw), len(p_src),
+                       C.c_double(huber_delta), C.byref(opt), _p(summary))
+    return q, t, summary
+
+
+def odometry_frame(q, t, cur, last, vote, n_outer=3, huber_delta=0.1, opt=None):
+    """cur / last: dicts from extract() (cur: sharp, flat; last: less_sharp, less_flat).  Returns updated (q, t)."""
+    q = _d(q, 4).copy(); t = _d(t, 3).copy()
+    sharp = _f4(cur["sharp"]); flat = _f4(cur["flat"]); cl = _f4(last["less_sharp"]); sl = _f4(last["less_flat"])
+    opt = opt or lm_options()
+    lib().orc_odometry_frame(_p(q), _p(t), _p(sharp), len(sharp), _p(flat), len(flat), _p(cl), len(cl), _p(sl), len(sl),
+                             int(bool(vote)), n_outer, C.c_double(huber_delta), C.byref(opt))
+    return q, t

@@ -459,3 +459,41 @@ def test_gauss_newton_recovers_a_known_motion(orc, synth):
         assert rc == 0
         q, t = orc.pose_update(q, t, d)
     assert np.allclose(t, tt, atol=2e-3) and min(np.abs(q - qt).max(), np.abs(q + qt).max()) < 1e-3
+
+
+# ----------------------------------------------------------------------------- f1: LM solver + frame loop
+def _pair(orc, synth, rings=16):
+    cfg = synth.default_cfg(rings)
+    P = orc.params(rings)
+    return cfg, orc.extract(synth.scan(cfg, 0), P), orc.extract(synth.scan(cfg, 1), P)
+
+
+def test_lm_never_increases_the_cost_and_beats_one_gn_step(orc, synth):
+    cfg, e0, e1 = _pair(orc, synth)
+    q = np.array([0, 0, 0, 1.0]); t = np.array([0.5, 0.1, 0.0])
+    es, ea, eb = orc.associate_corner(q, t, e1["sharp"], e0["less_sharp"])
+    ps, pa, pb, pc = orc.associate_plane(q, t, e1["flat"], e0["less_flat"])
+    w = np.ones(len(ps), np.float32)
+    args = (e1["sharp"], es, e0["less_sharp"], ea, eb, e1["flat"], ps, e0["less_flat"], pa, pb, pc, w)
+    q1, t1, summ = orc.lm_solve(q, t, *args)
+    assert summ[1] <= summ[0] and 1 <= summ[2] <= 4 and summ[3] >= 1
+    # a zero-iteration solve leaves the pose alone
+    o = orc.lm_options(); o.max_num_iterations = 0
+    q0, t0, s0 = orc.lm_solve(q, t, *args, opt=o)
+    assert (q0 == q).all() and (t0 == t).all() and s0[2] == 0
+    # with a huge trust region and one iteration LM is (almost) the Gauss-Newton step of a10
+    o = orc.lm_options(); o.max_num_iterations = 1; o.initial_radius = 1e30; o.min_lm_diagonal = 0.0
+    qa, ta, _ = orc.lm_solve(q, t, *args, opt=o)
+    H, g, _ = orc.normal_equations(q, t, *args)
+    rc, d = orc.gn_solve(H, g)
+    qb, tb = orc.pose_update(q, t, d)
+    assert np.allclose(qa, qb, atol=1e-9) and np.allclose(ta, tb, atol=1e-9)
+
+
+def test_odometry_frame_recovers_the_synthetic_motion(orc, synth):
+    cfg, e0, e1 = _pair(orc, synth)
+    orc.set_nn_mode(1)
+    q, t = orc.odometry_frame([0, 0, 0, 1.0], [0.9, 0, 0], e1, e0, vote=True)
+    orc.set_nn_mode(0)
+    gt0, gt1 = synth.pose(cfg, 0), synth.pose(cfg, 1)
+    assert abs(t[0] - (gt1[0] - gt0[0])) < 0.05 and abs(t[1]) < 0.05 and abs(2 * np.arctan2(q[2], q[3]) - 0.01) < 2e-3
