@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -155,6 +156,81 @@ public:
 private:
     Context &c_;
 };
+
+/* ---- I/O surface ---------------------------------------------------------------------------------- */
+
+/* KITTI velodyne .bin: float32 (x, y, z, reflectance) per point -- src/kittiHelper.cpp:22-32, same name */
+inline std::vector<float> read_lidar_data(const std::string &lidar_data_path)
+{
+    std::FILE *f = std::fopen(lidar_data_path.c_str(), "rb");
+    if (!f) throw Error(LL_ERR_ARG, "cannot open " + lidar_data_path);
+    std::fseek(f, 0, SEEK_END);
+    const size_t num_elements = (size_t)std::ftell(f) / sizeof(float);
+    std::fseek(f, 0, SEEK_SET);
+    std::vector<float> lidar_data_buffer(num_elements);
+    const size_t got = std::fread(lidar_data_buffer.data(), sizeof(float), num_elements, f);
+    std::fclose(f);
+    lidar_data_buffer.resize(got);
+    return lidar_data_buffer;
+}
+
+/* World pose accumulation of laserOdometry (:830-831): t_w = t_w + q_w * t ; q_w = q_w * q   (q = x,y,z,w) */
+struct WorldPose {
+    double q[4] = {0, 0, 0, 1}, t[3] = {0, 0, 0};
+    void compose(const double ql[4], const double tl[3]) {
+        const double ux = q[0], uy = q[1], uz = q[2], w = q[3];
+        double uv[3] = {uy * tl[2] - uz * tl[1], uz * tl[0] - ux * tl[2], ux * tl[1] - uy * tl[0]};
+        for (double &v : uv) v += v;
+        t[0] += (tl[0] + w * uv[0]) + (uy * uv[2] - uz * uv[1]);
+        t[1] += (tl[1] + w * uv[1]) + (uz * uv[0] - ux * uv[2]);
+        t[2] += (tl[2] + w * uv[2]) + (ux * uv[1] - uy * uv[0]);
+        const double ax = q[0], ay = q[1], az = q[2], aw = q[3], bx = ql[0], by = ql[1], bz = ql[2], bw = ql[3];
+        q[3] = aw * bw - ax * bx - ay * by - az * bz;
+        q[0] = aw * bx + ax * bw + ay * bz - az * by;
+        q[1] = aw * by - ax * bz + ay * bw + az * bx;
+        q[2] = aw * bz + ax * by - ay * bx + az * bw;
+    }
+    void matrix(double H[12]) const {                      /* 3x4 row-major [R | t], Eigen toRotationMatrix() */
+        const double x = q[0], y = q[1], z = q[2], w = q[3];
+        H[0] = 1 - 2 * (y * y + z * z); H[1] = 2 * (x * y - z * w);     H[2] = 2 * (x * z + y * w);     H[3] = t[0];
+        H[4] = 2 * (x * y + z * w);     H[5] = 1 - 2 * (x * x + z * z); H[6] = 2 * (y * z - x * w);     H[7] = t[1];
+        H[8] = 2 * (x * z - y * w);     H[9] = 2 * (y * z + x * w);     H[10] = 1 - 2 * (x * x + y * y); H[11] = t[2];
+    }
+};
+
+/* The evaluation artefact of src/laserMapping.cpp:2284-2325: one line per frame, H_init^-1 * H as 12 values in
+ * scientific notation with precision 6, appended to RESULT_PATH. */
+class TrajectoryWriter {
+public:
+    explicit TrajectoryWriter(const std::string &result_path) : path_(result_path) {}
+    void append(const WorldPose &p) {
+        double H[12]; p.matrix(H);
+        if (init_flag_) { for (int i = 0; i < 12; ++i) Hinit_[i] = H[i]; init_flag_ = false; }
+        /* H_init^-1 * H for rigid transforms: R0^T R, R0^T (t - t0) */
+        double out[12];
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) out[r * 4 + c] = Hinit_[0 * 4 + r] * H[0 * 4 + c] + Hinit_[1 * 4 + r] * H[1 * 4 + c] + Hinit_[2 * 4 + r] * H[2 * 4 + c];
+            out[r * 4 + 3] = Hinit_[0 * 4 + r] * (H[3] - Hinit_[3]) + Hinit_[1 * 4 + r] * (H[7] - Hinit_[7]) + Hinit_[2 * 4 + r] * (H[11] - Hinit_[11]);
+        }
+        std::FILE *f = std::fopen(path_.c_str(), "a");
+        if (!f) throw Error(LL_ERR_ARG, "cannot open " + path_);
+        for (int i = 0; i < 12; ++i) std::fprintf(f, i == 11 ? "%.6e\n" : "%.6e ", out[i]);
+        std::fclose(f);
+    }
+private:
+    std::string path_;
+    bool init_flag_ = true;
+    double Hinit_[12];
+};
+
+/* laserOdometry over a whole sequence of registered scans in slots [first, first+count): the reference's frame loop
+ * (3 outer iterations x ceres::Solve, vote from the 6th frame, warm start) -- ll_odometry_frames. */
+inline std::vector<double> odometry_frames(Context &c, int first, int count, const double *pose0 = nullptr, int first_frame_index = 1)
+{
+    std::vector<double> rel((size_t)count * 7);
+    c.check(ll_odometry_frames(c.get(), first, count, pose0, 3, first_frame_index, nullptr, rel.data()));
+    return rel;
+}
 
 }  // namespace lightloam
 

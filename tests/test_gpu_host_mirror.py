@@ -52,3 +52,43 @@ def test_host_mirror_pipeline(tmp_path, orc, synth, api):
     for r in range(10):
         c = cnt[got_idx[region == r]]
         assert (np.diff(c) >= 0).all()
+
+
+def test_kitti_directory_tool_writes_the_reference_trajectory_format(tmp_path, synth, api):
+    """tools/ll_odometry_kitti.cpp: *.bin directory in, laserMapping.cpp:2306-2325 text format out."""
+    from lightloam_amd import build
+    lib_dir = os.path.dirname(build.lib_path())
+    exe = str(tmp_path / "ll_odometry_kitti")
+    subprocess.check_call(["g++", "-O2", "-std=c++14", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tools", "ll_odometry_kitti.cpp"), "-o", exe,
+                           "-L", lib_dir, "-llightloam_hip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
+    cfg = synth.default_cfg(16)
+    n = 10
+    scans = [synth.scan(cfg, k) for k in range(n)]
+    d = tmp_path / "velodyne"; d.mkdir()
+    for k, s in enumerate(scans):
+        s.astype("<f4").tofile(d / f"{k:06d}.bin")
+    res = tmp_path / "traj.txt"
+    out = subprocess.run([exe, str(d), str(res), "16", "0.9"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    T = np.loadtxt(res)
+    assert T.shape == (n, 12)
+    assert np.allclose(T[0], [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0])           # H_init^-1 * H_init
+    line = open(res).readline().split()
+    assert all("e" in v and len(v.split("e")[0].split(".")[1]) == 6 for v in line)   # scientific, precision 6
+    # same numbers as the Python-side integration of the device's relative poses
+    ctx = api.Context(api.default_params(16, batch=n, max_points=max(map(len, scans))))
+    for k, s in enumerate(scans):
+        ctx.upload_scan(k, s)
+    ctx.extract(0, n); ctx.set_target_from_slot(0)
+    rel = ctx.odometry_frames(1, n - 1, pose0=[0, 0, 0, 1, 0.9, 0, 0])
+    ctx.close()
+    qw = np.array([0, 0, 0, 1.0]); tw = np.zeros(3)
+    for k, p in enumerate(rel):
+        u, w = qw[:3], qw[3]; uv = 2 * np.cross(u, p[4:]); tw = tw + p[4:] + w * uv + np.cross(u, uv)
+        ax, ay, az, aw = qw; bx, by, bz, bw = p[:4]
+        qw = np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                       aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz])
+        assert np.allclose(T[k + 1, [3, 7, 11]], tw, atol=2e-6 * max(1, np.abs(tw).max()))
+    gt = synth.pose(cfg, n - 1)
+    assert abs(T[-1, 3] - gt[0]) < 0.2 and abs(T[-1, 7] - gt[1]) < 0.2

@@ -1,0 +1,56 @@
+// Scan-to-scan LiDAR odometry over a directory of KITTI-format velodyne scans (*.bin, float32 x,y,z,reflectance),
+// the way the reference's kittiHelper -> scanRegistration -> laserOdometry chain would process them, writing the
+// reference's trajectory-file format (laserMapping.cpp:2284-2325: 12 values of H_init^-1 * H per frame).
+//
+//   ll_odometry_kitti <scan_dir> <result_path> [scan_line = 64] [first-frame forward guess in metres = 0]
+//
+// Build:  g++ -O2 -std=c++14 -I include tools/ll_odometry_kitti.cpp -L light-loam_amd -llightloam_hip -o ll_odometry_kitti
+#include <algorithm>
+#include <cstdlib>
+#include <dirent.h>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "lightloam_host.hpp"
+
+int main(int argc, char **argv)
+{
+    if (argc < 3) { std::cerr << "usage: ll_odometry_kitti <scan_dir> <result_path> [scan_line] [first guess tx]\n"; return 2; }
+    const std::string dir = argv[1], result = argv[2];
+    const int scan_line = argc > 3 ? std::atoi(argv[3]) : 64;
+    const double tx0 = argc > 4 ? std::atof(argv[4]) : 0.0;
+    std::vector<std::string> files;
+    if (DIR *d = opendir(dir.c_str())) {
+        while (dirent *e = readdir(d)) {
+            const std::string n = e->d_name;
+            if (n.size() > 4 && n.substr(n.size() - 4) == ".bin") files.push_back(dir + "/" + n);
+        }
+        closedir(d);
+    }
+    std::sort(files.begin(), files.end());
+    if (files.size() < 2) { std::cerr << "need at least two .bin scans in " << dir << "\n"; return 2; }
+    try {
+        using namespace lightloam;
+        const int n = (int)files.size();
+        Context ctx(scan_line, n);
+        for (int k = 0; k < n; ++k) {
+            const std::vector<float> pts = read_lidar_data(files[k]);
+            ctx.check(ll_upload_scan(ctx.get(), k, pts.data(), 4, (int)(pts.size() / 4)));
+        }
+        ctx.check(ll_extract_batch(ctx.get(), 0, n));                       // scanRegistration for every scan
+        ctx.check(ll_set_target_from_slot(ctx.get(), 0));                   // frame 0 only initialises (laserOdometry.cpp:427-431)
+        const double pose0[7] = {0, 0, 0, 1, tx0, 0, 0};
+        const std::vector<double> rel = odometry_frames(ctx, 1, n - 1, pose0, 1);
+        std::remove(result.c_str());
+        TrajectoryWriter out(result);
+        WorldPose w;
+        out.append(w);
+        for (int k = 0; k < n - 1; ++k) { w.compose(&rel[(size_t)k * 7], &rel[(size_t)k * 7 + 4]); out.append(w); }
+        std::cout << "wrote " << n << " poses to " << result << "; final position " << w.t[0] << " " << w.t[1] << " " << w.t[2] << "\n";
+    } catch (const lightloam::Error &e) {
+        std::cerr << "lightloam error " << e.code << ": " << e.what() << "\n";
+        return 1;
+    }
+    return 0;
+}
