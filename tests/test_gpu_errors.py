@@ -1,0 +1,69 @@
+"""Error behaviour through the C ABI on the GPU: per-slot failures must not disturb the rest of a batch."""
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def scans(synth):
+    cfg = synth.default_cfg(16)
+    return [synth.scan(cfg, k) for k in range(3)]
+
+
+def test_empty_and_all_nan_slots_inside_a_batch(api, orc, scans):
+    """slot 1: no points at all; slot 2: only NaNs and points inside minimum_range -> LL_ERR_EMPTY for both (the reference
+    would read points[0] of an empty cloud); slots 0 and 3 must come out exactly as if they were alone."""
+    P = orc.params(16)
+    bad = np.full((500, 4), np.nan, np.float32); bad[::2] = [0.05, 0.05, 0.0, 0.0]
+    ctx = api.Context(api.default_params(16, batch=4, max_points=max(map(len, scans))))
+    ctx.upload_scan(0, scans[0]); ctx.upload_scan(1, np.zeros((0, 4), np.float32)); ctx.upload_scan(2, bad); ctx.upload_scan(3, scans[1])
+    ctx.extract(0, 4)
+    assert [ctx.scan_info(k).status for k in range(4)] == [0, -5, -5, 0]
+    assert ctx.scan_info(1).n == 0 and ctx.scan_info(2).n_sharp == 0
+    for slot, s in ((0, scans[0]), (3, scans[1])):
+        ref = orc.extract(s, P)
+        f = ctx.features(slot)
+        for name in ("sharp", "less_sharp", "flat", "less_flat"):
+            assert_bit_equal(f[name], ref[name], name)
+    # the whole hot path over the batch: failed slots produce no correspondences, and a slot whose TARGET failed
+    # (slot 3, target = slot 2) has nothing to match against
+    ctx.set_target_from_slot(0)
+    ctx.hot_path(0, 4, np.array([0, 0, 0, 1, 0, 0, 0.0]), vote=True)
+    ctx.synchronize()
+    assert ctx.pair_info(1).n_edge == 0 and ctx.pair_info(2).n_plane == 0 and ctx.pair_info(3).n_plane == 0
+    assert ctx.pair_info(0).n_plane > 50                    # slot 0 against the carry (itself): dense correspondences
+    assert np.isfinite(ctx.pose(0)).all() and (ctx.pose(3) == [0, 0, 0, 1, 0, 0, 0]).all()   # singular system: pose untouched
+    ctx.close()
+
+
+def test_ring_longer_than_capacity_is_reported(api, scans):
+    ctx = api.Context(api.default_params(16, batch=1, max_points=len(scans[0]), max_ring_points=1024))
+    ctx.upload_scan(0, scans[0])                               # 1800 azimuths per ring > 1024
+    ctx.extract(0, 1)
+    info = ctx.scan_info(0)
+    assert info.status == -4 and info.max_ring > 1024 and info.n_sharp == 0
+    ctx.close()
+
+
+def test_upload_larger_than_max_points_is_refused(api, scans):
+    ctx = api.Context(api.default_params(16, batch=1, max_points=1000))
+    with pytest.raises(api.LightLoamError) as e:
+        ctx.upload_scan(0, scans[0])
+    assert e.value.code == -4
+    with pytest.raises(api.LightLoamError) as e:
+        ctx.extract(0, 2)                                      # slot range out of bounds
+    assert e.value.code == -2
+    ctx.close()
+
+
+def test_download_capacity_checks(api, scans):
+    import ctypes as C
+    ctx = api.Context(api.default_params(16, batch=1, max_points=len(scans[0])))
+    ctx.upload_scan(0, scans[0]); ctx.extract(0, 1)
+    small = np.zeros((10, 4), np.float32)
+    rc = ctx.lib.ll_download_cloud(ctx.h, 0, small.ctypes.data_as(C.c_void_p), 10, None, None)
+    assert rc == -4
+    ctx.close()
