@@ -321,21 +321,33 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features
     __syncthreads();
 
     LL_PHASE(2);
-    /* ---------------- phase 4: less-flat compaction + VoxelGrid (:361-376) ---------------- */
+    /* ---------------- phase 4: less-flat compaction + VoxelGrid (:361-376) ----------------
+     * Blocked layout: thread t owns the `per` consecutive slots [t*per, (t+1)*per), so a workgroup exclusive scan of the
+     * per-thread less-flat counts compacts in input order.  The points are read once (independent loads) and stay in
+     * registers for the bounding box and for PCL's voxel index; after the stable sort by voxel the same blocked layout
+     * prefetches every thread's points before the left-to-right f32 centroid sums. */
     int n_lf_out = 0;
     if (active) {
-        const int per = (Lseg + LL_BLOCK - 1) / LL_BLOCK;
+        const int per = (Lseg + LL_BLOCK - 1) / LL_BLOCK;                        /* <= ROWS */
         const int a0 = min(Lseg, tid * per), a1 = min(Lseg, a0 + per);          /* slots -> local index slot + 5 */
-        int cntl = 0;
-        float mnx = INFINITY, mny = INFINITY, mnz = INFINITY, mxx = -INFINITY, mxy = -INFINITY, mxz = -INFINITY;
-        for (int q = a0; q < a1; ++q) {
-            if (L.lab[q + 5] <= 0) {
-                cntl++;
+        float px[ROWS], py[ROWS], pz[ROWS];
+        unsigned lfm = 0;                                                        /* bit u: slot a0 + u is less-flat */
+#pragma unroll
+        for (int u = 0; u < ROWS; ++u) {
+            const int q = a0 + u;
+            if (q < a1) {
                 const float4 p = cloud[off + q + 5];
-                mnx = fminf(mnx, p.x); mny = fminf(mny, p.y); mnz = fminf(mnz, p.z);
-                mxx = fmaxf(mxx, p.x); mxy = fmaxf(mxy, p.y); mxz = fmaxf(mxz, p.z);
+                px[u] = p.x; py[u] = p.y; pz[u] = p.z;
+                if (L.lab[q + 5] <= 0) lfm |= 1u << u;
             }
         }
+        float mnx = INFINITY, mny = INFINITY, mnz = INFINITY, mxx = -INFINITY, mxy = -INFINITY, mxz = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < ROWS; ++u)
+            if ((lfm >> u) & 1u) {
+                mnx = fminf(mnx, px[u]); mny = fminf(mny, py[u]); mnz = fminf(mnz, pz[u]);
+                mxx = fmaxf(mxx, px[u]); mxy = fmaxf(mxy, py[u]); mxz = fmaxf(mxz, pz[u]);
+            }
         /* wave reduce min/max, then across the 4 waves through LDS */
         for (int o = 32; o > 0; o >>= 1) {
             mnx = fminf(mnx, __shfl_xor(mnx, o)); mny = fminf(mny, __shfl_xor(mny, o)); mnz = fminf(mnz, __shfl_xor(mnz, o));
@@ -343,12 +355,10 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features
         }
         if (lane == 0) { float *w = fs + (tid >> 6) * 6; w[0] = mnx; w[1] = mny; w[2] = mnz; w[3] = mxx; w[4] = mxy; w[5] = mxz; }
         int m = 0;
-        int pos = ll_block_exscan(cntl, L.sc, m);                    /* barriers inside also publish fs[] */
-        for (int q = a0; q < a1; ++q) if (L.lab[q + 5] <= 0) L.lf_list[pos++] = (unsigned short)(q + 5);
+        int pos = ll_block_exscan(__popc(lfm), L.sc, m);             /* barriers inside also publish fs[] */
         float mn[3] = {fs[0], fs[1], fs[2]}, mx[3] = {fs[3], fs[4], fs[5]};
         for (int w = 1; w < LL_BLOCK / 64; ++w)
             for (int c = 0; c < 3; ++c) { mn[c] = fminf(mn[c], fs[w * 6 + c]); mx[c] = fmaxf(mx[c], fs[w * 6 + 3 + c]); }
-        __syncthreads();
         if (m > 0) {
             /* pcl::VoxelGrid::applyFilter (PCL 1.10), restated */
             const float inv = V.inv_leaf;
@@ -360,47 +370,65 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features
             }
             const bool too_small = d[0] * d[1] * d[2] > (long long)INT_MAX;        /* "leaf size too small": output = input */
             const int mul1 = div_b[0], mul2 = div_b[0] * div_b[1];
-            for (int jx = tid; jx < m; jx += LL_BLOCK) {
-                const float4 p = cloud[off + L.lf_list[jx]];
-                unsigned idx;
-                if (too_small) idx = (unsigned)jx;
-                else {
-                    const int i0 = (int)(floorf(p.x * inv) - (float)min_b[0]);
-                    const int i1 = (int)(floorf(p.y * inv) - (float)min_b[1]);
-                    const int i2 = (int)(floorf(p.z * inv) - (float)min_b[2]);
-                    idx = (unsigned)(i0 + i1 * mul1 + i2 * mul2);
+            const float fb0 = (float)min_b[0], fb1 = (float)min_b[1], fb2 = (float)min_b[2];
+#pragma unroll
+            for (int u = 0; u < ROWS; ++u)
+                if ((lfm >> u) & 1u) {
+                    unsigned idx;
+                    if (too_small) idx = (unsigned)pos;
+                    else {
+                        const int i0 = (int)(floorf(px[u] * inv) - fb0);
+                        const int i1 = (int)(floorf(py[u] * inv) - fb1);
+                        const int i2 = (int)(floorf(pz[u] * inv) - fb2);
+                        idx = (unsigned)(i0 + i1 * mul1 + i2 * mul2);
+                    }
+                    L.k32[pos] = idx; L.k16[pos] = (unsigned short)(a0 + u + 5);       /* payload: local index */
+                    ++pos;
                 }
-                L.k32[jx] = idx; L.k16[jx] = (unsigned short)jx;
-            }
             __syncthreads();
             LL_PHASE(3);
             ll_radix_sort<ROWS, false>(L.k32, L.k16, m, L.cnt, L.sc, segb, tid);
             LL_PHASE(4);
             __syncthreads();
-            /* run heads -> output rank */
-            const int perm = (m + LL_BLOCK - 1) / LL_BLOCK;
+            /* voxel runs -> centroids.  Thread t owns sorted positions [t*perm, (t+1)*perm): its points are fetched up
+             * front, a run is summed by the thread that owns its head and may continue into the following threads' range */
+            const int perm = (m + LL_BLOCK - 1) / LL_BLOCK;                          /* <= ROWS */
             const int b0 = min(m, tid * perm), b1 = min(m, b0 + perm);
-            int heads = 0;
-            for (int p = b0; p < b1; ++p)
-                if (p == 0 || L.k32[p] != L.k32[p - 1]) heads++;
-            int o = ll_block_exscan(heads, L.sc, n_lf_out);
+            float4 pt[ROWS]; unsigned vk[ROWS];
+#pragma unroll
+            for (int u = 0; u < ROWS; ++u)
+                if (b0 + u < b1) { vk[u] = L.k32[b0 + u]; pt[u] = cloud[off + L.k16[b0 + u]]; }
+            unsigned headm = 0;
+            {
+                unsigned prev = 0; bool has_prev = false;
+                if (b0 > 0 && b0 < b1) { prev = L.k32[b0 - 1]; has_prev = true; }
+#pragma unroll
+                for (int u = 0; u < ROWS; ++u)
+                    if (b0 + u < b1) {
+                        if (!has_prev || vk[u] != prev) headm |= 1u << u;
+                        prev = vk[u]; has_prev = true;
+                    }
+            }
+            int o = ll_block_exscan(__popc(headm), L.sc, n_lf_out);
             float4 *out = V.lflat_slot + (size_t)s * V.NP + off;
-            for (int p = b0; p < b1; ++p) {
-                const unsigned vid = L.k32[p];
-                if (p != 0 && vid == L.k32[p - 1]) continue;
-                /* CentroidPoint<PointXYZI>: f32 sums in input order, divided by float(n) */
-                float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f;
-                int e = p + 1;
-                while (e < m && L.k32[e] == vid) ++e;                                /* run = [p, e) */
-                for (int q = p; q < e; q += 4) {                                     /* 4 independent gathers in flight, */
-                    float4 pt[4];                                                    /* then the adds in input order     */
+            /* CentroidPoint<PointXYZI>: f32 sums from zero in input order, divided by float(n) */
+            float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f; int cn = 0;
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) if (q + u < e) pt[u] = cloud[off + L.lf_list[L.k16[q + u]]];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) if (q + u < e) { sx += pt[u].x; sy += pt[u].y; sz += pt[u].z; si += pt[u].w; }
+            for (int u = 0; u < ROWS; ++u)
+                if (b0 + u < b1) {
+                    if ((headm >> u) & 1u) {
+                        if (cn) { const float fn = (float)cn; out[o++] = make_float4(sx / fn, sy / fn, sz / fn, si / fn); }
+                        sx = 0.0f; sy = 0.0f; sz = 0.0f; si = 0.0f; cn = 0;
+                    } else if (!cn) continue;                                        /* tail of an earlier thread's run */
+                    sx += pt[u].x; sy += pt[u].y; sz += pt[u].z; si += pt[u].w; ++cn;
                 }
-                const float fn = (float)(e - p);
-                out[o++] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
+            if (cn) {
+                const unsigned vid = L.k32[b1 - 1];
+                for (int e = b1; e < m && L.k32[e] == vid; ++e) {
+                    const float4 q = cloud[off + L.k16[e]];
+                    sx += q.x; sy += q.y; sz += q.z; si += q.w; ++cn;
+                }
+                const float fn = (float)cn; out[o++] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
             }
         }
     }
