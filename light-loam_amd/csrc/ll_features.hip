@@ -285,34 +285,37 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features
                         for (int mm = 4; mm >= 0; --mm) if ((bits >> (4 - mm)) & 1u) bn = mm;
                         lo = li - bn; hi = li + fn;
                     }
+                    /* the serial part only decides: which lane is picked next and which lanes that suppresses.  Labels,
+                     * list entries and the cloudNeighborPicked marks are written by the picked lanes themselves after the
+                     * chunk (nothing inside the chunk reads them: in-chunk suppression is the register compare). */
+                    int myord = 0;                                                       /* 1-based pick number of this lane */
                     for (;;) {
                         const unsigned long long m = __ballot(elig);
                         if (!m) break;
                         const int f = __ffsll((long long)m) - 1;
-                        const int sel = __builtin_amdgcn_readlane(li, f);
                         const int slo = __builtin_amdgcn_readlane(lo, f), shi = __builtin_amdgcn_readlane(hi, f);
                         npick++;
-                        if (pass == 0) {
-                            if (npick > LL_LSHARP_PER_SEG) { done = true; break; }          /* :281-284 */
-                            if (lane == 0) {
-                                if (npick <= LL_SHARP_PER_SEG) { L.lab[sel] = 2; L.lists[ns] = sel; }
-                                else L.lab[sel] = 1;
-                                L.lists[12 + nls] = sel;
-                            }
-                            if (npick <= LL_SHARP_PER_SEG) ns++;
-                            nls++;
-                        } else {
-                            if (lane == 0) { L.lab[sel] = -1; L.lists[132 + nf] = sel; }
-                            nf++;
-                            if (npick >= LL_FLAT_PER_SEG) { done = true; break; }           /* :328-331: before marking */
-                        }
-                        /* cloudNeighborPicked[slo..shi] = 1: registers for this chunk, LDS bitmap for later ones */
-                        const int idx = slo + lane;
-                        if (idx <= shi) atomicOr(&L.picked[idx >> 5], 1u << (idx & 31));
+                        if (pass == 0 && npick > LL_LSHARP_PER_SEG) { done = true; break; }     /* :281-284 */
+                        if (lane == f) myord = npick;
+                        if (pass == 1 && npick >= LL_FLAT_PER_SEG) { done = true; break; }      /* :328-331: before marking */
                         if (li >= slo && li <= shi) elig = false;
+                    }
+                    if (myord) {
+                        if (pass == 0) {
+                            if (myord <= LL_SHARP_PER_SEG) { L.lab[li] = 2; L.lists[ns + myord - 1] = li; }
+                            else L.lab[li] = 1;
+                            L.lists[12 + nls + myord - 1] = li;
+                        } else { L.lab[li] = -1; L.lists[132 + nf + myord - 1] = li; }
+                        if (pass == 0 || myord < LL_FLAT_PER_SEG) {                      /* cloudNeighborPicked[lo..hi] = 1 */
+                            const unsigned long long bits = ((1ull << (hi - lo + 1)) - 1ull) << (lo & 31);
+                            atomicOr(&L.picked[lo >> 5], (unsigned)bits);
+                            if (bits >> 32) atomicOr(&L.picked[(lo >> 5) + 1], (unsigned)(bits >> 32));
+                        }
                     }
                     if (__ballot(have && !cand) != 0ull) break;                         /* the rest is beyond the threshold */
                 }
+                if (pass == 0) { ns += min(npick, LL_SHARP_PER_SEG); nls += min(npick, LL_LSHARP_PER_SEG); }
+                else nf += npick;
             }
         }
         if (lane == 0) { L.lists[156] = ns; L.lists[157] = nls; L.lists[158] = nf; }
