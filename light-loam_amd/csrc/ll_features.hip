@@ -288,18 +288,19 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features
                     /* the serial part only decides: which lane is picked next and which lanes that suppresses.  Labels,
                      * list entries and the cloudNeighborPicked marks are written by the picked lanes themselves after the
                      * chunk (nothing inside the chunk reads them: in-chunk suppression is the register compare). */
-                    int myord = 0;                                                       /* 1-based pick number of this lane */
-                    for (;;) {
-                        const unsigned long long m = __ballot(elig);
-                        if (!m) break;
-                        const int f = __ffsll((long long)m) - 1;
-                        const int slo = __builtin_amdgcn_readlane(lo, f), shi = __builtin_amdgcn_readlane(hi, f);
+                    /* picks go in ascending lane order (= sorted order), so the set of picked lanes is all the epilogue needs */
+                    unsigned long long em = __ballot(elig), pm = 0ull;                   /* uniform: eligible / picked lanes */
+                    const int base = npick;
+                    while (em) {
+                        const int f = __ffsll((long long)em) - 1;
                         npick++;
                         if (pass == 0 && npick > LL_LSHARP_PER_SEG) { done = true; break; }     /* :281-284 */
-                        if (lane == f) myord = npick;
+                        pm |= 1ull << f;
                         if (pass == 1 && npick >= LL_FLAT_PER_SEG) { done = true; break; }      /* :328-331: before marking */
-                        if (li >= slo && li <= shi) elig = false;
+                        const int slo = __builtin_amdgcn_readlane(lo, f), shi = __builtin_amdgcn_readlane(hi, f);
+                        em &= ~__ballot(li >= slo && li <= shi);
                     }
+                    const int myord = ((pm >> lane) & 1ull) ? base + __popcll(pm & ((1ull << lane) - 1ull)) + 1 : 0;
                     if (myord) {
                         if (pass == 0) {
                             if (myord <= LL_SHARP_PER_SEG) { L.lab[li] = 2; L.lists[ns + myord - 1] = li; }
