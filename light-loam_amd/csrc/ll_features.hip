@@ -33,7 +33,7 @@ __device__ __forceinline__ bool ll_xcd_map2(int id, int per_scan, int count, int
 }
 
 #define LL_FTILE 512      /* points per curvature tile */
-#define LL_NLIST 160      /* sharp[12] lsharp[120] flat[24] + 3 counters */
+#define LL_NLIST 176      /* per segment slots: sharp[6][2] lsharp[6][20] flat[6][4] + counters[6][3] */
 
 struct FeatLds {
     unsigned *k32;             /* [mr] sort key: curvature bits / voxel index */
@@ -168,6 +168,20 @@ __device__ __forceinline__ void ll_radix_sort(unsigned *k32, unsigned short *k16
     }
 }
 
+/* wave-wide max of a u32, result uniform: quad swaps, row shifts, row broadcasts (DPP), then lane 63 */
+__device__ __forceinline__ unsigned ll_wave_max_u32(unsigned v)
+{
+#define LL_DPP_MAX(ctrl, rmask) v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, false))
+    LL_DPP_MAX(0xb1, 0xf);        /* quad_perm [1,0,3,2] */
+    LL_DPP_MAX(0x4e, 0xf);        /* quad_perm [2,3,0,1] */
+    LL_DPP_MAX(0x114, 0xf);       /* row_shr:4 */
+    LL_DPP_MAX(0x118, 0xf);       /* row_shr:8  -> lanes 12..15 of a row hold the row max */
+    LL_DPP_MAX(0x142, 0xa);       /* row_bcast:15 into rows 1, 3 */
+    LL_DPP_MAX(0x143, 0xc);       /* row_bcast:31 into rows 2, 3 */
+#undef LL_DPP_MAX
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 __device__ __forceinline__ bool ll_bit(const unsigned *bm, int i) { return (bm[i >> 5] >> (i & 31)) & 1u; }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char ll_smem[];
@@ -209,7 +223,8 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features
     const int nwords = (nr + 31) / 32 + 1;
     for (int i = tid; i < nwords; i += LL_BLOCK) { L.picked[i] = 0; L.gapf[i] = 0; }
     for (int i = tid; i < nr; i += LL_BLOCK) L.lab[i] = 0;
-    if (tid < 3) L.lists[156 + tid] = 0;                              /* n_sharp, n_lsharp, n_flat */
+    if (tid < 3 * LL_SEGS) L.lists[156 + tid] = 0;                    /* per segment: n_sharp, n_lsharp, n_flat */
+    if (tid == 0) L.sc[60] = 0;                                       /* segments finished (bit j) */
     if (tid <= LL_SEGS) segb[tid] = Lseg * tid / LL_SEGS;             /* sp_j - S, int math of :253-254 */
     __syncthreads();
 
@@ -238,88 +253,139 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features
                 const float dZ = Z[-5] + Z[-4] + Z[-3] + Z[-2] + Z[-1] - 10 * Z[0] + Z[1] + Z[2] + Z[3] + Z[4] + Z[5];
                 const float cv = dX * dX + dY * dY + dZ * dZ;
                 if (V.write_curv) V.curv[(size_t)s * V.NP + g] = cv;
-                if (active && g >= S && g < E) { L.k32[g - S] = ll_f2u(cv); L.k16[g - S] = (unsigned short)li; }
+                if (active && g >= S && g < E) L.k32[g - S] = ll_f2u(cv);
             }
         }
         __syncthreads();
     }
 
     LL_PHASE(0);
-    /* ---------------- phase 2: sort the six segments (:251-257) ---------------- */
-    if (active) ll_radix_sort<ROWS, true>(L.k32, L.k16, Lseg, L.cnt, L.sc, segb, tid);
+    /* ---------------- phase 2: suppression extents (:288-311) per slot, all threads ----------------
+     * A pick at local index li marks li-bn .. li+fn: fn / bn = how far the forward / backward walk gets before a
+     * consecutive-point gap above the threshold stops it.  Bits gapf[li-4 .. li+5] straight from the LDS bitmap. */
+    for (int q = tid; q < Lseg; q += LL_BLOCK) {
+        const int b0 = q + 1;                                                        /* li - 4 */
+        const unsigned long long w = ((unsigned long long)L.gapf[(b0 >> 5) + 1] << 32) | L.gapf[b0 >> 5];
+        const unsigned bits = (unsigned)(w >> (b0 & 31)) & 0x3ffu;                   /* bit t = gapf[li - 4 + t] */
+        const unsigned fwd = bits >> 5;                                              /* l = 1..5  -> gapf[li + l] */
+        const int fn = fwd ? (__ffs(fwd) - 1) : 5;
+        int bn = 5;                                                                  /* l = -1..-5 -> gapf[li + l + 1] */
+#pragma unroll
+        for (int mm = 4; mm >= 0; --mm) if ((bits >> (4 - mm)) & 1u) bn = mm;
+        L.k16[q] = (unsigned short)(bn | (fn << 4));
+    }
     __syncthreads();
 
     LL_PHASE(1);
-    /* ---------------- phase 3: greedy pick, wave 0 ---------------- */
-    if (active && tid < 64) {
-        /* the pick is one long dependent instruction chain on a single wave while the other waves of the workgroup
-         * wait at the barrier: let it win issue arbitration against the co-resident workgroups' bulk phases */
+    /* ---------------- phase 3: the greedy pick (:251-359), one wave per segment, no sort ----------------
+     * Visiting a segment in descending (curvature, index) order and taking every candidate that is not yet suppressed is
+     * the same as repeatedly taking the arg-max over the still-eligible candidates, because suppression only grows;
+     * likewise arg-min for the flats.  A wave keeps its segment (<= 64 * SR records) in registers as masked keys (0 =
+     * not eligible): a pick is a lane-local max, one DPP wave max, a ballot for the owner, and a range compare.
+     * Segments run concurrently on the four waves.  The only coupling the reference has between them is forward:
+     * cloudNeighborPicked marks of segment j reach at most 5 points into the following segments, and they matter only
+     * if one of those points is about to be picked.  So a wave exports its forward marks to the LDS bitmap when its
+     * segment is finished, and a wave that is about to pick one of its first five points first waits for all earlier
+     * segments and imports their marks (at most once per segment). */
+    if (active) {
+        constexpr int SR = (ROWS * LL_BLOCK + 383) / 384;
+        int *donemask = L.sc + 60;
         __builtin_amdgcn_s_setprio(3);
-        int ns = 0, nls = 0, nf = 0;
-        for (int j = 0; j < LL_SEGS; ++j) {
+        for (int j = tid >> 6; j < LL_SEGS; j += LL_BLOCK / 64) {
             const int sp = Lseg * j / 6, ep = Lseg * (j + 1) / 6 - 1;     /* record slots; = (:253-254) - S */
             const int len = ep - sp + 1;
-            /* pass 0: corners, descending curvature (:261-313); pass 1: flats, ascending (:316-359) */
-            for (int pass = 0; pass < 2; ++pass) {
-                int npick = 0; bool done = false;
-                for (int c0 = 0; c0 < len && !done; c0 += 64) {
-                    const bool have = c0 + lane < len;
-                    const int slot = pass == 0 ? ep - (c0 + lane) : sp + c0 + lane;
-                    const int li = have ? (int)L.k16[slot] : 0;
-                    const double cv = have ? (double)ll_u2f(L.k32[slot]) : 0.0;
-                    const bool cand = have && (pass == 0 ? cv > V.curv_thr : cv < V.curv_thr);
-                    if (__ballot(cand) == 0ull) break;
-                    /* per candidate, once per chunk: is it already suppressed, and which index range [lo, hi] would its
-                     * own pick suppress (:288-311): bits gapf[li-4 .. li+5] straight from the LDS bitmap */
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");          /* marks of earlier chunks / segments */
-                    bool elig = false; int lo = 0, hi = 0;
-                    if (cand) {
-                        elig = !ll_bit(L.picked, li);
-                        const int b0 = li - 4;
-                        const unsigned long long w = ((unsigned long long)L.gapf[(b0 >> 5) + 1] << 32) | L.gapf[b0 >> 5];
-                        const unsigned bits = (unsigned)(w >> (b0 & 31)) & 0x3ffu;   /* bit t = gapf[li - 4 + t] */
-                        const unsigned fwd = bits >> 5;                              /* l = 1..5  -> gapf[li + l] */
-                        const int fn = fwd ? (__ffs(fwd) - 1) : 5;
-                        int bn = 5;                                                  /* l = -1..-5 -> gapf[li + l + 1] */
+            const int li0 = sp + 5 + lane;                                /* local index of this lane's row-0 record */
+            unsigned cb[SR];
+            unsigned candc = 0, candf = 0, sup = 0;                       /* row bitmasks: corner / flat candidate, suppressed */
 #pragma unroll
-                        for (int mm = 4; mm >= 0; --mm) if ((bits >> (4 - mm)) & 1u) bn = mm;
-                        lo = li - bn; hi = li + fn;
-                    }
-                    /* the serial part only decides: which lane is picked next and which lanes that suppresses.  Labels,
-                     * list entries and the cloudNeighborPicked marks are written by the picked lanes themselves after the
-                     * chunk (nothing inside the chunk reads them: in-chunk suppression is the register compare). */
-                    /* picks go in ascending lane order (= sorted order), so the set of picked lanes is all the epilogue needs */
-                    unsigned long long em = __ballot(elig), pm = 0ull;                   /* uniform: eligible / picked lanes */
-                    const int base = npick;
-                    while (em) {
-                        const int f = __ffsll((long long)em) - 1;
-                        npick++;
-                        if (pass == 0 && npick > LL_LSHARP_PER_SEG) { done = true; break; }     /* :281-284 */
-                        pm |= 1ull << f;
-                        if (pass == 1 && npick >= LL_FLAT_PER_SEG) { done = true; break; }      /* :328-331: before marking */
-                        const int slo = __builtin_amdgcn_readlane(lo, f), shi = __builtin_amdgcn_readlane(hi, f);
-                        em &= ~__ballot(li >= slo && li <= shi);
-                    }
-                    const int myord = ((pm >> lane) & 1ull) ? base + __popcll(pm & ((1ull << lane) - 1ull)) + 1 : 0;
-                    if (myord) {
-                        if (pass == 0) {
-                            if (myord <= LL_SHARP_PER_SEG) { L.lab[li] = 2; L.lists[ns + myord - 1] = li; }
-                            else L.lab[li] = 1;
-                            L.lists[12 + nls + myord - 1] = li;
-                        } else { L.lab[li] = -1; L.lists[132 + nf + myord - 1] = li; }
-                        if (pass == 0 || myord < LL_FLAT_PER_SEG) {                      /* cloudNeighborPicked[lo..hi] = 1 */
-                            const unsigned long long bits = ((1ull << (hi - lo + 1)) - 1ull) << (lo & 31);
-                            atomicOr(&L.picked[lo >> 5], (unsigned)bits);
-                            if (bits >> 32) atomicOr(&L.picked[(lo >> 5) + 1], (unsigned)(bits >> 32));
-                        }
-                    }
-                    if (__ballot(have && !cand) != 0ull) break;                         /* the rest is beyond the threshold */
+            for (int k = 0; k < SR; ++k) {
+                const int q = k * 64 + lane;
+                cb[k] = 0u;
+                if (q < len) {
+                    cb[k] = L.k32[sp + q];
+                    const double cv = (double)ll_u2f(cb[k]);              /* f32 curvature against the double literal 0.1 */
+                    if (cv > V.curv_thr) candc |= 1u << k;                /* :266 */
+                    if (cv < V.curv_thr) candf |= 1u << k;                /* :321 */
                 }
-                if (pass == 0) { ns += min(npick, LL_SHARP_PER_SEG); nls += min(npick, LL_LSHARP_PER_SEG); }
-                else nf += npick;
             }
+            bool imported = (j == 0);
+            int nrec[2] = {0, 0};
+            for (int pass = 0; pass < 2; ++pass) {
+                /* non-negative float bits order like the floats; the flats maximise the complement */
+                const unsigned el = (pass == 0 ? candc : candf) & ~sup;
+                unsigned mk[SR];
+#pragma unroll
+                for (int k = 0; k < SR; ++k) mk[k] = ((el >> k) & 1u) ? (pass == 0 ? cb[k] : ~cb[k]) : 0u;
+                int npick = 0;
+                unsigned myrec = 0;                                       /* lane n: pick n+1 as li | extents << 16 */
+                for (;;) {
+                    /* lane-local best; rows ascend in index, so on equal keys ">=" keeps the larger index (descending
+                     * visit order of the corners) and ">" the smaller (ascending order of the flats) */
+                    unsigned best = mk[0]; int row_l = 0;
+#pragma unroll
+                    for (int k = 1; k < SR; ++k) {
+                        const bool t = pass == 0 ? mk[k] >= best : mk[k] > best;
+                        best = t ? mk[k] : best; row_l = t ? k : row_l;
+                    }
+                    const unsigned kmax = ll_wave_max_u32(best);
+                    if (kmax == 0u) break;                                /* nothing eligible is left */
+                    const unsigned long long bal = __ballot(best == kmax);
+                    int selq;
+                    if (__popcll(bal) == 1) {
+                        const int f = __ffsll((long long)bal) - 1;
+                        selq = __builtin_amdgcn_readlane(row_l, f) * 64 + f;
+                    } else {                                              /* equal curvatures in several lanes: index decides */
+                        const int myq = row_l * 64 + lane;
+                        const unsigned t = (best == kmax) ? (pass == 0 ? (unsigned)(myq + 1) : (unsigned)(0x10000 - myq)) : 0u;
+                        const unsigned tm = ll_wave_max_u32(t);
+                        selq = pass == 0 ? (int)tm - 1 : 0x10000 - (int)tm;
+                    }
+                    if (!imported && selq < 5) {
+                        const int need = (1 << j) - 1;
+                        while ((__hip_atomic_load(donemask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & need) != need)
+                            __builtin_amdgcn_s_sleep(2);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        if (lane < 5 && lane < len && ll_bit(L.picked, li0)) { mk[0] = 0u; sup |= 1u; }
+                        imported = true;
+                        continue;                                         /* select again: the choice may be gone */
+                    }
+                    npick++;
+                    if (pass == 0 && npick > LL_LSHARP_PER_SEG) break;    /* :281-284 */
+                    const int sel = sp + selq + 5;
+                    const int e = (int)L.k16[sp + selq];
+                    if (lane == npick - 1) myrec = (unsigned)sel | ((unsigned)e << 16);
+                    if (pass == 1 && npick >= LL_FLAT_PER_SEG) break;     /* :328-331: labelled, but no marking */
+                    const int slo = sel - (e & 15), shi = sel + (e >> 4);
+#pragma unroll
+                    for (int k = 0; k < SR; ++k) {
+                        const int lik = li0 + 64 * k;
+                        if (lik >= slo && lik <= shi) { mk[k] = 0u; sup |= 1u << k; }
+                    }
+                }
+                /* the picked records, lane-parallel: labels, list entries, forward marks */
+                const int nr_ = pass == 0 ? min(npick, LL_LSHARP_PER_SEG) : npick;
+                nrec[pass] = nr_;
+                if (lane < nr_) {
+                    const int sel = (int)(myrec & 0xffffu), e = (int)(myrec >> 16);
+                    if (pass == 0) {
+                        if (lane < LL_SHARP_PER_SEG) { L.lab[sel] = 2; L.lists[j * LL_SHARP_PER_SEG + lane] = sel; }
+                        else L.lab[sel] = 1;
+                        L.lists[12 + j * LL_LSHARP_PER_SEG + lane] = sel;
+                    } else { L.lab[sel] = -1; L.lists[132 + j * LL_FLAT_PER_SEG + lane] = sel; }
+                    const int shi = sel + (e >> 4), f0 = max(sel - (e & 15), ep + 6);      /* marks beyond this segment */
+                    if ((pass == 0 || lane < LL_FLAT_PER_SEG - 1) && shi >= f0) {
+                        const unsigned long long bits = ((1ull << (shi - f0 + 1)) - 1ull) << (f0 & 31);
+                        atomicOr(&L.picked[f0 >> 5], (unsigned)bits);
+                        if (bits >> 32) atomicOr(&L.picked[(f0 >> 5) + 1], (unsigned)(bits >> 32));
+                    }
+                }
+            }
+            if (lane == 0) {
+                L.lists[156 + j * 3] = min(nrec[0], LL_SHARP_PER_SEG); L.lists[157 + j * 3] = nrec[0]; L.lists[158 + j * 3] = nrec[1];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) atomicOr(donemask, 1 << j);
         }
-        if (lane == 0) { L.lists[156] = ns; L.lists[157] = nls; L.lists[158] = nf; }
         __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
@@ -441,11 +507,26 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features
     /* ---------------- phase 5: labels + feature slots ---------------- */
     int8_t *label = V.label + (size_t)s * V.NP + off;
     for (int i = tid; i < nr; i += LL_BLOCK) label[i] = L.lab[i];
-    const int ns = L.lists[156], nls = L.lists[157], nf = L.lists[158];
-    const size_t ring_id = (size_t)s * V.R + r;
-    if (tid < ns) V.sharp_slot[ring_id * 12 + tid] = cloud[off + L.lists[tid]];
-    if (tid < nls) V.lsharp_slot[ring_id * 120 + tid] = cloud[off + L.lists[12 + tid]];
-    if (tid < nf) V.flat_slot[ring_id * 24 + tid] = cloud[off + L.lists[132 + tid]];
+    /* per-segment lists -> the ring's slots in (segment, pick order) */
+    int ns = 0, nls = 0, nf = 0;
+    {
+        const int js = tid / LL_SHARP_PER_SEG, jl = tid / LL_LSHARP_PER_SEG, jf = tid / LL_FLAT_PER_SEG;
+        int os = 0, ol = 0, of = 0;
+        for (int j = 0; j < LL_SEGS; ++j) {
+            const int a = L.lists[156 + j * 3], b = L.lists[157 + j * 3], c = L.lists[158 + j * 3];
+            if (j < js) os += a;
+            if (j < jl) ol += b;
+            if (j < jf) of += c;
+            ns += a; nls += b; nf += c;
+        }
+        const size_t ring_id = (size_t)s * V.R + r;
+        if (js < LL_SEGS && tid % LL_SHARP_PER_SEG < L.lists[156 + js * 3])
+            V.sharp_slot[ring_id * 12 + os + tid % LL_SHARP_PER_SEG] = cloud[off + L.lists[tid]];
+        if (jl < LL_SEGS && tid % LL_LSHARP_PER_SEG < L.lists[157 + jl * 3])
+            V.lsharp_slot[ring_id * 120 + ol + tid % LL_LSHARP_PER_SEG] = cloud[off + L.lists[12 + tid]];
+        if (jf < LL_SEGS && tid % LL_FLAT_PER_SEG < L.lists[158 + jf * 3])
+            V.flat_slot[ring_id * 24 + of + tid % LL_FLAT_PER_SEG] = cloud[off + L.lists[132 + tid]];
+    }
     if (tid == 0) { fcnt[0] = ns; fcnt[1] = nls; fcnt[2] = nf; fcnt[3] = n_lf_out; }
     LL_PHASE(6);
 #ifdef LL_PHASE_TIMING

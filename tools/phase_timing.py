@@ -25,7 +25,7 @@ buf = (C.c_ulonglong * 16)()
 ctx._ck(ctx.lib.ll_debug_counters(ctx.h, buf, 1))
 ctx.extract(0, B)
 ctx._ck(ctx.lib.ll_debug_counters(ctx.h, buf, 1))
-names = ["p1 curvature+keys", "p2 segment sort", "p3 greedy pick", "p4a compact+bounds+voxel keys", "p4b voxel sort",
+names = ["p1 curvature+keys", "p2 suppression extents", "p3 per-segment pick", "p4a compact+bounds+voxel keys", "p4b voxel sort",
          "p4c heads+centroids", "p5 outputs"]
 n = max(1, buf[15])
 tot = sum(buf[i] for i in range(7))
