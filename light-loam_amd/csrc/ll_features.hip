@@ -295,14 +295,18 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features
             const int sp = Lseg * j / 6, ep = Lseg * (j + 1) / 6 - 1;     /* record slots; = (:253-254) - S */
             const int len = ep - sp + 1;
             const int li0 = sp + 5 + lane;                                /* local index of this lane's row-0 record */
-            unsigned cb[SR];
+            constexpr int EW = (SR + 3) / 4;
+            unsigned cb[SR], exw[EW];                                     /* curvature bits; suppression extents, 4 rows per word */
             unsigned candc = 0, candf = 0, sup = 0;                       /* row bitmasks: corner / flat candidate, suppressed */
+#pragma unroll
+            for (int w = 0; w < EW; ++w) exw[w] = 0u;
 #pragma unroll
             for (int k = 0; k < SR; ++k) {
                 const int q = k * 64 + lane;
                 cb[k] = 0u;
                 if (q < len) {
                     cb[k] = L.k32[sp + q];
+                    exw[k >> 2] |= (unsigned)L.k16[sp + q] << ((k & 3) * 8);
                     const double cv = (double)ll_u2f(cb[k]);              /* f32 curvature against the double literal 0.1 */
                     if (cv > V.curv_thr) candc |= 1u << k;                /* :266 */
                     if (cv < V.curv_thr) candf |= 1u << k;                /* :321 */
@@ -352,15 +356,19 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features
                     npick++;
                     if (pass == 0 && npick > LL_LSHARP_PER_SEG) break;    /* :281-284 */
                     const int sel = sp + selq + 5;
-                    const int e = (int)L.k16[sp + selq];
+                    unsigned ew = 0u;                                     /* the owner's extents: uniform row, lane */
+#pragma unroll
+                    for (int w = 0; w < EW; ++w) if ((selq >> 8) == w) ew = (unsigned)__builtin_amdgcn_readlane((int)exw[w], selq & 63);
+                    const int e = (int)((ew >> (((selq >> 6) & 3) * 8)) & 0xffu);
                     if (lane == npick - 1) myrec = (unsigned)sel | ((unsigned)e << 16);
                     if (pass == 1 && npick >= LL_FLAT_PER_SEG) break;     /* :328-331: labelled, but no marking */
                     const int slo = sel - (e & 15), shi = sel + (e >> 4);
+                    /* rows are 64 apart and a pick marks at most 11 consecutive indices: per lane at most one row is hit */
+                    const int dd = shi - li0;
+                    const int kl = (dd >= 0 && (dd & 63) <= shi - slo) ? (dd >> 6) : -1;
 #pragma unroll
-                    for (int k = 0; k < SR; ++k) {
-                        const int lik = li0 + 64 * k;
-                        if (lik >= slo && lik <= shi) { mk[k] = 0u; sup |= 1u << k; }
-                    }
+                    for (int k = 0; k < SR; ++k) mk[k] = (kl == k) ? 0u : mk[k];
+                    if (kl >= 0) sup |= 1u << kl;
                 }
                 /* the picked records, lane-parallel: labels, list entries, forward marks */
                 const int nr_ = pass == 0 ? min(npick, LL_LSHARP_PER_SEG) : npick;
