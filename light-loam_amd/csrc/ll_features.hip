@@ -230,13 +230,28 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features
 
     LL_PHASE_BEGIN();
     /* ---------------- phase 1: curvature + gap flags + sort records ---------------- */
+    constexpr int TLOADS = (LL_FTILE + 10 + LL_BLOCK - 1) / LL_BLOCK;
+    float4 pre[TLOADS];                                               /* the next tile's points, in flight during the math */
+#pragma unroll
+    for (int u = 0; u < TLOADS; ++u) {
+        const int t = u * LL_BLOCK + tid, g = off - 5 + t;
+        if (t < LL_FTILE + 10 && g >= 0 && g < N) pre[u] = cloud[g];
+    }
     for (int c0 = 0; c0 < nr; c0 += LL_FTILE) {
         const int g0 = off + c0;                                      /* global index of tile slot 5 */
-        for (int t = tid; t < LL_FTILE + 10; t += LL_BLOCK) {
-            const int g = g0 - 5 + t;
-            if (g >= 0 && g < N) { const float4 p = cloud[g]; L.tx[t] = p.x; L.ty[t] = p.y; L.tz[t] = p.z; }
+#pragma unroll
+        for (int u = 0; u < TLOADS; ++u) {
+            const int t = u * LL_BLOCK + tid, g = g0 - 5 + t;
+            if (t < LL_FTILE + 10 && g >= 0 && g < N) { L.tx[t] = pre[u].x; L.ty[t] = pre[u].y; L.tz[t] = pre[u].z; }
         }
         __syncthreads();
+        if (c0 + LL_FTILE < nr) {
+#pragma unroll
+            for (int u = 0; u < TLOADS; ++u) {
+                const int t = u * LL_BLOCK + tid, g = g0 + LL_FTILE - 5 + t;
+                if (t < LL_FTILE + 10 && g >= 0 && g < N) pre[u] = cloud[g];
+            }
+        }
 #pragma unroll
         for (int k = 0; k < LL_FTILE / LL_BLOCK; ++k) {
             const int li = c0 + k * LL_BLOCK + tid;
