@@ -7,8 +7,8 @@
  * extract stage (no publish -> subscribe -> fromROSMsg -> kd-tree build).
  *
  * k_build_grid (one workgroup per (scan, cloud)) builds what replaces the kd-tree:
- *   - a uniform 2-D (x, y) cell grid: LDS histogram over 128 x 128 cells of 2 m, exclusive scan, scatter of
- *     (x, y, z, ring << 24 | original index) into cell order.  Points outside +-128 m saturate into the border
+ *   - a uniform 2-D (x, y) cell grid: LDS histogram over 128 x 128 cells of 1 m, exclusive scan, scatter of
+ *     (x, y, z, ring << 24 | original index) into cell order.  Points outside +-64 m saturate into the border
  *     cells, whose rectangles are treated as unbounded outwards;
  *   - ring tables first_ge[v] = min{j : ring_j >= v}, last_le[v] = max{j : ring_j <= v} (ring_j = int(intensity_j))
  *     and a flag saying whether they reproduce the reference's sequential walk bounds for EVERY start index
@@ -19,7 +19,7 @@
  *                is provably farther than the best so far, the ring loop stopped when the whole next ring is.
  *                Distance = FLANN L2_Simple in f32 ((dx*dx + dy*dy) + dz*dz, no FMA); equal distances -> lowest
  *                original index (traversal-dependent in the kd-tree; defined here and in the oracle).  Only
- *                neighbours closer than DISTANCE_SQ_THRESHOLD are ever used (:497 / :659): at most 4 rings.
+ *                neighbours closer than DISTANCE_SQ_THRESHOLD are ever used (:497 / :659): at most 7 rings.
  *   ring walks   (:504-553, :668-721) are sequential loops over a contiguous index window with early breaks and a
  *                running minimum under strict '<'.  With valid tables the window is (last_le[..], first_ge[..]),
  *                and the result is the lexicographic minimum of (distance, visiting order) over the window points
@@ -255,7 +255,7 @@ __device__ __forceinline__ void ll_ring_cell(int ring, int e, int &dx, int &dy)
 }
 
 #define LL_SCAN_UN 4              /* point loads a lane keeps in flight while scanning a cell */
-#define LL_RING_CELLS 24          /* 8 * 3: the widest ring ever searched (nn_max 25, cell 2 m -> rings 0..3) */
+#define LL_RING_CELLS 24          /* cell bounds fetched per round; wider rings take several rounds */
 
 /* visit the cells around (qx, qy) in Chebyshev rings; scan(cell_start, cell_end) scans one cell, bound() is the current
  * pruning radius^2 (shrinks as candidates are found), sync() shares the best inside the 8-lane group.
@@ -266,30 +266,32 @@ __device__ __forceinline__ void ll_grid_search(const int *gstart, float qx, floa
                                                Scan scan, Bound bound, Sync sync)
 {
     const int cx = ll_cell_coord(qx), cy = ll_cell_coord(qy);
-    if (rmax > 3) rmax = 3;                                   /* table capacity; larger radii would need more cells */
     for (int ring = 0; ring <= rmax; ++ring) {
         if (ring >= 2) { const float lbr = (float)(ring - 1) * LL_GRID_CELL - 1e-3f; if (lbr * lbr > bound()) break; }
         const int ncell = ring == 0 ? 1 : 8 * ring;
-        const float bnd = bound();
-        for (int e = sub; e < ncell; e += 8) {
-            int dx, dy; ll_ring_cell(ring, e, dx, dy);
-            const int xx = cx + dx, yy = cy + dy;
-            int st = 0, en = 0; float lb = 0.0f;
-            if (xx >= 0 && xx < LL_GRID_G && yy >= 0 && yy < LL_GRID_G) {
-                lb = ll_cell_lb2(qx, qy, xx, yy);
-                if (!(lb > bnd)) { const int c = yy * LL_GRID_G + xx; st = gstart[c]; en = gstart[c + 1]; }
+        for (int e0 = 0; e0 < ncell; e0 += LL_RING_CELLS) {           /* wide rings go through the table in chunks */
+            const int ne = min(LL_RING_CELLS, ncell - e0);
+            const float bnd = bound();
+            for (int e = sub; e < ne; e += 8) {
+                int dx, dy; ll_ring_cell(ring, e0 + e, dx, dy);
+                const int xx = cx + dx, yy = cy + dy;
+                int st = 0, en = 0; float lb = 0.0f;
+                if (xx >= 0 && xx < LL_GRID_G && yy >= 0 && yy < LL_GRID_G) {
+                    lb = ll_cell_lb2(qx, qy, xx, yy);
+                    if (!(lb > bnd)) { const int c = yy * LL_GRID_G + xx; st = gstart[c]; en = gstart[c + 1]; }
+                }
+                cellb[3 * e] = st; cellb[3 * e + 1] = en; cellb[3 * e + 2] = __float_as_int(lb);
             }
-            cellb[3 * e] = st; cellb[3 * e + 1] = en; cellb[3 * e + 2] = __float_as_int(lb);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            for (int e = 0; e < ne; ++e) {
+                const int st = cellb[3 * e], en = cellb[3 * e + 1];
+                if (st >= en) continue;
+                if (__int_as_float(cellb[3 * e + 2]) > bound()) continue;   /* the bound may have shrunk since the fetch */
+                scan(st, en);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            sync();
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        for (int e = 0; e < ncell; ++e) {
-            const int st = cellb[3 * e], en = cellb[3 * e + 1];
-            if (st >= en) continue;
-            if (__int_as_float(cellb[3 * e + 2]) > bound()) continue;       /* the bound may have shrunk since the fetch */
-            scan(st, en);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        sync();
     }
 }
 

@@ -27,10 +27,11 @@
 #define LL_LSHARP_PER_SEG 20
 #define LL_FLAT_PER_SEG 4
 #define LL_SEGS 6
-/* nearest-neighbour cell grid over (x, y): 128 x 128 cells of 2 m centred on the sensor */
+/* nearest-neighbour cell grid over (x, y): 128 x 128 cells of 1 m centred on the sensor; farther points saturate into
+ * the border cells, whose rectangles count as unbounded outwards */
 #define LL_GRID_G 128
-#define LL_GRID_CELL 2.0f
-#define LL_GRID_ORG 128.0f
+#define LL_GRID_CELL 1.0f
+#define LL_GRID_ORG 64.0f
 #define LL_GRID_NC (LL_GRID_G * LL_GRID_G)
 /* ring tables stored behind the cell starts: first_ge[LL_TAB+1], last_le[LL_TAB+1], ok flag, cloud size */
 #define LL_TAB 160
