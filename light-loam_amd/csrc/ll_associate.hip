@@ -67,7 +67,8 @@ extern __shared__ __attribute__((aligned(16))) unsigned char ll_gsm[];
 #endif
 
 /* grid + ring tables of a target cloud; carry != 0: the carry clouds, else slot first + blockIdx/2 */
-__global__ __launch_bounds__(LL_BLOCK) void k_build_grid(LLView V, int first, int count, int carry)
+#define LL_GB 1024      /* threads: the kernel is a chain of latency-bound sweeps and LDS (68 KB) allows two workgroups per CU */
+__global__ __launch_bounds__(LL_GB) void k_build_grid(LLView V, int first, int count, int carry)
 {
     const int which = blockIdx.x & 1, sl = blockIdx.x >> 1;
     if (sl >= count) return;
@@ -85,52 +86,52 @@ __global__ __launch_bounds__(LL_BLOCK) void k_build_grid(LLView V, int first, in
         gstart = V.gstart + ((size_t)s * 2 + which) * LL_GSTRIDE;
         gpts = which ? V.gpts_s + (size_t)s * V.NP : V.gpts_c + (size_t)s * V.cap_lsharp;
     }
-    /* cell c lives at hist[c + (c >> 6)]: the per-thread scan below walks 64 consecutive cells per lane, and the
-     * one-word skew per 64 cells spreads the lanes over all LDS banks instead of putting them on one */
-#define LL_HI(c) ((c) + ((c) >> 6))
-    int *hist = (int *)ll_gsm;                      /* [LL_GRID_NC + LL_GRID_NC / 64] */
-    __shared__ int sc[8];
+    /* cell c lives at hist[c + (c >> 4)]: the per-thread scan below walks 16 consecutive cells per lane, and the
+     * one-word skew per 16 cells spreads the lanes over all LDS banks instead of putting them on two */
+#define LL_HI(c) ((c) + ((c) >> 4))
+    int *hist = (int *)ll_gsm;                      /* [LL_GRID_NC + LL_GRID_NC / 16] */
+    __shared__ int sc[LL_GB / 64];
     __shared__ int feq[LL_TAB + 1], leq[LL_TAB + 1];
     __shared__ int okflag;
-    for (int i = tid; i < LL_GRID_NC + LL_GRID_NC / 64; i += LL_BLOCK) hist[i] = 0;
-    for (int i = tid; i <= LL_TAB; i += LL_BLOCK) { feq[i] = INT_MAX; leq[i] = -1; }
+    for (int i = tid; i < LL_GRID_NC + LL_GRID_NC / 16; i += LL_GB) hist[i] = 0;
+    for (int i = tid; i <= LL_TAB; i += LL_GB) { feq[i] = INT_MAX; leq[i] = -1; }
     if (tid == 0) okflag = (V.nearby >= 0.0) ? 1 : 0;
     __syncthreads();
     LL_GPHASE_BEGIN();
     constexpr int UN = 8;                            /* independent loads in flight per thread: the kernel is latency-bound */
-    for (int i0 = tid; i0 < m; i0 += LL_BLOCK * UN) {
+    for (int i0 = tid; i0 < m; i0 += LL_GB * UN) {
         float4 p[UN];
 #pragma unroll
-        for (int u = 0; u < UN; ++u) { const int i = i0 + u * LL_BLOCK; if (i < m) p[u] = pts[i]; }
+        for (int u = 0; u < UN; ++u) { const int i = i0 + u * LL_GB; if (i < m) p[u] = pts[i]; }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const int i = i0 + u * LL_BLOCK;
+            const int i = i0 + u * LL_GB;
             if (i < m) { const int c = ll_cell_coord(p[u].y) * LL_GRID_G + ll_cell_coord(p[u].x); atomicAdd(&hist[LL_HI(c)], 1); }
         }
     }
     __syncthreads();
     LL_GPHASE(8);
-    constexpr int PER = LL_GRID_NC / LL_BLOCK;      /* 64 */
+    constexpr int PER = LL_GRID_NC / LL_GB;         /* 16 */
     int sum = 0;
     for (int k = 0; k < PER; ++k) sum += hist[tid * (PER + 1) + k];
     int total = 0;
-    int run = ll_block_exscan(sum, sc, total);
+    int run = ll_block_exscan_n<LL_GB / 64>(sum, sc, total);
     for (int k = 0; k < PER; ++k) { const int c = hist[tid * (PER + 1) + k]; hist[tid * (PER + 1) + k] = run; gstart[tid * PER + k] = run; run += c; }
-    if (tid == LL_BLOCK - 1) gstart[LL_GRID_NC] = total;
+    if (tid == LL_GB - 1) gstart[LL_GRID_NC] = total;
     __syncthreads();
     LL_GPHASE(9);
-    for (int i0 = tid; i0 < m; i0 += LL_BLOCK * UN) {
+    for (int i0 = tid; i0 < m; i0 += LL_GB * UN) {
         float4 p[UN]; int pos[UN];
 #pragma unroll
-        for (int u = 0; u < UN; ++u) { const int i = i0 + u * LL_BLOCK; if (i < m) p[u] = pts[i]; }
+        for (int u = 0; u < UN; ++u) { const int i = i0 + u * LL_GB; if (i < m) p[u] = pts[i]; }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const int i = i0 + u * LL_BLOCK;
+            const int i = i0 + u * LL_GB;
             if (i < m) { const int c = ll_cell_coord(p[u].y) * LL_GRID_G + ll_cell_coord(p[u].x); pos[u] = atomicAdd(&hist[LL_HI(c)], 1); }
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const int i = i0 + u * LL_BLOCK;
+            const int i = i0 + u * LL_GB;
             if (i < m) {
                 const int r = (int)p[u].w;                                   /* int(intensity): the walk's scan id */
                 gpts[pos[u]] = make_float4(p[u].x, p[u].y, p[u].z, __int_as_float((i & 0xFFFFFF) | ((r & 0xFF) << 24)));
@@ -148,13 +149,13 @@ __global__ __launch_bounds__(LL_BLOCK) void k_build_grid(LLView V, int first, in
      * so validity is a check on the two 160-entry tables, no per-point scan. ---- */
     const int lane = tid & 63;
     bool bad = false;
-    for (int i0 = tid; i0 < m; i0 += LL_BLOCK * UN) {
+    for (int i0 = tid; i0 < m; i0 += LL_GB * UN) {
         float rw[UN];
 #pragma unroll
-        for (int u = 0; u < UN; ++u) { const int j = i0 + u * LL_BLOCK; rw[u] = (j < m) ? pts[j].w : 0.0f; }
+        for (int u = 0; u < UN; ++u) { const int j = i0 + u * LL_GB; rw[u] = (j < m) ? pts[j].w : 0.0f; }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const int j = i0 + u * LL_BLOCK;
+            const int j = i0 + u * LL_GB;
             const bool in = j < m;
             const int r = (int)rw[u];
             const bool oob = in && (r < 0 || r >= LL_TAB);
@@ -254,7 +255,7 @@ __device__ __forceinline__ void ll_ring_cell(int ring, int e, int &dx, int &dy)
     else { const int t = e - 2 * w; dy = -ring + 1 + (t >> 1); dx = (t & 1) ? ring : -ring; }
 }
 
-#define LL_SCAN_UN 4              /* point loads a lane keeps in flight while scanning a cell */
+#define LL_SCAN_UN 2              /* point loads a lane keeps in flight while scanning a cell */
 #define LL_RING_CELLS 24          /* cell bounds fetched per round; wider rings take several rounds */
 
 /* visit the cells around (qx, qy) in Chebyshev rings; scan(cell_start, cell_end) scans one cell, bound() is the current
@@ -485,12 +486,12 @@ __global__ __launch_bounds__(LL_BLOCK) void k_associate(LLView V, int first, int
 void ll_launch_build_grid(const LLView &V, int first, int count, int carry, hipStream_t st, LLProfiler *prof)
 {
     static bool attr_set = false;
-    if (!attr_set) {   /* 64 KiB histogram + static LDS exceeds the default dynamic-LDS limit */
-        (void)hipFuncSetAttribute((const void *)k_build_grid, hipFuncAttributeMaxDynamicSharedMemorySize, (LL_GRID_NC + LL_GRID_NC / 64) * sizeof(int));
+    if (!attr_set) {   /* 68 KiB histogram + static LDS exceeds the default dynamic-LDS limit */
+        (void)hipFuncSetAttribute((const void *)k_build_grid, hipFuncAttributeMaxDynamicSharedMemorySize, (LL_GRID_NC + LL_GRID_NC / 16) * sizeof(int));
         attr_set = true;
     }
     ll_prof_mark(prof, LL_K_GRID, st);
-    hipLaunchKernelGGL(k_build_grid, dim3(2 * (carry ? 1 : count)), dim3(LL_BLOCK), (LL_GRID_NC + LL_GRID_NC / 64) * sizeof(int), st, V, first, carry ? 1 : count, carry);
+    hipLaunchKernelGGL(k_build_grid, dim3(2 * (carry ? 1 : count)), dim3(LL_GB), (LL_GRID_NC + LL_GRID_NC / 16) * sizeof(int), st, V, first, carry ? 1 : count, carry);
     ll_prof_mark(prof, LL_K_END, st);
 }
 

@@ -116,9 +116,10 @@ __device__ __forceinline__ int ll_trunc_to_int(double v)
     return (int)v;
 }
 
-/* exclusive prefix sum of one int per thread over a 256-thread workgroup: 64-lane shuffle scan + 4 wave totals
- * through LDS (sc: >= 4 ints).  Returns the exclusive prefix; total = workgroup sum.  Ends with a barrier. */
-__device__ __forceinline__ int ll_block_exscan(int v, int *sc, int &total)
+/* exclusive prefix sum of one int per thread over a workgroup of NW waves: 64-lane shuffle scan + the wave totals
+ * through LDS (sc: >= NW ints).  Returns the exclusive prefix; total = workgroup sum.  Ends with a barrier. */
+template <int NW>
+__device__ __forceinline__ int ll_block_exscan_n(int v, int *sc, int &total)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int inc = v;
@@ -128,11 +129,12 @@ __device__ __forceinline__ int ll_block_exscan(int v, int *sc, int &total)
     __syncthreads();
     int base = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < LL_BLOCK / 64; ++w) { const int t = sc[w]; if (w < wave) base += t; tot += t; }
+    for (int w = 0; w < NW; ++w) { const int t = sc[w]; if (w < wave) base += t; tot += t; }
     total = tot;
     __syncthreads();
     return base + inc - v;
 }
+__device__ __forceinline__ int ll_block_exscan(int v, int *sc, int &total) { return ll_block_exscan_n<LL_BLOCK / 64>(v, sc, total); }
 
 /* target clouds of slot s: features of slot s-1, or the carry for the batch's first slot */
 __device__ __forceinline__ void ll_targets(const LLView &V, int s, const float4 *&corner, int &mc, const float4 *&surf, int &ms)
