@@ -171,21 +171,48 @@ __global__ __launch_bounds__(LL_GB) void k_build_grid(LLView V, int first, int c
     if (bad) okflag = 0;
     __syncthreads();
     int *tab = gstart + LL_GRID_NC + 1;              /* first_ge[LL_TAB+1], last_le[LL_TAB+1], ok, m */
-    if (tid == 0) {
-        int run_min = m;
-        for (int v = LL_TAB; v >= 0; --v) { if (feq[v] != INT_MAX) run_min = min(run_min, feq[v]); tab[v] = run_min; }
-        int run_max = -1;
-        for (int v = 0; v <= LL_TAB; ++v) { run_max = max(run_max, leq[v]); tab[LL_TAB + 1 + v] = run_max; }
-        int ok = okflag;
-        for (int bv = 0; bv < LL_TAB && ok; ++bv) {
-            if (feq[bv] == INT_MAX) continue;
-            const int hi = ll_ring_hi(bv, V.nearby), lo = ll_ring_lo(bv, V.nearby);
-            const int fg = (hi + 1 > LL_TAB) ? m : tab[max(hi + 1, 0)];
-            const int ll = (lo - 1 < 0) ? -1 : tab[LL_TAB + 1 + min(lo - 1, LL_TAB)];
-            if (fg < leq[bv] || ll > feq[bv]) ok = 0;
+    /* first_ge = suffix minimum of the first indices, last_le = prefix maximum of the last ones: wave 0, three
+     * 64-entry chunks with shuffle scans, the running value carried between chunks */
+    __shared__ int fge[LL_TAB + 1], lle[LL_TAB + 1];
+    if (tid < 64) {
+        constexpr int NCH = (LL_TAB + 1 + 63) / 64;
+        int carry_min = m;
+        for (int ch = NCH - 1; ch >= 0; --ch) {
+            const int v = ch * 64 + lane;
+            int x = (v <= LL_TAB && feq[v] != INT_MAX) ? feq[v] : m;
+            x = min(x, m);
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_down(x, o); if (lane + o < 64) x = min(x, t); }
+            x = min(x, carry_min);
+            if (v <= LL_TAB) { fge[v] = x; tab[v] = x; }
+            carry_min = __shfl(x, 0);
         }
-        tab[2 * (LL_TAB + 1)] = ok;
-        tab[2 * (LL_TAB + 1) + 1] = m;
+        int carry_max = -1;
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int v = ch * 64 + lane;
+            int x = (v <= LL_TAB) ? leq[v] : -1;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(x, o); if (lane >= o) x = max(x, t); }
+            x = max(x, carry_max);
+            if (v <= LL_TAB) { lle[v] = x; tab[LL_TAB + 1 + v] = x; }
+            carry_max = __shfl(x, 63);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        bool viol = false;
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int bv = ch * 64 + lane;
+            if (bv < LL_TAB && feq[bv] != INT_MAX) {
+                const int hi = ll_ring_hi(bv, V.nearby), lo = ll_ring_lo(bv, V.nearby);
+                const int fg = (hi + 1 > LL_TAB) ? m : fge[max(hi + 1, 0)];
+                const int ll = (lo - 1 < 0) ? -1 : lle[min(lo - 1, LL_TAB)];
+                if (fg < leq[bv] || ll > feq[bv]) viol = true;
+            }
+        }
+        const bool any_viol = __ballot(viol) != 0ull;
+        if (lane == 0) {
+            tab[2 * (LL_TAB + 1)] = (okflag && !any_viol) ? 1 : 0;
+            tab[2 * (LL_TAB + 1) + 1] = m;
+        }
     }
 }
 
