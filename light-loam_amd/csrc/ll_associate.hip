@@ -99,6 +99,8 @@ __global__ __launch_bounds__(LL_GB) void k_build_grid(LLView V, int first, int c
     __syncthreads();
     LL_GPHASE_BEGIN();
     constexpr int UN = 8;                            /* independent loads in flight per thread: the kernel is latency-bound */
+    const int lane = tid & 63;
+    bool bad = false;
     for (int i0 = tid; i0 < m; i0 += LL_GB * UN) {
         float4 p[UN];
 #pragma unroll
@@ -106,9 +108,20 @@ __global__ __launch_bounds__(LL_GB) void k_build_grid(LLView V, int first, int c
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int i = i0 + u * LL_GB;
-            if (i < m) { const int c = ll_cell_coord(p[u].y) * LL_GRID_G + ll_cell_coord(p[u].x); atomicAdd(&hist[LL_HI(c)], 1); }
+            const bool in = i < m;
+            if (in) { const int c = ll_cell_coord(p[u].y) * LL_GRID_G + ll_cell_coord(p[u].x); atomicAdd(&hist[LL_HI(c)], 1); }
+            /* ring tables, same sweep: first / last index of every ring value (only run boundaries touch LDS) */
+            const int r = in ? (int)p[u].w : 0;
+            const bool oob = in && (r < 0 || r >= LL_TAB);
+            if (oob) bad = true;
+            const int rprev = __shfl_up(r, 1), rnext = __shfl_down(r, 1);
+            if (in && !oob) {
+                if (lane == 0 || r != rprev) atomicMin(&feq[r], i);
+                if (lane == 63 || i == m - 1 || r != rnext) atomicMax(&leq[r], i);
+            }
         }
     }
+    if (bad) okflag = 0;
     __syncthreads();
     LL_GPHASE(8);
     constexpr int PER = LL_GRID_NC / LL_GB;         /* 16 */
@@ -141,34 +154,13 @@ __global__ __launch_bounds__(LL_GB) void k_build_grid(LLView V, int first, int c
 #undef LL_HI
 
     LL_GPHASE(10);
-    /* ---- ring tables + validity.  One sweep records the first / last index of every ring value (only run boundaries
-     * touch LDS).  The tables first_ge / last_le reproduce the reference's sequential walk bounds for EVERY start index
-     * iff no point lies before a point whose up-window it exceeds and none after a point whose down-window it undercuts:
+    /* ---- ring tables + validity.  The tables first_ge / last_le reproduce the reference's sequential walk bounds for
+     * EVERY start index iff no point lies before a point whose up-window it exceeds and none after a point whose
+     * down-window it undercuts:
      *   exists j < c with ring_j > hi(ring_c)   <=>   exists value b:  first_ge[hi(b) + 1] < last_eq[b]
      *   exists j > c with ring_j < lo(ring_c)   <=>   exists value b:  last_le[lo(b) - 1]  > first_eq[b]
      * so validity is a check on the two 160-entry tables, no per-point scan. ---- */
-    const int lane = tid & 63;
-    bool bad = false;
-    for (int i0 = tid; i0 < m; i0 += LL_GB * UN) {
-        float rw[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) { const int j = i0 + u * LL_GB; rw[u] = (j < m) ? pts[j].w : 0.0f; }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int j = i0 + u * LL_GB;
-            const bool in = j < m;
-            const int r = (int)rw[u];
-            const bool oob = in && (r < 0 || r >= LL_TAB);
-            if (oob) bad = true;
-            const int rprev = __shfl_up(r, 1), rnext = __shfl_down(r, 1);
-            if (in && !oob) {
-                if (lane == 0 || r != rprev) atomicMin(&feq[r], j);
-                if (lane == 63 || j == m - 1 || r != rnext) atomicMax(&leq[r], j);
-            }
-        }
-    }
     LL_GPHASE(11);
-    if (bad) okflag = 0;
     __syncthreads();
     int *tab = gstart + LL_GRID_NC + 1;              /* first_ge[LL_TAB+1], last_le[LL_TAB+1], ok, m */
     /* first_ge = suffix minimum of the first indices, last_le = prefix maximum of the last ones: wave 0, three
