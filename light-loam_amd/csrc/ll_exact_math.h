@@ -21,6 +21,10 @@
 LL_HD uint32_t ll_f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 LL_HD float ll_u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 
+/* fdlibm's argument reduction picks one of four quotients; a wave of lidar points takes all of them, so the ranges
+ * are evaluated branch-free: numerator / denominator of the taken range selected first, ONE division (the unreduced
+ * range divides by 1, which is exact), both result formulas, selects.  Operation for operation the same f32
+ * arithmetic as the branchy original, hence the same bits. */
 LL_HD float ll_atanf(float x)
 {
     const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f,
@@ -29,33 +33,41 @@ LL_HD float ll_atanf(float x)
                 aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
     const int32_t hx = (int32_t)ll_f2u(x);
     const int32_t ix = hx & 0x7fffffff;
-    if (ix >= 0x4c000000) {                       /* |x| >= 2^25 */
-        if (ix > 0x7f800000) return x + x;        /* NaN */
-        const float r = 1.5707962513e+00f + 7.5497894159e-08f;
-        return hx > 0 ? r : -r;
-    }
-    int id;
-    float hi = 0.0f, lo = 0.0f;
-    if (ix < 0x3ee00000) {                        /* |x| < 0.4375 */
-        if (ix < 0x31000000) return x;            /* |x| < 2^-29 */
-        id = -1;
-    } else {
-        x = ll_u2f((uint32_t)ix);                 /* fabsf */
-        if (ix < 0x3f980000) {                    /* |x| < 1.1875 */
-            if (ix < 0x3f300000) { id = 0; hi = 4.6364760399e-01f; lo = 5.0121582440e-09f; x = (2.0f * x - 1.0f) / (2.0f + x); }
-            else                 { id = 1; hi = 7.8539812565e-01f; lo = 3.7748947079e-08f; x = (x - 1.0f) / (x + 1.0f); }
-        } else {
-            if (ix < 0x401c0000) { id = 2; hi = 9.8279368877e-01f; lo = 3.4473217170e-08f; x = (x - 1.5f) / (1.0f + 1.5f * x); }
-            else                 { id = 3; hi = 1.5707962513e+00f; lo = 7.5497894159e-08f; x = -1.0f / x; }
-        }
-    }
-    const float z = x * x;
+    const float ax = ll_u2f((uint32_t)ix);        /* fabsf */
+    const bool r0 = ix < 0x3f300000, r1 = ix < 0x3f980000, r2 = ix < 0x401c0000, small = ix < 0x3ee00000;
+    /*                     |x| < 0.6875                    < 1.1875          < 2.4375          else  */
+    float num = r0 ? 2.0f * ax - 1.0f : (r1 ? ax - 1.0f : (r2 ? ax - 1.5f : -1.0f));
+    float den = r0 ? 2.0f + ax        : (r1 ? ax + 1.0f : (r2 ? 1.0f + 1.5f * ax : ax));
+    const float hi = r0 ? 4.6364760399e-01f : (r1 ? 7.8539812565e-01f : (r2 ? 9.8279368877e-01f : 1.5707962513e+00f));
+    const float lo = r0 ? 5.0121582440e-09f : (r1 ? 3.7748947079e-08f : (r2 ? 3.4473217170e-08f : 7.5497894159e-08f));
+    num = small ? x : num; den = small ? 1.0f : den;                /* |x| < 0.4375: no reduction, sign kept */
+    const float t = num / den;
+    const float z = t * t;
     const float w = z * z;
     const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
     const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
-    if (id < 0) return x - x * (s1 + s2);
-    const float r = hi - ((x * (s1 + s2) - lo) - x);
-    return hx < 0 ? -r : r;
+    const float rs = t - t * (s1 + s2);
+    const float rr = hi - ((t * (s1 + s2) - lo) - t);
+    float r = small ? rs : (hx < 0 ? -rr : rr);
+    if (ix < 0x31000000) r = x;                                     /* |x| < 2^-29 */
+    if (ix >= 0x4c000000) {                                         /* |x| >= 2^25 */
+        const float q = 1.5707962513e+00f + 7.5497894159e-08f;
+        r = ix > 0x7f800000 ? x + x : (hx > 0 ? q : -q);           /* NaN : +-pi/2 */
+    }
+    return r;
+}
+
+/* (float)((double)a / M_PI) without the f64 division (scanRegistration.cpp:139: "* 180 / M_PI" on a float).
+ * q = RN(a * RN(1/pi)); one FMA residual step gives the correctly rounded f64 quotient, which is then rounded to
+ * f32 like the reference's store.  tests/test_exact_math.py checks all 2^32 floats against the real division. */
+LL_HD float ll_div_pi_f32(float a)
+{
+    const double pi = 3.14159265358979323846, rpi = 0.31830988618379067154;
+    const double x = (double)a;
+    const double q = x * rpi;
+    if (x == 0.0 || q - q != 0.0) return (float)q;                  /* +-0 keeps its sign; inf and NaN pass through */
+    const double rem = __builtin_fma(-q, pi, x);
+    return (float)__builtin_fma(rem, rpi, q);
 }
 
 LL_HD float ll_atan2f(float y, float x)

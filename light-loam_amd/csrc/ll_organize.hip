@@ -34,8 +34,9 @@ __device__ __forceinline__ bool ll_keep(const float4 p, float thres)
 
 __device__ __forceinline__ int ll_scan_id(const LLView &V, const float4 p)
 {
-    /* float angle = atan(z / sqrt(x*x + y*y)) * 180 / M_PI  (:139): f32 atan, f32 product, f64 division, f32 store */
-    const float angle = (float)((double)(ll_atanf(p.z / sqrtf(p.x * p.x + p.y * p.y)) * 180.0f) / M_PI);
+    /* float angle = atan(z / sqrt(x*x + y*y)) * 180 / M_PI  (:139): f32 atan, f32 product, f64 division, f32 store
+     * (ll_div_pi_f32: the same f64 quotient without the division sequence, checked over all 2^32 floats) */
+    const float angle = ll_div_pi_f32(ll_atanf(p.z / sqrtf(p.x * p.x + p.y * p.y)) * 180.0f);
     int id;
     if (V.ring_model == 0 && V.R == 16)       id = ll_trunc_to_int((double)((angle + 15.0f) / 2.0f) + 0.5);       /* :144 */
     else if (V.ring_model == 0 && V.R == 32)  id = ll_trunc_to_int(((double)angle + 92.0 / 3.0) * 3.0 / 4.0);      /* :153 */
@@ -130,7 +131,10 @@ __global__ __launch_bounds__(LL_BLOCK) void k_classify(LLView V, int first, int 
         const unsigned long long pm = __ballot(firstp);
         if (pm && lane == 0) atomicMin(&sh_first_p, i0 + __ffsll((long long)pm) - 1);
         unsigned long long m = __ballot(id >= 0);
-        if (m) {
+        const int id0 = __builtin_amdgcn_readfirstlane(id);
+        if (__ballot(id != id0) == 0ull) {                                             /* ring-major input: one ring per wave */
+            if (id0 >= 0 && lane == 0) atomicAdd(&hist[id0], __popcll(m));
+        } else if (m) {
             for (int b = 0; b < bits; ++b) {
                 const bool bit = (id >> b) & 1;
                 const unsigned long long bal = __ballot(bit);

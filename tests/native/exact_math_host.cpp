@@ -31,6 +31,19 @@ long long em_check_atanf(unsigned long long first, unsigned long long stride, un
     return bad;
 }
 
+// (float)((double)a / M_PI) for every f32 a (bit patterns first, first+stride, ...): mismatches of ll_div_pi_f32
+long long em_check_div_pi(unsigned long long first, unsigned long long stride)
+{
+    long long bad = 0;
+#pragma omp parallel for reduction(+ : bad) schedule(static)
+    for (long long i = (long long)first; i < (1LL << 32); i += (long long)stride) {
+        const float x = ll_u2f((uint32_t)i);
+        const float a = (float)((double)x / M_PI), b = ll_div_pi_f32(x);
+        if (ll_f2u(a) != ll_f2u(b) && !(a != a && b != b)) bad++;
+    }
+    return bad;
+}
+
 // atan2f on n pseudo-random pairs in four regimes (raw bit patterns, lidar-range values, mixed exponents, tiny y)
 long long em_check_atan2f(long long n, unsigned long long seed)
 {

@@ -25,6 +25,8 @@ def em():
     lib.em_check_atan2f.restype = C.c_longlong
     lib.em_check_atan2f.argtypes = [C.c_longlong, C.c_ulonglong]
     lib.em_check_atan2f_specials.restype = C.c_longlong
+    lib.em_check_div_pi.restype = C.c_longlong
+    lib.em_check_div_pi.argtypes = [C.c_ulonglong, C.c_ulonglong]
     lib.em_check_vote.restype = C.c_longlong
     lib.em_check_vote.argtypes = [C.c_ulonglong, C.c_ulonglong]
     return lib
@@ -40,6 +42,16 @@ def test_atanf_stratified(em):
 def test_atanf_exhaustive(em):
     bad = C.c_uint(0xffffffff)
     assert em.em_check_atanf(0, 1, C.byref(bad)) == 0, hex(bad.value)
+
+
+def test_div_pi_stratified(em):
+    """(float)((double)a / M_PI) == ll_div_pi_f32(a) on every 61st bit pattern of all 2^32 floats."""
+    assert em.em_check_div_pi(5, 61) == 0
+
+
+@pytest.mark.slow
+def test_div_pi_exhaustive(em):
+    assert em.em_check_div_pi(0, 1) == 0
 
 
 def test_atan2f_special_values(em):
