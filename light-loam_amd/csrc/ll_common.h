@@ -121,7 +121,7 @@ __device__ __forceinline__ int ll_trunc_to_int(double v)
 template <int NW>
 __device__ __forceinline__ int ll_block_exscan_n(int v, int *sc, int &total)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int inc = v;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(LL_BLOCK) void k_normal_equations(LLView V, int fir
 {
     if ((int)blockIdx.x >= count) return;
     const int s = first + blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const PairHdr ph = V.pair[s];
     Pose P;
     double *pose = V.pose + (size_t)s * 7;

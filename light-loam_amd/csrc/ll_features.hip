@@ -98,7 +98,7 @@ __device__ __forceinline__ void ll_radix_sort(unsigned *k32, unsigned short *k16
     constexpr int SLOTS = ROWS * (LL_BLOCK / 64);               /* (row, wave) pairs */
     constexpr int NCNT = 16 * SLOTS;
     constexpr int PER = (NCNT + LL_BLOCK - 1) / LL_BLOCK;       /* counters per thread in the scan */
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      /* uniform: scalar registers / branches */
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     unsigned e32[ROWS]; unsigned short e16[ROWS];
     unsigned vary = 0;
@@ -306,7 +306,8 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features
         constexpr int SR = (ROWS * LL_BLOCK + 383) / 384;
         int *donemask = L.sc + 60;
         __builtin_amdgcn_s_setprio(3);
-        for (int j = tid >> 6; j < LL_SEGS; j += LL_BLOCK / 64) {
+        /* the wave index is uniform; saying so keeps the segment bounds and every branch on them scalar */
+        for (int j = __builtin_amdgcn_readfirstlane(tid >> 6); j < LL_SEGS; j += LL_BLOCK / 64) {
             const int sp = Lseg * j / 6, ep = Lseg * (j + 1) / 6 - 1;     /* record slots; = (:253-254) - S */
             const int len = ep - sp + 1;
             const int li0 = sp + 5 + lane;                                /* local index of this lane's row-0 record */

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(LL_BLOCK) void k_scatter(LLView V, int first, int c
     if (base >= n_in) return;
     const ScanHdr h = V.hdr[s];
     if (h.status == -5) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NK = LL_TILE / LL_BLOCK, NW = LL_BLOCK / 64;
     __shared__ int cnt[NK * NW][LL_MAX_RINGS];
     for (int i = tid; i < NK * NW * LL_MAX_RINGS; i += LL_BLOCK) (&cnt[0][0])[i] = 0;
