@@ -116,6 +116,25 @@ __device__ __forceinline__ int ll_trunc_to_int(double v)
     return (int)v;
 }
 
+/* Match-any over a wave: afterwards (mlo, mhi) = the lanes of `among` whose low `bits` bits of v equal this lane's.
+ * Per bit one ballot and, per mask half, one three-input bit operation  m & ~(ballot ^ y), y = the lane's bit as 0 / ~0
+ * (v_bitop3_b32, truth table 0x90 for inputs m, ballot, y).  Rank inside the group = ll_match_rank, size = ll_match_count. */
+__device__ __forceinline__ void ll_match_any(int v, int bits, unsigned long long among, unsigned &mlo, unsigned &mhi)
+{
+    mlo = (unsigned)among; mhi = (unsigned)(among >> 32);
+    for (int b = 0; b < bits; ++b) {
+        const int y = -((v >> b) & 1);
+        const unsigned long long s = __ballot(y != 0);
+        mlo = __builtin_amdgcn_bitop3_b32(mlo, (unsigned)s, (unsigned)y, 0x90);
+        mhi = __builtin_amdgcn_bitop3_b32(mhi, (unsigned)(s >> 32), (unsigned)y, 0x90);
+    }
+}
+__device__ __forceinline__ int ll_match_rank(unsigned mlo, unsigned mhi)     /* set bits below this lane */
+{
+    return (int)__builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+}
+__device__ __forceinline__ int ll_match_count(unsigned mlo, unsigned mhi) { return __popc(mlo) + __popc(mhi); }
+
 /* exclusive prefix sum of one int per thread over a workgroup of NW waves: 64-lane shuffle scan + the wave totals
  * through LDS (sc: >= NW ints).  Returns the exclusive prefix; total = workgroup sum.  Ends with a barrier. */
 template <int NW>

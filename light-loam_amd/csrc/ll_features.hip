@@ -88,27 +88,26 @@ __device__ __forceinline__ FeatLds ll_carve(unsigned char *base, int max_ring)
  * 4-bit digits.  Record g lives in row g / 256 of thread g % 256 (registers); its destination is
  *   #(records with a smaller digit) + #(same digit, earlier (row, wave)) + rank inside its wave,
  * the first two from one workgroup exclusive scan over the digit-major table cnt[digit][row*4 + wave], the last from a
- * ballot match (5 ballots).  Digits that are equal for every key are skipped (their pass would be the identity).
- * Stability makes the result ordered by (k32, original position): exactly the (curvature, index) / (voxel, input
- * order) orders the oracle defines.  SEG_PASS appends a pass on the segment of the local index in k16, so the six
- * curvature segments end up sorted in place in their own ranges. */
-template <int ROWS, bool SEG_PASS>
-__device__ __forceinline__ void ll_radix_sort(unsigned *k32, unsigned short *k16, int n, int *cnt, int *sc, const int *segb, int tid)
+ * wave match-any.  Digits that are equal for every key are skipped (their pass would be the identity).  The last row
+ * is padded with all-ones keys that take part like records (they stay at the end, no per-record guards); rows beyond
+ * it are skipped.  Keys must be < 0xffffffff.  Stability makes the result ordered by (k32, original position):
+ * exactly the (voxel, input order) order the oracle defines. */
+template <int ROWS>
+__device__ __forceinline__ void ll_radix_sort(unsigned *k32, unsigned short *k16, int n, int *cnt, int *sc, int tid)
 {
     constexpr int SLOTS = ROWS * (LL_BLOCK / 64);               /* (row, wave) pairs */
     constexpr int NCNT = 16 * SLOTS;
     constexpr int PER = (NCNT + LL_BLOCK - 1) / LL_BLOCK;       /* counters per thread in the scan */
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      /* uniform: scalar registers / branches */
-    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int nrows = (n + LL_BLOCK - 1) / LL_BLOCK;            /* uniform */
     unsigned e32[ROWS]; unsigned short e16[ROWS];
     unsigned vary = 0;
     const unsigned hi0 = (n > 0) ? k32[0] : 0u;
 #pragma unroll
     for (int k = 0; k < ROWS; ++k) {
         const int g = k * LL_BLOCK + tid;
-        e32[k] = (g < n) ? k32[g] : 0xffffffffu;
-        e16[k] = (g < n) ? k16[g] : (unsigned short)0;
-        if (g < n) vary |= e32[k] ^ hi0;
+        e32[k] = 0xffffffffu; e16[k] = 0;
+        if (k < nrows && g < n) { e32[k] = k32[g]; e16[k] = k16[g]; vary |= e32[k] ^ hi0; }
     }
     for (int o = 32; o > 0; o >>= 1) vary |= __shfl_xor(vary, o);
     if (tid == 0) cnt[NCNT] = 0;
@@ -116,30 +115,21 @@ __device__ __forceinline__ void ll_radix_sort(unsigned *k32, unsigned short *k16
     if (lane == 0 && vary) atomicOr((unsigned *)&cnt[NCNT], vary);
     __syncthreads();
     vary = (unsigned)cnt[NCNT];
-    int sb1 = 0, sb2 = 0, sb3 = 0, sb4 = 0, sb5 = 0;
-    if (SEG_PASS) { sb1 = segb[1]; sb2 = segb[2]; sb3 = segb[3]; sb4 = segb[4]; sb5 = segb[5]; }
-    for (int sh = 0; sh < (SEG_PASS ? 36 : 32); sh += 4) {
-        const bool segpass = sh >= 32;
-        if (!segpass && ((vary >> sh) & 15u) == 0u) continue;
+    for (int sh = 0; sh < 32; sh += 4) {
+        if (((vary >> sh) & 15u) == 0u) continue;
         for (int i = tid; i < NCNT; i += LL_BLOCK) cnt[i] = 0;
         __syncthreads();
-        int dig[ROWS], rnk[ROWS];
+        int rnk[ROWS];
 #pragma unroll
         for (int k = 0; k < ROWS; ++k) {
-            const int g = k * LL_BLOCK + tid;
-            const bool valid = g < n;
-            int d;
-            if (segpass) { const int q = (int)e16[k] - 5; d = (q >= sb1) + (q >= sb2) + (q >= sb3) + (q >= sb4) + (q >= sb5); }
-            else d = (int)((e32[k] >> sh) & 15u);
-            unsigned long long m = __ballot(valid);
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const bool bit = (d >> b) & 1;
-                const unsigned long long bal = __ballot(bit);
-                m &= bit ? bal : ~bal;
+            rnk[k] = 0;
+            if (k < nrows) {
+                const int d = (int)((e32[k] >> sh) & 15u);
+                unsigned mlo, mhi;
+                ll_match_any(d, 4, ~0ull, mlo, mhi);
+                rnk[k] = ll_match_rank(mlo, mhi);
+                if (rnk[k] == 0) cnt[d * SLOTS + k * (LL_BLOCK / 64) + wave] = ll_match_count(mlo, mhi);
             }
-            dig[k] = d; rnk[k] = __popcll(m & lt);
-            if (valid && rnk[k] == 0) cnt[d * SLOTS + k * (LL_BLOCK / 64) + wave] = __popcll(m);
         }
         __syncthreads();
         {   /* exclusive scan of the digit-major table: PER consecutive counters per thread */
@@ -155,15 +145,16 @@ __device__ __forceinline__ void ll_radix_sort(unsigned *k32, unsigned short *k16
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < ROWS; ++k) {
-            const int g = k * LL_BLOCK + tid;
-            if (g < n) { const int pos = cnt[dig[k] * SLOTS + k * (LL_BLOCK / 64) + wave] + rnk[k]; k32[pos] = e32[k]; k16[pos] = e16[k]; }
+            if (k < nrows) {
+                const int d = (int)((e32[k] >> sh) & 15u);
+                const int pos = cnt[d * SLOTS + k * (LL_BLOCK / 64) + wave] + rnk[k];
+                k32[pos] = e32[k]; k16[pos] = e16[k];
+            }
         }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < ROWS; ++k) {
-            const int g = k * LL_BLOCK + tid;
-            e32[k] = (g < n) ? k32[g] : 0xffffffffu;
-            e16[k] = (g < n) ? k16[g] : (unsigned short)0;
+            if (k < nrows) { const int g = k * LL_BLOCK + tid; e32[k] = k32[g]; e16[k] = k16[g]; }
         }
     }
 }
@@ -481,7 +472,7 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features
                 }
             __syncthreads();
             LL_PHASE(3);
-            ll_radix_sort<ROWS, false>(L.k32, L.k16, m, L.cnt, L.sc, segb, tid);
+            ll_radix_sort<ROWS>(L.k32, L.k16, m, L.cnt, L.sc, tid);
             LL_PHASE(4);
             __syncthreads();
             /* voxel runs -> centroids.  Thread t owns sorted positions [t*perm, (t+1)*perm): its points are fetched up

@@ -100,7 +100,6 @@ __global__ __launch_bounds__(LL_BLOCK) void k_classify(LLView V, int first, int 
     int8_t *ring = V.ring + (size_t)s * V.NP;
     const int lane = tid & 63;
     int bits = 0; while ((1 << bits) < V.R) ++bits;
-    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     /* the constants of the halfPassed predicate, hoisted (f64) */
     const double so_lo = (double)start_ori - M_PI / 2, so_hi = (double)start_ori + M_PI * 3 / 2;
 #pragma unroll
@@ -130,17 +129,14 @@ __global__ __launch_bounds__(LL_BLOCK) void k_classify(LLView V, int first, int 
         if (km && lane == 0) { atomicMin(&sh_fk, i0 + __ffsll((long long)km) - 1); atomicMax(&sh_lk, i0 + 63 - __clzll((long long)km)); }
         const unsigned long long pm = __ballot(firstp);
         if (pm && lane == 0) atomicMin(&sh_first_p, i0 + __ffsll((long long)pm) - 1);
-        unsigned long long m = __ballot(id >= 0);
+        const unsigned long long m = __ballot(id >= 0);
         const int id0 = __builtin_amdgcn_readfirstlane(id);
         if (__ballot(id != id0) == 0ull) {                                             /* ring-major input: one ring per wave */
             if (id0 >= 0 && lane == 0) atomicAdd(&hist[id0], __popcll(m));
         } else if (m) {
-            for (int b = 0; b < bits; ++b) {
-                const bool bit = (id >> b) & 1;
-                const unsigned long long bal = __ballot(bit);
-                m &= bit ? bal : ~bal;
-            }
-            if (id >= 0 && (m & lt) == 0ull) atomicAdd(&hist[id], __popcll(m));       /* one add per distinct ring in the wave */
+            unsigned mlo, mhi;
+            ll_match_any(id, bits, m, mlo, mhi);
+            if (id >= 0 && ll_match_rank(mlo, mhi) == 0) atomicAdd(&hist[id], ll_match_count(mlo, mhi));   /* one add per distinct ring */
         }
     }
     __syncthreads();
@@ -222,7 +218,7 @@ __global__ __launch_bounds__(LL_BLOCK) void k_scatter(LLView V, int first, int c
     if (base >= n_in) return;
     const ScanHdr h = V.hdr[s];
     if (h.status == -5) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NK = LL_TILE / LL_BLOCK, NW = LL_BLOCK / 64;
     __shared__ int cnt[NK * NW][LL_MAX_RINGS];
     for (int i = tid; i < NK * NW * LL_MAX_RINGS; i += LL_BLOCK) (&cnt[0][0])[i] = 0;
@@ -232,22 +228,17 @@ __global__ __launch_bounds__(LL_BLOCK) void k_scatter(LLView V, int first, int c
     const float *ori = V.ori + (size_t)s * V.NP;
     const int8_t *ring = V.ring + (size_t)s * V.NP;
     int bits = 0; while ((1 << bits) < V.R) ++bits;
-    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
     int my_ring[NK], my_rank[NK];
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
         const int i = base + k * LL_BLOCK + tid;
         const int r = (i < n_in) ? (int)ring[i] : -1;
-        unsigned long long m = __ballot(r >= 0);
-        for (int b = 0; b < bits; ++b) {
-            const bool bit = (r >> b) & 1;
-            const unsigned long long bal = __ballot(bit);
-            m &= bit ? bal : ~bal;
-        }
+        unsigned mlo, mhi;
+        ll_match_any(r, bits, __ballot(r >= 0), mlo, mhi);
         my_ring[k] = r;
-        my_rank[k] = __popcll(m & lt);
-        if (r >= 0 && my_rank[k] == 0) cnt[k * NW + wave][r] = __popcll(m);
+        my_rank[k] = ll_match_rank(mlo, mhi);
+        if (r >= 0 && my_rank[k] == 0) cnt[k * NW + wave][r] = ll_match_count(mlo, mhi);
     }
     __syncthreads();
     if (tid < V.R) {
