@@ -206,6 +206,84 @@ def test_long_ring_capacity_path(api, orc, synth):
     ctx.close()
 
 
+def _ring_scan(rings_xyz):
+    """ring-major scan (N x 4 float32, intensity 0) from a list of per-ring (n, 3) arrays."""
+    pts = np.concatenate(rings_xyz).astype(np.float32)
+    return np.concatenate([pts, np.zeros((len(pts), 1), np.float32)], axis=1)
+
+
+def _vlp16_ring(elev_deg, n, radius, phase=0.0):
+    """n points of one VLP-16 ring: a full sweep (the reference's start/end orientation logic expects one)."""
+    az = -(np.arange(n) + phase) * (2 * np.pi / n)
+    r = np.asarray(radius, np.float64) * np.ones(n)
+    e = np.deg2rad(elev_deg)
+    return np.stack([r * np.cos(az), r * np.sin(az), r * np.tan(e)], axis=1)
+
+
+def _assert_extract_equal(api, orc, scan, rings, what, max_ring_points=2304, **prm):
+    ref = orc.extract(scan, orc.params(rings, **prm))
+    ctx = api.Context(api.default_params(rings, batch=1, max_points=len(scan) + 8, write_curvature=1,
+                                         max_ring_points=max_ring_points, **prm))
+    ctx.upload_scan(0, scan)
+    ctx.extract(0, 1)
+    assert ctx.scan_info(0).status == 0 and ref["rc"] == 0
+    lab, curv = ctx.labels(0, curvature=True)
+    n = len(lab)
+    assert n == len(ref["label"])
+    assert_bit_equal(curv[5:n - 5], ref["curv"][5:n - 5], f"{what} curvature")
+    assert (lab[5:n - 5].astype(np.int32) == ref["label"][5:n - 5]).all(), f"{what} labels"
+    f = ctx.features(0)
+    for name in ("sharp", "less_sharp", "flat", "less_flat"):
+        assert_bit_equal(f[name], ref[name], f"{what} {name}")
+    ctx.close()
+    return ref
+
+
+def _square_room_ring(z, half=8.0, step=1.0 / 32, bump_every=16, bump=0.5):
+    """One sweep (clockwise from azimuth 0) along the walls of a square room, points every `step`; every
+    `bump_every`-th point is pushed `bump` outwards.  All coordinates are small multiples of 2^-5, so the 11-tap
+    curvature sums are exact and identical for every bump / every flat stretch on every wall."""
+    n_side = int(round(2 * half / step))
+    pts = []
+    for i in range(4 * n_side):
+        side, j = divmod((i + n_side // 2) % (4 * n_side), n_side)     # start in the middle of the wall x = +half
+        u = half - j * step                                            # runs +half -> -half along the wall
+        out = half + (bump if i % bump_every == 0 else 0.0)
+        x, y = [(out, u), (u, -out), (-out, -u), (-u, out)][side]
+        pts.append((x, y, z))
+    return np.array(pts, np.float64)
+
+
+@pytest.mark.parametrize("step,max_ring", [(1.0 / 16, 2304), (1.0 / 32, 4608)])
+def test_pick_with_exact_curvature_ties(api, orc, step, max_ring):
+    """Exactly repeated geometry: every curvature value occurs hundreds of times inside a segment, in many lanes and
+    rows of the picking wave.  std::sort leaves equal keys unspecified; the oracle and the device define ascending
+    index, so the device's arg-max tie path (second wave reduction on the index) must agree bit for bit.  The finer
+    step makes rings longer than 2304 points: the 18-row instantiation of the feature kernel."""
+    rings = [_square_room_ring(z=round(8.0 * np.tan(np.deg2rad(-15 + 2 * k)) * 32) / 32, step=step) for k in range(16)]
+    scan = _ring_scan(rings)
+    ref = _assert_extract_equal(api, orc, scan, 16, "ties", minimum_range=0.3, max_ring_points=max_ring)
+    c = ref["curv"]
+    assert len(np.unique(c[5:-5])) < 0.03 * len(c), "the construction must produce heavy ties"
+    assert len(ref["sharp"]) > 50 and len(ref["flat"]) > 100
+
+
+@pytest.mark.parametrize("n_az", [17, 23, 40, 71, 130])
+def test_pick_on_short_rings(api, orc, n_az):
+    """Rings of 17..130 points: segments of 1..20 points, so cloudNeighborPicked marks reach across one or more whole
+    segments and the waves of the feature kernel must import them in the reference's order."""
+    rng = np.random.default_rng(100 + n_az)
+    delta = 2 * np.pi / n_az
+    base = min(6.0, 0.25 / (55 * delta * delta))            # smooth stretches get curvature ~0.06 (< 0.1: flat candidates)
+    rings = []
+    for k in range(16):
+        radius = base * (1.0 + 0.002 * rng.standard_normal(n_az)) * np.where(rng.random(n_az) < 0.15, 1.5, 1.0)
+        rings.append(_vlp16_ring(-15 + 2 * k, n_az, radius, phase=0.25 * rng.random()))
+    scan = _ring_scan(rings)
+    ref = _assert_extract_equal(api, orc, scan, 16, f"short rings ({n_az})", minimum_range=0.5 * base)
+    assert len(ref["sharp"]) > 0 and len(ref["flat"]) > 0
+
+
 def test_vote_disabled_keeps_all(case, odo):
     """now_frame <= 5 branch (laserOdometry.cpp:781-787): every plane correspondence, weight 1."""
     ctx = case["ctx"]
