@@ -162,9 +162,16 @@ __global__ __launch_bounds__(LL_BLOCK) void k_offsets(LLView V, int first, int c
     if (tid == 0) { sh_first_p = INT_MAX; sh_lk = -1; }
     __syncthreads();
     const size_t tb = (size_t)s * V.T;
+    constexpr int TU = 8;                                   /* tile counters in flight per thread: the loops are latency chains */
     if (tid < V.R) {
         int run = 0;
-        for (int t = 0; t < nt; ++t) run += V.tile_hist[(tb + t) * V.R + tid];
+        for (int t = 0; t < nt; t += TU) {
+            int hh[TU];
+#pragma unroll
+            for (int u = 0; u < TU; ++u) hh[u] = (t + u < nt) ? V.tile_hist[(tb + t + u) * V.R + tid] : 0;
+#pragma unroll
+            for (int u = 0; u < TU; ++u) run += hh[u];
+        }
         ring_cnt[tid] = run;
     }
     int fp = INT_MAX, lk = -1;
@@ -199,11 +206,13 @@ __global__ __launch_bounds__(LL_BLOCK) void k_offsets(LLView V, int first, int c
     if (tid <= V.R) V.ring_off[(size_t)s * (V.R + 1) + tid] = ring_off[tid];
     if (tid < V.R) {
         int run = ring_off[tid];
-        for (int t = 0; t < nt; ++t) {
-            const size_t idx = (tb + t) * V.R + tid;
-            const int h = V.tile_hist[idx];
-            V.tile_base[idx] = run;
-            run += h;
+        for (int t = 0; t < nt; t += TU) {
+            int hh[TU];
+#pragma unroll
+            for (int u = 0; u < TU; ++u) hh[u] = (t + u < nt) ? V.tile_hist[(tb + t + u) * V.R + tid] : 0;
+#pragma unroll
+            for (int u = 0; u < TU; ++u)
+                if (t + u < nt) { V.tile_base[(tb + t + u) * V.R + tid] = run; run += hh[u]; }
         }
     }
 }
