@@ -1,5 +1,5 @@
 /*
- * ll_features.hip -- a2 + a3 + a4: curvature, per-segment sort, greedy feature pick, less-flat VoxelGrid.
+ * ll_features.hip -- a2 + a3 + a4: curvature, per-segment greedy feature pick, less-flat VoxelGrid.
  * Replaces scanRegistration.cpp:225-235, :246-368, :370-376 of /root/reference.
  *
  * One 256-thread workgroup per (scan, ring): the ring is the reference's unit of sequential dependence
@@ -7,19 +7,21 @@
  * because scanStartInd/EndInd keep a 5-point margin).  Everything between reading laserCloud and writing
  * labels + feature points stays on chip:
  *   phase 1  512-point tiles of x/y/z (+5 halo, the flat array is used like the reference: curvature
- *            crosses ring boundaries) staged in LDS -> 11-tap curvature (strict left-to-right f32, no FMA),
- *            consecutive-point gap flags (1 bit/point) and sort records (u32 curvature bits, u16 local index)
- *   phase 2  stable LSD radix sort (4-bit digits, ballot ranking) by curvature, then by segment: the six
- *            segments end up sorted in place by (curvature, index) -- std::sort leaves equal curvatures
- *            unspecified, this path and the oracle define ascending index
- *   phase 3  wave 0 replays the greedy pick: 64 candidates per step, eligibility and each candidate's suppression
- *            range in registers, a pick = ballot -> readlane -> range compare
- *   phase 4  less-flat points (label <= 0) compacted in index order, voxel index per PCL's formula, radix-sorted by
- *            (voxel, input order), one thread per voxel run sums in input order
+ *            crosses ring boundaries) staged in LDS, the next tile's loads in flight during the math ->
+ *            11-tap curvature (strict left-to-right f32, no FMA), consecutive-point gap flags (1 bit/point)
+ *   phase 2  per slot: how far a pick's cloudNeighborPicked marks reach forwards / backwards (:288-311)
+ *   phase 3  the pick without a sort: one wave per segment keeps the segment in registers as masked keys; a pick is
+ *            lane-local max -> DPP wave max -> ballot (ties: second reduction on the index) -> one-row range
+ *            compare.  std::sort leaves equal curvatures unspecified; this path and the oracle define ascending
+ *            index.  Segments run concurrently; a wave imports the earlier segments' forward marks only when it is
+ *            about to pick one of its first five points (the only place they can matter)
+ *   phase 4  less-flat points (label <= 0) compacted in index order with their coordinates in registers, voxel index
+ *            per PCL's formula, stable LSD radix sort (4-bit digits, match-any ranking) by (voxel, input order),
+ *            voxel runs summed left to right in f32 by the thread that owns the run head
  *   phase 5  labels + feature slots out; k_compact turns per-ring slots into the published clouds.
- * The kernel is latency-bound (dependent LDS round trips, one serial phase), so LDS is kept at ~26 KB for a
- * 2304-point ring capacity: six workgroups per CU.  ROWS = sort records per thread (capacity 256 * ROWS).
- * HBM traffic per ring point: 16 B read (+ L2-hot re-reads for the centroid gather), 1 B label, features.
+ * The kernel is VALU-bound (~80 % VALU busy at six workgroups per CU): LDS is kept at ~26 KB for a 2304-point
+ * ring capacity, VGPRs at 80.  ROWS = sort records per thread (capacity 256 * ROWS).
+ * HBM traffic per ring point: 16 B read (+ L2-hot re-reads for voxel keys and centroids), 1 B label, features.
  */
 #include "ll_common.h"
 #include <limits.h>

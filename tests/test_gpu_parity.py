@@ -192,8 +192,8 @@ def test_hot_path_matches_staged(case, odo):
 
 
 def test_long_ring_capacity_path(api, orc, synth):
-    """max_ring_points above the radix-sort capacity (2304) switches the feature kernel to its any-length bitonic
-    network; the published clouds must not change."""
+    """max_ring_points above 2304 switches the feature kernel to its 18-row instantiation (more records per thread in
+    the pick and the voxel sort); the published clouds must not change."""
     cfg = synth.default_cfg(64)
     scan = synth.scan(cfg, 3)
     ref = orc.extract(scan, orc.params(64))

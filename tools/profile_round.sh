@@ -1,0 +1,23 @@
+#!/bin/bash
+# The rocprofv3 passes behind profiles/<tag>_*.  Run on the GPU box from the repo root:
+#   gpurun --timeout 1500 -- 'bash tools/profile_round.sh r01'
+# then copy gpurun_out/<tag>_* and gpurun_out/pmc_traffic.json into profiles/.
+# Counter passes are separate runs with --kernel-trace only (TCC has 4 PMC slots; FETCH_SIZE takes 3, WRITE_SIZE 2).
+TAG=${1:-r01}
+ROOT=$(pwd)
+O=$ROOT/gpurun_out
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp && cd $ROOT
+B="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --calibrate"
+rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o $TAG -- $B > $O/prof_$TAG.log 2>&1
+python3 tools/rocpd_summary.py $O/prof_$TAG/${TAG}_results.db > $O/${TAG}_kernel_stats.txt
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $O/pmc_fetch -o fetch -- $B > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d $O/pmc_write -o write -- $B > $O/pmc_write.log 2>&1
+python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write --batch 1024 --rings 64 > $O/pmc_traffic.json
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY \
+    --kernel-trace -f csv -d $O/pmc_sq -o sq -- $B > $O/pmc_sq.log 2>&1
+python3 tools/sq_summary.py $O/pmc_sq > $O/${TAG}_sq_counters.txt
+cp $O/pmc_traffic.json profiles/pmc_traffic.json          # bench.py reads roofline.traffic from here
+python3 bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
+python3 tools/phase_timing.py 64 > $O/${TAG}_phase_timing.txt 2>&1
+tail -n 3 $O/${TAG}_kernel_stats.txt; tail -c 600 $O/${TAG}_bench.json
