@@ -25,6 +25,7 @@
  */
 #include "ll_common.h"
 #include <limits.h>
+#include <type_traits>
 
 __device__ __forceinline__ bool ll_xcd_map2(int id, int per_scan, int count, int &scan, int &item)
 {
@@ -40,8 +41,7 @@ __device__ __forceinline__ bool ll_xcd_map2(int id, int per_scan, int count, int
 struct FeatLds {
     unsigned *k32;             /* [mr] sort key: curvature bits / voxel index */
     unsigned short *k16;       /* [mr] payload: local index / input order */
-    float *tx, *ty, *tz;       /* [LL_FTILE + 16] phase 1; afterwards tx.. is reused as lf_list (u16 [mr]) */
-    unsigned short *lf_list;   /* aliases the tile */
+    float *tx, *ty, *tz;       /* [LL_FTILE + 16] phase 1; afterwards the region is the pick's per-wave scratch */
     unsigned *picked, *gapf;   /* bitmaps over local index */
     int8_t *lab;               /* [mr] */
     int *lists;                /* [LL_NLIST] */
@@ -49,14 +49,15 @@ struct FeatLds {
     int *sc;                   /* [64] scan scratch, bounds, segment table */
 };
 
-static size_t ll_feat_tile_bytes(size_t mr) { const size_t t = 3 * 4 * (size_t)(LL_FTILE + 16); return t > 2 * mr ? t : 2 * mr; }
+/* the curvature tile; afterwards four per-wave scratch rows of 64 * SR u16 (SR = ceil(ROWS * 256 / 384)) for the pick */
+static size_t ll_feat_tile_bytes(size_t rows) { const size_t t = 3 * 4 * (size_t)(LL_FTILE + 16), w = 4 * 64 * ((rows * 256 + 383) / 384) * 2; return t > w ? t : w; }
 
 size_t ll_features_lds_bytes(int max_ring)
 {
     const size_t mr = (size_t)((max_ring + 255) / 256 * 256);
     const size_t rows = (mr / 256 <= 9) ? 9 : (mr / 256 <= 18) ? 18 : 36;     /* the ROWS instantiation that will run */
     size_t b = 4 * mr + 2 * mr;              /* k32 + k16 */
-    b += ll_feat_tile_bytes(mr);             /* tile / lf_list */
+    b += ll_feat_tile_bytes(rows);           /* tile / pick scratch */
     b += 2 * 4 * (mr / 32 + 2);              /* bitmaps */
     b += mr;                                 /* labels */
     b += 4 * LL_NLIST;
@@ -69,13 +70,13 @@ __device__ __forceinline__ FeatLds ll_carve(unsigned char *base, int max_ring)
 {
     const size_t mr = (size_t)((max_ring + 255) / 256 * 256);
     const size_t rows = (mr / 256 <= 9) ? 9 : (mr / 256 <= 18) ? 18 : 36;     /* the ROWS instantiation that will run */
-    const size_t tile = 3 * 4 * (size_t)(LL_FTILE + 16);
-    const size_t tile_bytes = tile > 2 * mr ? tile : 2 * mr;
+    const size_t tile = 3 * 4 * (size_t)(LL_FTILE + 16), wscr = 4 * 64 * ((rows * 256 + 383) / 384) * 2;
+    const size_t tile_bytes = tile > wscr ? tile : wscr;
     FeatLds L;
     unsigned char *p = base;
     L.k32 = (unsigned *)p; p += 4 * mr;
     L.tx = (float *)p; L.ty = L.tx + (LL_FTILE + 16); L.tz = L.ty + (LL_FTILE + 16);
-    L.lf_list = (unsigned short *)p; p += tile_bytes;
+    p += tile_bytes;
     L.picked = (unsigned *)p; p += 4 * (mr / 32 + 2);
     L.gapf = (unsigned *)p; p += 4 * (mr / 32 + 2);
     L.lists = (int *)p; p += 4 * LL_NLIST;
@@ -323,62 +324,104 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features
             }
             bool imported = (j == 0);
             int nrec[2] = {0, 0};
-            for (int pass = 0; pass < 2; ++pass) {
-                /* non-negative float bits order like the floats; the flats maximise the complement */
-                const unsigned el = (pass == 0 ? candc : candf) & ~sup;
-                unsigned mk[SR];
+            /* the corner candidates (usually a small part of the segment) compacted to the front rows, ascending index:
+             * the corner pass then scans ceil(nc / 64) rows per pick instead of SR */
+            unsigned short *wbuf = (unsigned short *)L.tx + (size_t)j % (LL_BLOCK / 64) * (64 * SR);   /* this wave's scratch */
+            int nc = 0;
 #pragma unroll
-                for (int k = 0; k < SR; ++k) mk[k] = ((el >> k) & 1u) ? (pass == 0 ? cb[k] : ~cb[k]) : 0u;
+            for (int k = 0; k < SR; ++k) {
+                const bool c = (candc >> k) & 1u;
+                const unsigned long long m = __ballot(c);
+                if (c) wbuf[nc + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (unsigned short)(k * 64 + lane);
+                nc += __popcll(m);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            const int ncr = (nc + 63) >> 6;
+            unsigned ck[SR]; int cli[SR];                                  /* masked key (0 = not eligible), local index */
+#pragma unroll
+            for (int r = 0; r < SR; ++r) {
+                ck[r] = 0u; cli[r] = 0;
+                if (r < ncr && r * 64 + lane < nc) { const int q = (int)wbuf[r * 64 + lane]; ck[r] = L.k32[sp + q]; cli[r] = sp + 5 + q; }
+            }
+            for (int pass = 0; pass < 2; ++pass) {
                 int npick = 0;
                 unsigned myrec = 0;                                       /* lane n: pick n+1 as li | extents << 16 */
-                for (;;) {
-                    /* lane-local best; rows ascend in index, so on equal keys ">=" keeps the larger index (descending
-                     * visit order of the corners) and ">" the smaller (ascending order of the flats) */
-                    unsigned best = mk[0]; int row_l = 0;
+                /* non-negative float bits order like the floats; the flats maximise the complement */
+                unsigned mk[SR];
 #pragma unroll
-                    for (int k = 1; k < SR; ++k) {
-                        const bool t = pass == 0 ? mk[k] >= best : mk[k] > best;
-                        best = t ? mk[k] : best; row_l = t ? k : row_l;
-                    }
-                    const unsigned kmax = ll_wave_max_u32(best);
-                    if (kmax == 0u) break;                                /* nothing eligible is left */
-                    const unsigned long long bal = __ballot(best == kmax);
-                    int selq;
-                    if (__popcll(bal) == 1) {
-                        const int f = __ffsll((long long)bal) - 1;
-                        selq = __builtin_amdgcn_readlane(row_l, f) * 64 + f;
-                    } else {                                              /* equal curvatures in several lanes: index decides */
-                        const int myq = row_l * 64 + lane;
-                        const unsigned t = (best == kmax) ? (pass == 0 ? (unsigned)(myq + 1) : (unsigned)(0x10000 - myq)) : 0u;
-                        const unsigned tm = ll_wave_max_u32(t);
-                        selq = pass == 0 ? (int)tm - 1 : 0x10000 - (int)tm;
-                    }
-                    if (!imported && selq < 5) {
-                        const int need = (1 << j) - 1;
-                        while ((__hip_atomic_load(donemask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & need) != need)
-                            __builtin_amdgcn_s_sleep(2);
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                        if (lane < 5 && lane < len && ll_bit(L.picked, li0)) { mk[0] = 0u; sup |= 1u; }
-                        imported = true;
-                        continue;                                         /* select again: the choice may be gone */
-                    }
-                    npick++;
-                    if (pass == 0 && npick > LL_LSHARP_PER_SEG) break;    /* :281-284 */
-                    const int sel = sp + selq + 5;
-                    unsigned ew = 0u;                                     /* the owner's extents: uniform row, lane */
+                for (int k = 0; k < SR; ++k) mk[k] = (pass == 1 && ((candf & ~sup) >> k) & 1u) ? ~cb[k] : 0u;
+                /* one pick loop, instantiated for the row count it scans (NR rows of `key`): the corner pass over the
+                 * compacted candidates (1, 2 or SR rows), the flat pass over the whole segment */
+                auto pick_loop = [&](auto nr_tag, auto corner_tag, unsigned (&key)[SR]) __attribute__((always_inline)) {
+                    constexpr int NR = decltype(nr_tag)::value;
+                    constexpr bool CORNER = decltype(corner_tag)::value;
+                    for (;;) {
+                        /* lane-local best; rows ascend in index, so on equal keys ">=" keeps the larger index (descending
+                         * visit order of the corners) and ">" the smaller (ascending order of the flats) */
+                        unsigned best = key[0]; int row_l = 0;
 #pragma unroll
-                    for (int w = 0; w < EW; ++w) if ((selq >> 8) == w) ew = (unsigned)__builtin_amdgcn_readlane((int)exw[w], selq & 63);
-                    const int e = (int)((ew >> (((selq >> 6) & 3) * 8)) & 0xffu);
-                    if (lane == npick - 1) myrec = (unsigned)sel | ((unsigned)e << 16);
-                    if (pass == 1 && npick >= LL_FLAT_PER_SEG) break;     /* :328-331: labelled, but no marking */
-                    const int slo = sel - (e & 15), shi = sel + (e >> 4);
-                    /* rows are 64 apart and a pick marks at most 11 consecutive indices: per lane at most one row is hit */
-                    const int dd = shi - li0;
-                    const int kl = (dd >= 0 && (dd & 63) <= shi - slo) ? (dd >> 6) : -1;
+                        for (int r = 1; r < NR; ++r) {
+                            const bool t = CORNER ? key[r] >= best : key[r] > best;
+                            best = t ? key[r] : best; row_l = t ? r : row_l;
+                        }
+                        const unsigned kmax = ll_wave_max_u32(best);
+                        if (kmax == 0u) break;                            /* nothing eligible is left */
+                        const unsigned long long bal = __ballot(best == kmax);
+                        int selp;                                         /* row * 64 + lane of the choice */
+                        if (__popcll(bal) == 1) {
+                            const int f = __ffsll((long long)bal) - 1;
+                            selp = (NR > 1 ? __builtin_amdgcn_readlane(row_l, f) * 64 : 0) + f;
+                        } else {                                          /* equal curvatures in several lanes: index decides */
+                            const int myp = row_l * 64 + lane;
+                            const unsigned t = (best == kmax) ? (CORNER ? (unsigned)(myp + 1) : (unsigned)(0x10000 - myp)) : 0u;
+                            const unsigned tm = ll_wave_max_u32(t);
+                            selp = CORNER ? (int)tm - 1 : 0x10000 - (int)tm;
+                        }
+                        int selq = selp;                                  /* slot inside the segment */
+                        if (CORNER) {                                     /* compacted layout -> the element's own slot */
+                            int sl = __builtin_amdgcn_readlane(cli[0], selp & 63);
 #pragma unroll
-                    for (int k = 0; k < SR; ++k) mk[k] = (kl == k) ? 0u : mk[k];
-                    if (kl >= 0) sup |= 1u << kl;
-                }
+                            for (int r = 1; r < NR; ++r) if ((selp >> 6) == r) sl = __builtin_amdgcn_readlane(cli[r], selp & 63);
+                            selq = sl - sp - 5;
+                        }
+                        if (!imported && selq < 5) {
+                            const int need = (1 << j) - 1;
+                            while ((__hip_atomic_load(donemask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & need) != need)
+                                __builtin_amdgcn_s_sleep(2);
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                            if (lane < 5 && lane < len && ll_bit(L.picked, li0)) { mk[0] = 0u; sup |= 1u; }
+                            if (cli[0] - sp - 5 < 5 && ck[0] != 0u && ll_bit(L.picked, cli[0])) ck[0] = 0u;   /* ascending order: row 0 */
+                            imported = true;
+                            continue;                                     /* select again: the choice may be gone */
+                        }
+                        npick++;
+                        if (CORNER && npick > LL_LSHARP_PER_SEG) break;   /* :281-284 */
+                        const int sel = sp + selq + 5;
+                        unsigned ew = 0u;                                 /* the owner's extents: uniform row, lane */
+#pragma unroll
+                        for (int w = 0; w < EW; ++w) if ((selq >> 8) == w) ew = (unsigned)__builtin_amdgcn_readlane((int)exw[w], selq & 63);
+                        const int e = (int)((ew >> (((selq >> 6) & 3) * 8)) & 0xffu);
+                        if (lane == npick - 1) myrec = (unsigned)sel | ((unsigned)e << 16);
+                        if (!CORNER && npick >= LL_FLAT_PER_SEG) break;   /* :328-331: labelled, but no marking */
+                        const int slo = sel - (e & 15), shi = sel + (e >> 4);
+                        /* rows are 64 apart and a pick marks at most 11 consecutive indices: per lane at most one row is hit */
+                        const int dd = shi - li0;
+                        const int kl = (dd >= 0 && (dd & 63) <= shi - slo) ? (dd >> 6) : -1;
+                        if (kl >= 0) sup |= 1u << kl;
+                        if (CORNER) {
+#pragma unroll
+                            for (int r = 0; r < NR; ++r) key[r] = ((unsigned)(cli[r] - slo) <= (unsigned)(shi - slo)) ? 0u : key[r];
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < NR; ++k) key[k] = (kl == k) ? 0u : key[k];
+                        }
+                    }
+                };
+                using std::integral_constant;
+                if (pass == 1) pick_loop(integral_constant<int, SR>{}, integral_constant<bool, false>{}, mk);
+                else if (ncr <= 1) pick_loop(integral_constant<int, 1>{}, integral_constant<bool, true>{}, ck);
+                else if (ncr <= 2) pick_loop(integral_constant<int, 2>{}, integral_constant<bool, true>{}, ck);
+                else pick_loop(integral_constant<int, SR>{}, integral_constant<bool, true>{}, ck);
                 /* the picked records, lane-parallel: labels, list entries, forward marks */
                 const int nr_ = pass == 0 ? min(npick, LL_LSHARP_PER_SEG) : npick;
                 nrec[pass] = nr_;
