@@ -180,6 +180,33 @@ int ll_lm_solve_batch(ll_ctx *ctx, int first, int count, const ll_lm_options *op
 int ll_odometry_frames(ll_ctx *ctx, int first, int count, const double *host_pose0, int n_outer, int first_frame_index,
                        const ll_lm_options *opt, double *host_poses_out);
 
+/* ---------------------------------------------------------------- laserMapping scan-to-submap (first stage)
+ * The optimisation laserMapping runs per frame (laserMapping.cpp:1822-2095) for ONE scan against the corner / surf clouds
+ * gathered from the cube map.  The cube bookkeeping (:1584-1808, :2101-2165) stays with the caller for now.
+ * An ll_map shares the device and stream of the ll_ctx it was created from and must be destroyed before it.            */
+typedef struct ll_map ll_map;
+int  ll_map_create(ll_ctx *ctx, int max_map_corner, int max_map_surf, int max_scan_corner, int max_scan_surf, ll_map **out);
+void ll_map_destroy(ll_map *m);
+const char *ll_map_last_error(const ll_map *m);
+/* kdtreeCornerFromMap->setInputCloud(laserCloudCornerFromMap) / kdtreeSurfFromMap (:1826-1827): upload + search grid */
+int ll_map_set_map(ll_map *m, const ll_point *host_corner_from_map, int n_corner, const ll_point *host_surf_from_map, int n_surf);
+/* laserCloudCornerStack / laserCloudSurfStack: the scan's (already down-sized, :1813-1821) feature clouds, sensor frame */
+int ll_map_set_scan(ll_map *m, const ll_point *host_corner_stack, int n_corner, const ll_point *host_surf_stack, int n_surf);
+/* One data-association pass (:1877-2047) at pose_w = parameters[7] (q_w_curr x,y,z,w, t_w_curr); NULL = the map's
+ * current pose.  Produces the residual blocks in stack order: edges (stack index, point_a, point_b), planes (stack
+ * index, unit norm, negative_OA_dot_norm).                                                                           */
+int ll_map_associate(ll_map *m, const double *pose_w7);
+int ll_map_get_counts(ll_map *m, int *n_edge, int *n_plane);
+int ll_map_download_edges(ll_map *m, int *src, double *a3, double *b3, int cap);
+int ll_map_download_planes(ll_map *m, int *src, double *norm3, double *d, int cap);
+/* H (6x6 row-major over the manifold tangent + t), g, cost of the current blocks at pose_w (NULL = current pose),
+ * HuberLoss(0.1) + EigenQuaternionManifold as :1863-1866                                                            */
+int ll_map_normal_equations(ll_map *m, const double *pose_w7, double *H36, double *g6, double *cost);
+/* The whole block :1822-2095: if the map holds > 10 corner and > 50 surf points, n_outer (2, :1832) x { associate,
+ * ceres::Solve restated (LM, <= 4 iterations; opt NULL = ll_lm_default_options) }.  pose_w7 in/out; *ran = 0 when the
+ * map is too small (the reference then keeps the odometry guess, :2096-2100).                                        */
+int ll_map_optimize(ll_map *m, double *pose_w7, int n_outer, const ll_lm_options *opt, int *ran);
+
 /* ---------------------------------------------------------------- whole hot path
  * One pass: extract + associate + vote + normal equations + one GN step for slots [first, first+count),
  * everything device-resident, no host synchronisation inside.  `vote_enable` as above.                   */

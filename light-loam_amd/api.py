@@ -23,6 +23,8 @@ EXPORTS = [
     "ll_normal_equations_batch", "ll_download_normal_equations", "ll_gn_step_batch", "ll_download_pose",
     "ll_residual_jacobian", "ll_hot_path_batch", "ll_algorithmic_bytes", "ll_profile_enable", "ll_profile_read", "ll_set_pose_guess", "ll_debug_counters", "ll_vote_host", "ll_debug_calibration_copy",
     "ll_lm_default_options", "ll_lm_solve_batch", "ll_odometry_frames",
+    "ll_map_create", "ll_map_destroy", "ll_map_last_error", "ll_map_set_map", "ll_map_set_scan", "ll_map_associate",
+    "ll_map_get_counts", "ll_map_download_edges", "ll_map_download_planes", "ll_map_normal_equations", "ll_map_optimize",
 ]
 
 
@@ -269,3 +271,80 @@ class Context:
         b = [C.c_double(0) for _ in range(4)]
         self._ck(self.lib.ll_algorithmic_bytes(self.h, first, count, *[C.byref(x) for x in b]))
         return dict(ext=b[0].value, assoc=b[1].value, vote=b[2].value, rj=b[3].value)
+
+
+class Map:
+    """One ll_map: laserMapping's scan-to-submap optimisation (laserMapping.cpp:1822-2095) on the device of `ctx`."""
+
+    def __init__(self, ctx, max_map_corner, max_map_surf, max_scan_corner, max_scan_surf):
+        self.ctx = ctx; self.lib = ctx.lib
+        self.lib.ll_map_last_error.restype = C.c_char_p
+        self.lib.ll_map_last_error.argtypes = [C.c_void_p]
+        self.lib.ll_map_destroy.argtypes = [C.c_void_p]
+        self.h = C.c_void_p()
+        rc = self.lib.ll_map_create(ctx.h, int(max_map_corner), int(max_map_surf), int(max_scan_corner), int(max_scan_surf), C.byref(self.h))
+        if rc != LL_OK:
+            raise LightLoamError(rc, ctx.lib.ll_last_error(ctx.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ll_map_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != LL_OK:
+            raise LightLoamError(rc, self.lib.ll_map_last_error(self.h).decode())
+
+    @staticmethod
+    def _pts(a):
+        a = np.ascontiguousarray(a, np.float32)
+        assert a.ndim == 2 and a.shape[1] == 4
+        return a
+
+    def set_map(self, corner_from_map, surf_from_map):
+        c, s_ = self._pts(corner_from_map), self._pts(surf_from_map)
+        self._ck(self.lib.ll_map_set_map(self.h, _ptr(c), len(c), _ptr(s_), len(s_)))
+
+    def set_scan(self, corner_stack, surf_stack):
+        c, s_ = self._pts(corner_stack), self._pts(surf_stack)
+        self._n_stack = (len(c), len(s_))
+        self._ck(self.lib.ll_map_set_scan(self.h, _ptr(c), len(c), _ptr(s_), len(s_)))
+
+    def associate(self, pose_w=None):
+        p = None if pose_w is None else np.ascontiguousarray(pose_w, np.float64)
+        self._ck(self.lib.ll_map_associate(self.h, _ptr(p)))
+
+    def counts(self):
+        ne, npl = C.c_int(0), C.c_int(0)
+        self._ck(self.lib.ll_map_get_counts(self.h, C.byref(ne), C.byref(npl)))
+        return ne.value, npl.value
+
+    def edges(self):
+        ne, _ = self.counts()
+        src = np.zeros(max(ne, 1), np.int32); a = np.zeros((max(ne, 1), 3)); b = np.zeros((max(ne, 1), 3))
+        self._ck(self.lib.ll_map_download_edges(self.h, _ptr(src), _ptr(a), _ptr(b), len(src)))
+        return src[:ne], a[:ne], b[:ne]
+
+    def planes(self):
+        _, npl = self.counts()
+        src = np.zeros(max(npl, 1), np.int32); n = np.zeros((max(npl, 1), 3)); d = np.zeros(max(npl, 1))
+        self._ck(self.lib.ll_map_download_planes(self.h, _ptr(src), _ptr(n), _ptr(d), len(src)))
+        return src[:npl], n[:npl], d[:npl]
+
+    def normal_equations(self, pose_w=None):
+        p = None if pose_w is None else np.ascontiguousarray(pose_w, np.float64)
+        H = np.zeros((6, 6)); g = np.zeros(6); cost = C.c_double(0)
+        self._ck(self.lib.ll_map_normal_equations(self.h, _ptr(p), _ptr(H), _ptr(g), C.byref(cost)))
+        return H, g, cost.value
+
+    def optimize(self, pose_w, n_outer=2, opt=None):
+        p = np.ascontiguousarray(pose_w, np.float64).copy()
+        ran = C.c_int(0)
+        self._ck(self.lib.ll_map_optimize(self.h, _ptr(p), n_outer, None if opt is None else C.byref(opt), C.byref(ran)))
+        return p, bool(ran.value)

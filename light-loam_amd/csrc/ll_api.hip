@@ -460,6 +460,228 @@ extern "C" int ll_hot_path_batch(ll_ctx *ctx, int first, int count, const double
     return LL_OK;
 }
 
+/* ------------------------------------------------------------------ mapping stage (ll_mapping.hip) */
+struct ll_map {
+    ll_ctx *ctx = nullptr;
+    LLMapView M;
+    int cap_map[2] = {0, 0}, cap_stk[2] = {0, 0};
+    int max_cells = 0;
+    float4 *d_map[2] = {nullptr, nullptr}, *d_stk[2] = {nullptr, nullptr};
+    int *d_bbox = nullptr, *d_tile = nullptr;
+    std::vector<void *> allocs;
+    std::string err;
+};
+
+#define LLM_HIP(call)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) { m->err = std::string(#call) + ": " + hipGetErrorString(e_); return LL_ERR_HIP; } \
+    } while (0)
+
+template <typename T>
+static bool map_alloc(ll_map *m, T *&ptr, size_t count)
+{
+    void *p = nullptr;
+    const size_t bytes = (count ? count : 1) * sizeof(T);
+    if (hipMalloc(&p, bytes) != hipSuccess) { m->err = "hipMalloc failed (" + std::to_string(bytes) + " bytes)"; return false; }
+    if (hipMemset(p, 0, bytes) != hipSuccess) { m->err = "hipMemset failed"; (void)hipFree(p); return false; }
+    m->allocs.push_back(p);
+    ptr = (T *)p;
+    return true;
+}
+
+extern "C" void ll_map_destroy(ll_map *m)
+{
+    if (!m) return;
+    if (m->ctx) { (void)hipSetDevice(m->ctx->device); (void)hipStreamSynchronize(m->ctx->stream); }
+    for (void *p : m->allocs) (void)hipFree(p);
+    delete m;
+}
+
+extern "C" const char *ll_map_last_error(const ll_map *m) { return m ? m->err.c_str() : "null map"; }
+
+extern "C" int ll_map_create(ll_ctx *ctx, int max_map_corner, int max_map_surf, int max_scan_corner, int max_scan_surf, ll_map **out)
+{
+    if (!ctx || !out) return LL_ERR_ARG;
+    *out = nullptr;
+    if (max_map_corner < 1 || max_map_surf < 1 || max_scan_corner < 1 || max_scan_surf < 1 ||
+        max_map_corner > (1 << 24) || max_map_surf > (1 << 24)) { ctx->err = "bad mapping capacities"; return LL_ERR_ARG; }
+    LL_HIP(hipSetDevice(ctx->device));
+    ll_map *m = new ll_map();
+    m->ctx = ctx;
+    m->cap_map[0] = max_map_corner; m->cap_map[1] = max_map_surf; m->cap_stk[0] = max_scan_corner; m->cap_stk[1] = max_scan_surf;
+    m->max_cells = 1 << 23;                                     /* 32 MB of cell starts per cloud at most */
+    LLMapView &M = m->M;
+    std::memset(&M, 0, sizeof(M));
+    bool ok = true;
+    for (int w = 0; w < 2 && ok; ++w) {
+        ok = ok && map_alloc(m, m->d_map[w], (size_t)m->cap_map[w]) && map_alloc(m, m->d_stk[w], (size_t)m->cap_stk[w]);
+        ok = ok && map_alloc(m, M.grid[w].start, (size_t)m->max_cells + 1) && map_alloc(m, M.grid[w].cursor, (size_t)m->max_cells) &&
+             map_alloc(m, M.grid[w].pts, (size_t)m->cap_map[w]);
+        ok = ok && map_alloc(m, M.ok[w], (size_t)m->cap_stk[w]) && map_alloc(m, M.src[w], (size_t)m->cap_stk[w]);
+        M.map[w] = m->d_map[w]; M.stk[w] = m->d_stk[w];
+    }
+    ok = ok && map_alloc(m, M.qa, (size_t)m->cap_stk[0] * 3) && map_alloc(m, M.qb, (size_t)m->cap_stk[0] * 3) &&
+         map_alloc(m, M.fa, (size_t)m->cap_stk[0] * 3) && map_alloc(m, M.fb, (size_t)m->cap_stk[0] * 3);
+    ok = ok && map_alloc(m, M.qn, (size_t)m->cap_stk[1] * 3) && map_alloc(m, M.qd, (size_t)m->cap_stk[1]) &&
+         map_alloc(m, M.fn, (size_t)m->cap_stk[1] * 3) && map_alloc(m, M.fd, (size_t)m->cap_stk[1]);
+    ok = ok && map_alloc(m, M.counts, 2) && map_alloc(m, M.pose, 7) && map_alloc(m, M.neq, LL_NEQ_STRIDE) && map_alloc(m, M.lm, LL_LM_STRIDE);
+    ok = ok && map_alloc(m, m->d_bbox, 12) && map_alloc(m, m->d_tile, (size_t)(m->max_cells + 1 + 4095) / 4096 + 1);
+    if (!ok) { ctx->err = m->err; ll_map_destroy(m); return LL_ERR_HIP; }
+    M.huber = ctx->V.huber;
+    const double ident[7] = {0, 0, 0, 1, 0, 0, 0};
+    if (hipMemcpy(M.pose, ident, sizeof(ident), hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "initial upload failed"; ll_map_destroy(m); return LL_ERR_HIP; }
+    *out = m;
+    return LL_OK;
+}
+
+static int map_upload(ll_map *m, float4 *dst, const ll_point *src, int n)
+{
+    if (n > 0) LLM_HIP(hipMemcpyAsync(dst, src, (size_t)n * sizeof(ll_point), hipMemcpyHostToDevice, m->ctx->stream));
+    return LL_OK;
+}
+
+extern "C" int ll_map_set_map(ll_map *m, const ll_point *corner, int n_corner, const ll_point *surf, int n_surf)
+{
+    if (!m) return LL_ERR_ARG;
+    if (n_corner < 0 || n_surf < 0 || (!corner && n_corner > 0) || (!surf && n_surf > 0)) { m->err = "bad map clouds"; return LL_ERR_ARG; }
+    if (n_corner > m->cap_map[0] || n_surf > m->cap_map[1]) { m->err = "map cloud larger than the capacity given to ll_map_create"; return LL_ERR_CAPACITY; }
+    LLM_HIP(hipSetDevice(m->ctx->device));
+    hipStream_t st = m->ctx->stream;
+    const ll_point *src[2] = {corner, surf}; const int n[2] = {n_corner, n_surf};
+    int bbox[12];
+    for (int w = 0; w < 2; ++w) {
+        int rc = map_upload(m, m->d_map[w], src[w], n[w]); if (rc) return rc;
+        m->M.n_map[w] = n[w];
+        ll_map_launch_bbox(m->d_map[w], n[w], m->d_bbox + 6 * w, st);
+    }
+    LLM_HIP(hipMemcpyAsync(bbox, m->d_bbox, sizeof(bbox), hipMemcpyDeviceToHost, st));
+    LLM_HIP(hipStreamSynchronize(st));                          /* the grid dimensions are launch parameters */
+    for (int w = 0; w < 2; ++w) {
+        ll_map_bbox_to_grid(bbox + 6 * w, n[w], m->max_cells, &m->M.grid[w]);
+        ll_map_launch_build(m->M.grid[w], m->d_map[w], n[w], m->d_tile, st);
+    }
+    LLM_HIP(hipGetLastError());
+    LLM_HIP(hipStreamSynchronize(st));                          /* host buffers may be reused by the caller */
+    return LL_OK;
+}
+
+extern "C" int ll_map_set_scan(ll_map *m, const ll_point *corner, int n_corner, const ll_point *surf, int n_surf)
+{
+    if (!m) return LL_ERR_ARG;
+    if (n_corner < 0 || n_surf < 0 || (!corner && n_corner > 0) || (!surf && n_surf > 0)) { m->err = "bad scan clouds"; return LL_ERR_ARG; }
+    if (n_corner > m->cap_stk[0] || n_surf > m->cap_stk[1]) { m->err = "scan cloud larger than the capacity given to ll_map_create"; return LL_ERR_CAPACITY; }
+    LLM_HIP(hipSetDevice(m->ctx->device));
+    int rc = map_upload(m, m->d_stk[0], corner, n_corner); if (rc) return rc;
+    rc = map_upload(m, m->d_stk[1], surf, n_surf); if (rc) return rc;
+    m->M.n_stk[0] = n_corner; m->M.n_stk[1] = n_surf;
+    LLM_HIP(hipStreamSynchronize(m->ctx->stream));
+    return LL_OK;
+}
+
+static int map_set_pose(ll_map *m, const double *pose_w7)
+{
+    if (pose_w7) {
+        LLM_HIP(hipMemcpyAsync(m->M.pose, pose_w7, 7 * sizeof(double), hipMemcpyHostToDevice, m->ctx->stream));
+        LLM_HIP(hipStreamSynchronize(m->ctx->stream));
+    }
+    return LL_OK;
+}
+
+extern "C" int ll_map_associate(ll_map *m, const double *pose_w7)
+{
+    if (!m) return LL_ERR_ARG;
+    LLM_HIP(hipSetDevice(m->ctx->device));
+    int rc = map_set_pose(m, pose_w7); if (rc) return rc;
+    ll_map_launch_associate(m->M, m->ctx->stream);
+    LLM_HIP(hipGetLastError());
+    return LL_OK;
+}
+
+extern "C" int ll_map_get_counts(ll_map *m, int *n_edge, int *n_plane)
+{
+    if (!m) return LL_ERR_ARG;
+    int c[2];
+    LLM_HIP(hipMemcpyAsync(c, m->M.counts, sizeof(c), hipMemcpyDeviceToHost, m->ctx->stream));
+    LLM_HIP(hipStreamSynchronize(m->ctx->stream));
+    if (n_edge) *n_edge = c[0];
+    if (n_plane) *n_plane = c[1];
+    return LL_OK;
+}
+
+extern "C" int ll_map_download_edges(ll_map *m, int *src, double *a3, double *b3, int cap)
+{
+    int ne = 0; int rc = ll_map_get_counts(m, &ne, nullptr); if (rc) return rc;
+    if (cap < ne) { m->err = "edge capacity too small"; return LL_ERR_CAPACITY; }
+    hipStream_t st = m->ctx->stream;
+    if (ne > 0) {
+        if (src) LLM_HIP(hipMemcpyAsync(src, m->M.src[0], (size_t)ne * sizeof(int), hipMemcpyDeviceToHost, st));
+        if (a3) LLM_HIP(hipMemcpyAsync(a3, m->M.fa, (size_t)ne * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+        if (b3) LLM_HIP(hipMemcpyAsync(b3, m->M.fb, (size_t)ne * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    LLM_HIP(hipStreamSynchronize(st));
+    return LL_OK;
+}
+
+extern "C" int ll_map_download_planes(ll_map *m, int *src, double *norm3, double *d, int cap)
+{
+    int np = 0; int rc = ll_map_get_counts(m, nullptr, &np); if (rc) return rc;
+    if (cap < np) { m->err = "plane capacity too small"; return LL_ERR_CAPACITY; }
+    hipStream_t st = m->ctx->stream;
+    if (np > 0) {
+        if (src) LLM_HIP(hipMemcpyAsync(src, m->M.src[1], (size_t)np * sizeof(int), hipMemcpyDeviceToHost, st));
+        if (norm3) LLM_HIP(hipMemcpyAsync(norm3, m->M.fn, (size_t)np * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+        if (d) LLM_HIP(hipMemcpyAsync(d, m->M.fd, (size_t)np * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    LLM_HIP(hipStreamSynchronize(st));
+    return LL_OK;
+}
+
+extern "C" int ll_map_normal_equations(ll_map *m, const double *pose_w7, double *H36, double *g6, double *cost)
+{
+    if (!m) return LL_ERR_ARG;
+    LLM_HIP(hipSetDevice(m->ctx->device));
+    int rc = map_set_pose(m, pose_w7); if (rc) return rc;
+    ll_map_launch_normal_eq(m->M, m->ctx->stream);
+    double out[LL_NEQ_STRIDE];
+    LLM_HIP(hipMemcpyAsync(out, m->M.neq, sizeof(out), hipMemcpyDeviceToHost, m->ctx->stream));
+    LLM_HIP(hipStreamSynchronize(m->ctx->stream));
+    if (H36) std::memcpy(H36, out, 36 * sizeof(double));
+    if (g6) std::memcpy(g6, out + 36, 6 * sizeof(double));
+    if (cost) *cost = out[42];
+    return LL_OK;
+}
+
+extern "C" int ll_map_optimize(ll_map *m, double *pose_w7, int n_outer, const ll_lm_options *opt, int *ran)
+{
+    if (!m || !pose_w7) return LL_ERR_ARG;
+    if (n_outer < 1 || n_outer > 16) { m->err = "n_outer out of range"; return LL_ERR_ARG; }
+    const LLLmOpt o = to_dev_opt(opt);
+    if (o.max_num_iterations < 0 || o.max_num_iterations > 64) { m->err = "max_num_iterations out of range"; return LL_ERR_ARG; }
+    LLM_HIP(hipSetDevice(m->ctx->device));
+    if (ran) *ran = 0;
+    if (!(m->M.n_map[0] > 10 && m->M.n_map[1] > 50)) return LL_OK;           /* :1822 */
+    int rc = map_set_pose(m, pose_w7); if (rc) return rc;
+    hipStream_t st = m->ctx->stream;
+    LLView Vm = m->ctx->V;                                    /* the LM kernels on a one-slot view of the map's state */
+    Vm.pose = m->M.pose; Vm.neq = m->M.neq; Vm.lm = m->M.lm;
+    for (int it = 0; it < n_outer; ++it) {                                     /* :1832 */
+        ll_map_launch_associate(m->M, st);
+        ll_map_launch_normal_eq(m->M, st);
+        ll_launch_lm_begin(Vm, 0, 1, o, st);
+        for (int k = 0; k < o.max_num_iterations; ++k) {
+            ll_launch_lm_propose(Vm, 0, 1, o, st);
+            ll_map_launch_normal_eq(m->M, st);
+            ll_launch_lm_accept(Vm, 0, 1, o, st);
+        }
+    }
+    LLM_HIP(hipGetLastError());
+    LLM_HIP(hipMemcpyAsync(pose_w7, m->M.pose, 7 * sizeof(double), hipMemcpyDeviceToHost, st));
+    LLM_HIP(hipStreamSynchronize(st));
+    if (ran) *ran = 1;
+    return LL_OK;
+}
+
 /* ------------------------------------------------------------------ downloads */
 static int dl(ll_ctx *ctx, void *dst, const void *src, size_t bytes)
 {

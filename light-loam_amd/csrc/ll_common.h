@@ -171,6 +171,31 @@ __device__ __forceinline__ void ll_targets(const LLView &V, int s, const float4 
 /* per-kernel HIP-event profiler (ll_api.hip); mark(id) = "kernel id starts here, the previous one ended" */
 enum { LL_K_CLASSIFY = 0, LL_K_OFFSETS, LL_K_SCATTER, LL_K_RING_FEATURES, LL_K_COMPACT, LL_K_ASSOCIATE, LL_K_VOTE,
        LL_K_NORMAL_EQ, LL_K_GN_STEP, LL_K_GRID, LL_K_FIRST, LL_K_COUNT, LL_K_END = -1 };
+/* ---- mapping stage (ll_mapping.hip): one scan against the clouds gathered from the cube map ---- */
+struct LLGrid3 {                       /* dense cell grid over a cloud's bounding box */
+    float org[3]; float cell; int dim[3]; int ncell;
+    int *start;                        /* [ncell + 1] first cell-ordered point of every cell */
+    int *cursor;                       /* [ncell] scatter cursors */
+    float4 *pts;                       /* cell-ordered (x, y, z, original index as int bits) */
+};
+struct LLMapView {
+    const float4 *map[2]; int n_map[2];          /* 0: laserCloudCornerFromMap, 1: laserCloudSurfFromMap */
+    LLGrid3 grid[2];
+    const float4 *stk[2]; int n_stk[2];          /* laserCloudCornerStack / laserCloudSurfStack */
+    unsigned char *ok[2];                        /* per stack point: produced a residual block */
+    double *qa, *qb, *qn, *qd;                   /* per stack point: line points a, b [n][3]; plane normal [n][3], d [n] */
+    int *src[2];                                 /* residual blocks in stack order: stack index ... */
+    double *fa, *fb, *fn, *fd;                   /* ... and their line points / plane */
+    int *counts;                                 /* [2] edge blocks, plane blocks */
+    double *pose, *neq, *lm;                     /* one slot: parameters[7], normal equations [44], LM state */
+    double huber;
+};
+void ll_map_launch_bbox(const float4 *pts, int n, int *bbox_dev, hipStream_t st);
+void ll_map_bbox_to_grid(const int bbox_host[6], int n, int max_cells, LLGrid3 *G);
+void ll_map_launch_build(const LLGrid3 &G, const float4 *pts, int n, int *tile_sum, hipStream_t st);
+void ll_map_launch_associate(const LLMapView &M, hipStream_t st);
+void ll_map_launch_normal_eq(const LLMapView &M, hipStream_t st);
+
 struct LLProfiler;
 void ll_prof_mark(LLProfiler *p, int kernel_id, hipStream_t st);
 

@@ -1,0 +1,424 @@
+/*
+ * ll_mapping.hip -- SURVEY 8f #2, first stage: the scan-to-submap optimisation of laserMapping
+ * (/root/reference/src/laserMapping.cpp:1822-2095) for one scan against the corner / surf clouds gathered from the
+ * cube map (laserCloudCornerFromMap / laserCloudSurfFromMap, :1803-1808).
+ *
+ *   k_map_bbox, k_map_count, scan, k_map_scatter   what replaces kdtree->setInputCloud (:1826-1827): a dense 3-D cell grid
+ *                       over the cloud's bounding box, cells >= 1.01 m.  The search below only has to be exact when the
+ *                       fifth neighbour is closer than 1 m (:1884, :1952), and then all five lie in the 3 x 3 x 3 cells
+ *                       around the query's cell (the 1 % margin absorbs the f32 rounding of the cell coordinate).
+ *   k_map_knn<CORNER>   one thread per stack point: pointAssociateToMap (:125-134, f64 rotate + translate, f32 store),
+ *                       exact K = 5 by (FLANN L2_Simple f32 distance, index) -- PCL's kd-tree leaves equal distances
+ *                       to traversal order, here and in the oracle the lower index wins -- then
+ *                         corners (:1886-1921): mean, 3 x 3 covariance, symmetric eigen-decomposition (cyclic Jacobi in
+ *                           f64 for Eigen's SelfAdjointEigenSolver), line if l2 > 3 l1, a / b = mean +- 0.1 direction;
+ *                         surfs (:1954-2035): 5 x 3 least squares n.x = -1 by Householder QR with column pivoting
+ *                           (Eigen's colPivHouseholderQr), unit normal + negative_OA_dot_norm, valid if all five points
+ *                           are within 0.2 of the plane.
+ *   k_map_compact       residual blocks in stack order (the order AddResidualBlock sees them).
+ *   k_map_normal_eq     LidarEdgeFactor + LidarPlaneNormFactor rows (lidarFactor.hpp:9-52, :253-285), HuberLoss(0.1),
+ *                       EigenQuaternionManifold, 28 f64 accumulators per thread -> shuffle tree -> LDS.
+ * The LM iterations reuse k_lm_begin / k_lm_propose / k_lm_accept of ll_factors.hip on a one-slot view.
+ * Everything after the f32 distances is f64; parity with the oracle is to rounding (1e-9), the selected blocks exact.
+ */
+#include "ll_factor_math.h"
+#include <limits.h>
+#include <string.h>
+
+#define LL_MAPB 256
+
+/* order-preserving float <-> int for atomicMin / atomicMax */
+__device__ __forceinline__ int ll_f2ord(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
+static inline float ll_ord2f_host(int i) { const int j = i >= 0 ? i : i ^ 0x7fffffff; float f; memcpy(&f, &j, 4); return f; }
+
+__global__ __launch_bounds__(LL_MAPB) void k_map_bbox(const float4 *pts, int n, int *bbox /* min xyz, max xyz as ordered ints */)
+{
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = blockIdx.x * LL_MAPB + threadIdx.x; i < n; i += gridDim.x * LL_MAPB) {
+        const float4 p = pts[i];
+        mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+        mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+    }
+    for (int o = 32; o > 0; o >>= 1)
+        for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], o)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o)); }
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 3; ++k) { atomicMin(&bbox[k], ll_f2ord(mn[k])); atomicMax(&bbox[3 + k], ll_f2ord(mx[k])); }
+}
+
+__device__ __forceinline__ int ll_cell3(const LLGrid3 &G, float x, float y, float z)
+{
+    int cx = (int)floorf((x - G.org[0]) / G.cell), cy = (int)floorf((y - G.org[1]) / G.cell), cz = (int)floorf((z - G.org[2]) / G.cell);
+    cx = min(max(cx, 0), G.dim[0] - 1); cy = min(max(cy, 0), G.dim[1] - 1); cz = min(max(cz, 0), G.dim[2] - 1);
+    return (cz * G.dim[1] + cy) * G.dim[0] + cx;
+}
+
+__global__ __launch_bounds__(LL_MAPB) void k_map_count(LLGrid3 G, const float4 *pts, int n)
+{
+    const int i = blockIdx.x * LL_MAPB + threadIdx.x;
+    if (i < n) { const float4 p = pts[i]; atomicAdd(&G.start[ll_cell3(G, p.x, p.y, p.z)], 1); }
+}
+
+/* exclusive scan of a device int array in three launches: 4096-element tiles, the tile totals, the offsets */
+#define LL_SCAN_TILE 4096
+__global__ __launch_bounds__(1024) void k_scan_tiles(int *data, int n, int *tile_sum)
+{
+    __shared__ int sc[16];
+    const int base = blockIdx.x * LL_SCAN_TILE + threadIdx.x * 4;
+    int v[4], s = 0;
+    for (int u = 0; u < 4; ++u) { v[u] = (base + u < n) ? data[base + u] : 0; s += v[u]; }
+    int total;
+    int run = ll_block_exscan_n<16>(s, sc, total);
+    for (int u = 0; u < 4; ++u) { if (base + u < n) data[base + u] = run; run += v[u]; }
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(1024) void k_scan_totals(int *tile_sum, int nt)
+{
+    __shared__ int sc[16];
+    const int per = (nt + 1023) / 1024;
+    const int a0 = min(nt, (int)threadIdx.x * per), a1 = min(nt, a0 + per);
+    int s = 0;
+    for (int i = a0; i < a1; ++i) s += tile_sum[i];
+    int total;
+    int run = ll_block_exscan_n<16>(s, sc, total);
+    for (int i = a0; i < a1; ++i) { const int v = tile_sum[i]; tile_sum[i] = run; run += v; }
+}
+__global__ __launch_bounds__(1024) void k_scan_add(int *data, int n, const int *tile_sum)
+{
+    const int base = blockIdx.x * LL_SCAN_TILE + threadIdx.x * 4;
+    const int o = tile_sum[blockIdx.x];
+    for (int u = 0; u < 4; ++u) if (base + u < n) data[base + u] += o;
+}
+
+__global__ __launch_bounds__(LL_MAPB) void k_map_scatter(LLGrid3 G, const float4 *pts, int n)
+{
+    const int i = blockIdx.x * LL_MAPB + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    const int pos = atomicAdd(&G.cursor[ll_cell3(G, p.x, p.y, p.z)], 1);
+    G.pts[pos] = make_float4(p.x, p.y, p.z, __int_as_float(i));
+}
+
+/* ---- 3 x 3 symmetric eigen-decomposition, cyclic Jacobi ---- */
+__device__ __forceinline__ void ll_sym_eig3(const double Ain[3][3], double w[3], double V[3][3])
+{
+    double A[3][3], Q[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) A[i][j] = Ain[i][j];
+    for (int sweep = 0; sweep < 32; ++sweep) {
+        const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+        const double diag = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+        if (off <= 1e-32 * diag || off == 0.0) break;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 3; ++q) {
+                if (A[p][q] == 0.0) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { const double akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - sn * akq; A[k][q] = sn * akp + c * akq; }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { const double apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - sn * aqk; A[q][k] = sn * apk + c * aqk; }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { const double qkp = Q[k][p], qkq = Q[k][q]; Q[k][p] = c * qkp - sn * qkq; Q[k][q] = sn * qkp + c * qkq; }
+            }
+    }
+    /* ascending eigenvalues: bubble the three diagonal entries, columns follow */
+    double d[3] = {A[0][0], A[1][1], A[2][2]};
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2 - i; ++j)
+            if (d[j] > d[j + 1]) {
+                const double td = d[j]; d[j] = d[j + 1]; d[j + 1] = td;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { const double tq = Q[k][j]; Q[k][j] = Q[k][j + 1]; Q[k][j + 1] = tq; }
+            }
+    for (int k = 0; k < 3; ++k) { w[k] = d[k]; for (int i = 0; i < 3; ++i) V[i][k] = Q[i][k]; }
+}
+
+/* ---- 5 x 3 least squares by Householder QR with column pivoting ---- */
+__device__ __forceinline__ void ll_qr_solve_5x3(double A[5][3], double b[5], double x[3])
+{
+    int perm[3] = {0, 1, 2};
+    double maxn2 = 0.0;
+    for (int j = 0; j < 3; ++j) { double n2 = 0.0; for (int i = 0; i < 5; ++i) n2 += A[i][j] * A[i][j]; if (n2 > maxn2) maxn2 = n2; }
+    const double thr = maxn2 * (2.220446049250313e-16 * 2.220446049250313e-16) / 5.0;
+    int rank = 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (k >= rank) break;
+        int piv = k; double best = -1.0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (j < k) continue;
+            double n2 = 0.0;
+            for (int i = k; i < 5; ++i) n2 += A[i][j] * A[i][j];
+            if (n2 > best) { best = n2; piv = j; }
+        }
+        if (best < thr) { rank = k; break; }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (j == piv && piv != k) {
+                for (int i = 0; i < 5; ++i) { const double tmp = A[i][k]; A[i][k] = A[i][j]; A[i][j] = tmp; }
+                const int tp = perm[k]; perm[k] = perm[j]; perm[j] = tp;
+            }
+        double tail = 0.0;
+        for (int i = k + 1; i < 5; ++i) tail += A[i][k] * A[i][k];
+        const double c0 = A[k][k];
+        double tau, beta, v[5];
+        if (tail <= 2.2250738585072014e-308) { tau = 0.0; beta = c0; for (int i = 0; i < 5; ++i) v[i] = 0.0; }
+        else {
+            beta = sqrt(c0 * c0 + tail); if (c0 >= 0.0) beta = -beta;
+            for (int i = 0; i < 5; ++i) v[i] = (i > k) ? A[i][k] / (c0 - beta) : 0.0;
+            tau = (beta - c0) / beta;
+        }
+        v[k] = 1.0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (j <= k) continue;
+            double d = 0.0;
+            for (int i = k; i < 5; ++i) d += v[i] * A[i][j];
+            d *= tau;
+            for (int i = k; i < 5; ++i) A[i][j] -= d * v[i];
+        }
+        { double d = 0.0; for (int i = k; i < 5; ++i) d += v[i] * b[i]; d *= tau; for (int i = k; i < 5; ++i) b[i] -= d * v[i]; }
+        A[k][k] = beta;
+        for (int i = k + 1; i < 5; ++i) A[i][k] = 0.0;
+    }
+    double z[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 2; i >= 0; --i) {
+        if (i >= rank) continue;
+        double sacc = b[i];
+        for (int j = i + 1; j < 3; ++j) if (j < rank) sacc -= A[i][j] * z[j];
+        z[i] = sacc / A[i][i];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) if (perm[k] == c) x[c] = z[k];
+}
+
+template <bool CORNER>
+__global__ __launch_bounds__(LL_MAPB) void k_map_knn(LLMapView M)
+{
+    const int which = CORNER ? 0 : 1;
+    const int i = blockIdx.x * LL_MAPB + threadIdx.x;
+    if (i >= M.n_stk[which]) return;
+    const LLGrid3 &G = M.grid[which];
+    const float4 po = M.stk[which][i];
+    /* pointAssociateToMap */
+    float sx, sy, sz;
+    {
+        const double *pose = M.pose;
+        const double ux = pose[0], uy = pose[1], uz = pose[2], w = pose[3];
+        const double v[3] = {(double)po.x, (double)po.y, (double)po.z};
+        double uvx = uy * v[2] - uz * v[1], uvy = uz * v[0] - ux * v[2], uvz = ux * v[1] - uy * v[0];
+        uvx += uvx; uvy += uvy; uvz += uvz;
+        sx = (float)(((v[0] + w * uvx) + (uy * uvz - uz * uvy)) + pose[4]);
+        sy = (float)(((v[1] + w * uvy) + (uz * uvx - ux * uvz)) + pose[5]);
+        sz = (float)(((v[2] + w * uvz) + (ux * uvy - uy * uvx)) + pose[6]);
+    }
+    /* exact K = 5 over the 27 cells around the query, ascending (distance, index) */
+    float bd[5]; int bi[5]; int nb = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { bd[k] = INFINITY; bi[k] = INT_MAX; }
+    if (M.n_map[which] > 0) {
+        int cx = (int)floorf((sx - G.org[0]) / G.cell), cy = (int)floorf((sy - G.org[1]) / G.cell), cz = (int)floorf((sz - G.org[2]) / G.cell);
+        cx = min(max(cx, 0), G.dim[0] - 1); cy = min(max(cy, 0), G.dim[1] - 1); cz = min(max(cz, 0), G.dim[2] - 1);
+        for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = cy + dy, zz = cz + dz;
+            if (yy < 0 || zz < 0 || yy >= G.dim[1] || zz >= G.dim[2]) continue;
+            const int x0 = max(cx - 1, 0), x1 = min(cx + 1, G.dim[0] - 1);
+            const int row = (zz * G.dim[1] + yy) * G.dim[0];
+            const int st = G.start[row + x0], en = G.start[row + x1 + 1];          /* the three x-cells are contiguous */
+            for (int k = st; k < en; ++k) {
+                const float4 p = G.pts[k];
+                float diff = sx - p.x; float d = diff * diff;                  /* FLANN L2_Simple: a = query, b = data */
+                diff = sy - p.y; d += diff * diff;
+                diff = sz - p.z; d += diff * diff;
+                const int j = __float_as_int(p.w);
+                if (d < bd[4] || (d == bd[4] && j < bi[4])) {
+                    /* insertion into the sorted five */
+                    bd[4] = d; bi[4] = j;
+#pragma unroll
+                    for (int s = 4; s > 0; --s)
+                        if (bd[s] < bd[s - 1] || (bd[s] == bd[s - 1] && bi[s] < bi[s - 1])) {
+                            const float td = bd[s]; bd[s] = bd[s - 1]; bd[s - 1] = td;
+                            const int ti = bi[s]; bi[s] = bi[s - 1]; bi[s - 1] = ti;
+                        }
+                    if (nb < 5) ++nb;
+                }
+            }
+        }
+    }
+    unsigned char ok = 0;
+    if (nb == 5 && bd[4] < 1.0f) {
+        const float4 *cloud = M.map[which];
+        double P5[5][3];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { const float4 p = cloud[bi[j]]; P5[j][0] = p.x; P5[j][1] = p.y; P5[j][2] = p.z; }
+        if (CORNER) {
+            double c[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int j = 0; j < 5; ++j) for (int k = 0; k < 3; ++k) c[k] = c[k] + P5[j][k];              /* :1888-1895 */
+            for (int k = 0; k < 3; ++k) c[k] = c[k] / 5.0;
+            double cov[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {                                                                  /* :1898-1903 */
+                const double z[3] = {P5[j][0] - c[0], P5[j][1] - c[1], P5[j][2] - c[2]};
+                for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) cov[a][b] = cov[a][b] + z[a] * z[b];
+            }
+            double w[3], V[3][3];
+            ll_sym_eig3(cov, w, V);
+            if (w[2] > 3 * w[1]) {                                                                         /* :1911 */
+                ok = 1;
+                for (int k = 0; k < 3; ++k) { M.qa[(size_t)i * 3 + k] = 0.1 * V[k][2] + c[k]; M.qb[(size_t)i * 3 + k] = -0.1 * V[k][2] + c[k]; }
+            }
+        } else {
+            double A[5][3], b[5] = {-1.0, -1.0, -1.0, -1.0, -1.0}, nrm[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int j = 0; j < 5; ++j) for (int k = 0; k < 3; ++k) A[j][k] = P5[j][k];
+            ll_qr_solve_5x3(A, b, nrm);                                                                     /* :1972 */
+            const double len = sqrt((nrm[0] * nrm[0] + nrm[1] * nrm[1]) + nrm[2] * nrm[2]);
+            const double nd = 1 / len;                                                                     /* :1973 */
+            if (len * len > 0.0) { nrm[0] /= len; nrm[1] /= len; nrm[2] /= len; }                        /* :1974 */
+            bool valid = true;
+#pragma unroll
+            for (int j = 0; j < 5; ++j)                                                                    /* :1980-1990 */
+                if (fabs(nrm[0] * P5[j][0] + nrm[1] * P5[j][1] + nrm[2] * P5[j][2] + nd) > 0.2) valid = false;
+            if (valid) {
+                ok = 1;
+                for (int k = 0; k < 3; ++k) M.qn[(size_t)i * 3 + k] = nrm[k];
+                M.qd[i] = nd;
+            }
+        }
+    }
+    M.ok[which][i] = ok;
+}
+
+/* per-query results -> residual blocks in stack order; one 1024-thread workgroup */
+__global__ __launch_bounds__(1024) void k_map_compact(LLMapView M)
+{
+    __shared__ int sc[16];
+    const int tid = threadIdx.x;
+    for (int which = 0; which < 2; ++which) {
+        const int n = M.n_stk[which];
+        const int per = (n + 1023) / 1024;
+        const int a0 = min(n, tid * per), a1 = min(n, a0 + per);
+        int c = 0;
+        for (int i = a0; i < a1; ++i) c += M.ok[which][i];
+        int total;
+        int pos = ll_block_exscan_n<16>(c, sc, total);
+        for (int i = a0; i < a1; ++i) {
+            if (!M.ok[which][i]) continue;
+            M.src[which][pos] = i;
+            if (which == 0) for (int k = 0; k < 3; ++k) { M.fa[(size_t)pos * 3 + k] = M.qa[(size_t)i * 3 + k]; M.fb[(size_t)pos * 3 + k] = M.qb[(size_t)i * 3 + k]; }
+            else { for (int k = 0; k < 3; ++k) M.fn[(size_t)pos * 3 + k] = M.qn[(size_t)i * 3 + k]; M.fd[pos] = M.qd[i]; }
+            ++pos;
+        }
+        if (tid == 0) M.counts[which] = total;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_map_normal_eq(LLMapView M)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    Pose P;
+    for (int k = 0; k < 4; ++k) P.q[k] = M.pose[k];
+    for (int k = 0; k < 3; ++k) P.t[k] = M.pose[4 + k];
+    const int n_e = M.counts[0], n_p = M.counts[1];
+    double acc[LL_NACC];
+#pragma unroll
+    for (int k = 0; k < LL_NACC; ++k) acc[k] = 0.0;
+    for (int i = tid; i < n_e; i += 1024) {
+        double r[3], Jq[3][4], Jt[3][3];
+        ll_edge_d(P, M.stk[0][M.src[0][i]], &M.fa[(size_t)i * 3], &M.fb[(size_t)i * 3], r, Jq, Jt);
+        const double sc = ll_huber_scale(r[0] * r[0] + r[1] * r[1] + r[2] * r[2], M.huber, acc[27]);
+        for (int row = 0; row < 3; ++row) {
+            double J[6];
+            ll_to_local(P, Jq[row], J);
+            J[3] = Jt[row][0]; J[4] = Jt[row][1]; J[5] = Jt[row][2];
+            for (int k = 0; k < 6; ++k) J[k] *= sc;
+            ll_acc_row(acc, J, r[row] * sc);
+        }
+    }
+    for (int i = tid; i < n_p; i += 1024) {
+        double r, Jq[4], Jt[3], J[6];
+        ll_plane_norm(P, M.stk[1][M.src[1][i]], &M.fn[(size_t)i * 3], M.fd[i], r, Jq, Jt);
+        const double sc = ll_huber_scale(r * r, M.huber, acc[27]);
+        ll_to_local(P, Jq, J);
+        J[3] = Jt[0]; J[4] = Jt[1]; J[5] = Jt[2];
+        for (int k = 0; k < 6; ++k) J[k] *= sc;
+        ll_acc_row(acc, J, r * sc);
+    }
+    __shared__ double red[16][LL_NACC];
+#pragma unroll
+    for (int k = 0; k < LL_NACC; ++k) {
+        double v = acc[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double tot[LL_NACC];
+        for (int k = 0; k < LL_NACC; ++k) { double v = 0.0; for (int w = 0; w < 16; ++w) v += red[w][k]; tot[k] = v; }
+        double *out = M.neq;
+        int k = 0;
+        for (int a = 0; a < 6; ++a) for (int b = a; b < 6; ++b) { out[a * 6 + b] = tot[k]; out[b * 6 + a] = tot[k]; ++k; }
+        for (int a = 0; a < 6; ++a) out[36 + a] = tot[21 + a];
+        out[42] = tot[27];
+        out[43] = (double)(3 * n_e + n_p);
+    }
+}
+
+/* ------------------------------------------------------------------ launchers */
+void ll_map_launch_bbox(const float4 *pts, int n, int *bbox_dev, hipStream_t st)
+{
+    const int init[6] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN};
+    (void)hipMemcpyAsync(bbox_dev, init, sizeof(init), hipMemcpyHostToDevice, st);
+    if (n > 0) hipLaunchKernelGGL(k_map_bbox, dim3(min(1024, (n + LL_MAPB - 1) / LL_MAPB)), dim3(LL_MAPB), 0, st, pts, n, bbox_dev);
+}
+
+void ll_map_bbox_to_grid(const int bbox_host[6], int n, int max_cells, LLGrid3 *G)
+{
+    float mn[3], mx[3];
+    for (int k = 0; k < 3; ++k) { mn[k] = n > 0 ? ll_ord2f_host(bbox_host[k]) : 0.0f; mx[k] = n > 0 ? ll_ord2f_host(bbox_host[3 + k]) : 0.0f; }
+    float cell = 1.01f;                      /* >= the 1 m acceptance radius + rounding margin */
+    for (;;) {
+        double nc = 1.0;
+        for (int k = 0; k < 3; ++k) { G->dim[k] = (int)floorf((mx[k] - mn[k]) / cell) + 1; nc *= G->dim[k]; }
+        if (nc <= (double)max_cells) break;
+        cell *= 1.5f;
+    }
+    for (int k = 0; k < 3; ++k) G->org[k] = mn[k];
+    G->cell = cell;
+    G->ncell = G->dim[0] * G->dim[1] * G->dim[2];
+}
+
+void ll_map_launch_build(const LLGrid3 &G, const float4 *pts, int n, int *tile_sum, hipStream_t st)
+{
+    const int ns = G.ncell + 1;
+    (void)hipMemsetAsync(G.start, 0, (size_t)ns * sizeof(int), st);
+    if (n > 0) hipLaunchKernelGGL(k_map_count, dim3((n + LL_MAPB - 1) / LL_MAPB), dim3(LL_MAPB), 0, st, G, pts, n);
+    const int nt = (ns + LL_SCAN_TILE - 1) / LL_SCAN_TILE;
+    hipLaunchKernelGGL(k_scan_tiles, dim3(nt), dim3(1024), 0, st, G.start, ns, tile_sum);
+    hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, st, tile_sum, nt);
+    hipLaunchKernelGGL(k_scan_add, dim3(nt), dim3(1024), 0, st, G.start, ns, tile_sum);
+    (void)hipMemcpyAsync(G.cursor, G.start, (size_t)G.ncell * sizeof(int), hipMemcpyDeviceToDevice, st);
+    if (n > 0) hipLaunchKernelGGL(k_map_scatter, dim3((n + LL_MAPB - 1) / LL_MAPB), dim3(LL_MAPB), 0, st, G, pts, n);
+}
+
+void ll_map_launch_associate(const LLMapView &M, hipStream_t st)
+{
+    if (M.n_stk[0] > 0) hipLaunchKernelGGL(k_map_knn<true>, dim3((M.n_stk[0] + LL_MAPB - 1) / LL_MAPB), dim3(LL_MAPB), 0, st, M);
+    if (M.n_stk[1] > 0) hipLaunchKernelGGL(k_map_knn<false>, dim3((M.n_stk[1] + LL_MAPB - 1) / LL_MAPB), dim3(LL_MAPB), 0, st, M);
+    hipLaunchKernelGGL(k_map_compact, dim3(1), dim3(1024), 0, st, M);
+}
+
+void ll_map_launch_normal_eq(const LLMapView &M, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_map_normal_eq, dim3(1), dim3(1024), 0, st, M);
+}

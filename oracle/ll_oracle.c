@@ -879,16 +879,12 @@ static int lm_step(const double H[36], const double g[6], const double scale[6],
     return orc_gn_solve(A, b, step_scaled);
 }
 
-void orc_lm_solve(double q[4], double t[3],
-                  const orc_point *sharp, const int *e_src, const orc_point *corner_last, const int *e_a, const int *e_b, int n_e,
-                  const orc_point *flat, const int *p_src, const orc_point *surf_last,
-                  const int *p_a, const int *p_b, const int *p_c, const float *p_w, int n_p,
-                  double huber_delta, const orc_lm_options *opt, double summary[4])
+typedef void (*lm_eval_fn)(void *ctx, const double q[4], const double t[3], double H[36], double g[6], double *cost);
+
+static void lm_core(double q[4], double t[3], lm_eval_fn eval, void *ctx, const orc_lm_options *opt, double summary[4])
 {
-#define EVAL(qq, tt, HH, gg, cc) orc_normal_equations(qq, tt, sharp, e_src, corner_last, e_a, e_b, n_e, flat, p_src, surf_last, \
-                                                      p_a, p_b, p_c, p_w, n_p, huber_delta, HH, gg, cc)
     double H[36], g[6], cost;
-    EVAL(q, t, H, g, &cost);
+    eval(ctx, q, t, H, g, &cost);
     summary[0] = cost; summary[1] = cost; summary[2] = 0; summary[3] = 0;
     double scale[6];
     for (int i = 0; i < 6; ++i) scale[i] = opt->jacobi_scaling ? 1.0 / (1.0 + sqrt(H[i * 6 + i])) : 1.0;
@@ -923,7 +919,7 @@ void orc_lm_solve(double q[4], double t[3],
         double qc[4], tc[3], Hc[36], gc[6], cc;
         memcpy(qc, q, sizeof(qc)); memcpy(tc, t, sizeof(tc));
         orc_pose_update(qc, tc, delta);
-        EVAL(qc, tc, Hc, gc, &cc);
+        eval(ctx, qc, tc, Hc, gc, &cc);
         /* ParameterToleranceReached / FunctionToleranceReached: both return BEFORE the candidate is taken */
         double step_norm = 0.0, x_norm = 0.0;
         for (int i = 0; i < 4; ++i) { step_norm += (qc[i] - q[i]) * (qc[i] - q[i]); x_norm += q[i] * q[i]; }
@@ -946,7 +942,29 @@ void orc_lm_solve(double q[4], double t[3],
         }
     }
     summary[1] = cost; summary[2] = iter;
-#undef EVAL
+}
+
+typedef struct {
+    const orc_point *sharp; const int *e_src; const orc_point *corner_last; const int *e_a, *e_b; int n_e;
+    const orc_point *flat; const int *p_src; const orc_point *surf_last; const int *p_a, *p_b, *p_c; const float *p_w; int n_p;
+    double huber_delta;
+} odo_eval_ctx;
+
+static void odo_eval(void *vc, const double q[4], const double t[3], double H[36], double g[6], double *cost)
+{
+    const odo_eval_ctx *c = (const odo_eval_ctx *)vc;
+    orc_normal_equations(q, t, c->sharp, c->e_src, c->corner_last, c->e_a, c->e_b, c->n_e, c->flat, c->p_src, c->surf_last,
+                         c->p_a, c->p_b, c->p_c, c->p_w, c->n_p, c->huber_delta, H, g, cost);
+}
+
+void orc_lm_solve(double q[4], double t[3],
+                  const orc_point *sharp, const int *e_src, const orc_point *corner_last, const int *e_a, const int *e_b, int n_e,
+                  const orc_point *flat, const int *p_src, const orc_point *surf_last,
+                  const int *p_a, const int *p_b, const int *p_c, const float *p_w, int n_p,
+                  double huber_delta, const orc_lm_options *opt, double summary[4])
+{
+    odo_eval_ctx c = {sharp, e_src, corner_last, e_a, e_b, n_e, flat, p_src, surf_last, p_a, p_b, p_c, p_w, n_p, huber_delta};
+    lm_core(q, t, odo_eval, &c, opt, summary);
 }
 
 void orc_odometry_frame(double q[4], double t[3], const orc_point *sharp, int ns, const orc_point *flat, int nf,
@@ -982,4 +1000,215 @@ void orc_odometry_frame(double q[4], double t[3], const orc_point *sharp, int ns
         orc_lm_solve(q, t, sharp, es, corner_last, ea, eb, ne, flat, qs, surf_last, qa, qb, qc, w, nsel, huber_delta, opt, summary);
     }
     free(qs); free(src); free(sw); free(cnt); free(ps); free(es);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* f2  laserMapping scan-to-submap (laserMapping.cpp:1826-2095)                                 */
+/* ------------------------------------------------------------------------------------------ */
+/* pointAssociateToMap (:125-134): Eigen q_w_curr * p + t_w_curr in f64, stored to the float PointType */
+void orc_point_associate_to_map(const double q[4], const double t[3], const orc_point *pi, orc_point *po)
+{
+    const double v[3] = {pi->x, pi->y, pi->z};
+    double r[3];
+    quat_rotate(q, v, r);
+    po->x = (float)(r[0] + t[0]); po->y = (float)(r[1] + t[1]); po->z = (float)(r[2] + t[2]);
+    po->intensity = pi->intensity;
+}
+
+/* kdtree->nearestKSearch(pointSel, 5, ...) (:1882, :1948): the five smallest (FLANN L2_Simple f32 distance, index)
+ * pairs in ascending order.  The callers use the result only when the fifth distance is < 1.0, so a grid with
+ * cells >= 1 m searched one cell around the query gives the same answer in every case that matters; otherwise
+ * found < 5 or d[4] >= 1 and the point is rejected either way. */
+static int knn5(const orc_point *q, const orc_point *cloud, int m, const nn_grid *g, int idx[5], float d[5])
+{
+    int n = 0;
+#define KNN_TAKE(j) do { const float dj = flann_l2(q, &cloud[j]); int pos = n < 5 ? n : 5;                                    \
+        while (pos > 0 && (dj < d[pos - 1] || (dj == d[pos - 1] && (j) < idx[pos - 1]))) --pos;                                    \
+        if (pos < 5) { for (int k = (n < 5 ? n : 4); k > pos; --k) { d[k] = d[k - 1]; idx[k] = idx[k - 1]; }                      \
+                       d[pos] = dj; idx[pos] = (j); if (n < 5) ++n; } } while (0)
+    if (!g) { for (int j = 0; j < m; ++j) KNN_TAKE(j); return n; }
+    int c0[3]; grid_cell_of(g, q, c0);
+    for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
+        const int cx = c0[0] + dx, cy = c0[1] + dy, cz = c0[2] + dz;
+        if (cx < 0 || cy < 0 || cz < 0 || cx >= g->dim[0] || cy >= g->dim[1] || cz >= g->dim[2]) continue;
+        const size_t c = ((size_t)cz * g->dim[1] + cy) * g->dim[0] + cx;
+        for (int k = g->start[c]; k < g->start[c + 1]; ++k) KNN_TAKE(g->idx[k]);
+    }
+#undef KNN_TAKE
+    return n;
+}
+
+/* Eigen::SelfAdjointEigenSolver<Matrix3d> (:1905) restated as cyclic Jacobi in f64 (Eigen tridiagonalises and runs
+ * implicit QL; the results agree to rounding, the decomposition is only used through eigenvalue ratios and the
+ * direction of the largest eigenvector, whose sign cancels in the edge factor).  Eigenvalues ascending. */
+void orc_sym_eig3(const double A_in[9], double w[3], double V[9])
+{
+    double A[3][3], Q[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) A[i][j] = A_in[i * 3 + j];
+    for (int sweep = 0; sweep < 32; ++sweep) {
+        const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+        const double diag = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+        if (off <= 1e-32 * diag || off == 0.0) break;
+        for (int p = 0; p < 2; ++p) for (int q = p + 1; q < 3; ++q) {
+            if (A[p][q] == 0.0) continue;
+            const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+            const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+            for (int k = 0; k < 3; ++k) { const double akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - sn * akq; A[k][q] = sn * akp + c * akq; }
+            for (int k = 0; k < 3; ++k) { const double apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - sn * aqk; A[q][k] = sn * apk + c * aqk; }
+            for (int k = 0; k < 3; ++k) { const double qkp = Q[k][p], qkq = Q[k][q]; Q[k][p] = c * qkp - sn * qkq; Q[k][q] = sn * qkp + c * qkq; }
+        }
+    }
+    int o[3] = {0, 1, 2};
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2 - i; ++j) if (A[o[j]][o[j]] > A[o[j + 1]][o[j + 1]]) { const int tmp = o[j]; o[j] = o[j + 1]; o[j + 1] = tmp; }
+    for (int k = 0; k < 3; ++k) { w[k] = A[o[k]][o[k]]; for (int i = 0; i < 3; ++i) V[i * 3 + k] = Q[i][o[k]]; }
+}
+
+/* matA0.colPivHouseholderQr().solve(matB0) (:1972) for the 5 x 3 system A x = b: Householder QR with column pivoting
+ * on the largest remaining column norm, least-squares solution (Eigen 3.3 ColPivHouseholderQR, restated). */
+void orc_qr_solve_5x3(const double A_in[15], const double b_in[5], double x[3])
+{
+    double A[5][3], b[5]; int perm[3] = {0, 1, 2};
+    for (int i = 0; i < 5; ++i) { for (int j = 0; j < 3; ++j) A[i][j] = A_in[i * 3 + j]; b[i] = b_in[i]; }
+    double maxn2 = 0.0;
+    for (int j = 0; j < 3; ++j) { double n2 = 0.0; for (int i = 0; i < 5; ++i) n2 += A[i][j] * A[i][j]; if (n2 > maxn2) maxn2 = n2; }
+    const double thr = maxn2 * (2.220446049250313e-16 * 2.220446049250313e-16) / 5.0;     /* threshold_helper */
+    int rank = 3;
+    for (int k = 0; k < 3; ++k) {
+        int piv = k; double best = -1.0;
+        for (int j = k; j < 3; ++j) { double n2 = 0.0; for (int i = k; i < 5; ++i) n2 += A[i][j] * A[i][j]; if (n2 > best) { best = n2; piv = j; } }
+        if (best < thr) { rank = k; break; }
+        if (piv != k) { for (int i = 0; i < 5; ++i) { const double tmp = A[i][k]; A[i][k] = A[i][piv]; A[i][piv] = tmp; } const int tp = perm[k]; perm[k] = perm[piv]; perm[piv] = tp; }
+        /* makeHouseholderInPlace */
+        double tail = 0.0; for (int i = k + 1; i < 5; ++i) tail += A[i][k] * A[i][k];
+        const double c0 = A[k][k];
+        double tau, beta, v[5];
+        if (tail <= 2.2250738585072014e-308) { tau = 0.0; beta = c0; for (int i = k + 1; i < 5; ++i) v[i] = 0.0; }
+        else {
+            beta = sqrt(c0 * c0 + tail); if (c0 >= 0.0) beta = -beta;
+            for (int i = k + 1; i < 5; ++i) v[i] = A[i][k] / (c0 - beta);
+            tau = (beta - c0) / beta;
+        }
+        v[k] = 1.0;
+        for (int j = k + 1; j < 3; ++j) { double d = 0.0; for (int i = k; i < 5; ++i) d += v[i] * A[i][j]; d *= tau; for (int i = k; i < 5; ++i) A[i][j] -= d * v[i]; }
+        { double d = 0.0; for (int i = k; i < 5; ++i) d += v[i] * b[i]; d *= tau; for (int i = k; i < 5; ++i) b[i] -= d * v[i]; }
+        A[k][k] = beta; for (int i = k + 1; i < 5; ++i) A[i][k] = 0.0;
+    }
+    double z[3] = {0, 0, 0};
+    for (int i = rank - 1; i >= 0; --i) { double sacc = b[i]; for (int j = i + 1; j < rank; ++j) sacc -= A[i][j] * z[j]; z[i] = sacc / A[i][i]; }
+    for (int k = 0; k < 3; ++k) x[perm[k]] = z[k];
+}
+
+/* one data-association pass (:1877-2047).  Edge blocks: (stack index, a, b); plane blocks: (stack index, unit normal, d) */
+int orc_map_associate(const double q[4], const double t[3],
+                      const orc_point *corner_stack, int n_cs, const orc_point *corner_map, int n_cm,
+                      const orc_point *surf_stack, int n_ss, const orc_point *surf_map, int n_sm,
+                      int *e_src, double *e_a, double *e_b, int *n_e, int *p_src, double *p_n, double *p_d, int *n_p)
+{
+    /* cells a little over the 1 m acceptance radius: the f32 rounding of the cell coordinate cannot push a neighbour
+     * that is closer than 1 m two cells away */
+    nn_grid *gc = (g_nn_mode && n_cm > 0) ? grid_build(corner_map, n_cm, 1.01f) : NULL;
+    nn_grid *gs = (g_nn_mode && n_sm > 0) ? grid_build(surf_map, n_sm, 1.01f) : NULL;
+    int ne = 0, np = 0;
+    for (int i = 0; i < n_cs; ++i) {
+        orc_point sel; int idx[5]; float d[5];
+        orc_point_associate_to_map(q, t, &corner_stack[i], &sel);
+        if (knn5(&sel, corner_map, n_cm, gc, idx, d) < 5 || !(d[4] < 1.0)) continue;                 /* :1884 */
+        double c[3] = {0, 0, 0}, pts[5][3];
+        for (int j = 0; j < 5; ++j) {                                                                  /* :1888-1895 */
+            pts[j][0] = corner_map[idx[j]].x; pts[j][1] = corner_map[idx[j]].y; pts[j][2] = corner_map[idx[j]].z;
+            for (int k = 0; k < 3; ++k) c[k] = c[k] + pts[j][k];
+        }
+        for (int k = 0; k < 3; ++k) c[k] = c[k] / 5.0;
+        double cov[9] = {0};
+        for (int j = 0; j < 5; ++j) {                                                                  /* :1898-1903 */
+            const double z[3] = {pts[j][0] - c[0], pts[j][1] - c[1], pts[j][2] - c[2]};
+            for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) cov[a * 3 + b] = cov[a * 3 + b] + z[a] * z[b];
+        }
+        double w[3], V[9];
+        orc_sym_eig3(cov, w, V);
+        if (!(w[2] > 3 * w[1])) continue;                                                              /* :1911 */
+        e_src[ne] = i;
+        for (int k = 0; k < 3; ++k) { e_a[ne * 3 + k] = 0.1 * V[k * 3 + 2] + c[k]; e_b[ne * 3 + k] = -0.1 * V[k * 3 + 2] + c[k]; }   /* :1915-1916 */
+        ++ne;
+    }
+    for (int i = 0; i < n_ss; ++i) {
+        orc_point sel; int idx[5]; float d[5];
+        orc_point_associate_to_map(q, t, &surf_stack[i], &sel);
+        if (knn5(&sel, surf_map, n_sm, gs, idx, d) < 5 || !(d[4] < 1.0)) continue;                   /* :1952 */
+        double A[15], b[5] = {-1, -1, -1, -1, -1}, nrm[3];
+        for (int j = 0; j < 5; ++j) { A[j * 3] = surf_map[idx[j]].x; A[j * 3 + 1] = surf_map[idx[j]].y; A[j * 3 + 2] = surf_map[idx[j]].z; }
+        orc_qr_solve_5x3(A, b, nrm);                                                                    /* :1972 */
+        const double len = sqrt((nrm[0] * nrm[0] + nrm[1] * nrm[1]) + nrm[2] * nrm[2]);
+        const double negative_OA_dot_norm = 1 / len;                                                   /* :1973 */
+        if (len * len > 0.0) { nrm[0] /= len; nrm[1] /= len; nrm[2] /= len; }                        /* :1974 normalize() */
+        int valid = 1;
+        for (int j = 0; j < 5; ++j)                                                                    /* :1980-1990 */
+            if (fabs(nrm[0] * A[j * 3] + nrm[1] * A[j * 3 + 1] + nrm[2] * A[j * 3 + 2] + negative_OA_dot_norm) > 0.2) { valid = 0; break; }
+        if (!valid) continue;
+        p_src[np] = i; p_n[np * 3] = nrm[0]; p_n[np * 3 + 1] = nrm[1]; p_n[np * 3 + 2] = nrm[2]; p_d[np] = negative_OA_dot_norm;
+        ++np;
+    }
+    grid_free(gc); grid_free(gs);
+    *n_e = ne; *n_p = np;
+    return 0;
+}
+
+/* the residual blocks of one pass (:1918-1919, :2033-2034) under HuberLoss(0.1) + EigenQuaternionManifold */
+void orc_map_normal_equations(const double q[4], const double t[3],
+                              const orc_point *corner_stack, const int *e_src, const double *e_a, const double *e_b, int n_e,
+                              const orc_point *surf_stack, const int *p_src, const double *p_n, const double *p_d, int n_p,
+                              double huber_delta, double H[36], double g[6], double *cost)
+{
+    double P[12];
+    orc_quat_plus_jacobian(q, P);
+    memset(H, 0, 36 * sizeof(double)); memset(g, 0, 6 * sizeof(double)); *cost = 0.0;
+    for (int i = 0; i < n_e; ++i) {
+        const orc_point *c = &corner_stack[e_src[i]];
+        const double cp[3] = {c->x, c->y, c->z};
+        double r[3], Jq[12], Jt[9];
+        orc_edge_factor(q, t, cp, &e_a[i * 3], &e_b[i * 3], 1.0, r, Jq, Jt);
+        accumulate_block(3, r, Jq, Jt, P, huber_delta, H, g, cost);
+    }
+    for (int i = 0; i < n_p; ++i) {
+        const orc_point *c = &surf_stack[p_src[i]];
+        const double cp[3] = {c->x, c->y, c->z};
+        double r[1], Jq[4], Jt[3];
+        orc_plane_norm_factor(q, t, cp, &p_n[i * 3], p_d[i], r, Jq, Jt);
+        accumulate_block(1, r, Jq, Jt, P, huber_delta, H, g, cost);
+    }
+}
+
+typedef struct {
+    const orc_point *corner_stack; const int *e_src; const double *e_a, *e_b; int n_e;
+    const orc_point *surf_stack; const int *p_src; const double *p_n, *p_d; int n_p; double huber_delta;
+} map_eval_ctx;
+
+static void map_eval(void *vc, const double q[4], const double t[3], double H[36], double g[6], double *cost)
+{
+    const map_eval_ctx *c = (const map_eval_ctx *)vc;
+    orc_map_normal_equations(q, t, c->corner_stack, c->e_src, c->e_a, c->e_b, c->n_e, c->surf_stack, c->p_src, c->p_n, c->p_d, c->n_p,
+                             c->huber_delta, H, g, cost);
+}
+
+/* the optimisation of one mapping frame (:1822-2095): if the map holds > 10 corner and > 50 surf points, n_outer (2)
+ * times { data association at the current pose, ceres::Solve (<= 4 LM iterations) }.  Returns 1 when it ran. */
+int orc_map_optimize(double q[4], double t[3],
+                     const orc_point *corner_stack, int n_cs, const orc_point *corner_map, int n_cm,
+                     const orc_point *surf_stack, int n_ss, const orc_point *surf_map, int n_sm,
+                     int n_outer, double huber_delta, const orc_lm_options *opt)
+{
+    if (!(n_cm > 10 && n_sm > 50)) return 0;                                                           /* :1822 */
+    int *e_src = (int *)malloc(sizeof(int) * (size_t)(n_cs + 1)), *p_src = (int *)malloc(sizeof(int) * (size_t)(n_ss + 1));
+    double *e_a = (double *)malloc(sizeof(double) * 6 * (size_t)(n_cs + 1)), *e_b = e_a + 3 * (size_t)(n_cs + 1);
+    double *p_n = (double *)malloc(sizeof(double) * 4 * (size_t)(n_ss + 1)), *p_d = p_n + 3 * (size_t)(n_ss + 1);
+    for (int it = 0; it < n_outer; ++it) {                                                             /* :1832 */
+        int ne = 0, np = 0;
+        orc_map_associate(q, t, corner_stack, n_cs, corner_map, n_cm, surf_stack, n_ss, surf_map, n_sm, e_src, e_a, e_b, &ne, p_src, p_n, p_d, &np);
+        map_eval_ctx c = {corner_stack, e_src, e_a, e_b, ne, surf_stack, p_src, p_n, p_d, np, huber_delta};
+        double summary[4];
+        lm_core(q, t, map_eval, &c, opt, summary);
+    }
+    free(p_n); free(e_a); free(p_src); free(e_src);
+    return 1;
 }

@@ -141,6 +141,25 @@ void orc_odometry_frame(double q[4], double t[3], const orc_point *sharp, int ns
                         const orc_point *corner_last, int mc, const orc_point *surf_last, int ms,
                         int vote, int n_outer, double huber_delta, const orc_lm_options *opt);
 
+/* ---- f2: laserMapping scan-to-submap optimisation (laserMapping.cpp:1822-2095).  PARITY UNPINNED like the rest:
+ * Eigen's SelfAdjointEigenSolver / ColPivHouseholderQR and PCL's kd-tree are restated (Jacobi sweeps, Householder QR with
+ * column pivoting, exact 5-NN with (distance, index) order).  Pose = parameters[7] of the reference: q_w_curr, t_w_curr. */
+void orc_point_associate_to_map(const double q[4], const double t[3], const orc_point *pi, orc_point *po);   /* :125-134 */
+void orc_sym_eig3(const double A[9], double w[3], double V[9]);               /* eigenvalues ascending, eigenvectors in columns */
+void orc_qr_solve_5x3(const double A[15], const double b[5], double x[3]);
+int orc_map_associate(const double q[4], const double t[3],
+                      const orc_point *corner_stack, int n_cs, const orc_point *corner_map, int n_cm,
+                      const orc_point *surf_stack, int n_ss, const orc_point *surf_map, int n_sm,
+                      int *e_src, double *e_a, double *e_b, int *n_e, int *p_src, double *p_n, double *p_d, int *n_p);
+void orc_map_normal_equations(const double q[4], const double t[3],
+                              const orc_point *corner_stack, const int *e_src, const double *e_a, const double *e_b, int n_e,
+                              const orc_point *surf_stack, const int *p_src, const double *p_n, const double *p_d, int n_p,
+                              double huber_delta, double H[36], double g[6], double *cost);
+int orc_map_optimize(double q[4], double t[3],
+                     const orc_point *corner_stack, int n_cs, const orc_point *corner_map, int n_cm,
+                     const orc_point *surf_stack, int n_ss, const orc_point *surf_map, int n_sm,
+                     int n_outer, double huber_delta, const orc_lm_options *opt);
+
 #ifdef __cplusplus
 }
 #endif

@@ -256,3 +256,57 @@ def odometry_frame(q, t, cur, last, vote, n_outer=3, huber_delta=0.1, opt=None):
     lib().orc_odometry_frame(_p(q), _p(t), _p(sharp), len(sharp), _p(flat), len(flat), _p(cl), len(cl), _p(sl), len(sl),
                              int(bool(vote)), n_outer, C.c_double(huber_delta), C.byref(opt))
     return q, t
+
+
+# ---- f2: laserMapping scan-to-submap (laserMapping.cpp:1822-2095)
+def sym_eig3(A):
+    A = np.ascontiguousarray(A, np.float64).reshape(9); w = np.zeros(3); V = np.zeros((3, 3))
+    lib().orc_sym_eig3(_p(A), _p(w), _p(V))
+    return w, V
+
+
+def qr_solve_5x3(A, b):
+    A = np.ascontiguousarray(A, np.float64).reshape(15); b = _d(b, 5); x = np.zeros(3)
+    lib().orc_qr_solve_5x3(_p(A), _p(b), _p(x))
+    return x
+
+
+def point_associate_to_map(q, t, pts):
+    pts = _f4(pts); out = np.zeros_like(pts); q = _d(q, 4); t = _d(t, 3)
+    f = lib().orc_point_associate_to_map
+    for i in range(len(pts)):
+        f(_p(q), _p(t), C.c_void_p(pts.ctypes.data + 16 * i), C.c_void_p(out.ctypes.data + 16 * i))
+    return out
+
+
+def map_associate(q, t, corner_stack, corner_map, surf_stack, surf_map):
+    """-> (e_src, e_a[n,3], e_b[n,3], p_src, p_n[n,3], p_d[n])"""
+    q = _d(q, 4); t = _d(t, 3)
+    cs, cm, ss, sm = _f4(corner_stack), _f4(corner_map), _f4(surf_stack), _f4(surf_map)
+    e_src = np.zeros(len(cs) + 1, np.int32); e_a = np.zeros((len(cs) + 1, 3)); e_b = np.zeros((len(cs) + 1, 3))
+    p_src = np.zeros(len(ss) + 1, np.int32); p_n = np.zeros((len(ss) + 1, 3)); p_d = np.zeros(len(ss) + 1)
+    ne = C.c_int(0); npl = C.c_int(0)
+    lib().orc_map_associate(_p(q), _p(t), _p(cs), len(cs), _p(cm), len(cm), _p(ss), len(ss), _p(sm), len(sm),
+                            _p(e_src), _p(e_a), _p(e_b), C.byref(ne), _p(p_src), _p(p_n), _p(p_d), C.byref(npl))
+    return (e_src[:ne.value].copy(), e_a[:ne.value].copy(), e_b[:ne.value].copy(),
+            p_src[:npl.value].copy(), p_n[:npl.value].copy(), p_d[:npl.value].copy())
+
+
+def map_normal_equations(q, t, corner_stack, e_src, e_a, e_b, surf_stack, p_src, p_n, p_d, huber_delta=0.1):
+    q = _d(q, 4); t = _d(t, 3); cs, ss = _f4(corner_stack), _f4(surf_stack)
+    e_src = np.ascontiguousarray(e_src, np.int32); p_src = np.ascontiguousarray(p_src, np.int32)
+    e_a = np.ascontiguousarray(e_a, np.float64); e_b = np.ascontiguousarray(e_b, np.float64)
+    p_n = np.ascontiguousarray(p_n, np.float64); p_d = np.ascontiguousarray(p_d, np.float64)
+    H = np.zeros((6, 6)); g = np.zeros(6); cost = C.c_double(0)
+    lib().orc_map_normal_equations(_p(q), _p(t), _p(cs), _p(e_src), _p(e_a), _p(e_b), len(e_src),
+                                   _p(ss), _p(p_src), _p(p_n), _p(p_d), len(p_src), C.c_double(huber_delta), _p(H), _p(g), C.byref(cost))
+    return H, g, cost.value
+
+
+def map_optimize(q, t, corner_stack, corner_map, surf_stack, surf_map, n_outer=2, huber_delta=0.1, opt=None):
+    q = _d(q, 4).copy(); t = _d(t, 3).copy()
+    cs, cm, ss, sm = _f4(corner_stack), _f4(corner_map), _f4(surf_stack), _f4(surf_map)
+    opt = opt or lm_options()
+    ran = lib().orc_map_optimize(_p(q), _p(t), _p(cs), len(cs), _p(cm), len(cm), _p(ss), len(ss), _p(sm), len(sm),
+                                 n_outer, C.c_double(huber_delta), C.byref(opt))
+    return q, t, bool(ran)

@@ -1,0 +1,122 @@
+"""SURVEY.md section 8f #2, first stage: laserMapping's scan-to-submap optimisation (laserMapping.cpp:1822-2095) on the
+device against the oracle's restatement: same residual blocks (exact), line points / plane parameters, normal equations
+and the optimised pose within f64 rounding, and the optimised pose against the synthetic ground truth."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-9
+
+
+def _to_world(pts, pose3):
+    x, y, yaw = pose3
+    c, s = np.cos(yaw), np.sin(yaw)
+    out = pts.astype(np.float64).copy()
+    out[:, 0] = c * pts[:, 0] - s * pts[:, 1] + x
+    out[:, 1] = s * pts[:, 0] + c * pts[:, 1] + y
+    return out.astype(np.float32)
+
+
+def _pose7(pose3):
+    x, y, yaw = pose3
+    return np.array([0.0, 0.0, np.sin(yaw / 2), np.cos(yaw / 2), x, y, 0.0])
+
+
+@pytest.fixture(scope="module", params=[16, 64])
+def scene(request, orc, synth):
+    rings = request.param
+    n_hist = 5 if rings == 16 else 3
+    cfg = synth.default_cfg(rings)
+    P = orc.params(rings)
+    feats = [orc.extract(synth.scan(cfg, k), P) for k in range(n_hist + 1)]
+    poses = [synth.pose(cfg, k) for k in range(n_hist + 1)]
+    # the cube map's content: earlier scans' features in the world frame, down-sized like :2151-2165 (0.4 / 0.8 m)
+    corner_map = orc.voxel_grid(np.concatenate([_to_world(f["less_sharp"], p) for f, p in zip(feats[:-1], poses[:-1])]), 0.4)
+    surf_map = orc.voxel_grid(np.concatenate([_to_world(f["less_flat"], p) for f, p in zip(feats[:-1], poses[:-1])]), 0.8)
+    corner_stack = orc.voxel_grid(feats[-1]["less_sharp"], 0.4)              # :1813-1821
+    surf_stack = orc.voxel_grid(feats[-1]["less_flat"], 0.8)
+    gt = _pose7(poses[-1])
+    guess = gt.copy(); guess[4:] += [0.15, -0.1, 0.03]
+    dq = np.array([0.002, -0.001, 0.004, 1.0]); dq /= np.linalg.norm(dq)
+    ax, ay, az, aw = dq; bx, by, bz, bw = guess[:4]
+    guess[:4] = [aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                 aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz]
+    return dict(rings=rings, corner_map=corner_map, surf_map=surf_map, corner_stack=corner_stack, surf_stack=surf_stack, gt=gt, guess=guess)
+
+
+@pytest.fixture(scope="module")
+def dev(scene, api):
+    ctx = api.Context(api.default_params(scene["rings"], batch=1, max_points=4096))
+    m = api.Map(ctx, len(scene["corner_map"]) + 8, len(scene["surf_map"]) + 8, len(scene["corner_stack"]) + 8, len(scene["surf_stack"]) + 8)
+    m.set_map(scene["corner_map"], scene["surf_map"])
+    m.set_scan(scene["corner_stack"], scene["surf_stack"])
+    yield m
+    m.close(); ctx.close()
+
+
+def close(a, b, what):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, what
+    scale = max(1.0, float(np.abs(b).max()) if b.size else 1.0)
+    assert (float(np.abs(a - b).max()) if a.size else 0.0) <= REL * scale, what
+
+
+def test_blocks_match_oracle(scene, dev, orc):
+    q, t = scene["guess"][:4], scene["guess"][4:]
+    e_src, e_a, e_b, p_src, p_n, p_d = orc.map_associate(q, t, scene["corner_stack"], scene["corner_map"], scene["surf_stack"], scene["surf_map"])
+    assert len(e_src) > 20 and len(p_src) > 100, (len(e_src), len(p_src))
+    dev.associate(scene["guess"])
+    ne, npl = dev.counts()
+    assert (ne, npl) == (len(e_src), len(p_src))
+    src, a, b = dev.edges()
+    assert (src == e_src).all()
+    # the eigenvector's sign is a convention: (a, b) may come out swapped, the residual block is the same
+    same = np.abs(a - e_a).max(axis=1) <= 1e-9 * np.maximum(1, np.abs(e_a).max(axis=1))
+    swapped = np.abs(a - e_b).max(axis=1) <= 1e-9 * np.maximum(1, np.abs(e_b).max(axis=1))
+    assert (same | swapped).all()
+    assert (np.where(same[:, None], b - e_b, b - e_a).__abs__().max() <= 1e-9 * max(1, np.abs(e_b).max()))
+    src, n, d = dev.planes()
+    assert (src == p_src).all()
+    close(n, p_n, "plane normals"); close(d, p_d, "negative_OA_dot_norm")
+    assert np.allclose(np.linalg.norm(n, axis=1), 1.0, atol=1e-12)
+
+
+def test_normal_equations_match_oracle(scene, dev, orc):
+    q, t = scene["guess"][:4], scene["guess"][4:]
+    blocks = orc.map_associate(q, t, scene["corner_stack"], scene["corner_map"], scene["surf_stack"], scene["surf_map"])
+    Ho, go, co = orc.map_normal_equations(q, t, scene["corner_stack"], blocks[0], blocks[1], blocks[2], scene["surf_stack"], blocks[3], blocks[4], blocks[5])
+    dev.associate(scene["guess"])
+    H, g, cost = dev.normal_equations(scene["guess"])
+    close(H, Ho, "H"); close(g, go, "g"); close(cost, co, "cost")
+    # and at another pose with the same blocks (what the LM iterations evaluate)
+    other = scene["guess"].copy(); other[4:] += [0.01, 0.02, -0.01]
+    Ho, go, co = orc.map_normal_equations(other[:4], other[4:], scene["corner_stack"], blocks[0], blocks[1], blocks[2], scene["surf_stack"], blocks[3], blocks[4], blocks[5])
+    H, g, cost = dev.normal_equations(other)
+    close(H, Ho, "H'"); close(g, go, "g'"); close(cost, co, "cost'")
+
+
+def test_optimize_matches_oracle_and_ground_truth(scene, dev, orc):
+    q, t, ran = orc.map_optimize(scene["guess"][:4], scene["guess"][4:], scene["corner_stack"], scene["corner_map"], scene["surf_stack"], scene["surf_map"])
+    assert ran
+    pose, ran_d = dev.optimize(scene["guess"])
+    assert ran_d
+    assert np.abs(pose[:4] - q).max() < 1e-7 and np.abs(pose[4:] - t).max() < 1e-7, (pose, q, t)
+    gt = scene["gt"]
+    assert np.abs(pose[4:6] - gt[4:6]).max() < 0.05, (pose, gt)                   # pulled back onto the map
+    assert np.abs(pose[4:6] - gt[4:6]).max() < np.abs(scene["guess"][4:6] - gt[4:6]).max()
+    assert abs(abs(np.dot(pose[:4], gt[:4])) - 1.0) < 1e-4
+
+
+def test_small_map_is_left_alone(scene, api):
+    """:1822 -- the optimisation only runs with more than 10 corner and 50 surf map points"""
+    ctx = api.Context(api.default_params(scene["rings"], batch=1, max_points=4096))
+    m = api.Map(ctx, 64, 64, len(scene["corner_stack"]) + 8, len(scene["surf_stack"]) + 8)
+    m.set_map(scene["corner_map"][:10], scene["surf_map"][:60])
+    m.set_scan(scene["corner_stack"], scene["surf_stack"])
+    pose, ran = m.optimize(scene["guess"])
+    assert not ran and (pose == scene["guess"]).all()
+    with pytest.raises(api.LightLoamError) as e:
+        m.set_map(scene["corner_map"][:65], scene["surf_map"][:60])
+    assert e.value.code == -4
+    m.close(); ctx.close()

@@ -497,3 +497,62 @@ def test_odometry_frame_recovers_the_synthetic_motion(orc, synth):
     orc.set_nn_mode(0)
     gt0, gt1 = synth.pose(cfg, 0), synth.pose(cfg, 1)
     assert abs(t[0] - (gt1[0] - gt0[0])) < 0.05 and abs(t[1]) < 0.05 and abs(2 * np.arctan2(q[2], q[3]) - 0.01) < 2e-3
+
+
+# ---- f2: the mapping stage's restated third-party pieces and the grid-accelerated K = 5 search
+def test_sym_eig3_and_qr_against_numpy(orc):
+    rng = np.random.default_rng(7)
+    for _ in range(300):
+        B = rng.standard_normal((5, 3)) * rng.uniform(0.01, 10)
+        A = B.T @ B
+        w, V = orc.sym_eig3(A); w2, V2 = np.linalg.eigh(A)
+        assert np.allclose(w, w2, atol=1e-12 * max(1.0, abs(w2).max()))
+        assert (np.diff(w) >= 0).all() and np.allclose(V.T @ V, np.eye(3), atol=1e-12)
+        assert np.allclose(A @ V, V * w, atol=1e-10 * max(1.0, abs(w2).max()))
+        M = rng.standard_normal((5, 3)) + rng.uniform(-5, 5, 3)
+        x = orc.qr_solve_5x3(M, -np.ones(5)); x2 = np.linalg.lstsq(M, -np.ones(5), rcond=None)[0]
+        assert np.allclose(x, x2, atol=1e-9 * max(1.0, abs(x2).max()))
+
+
+def test_map_associate_known_answers(orc):
+    """five collinear map points -> one edge block along the line; five coplanar points -> one plane block with the
+    plane's normal and offset; a 5th neighbour at >= 1 m -> nothing (laserMapping.cpp:1884, :1911, :1952, :1980-1990)."""
+    def pts(a):
+        a = np.asarray(a, np.float32); return np.concatenate([a, np.zeros((len(a), 1), np.float32)], 1)
+    line = pts([[10, 0.0, 1], [10, 0.2, 1], [10, 0.4, 1], [10, -0.2, 1], [10, -0.4, 1]])
+    plane = pts([[5, 0.0, 0], [5, 0.3, 0.1], [5, -0.3, 0.2], [5, 0.1, -0.3], [5, -0.2, -0.2]])
+    q, t = np.array([0, 0, 0, 1.0]), np.zeros(3)
+    es, ea, eb, ps, pn, pd = orc.map_associate(q, t, pts([[10, 0.05, 1.02]]), line, pts([[5.05, 0, 0]]), plane)
+    assert list(es) == [0] and list(ps) == [0]
+    d = ea[0] - eb[0]
+    assert np.allclose(np.abs(d), [0, 0.2, 0], atol=1e-9) and np.allclose((ea[0] + eb[0]) / 2, [10, 0, 1], atol=1e-6)
+    assert np.allclose(np.abs(pn[0]), [1, 0, 0], atol=1e-9) and abs(abs(pd[0]) - 5.0) < 1e-6 and pn[0, 0] * pd[0] < 0
+    far = line.copy(); far[4, 1] = 1.5                                   # fifth neighbour beyond 1 m
+    es, *_ = orc.map_associate(q, t, pts([[10, 0.05, 1.02]]), far, pts([[5.05, 0, 0]]), plane)
+    assert len(es) == 0
+    blob = pts(np.array([[10, 0, 1]]) + 0.05 * np.random.default_rng(1).standard_normal((5, 3)))   # no dominant direction
+    es, *_ = orc.map_associate(q, t, pts([[10, 0.0, 1.0]]), blob, pts([[5.05, 0, 0]]), plane)
+    assert len(es) == 0
+    rough = plane.copy(); rough[:, 0] += np.array([0.45, -0.45, 0.45, -0.45, 0], np.float32)   # the fit misses one point by > 0.2
+    nrm = np.linalg.lstsq(rough[:, :3].astype(np.float64), -np.ones(5), rcond=None)[0]
+    assert np.abs(rough[:, :3] @ nrm / np.linalg.norm(nrm) + 1 / np.linalg.norm(nrm)).max() > 0.2
+    *_, ps, pn, pd = orc.map_associate(q, t, pts([[10, 0.05, 1.02]]), line, pts([[5.05, 0, 0]]), rough)
+    assert len(ps) == 0
+
+
+def test_map_grid_search_equals_brute_force(orc):
+    rng = np.random.default_rng(3)
+    mp = np.zeros((4000, 4), np.float32); mp[:, :3] = rng.uniform(-12, 12, (4000, 3)) * [1, 1, 0.2]
+    mp[:, :3] = np.round(mp[:, :3] * 4) / 4                              # a 0.25 m lattice: many exactly equal distances
+    st = np.zeros((600, 4), np.float32); st[:, :3] = rng.uniform(-12, 12, (600, 3)) * [1, 1, 0.2]
+    st[:300, :3] = np.round(st[:300, :3] * 4) / 4
+    q = np.array([0.01, -0.02, 0.03, 1.0]); q /= np.linalg.norm(q); t = np.array([0.3, -0.2, 0.05])
+    a = orc.map_associate(q, t, st, mp, st, mp)
+    orc.set_nn_mode(1)
+    try:
+        b = orc.map_associate(q, t, st, mp, st, mp)
+    finally:
+        orc.set_nn_mode(0)
+    assert len(a[0]) > 5 and len(a[3]) > 50
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and (x == y).all()
