@@ -207,6 +207,20 @@ int ll_map_normal_equations(ll_map *m, const double *pose_w7, double *H36, doubl
  * map is too small (the reference then keeps the odometry guess, :2096-2100).                                        */
 int ll_map_optimize(ll_map *m, double *pose_w7, int n_outer, const ll_lm_options *opt, int *ran);
 
+/* Row-parallel use over several GPUs (BASELINE config 4): every rank holds the same map and its share of the
+ * stack points (ll_map_set_scan with a slice).  The residual blocks are independent, so the normal equations of the
+ * whole scan are the SUM over ranks of ll_map_evaluate's 44-double record (H 36, g 6, cost, rows); the caller
+ * all-reduces it (RCCL over xGMI: 28 unique doubles matter) and feeds the sum to ll_map_lm_begin / ll_map_lm_accept,
+ * so that every rank advances an identical Levenberg-Marquardt state:
+ *     associate;  evaluate -> all-reduce -> lm_begin;  repeat max_num_iterations x { lm_propose; evaluate -> all-reduce -> lm_accept }
+ * ll_map_optimize is exactly this sequence on one rank without the all-reduce.                                          */
+int ll_map_set_pose(ll_map *m, const double *pose_w7);
+int ll_map_get_pose(ll_map *m, double *pose_w7);
+int ll_map_evaluate(ll_map *m, double *neq44);                                           /* at the map's current pose */
+int ll_map_lm_begin(ll_map *m, const double *neq44_sum, const ll_lm_options *opt);
+int ll_map_lm_propose(ll_map *m, const ll_lm_options *opt);                               /* current pose <- candidate (or unchanged) */
+int ll_map_lm_accept(ll_map *m, const double *neq44_sum, const ll_lm_options *opt);       /* current pose <- accepted state */
+
 /* ---------------------------------------------------------------- whole hot path
  * One pass: extract + associate + vote + normal equations + one GN step for slots [first, first+count),
  * everything device-resident, no host synchronisation inside.  `vote_enable` as above.                   */

@@ -25,6 +25,7 @@ EXPORTS = [
     "ll_lm_default_options", "ll_lm_solve_batch", "ll_odometry_frames",
     "ll_map_create", "ll_map_destroy", "ll_map_last_error", "ll_map_set_map", "ll_map_set_scan", "ll_map_associate",
     "ll_map_get_counts", "ll_map_download_edges", "ll_map_download_planes", "ll_map_normal_equations", "ll_map_optimize",
+    "ll_map_set_pose", "ll_map_get_pose", "ll_map_evaluate", "ll_map_lm_begin", "ll_map_lm_propose", "ll_map_lm_accept",
 ]
 
 
@@ -348,3 +349,29 @@ class Map:
         ran = C.c_int(0)
         self._ck(self.lib.ll_map_optimize(self.h, _ptr(p), n_outer, None if opt is None else C.byref(opt), C.byref(ran)))
         return p, bool(ran.value)
+
+    # ---- row-parallel stepping: the caller sums `evaluate()` over ranks between the LM stages
+    def set_pose(self, pose_w):
+        p = np.ascontiguousarray(pose_w, np.float64)
+        self._ck(self.lib.ll_map_set_pose(self.h, _ptr(p)))
+
+    def pose(self):
+        p = np.zeros(7)
+        self._ck(self.lib.ll_map_get_pose(self.h, _ptr(p)))
+        return p
+
+    def evaluate(self):
+        v = np.zeros(44)
+        self._ck(self.lib.ll_map_evaluate(self.h, _ptr(v)))
+        return v
+
+    def lm_begin(self, neq44, opt=None):
+        v = np.ascontiguousarray(neq44, np.float64)
+        self._ck(self.lib.ll_map_lm_begin(self.h, _ptr(v), None if opt is None else C.byref(opt)))
+
+    def lm_propose(self, opt=None):
+        self._ck(self.lib.ll_map_lm_propose(self.h, None if opt is None else C.byref(opt)))
+
+    def lm_accept(self, neq44, opt=None):
+        v = np.ascontiguousarray(neq44, np.float64)
+        self._ck(self.lib.ll_map_lm_accept(self.h, _ptr(v), None if opt is None else C.byref(opt)))

@@ -682,6 +682,52 @@ extern "C" int ll_map_optimize(ll_map *m, double *pose_w7, int n_outer, const ll
     return LL_OK;
 }
 
+extern "C" int ll_map_set_pose(ll_map *m, const double *pose_w7)
+{
+    if (!m || !pose_w7) return LL_ERR_ARG;
+    LLM_HIP(hipSetDevice(m->ctx->device));
+    return map_set_pose(m, pose_w7);
+}
+
+extern "C" int ll_map_get_pose(ll_map *m, double *pose_w7)
+{
+    if (!m || !pose_w7) return LL_ERR_ARG;
+    LLM_HIP(hipMemcpyAsync(pose_w7, m->M.pose, 7 * sizeof(double), hipMemcpyDeviceToHost, m->ctx->stream));
+    LLM_HIP(hipStreamSynchronize(m->ctx->stream));
+    return LL_OK;
+}
+
+extern "C" int ll_map_evaluate(ll_map *m, double *neq44)
+{
+    if (!m || !neq44) return LL_ERR_ARG;
+    LLM_HIP(hipSetDevice(m->ctx->device));
+    ll_map_launch_normal_eq(m->M, m->ctx->stream);
+    LLM_HIP(hipMemcpyAsync(neq44, m->M.neq, LL_NEQ_STRIDE * sizeof(double), hipMemcpyDeviceToHost, m->ctx->stream));
+    LLM_HIP(hipStreamSynchronize(m->ctx->stream));
+    return LL_OK;
+}
+
+static int map_lm_stage(ll_map *m, int stage, const double *neq44_sum, const ll_lm_options *opt)
+{
+    if (!m || (stage != 1 && !neq44_sum)) return LL_ERR_ARG;
+    const LLLmOpt o = to_dev_opt(opt);
+    LLM_HIP(hipSetDevice(m->ctx->device));
+    hipStream_t st = m->ctx->stream;
+    if (neq44_sum) LLM_HIP(hipMemcpyAsync(m->M.neq, neq44_sum, LL_NEQ_STRIDE * sizeof(double), hipMemcpyHostToDevice, st));
+    LLView Vm = m->ctx->V;
+    Vm.pose = m->M.pose; Vm.neq = m->M.neq; Vm.lm = m->M.lm;
+    if (stage == 0) ll_launch_lm_begin(Vm, 0, 1, o, st);
+    else if (stage == 1) ll_launch_lm_propose(Vm, 0, 1, o, st);
+    else ll_launch_lm_accept(Vm, 0, 1, o, st);
+    LLM_HIP(hipGetLastError());
+    LLM_HIP(hipStreamSynchronize(st));                          /* neq44_sum may be reused by the caller */
+    return LL_OK;
+}
+
+extern "C" int ll_map_lm_begin(ll_map *m, const double *neq44_sum, const ll_lm_options *opt) { return map_lm_stage(m, 0, neq44_sum, opt); }
+extern "C" int ll_map_lm_propose(ll_map *m, const ll_lm_options *opt) { return map_lm_stage(m, 1, nullptr, opt); }
+extern "C" int ll_map_lm_accept(ll_map *m, const double *neq44_sum, const ll_lm_options *opt) { return map_lm_stage(m, 2, neq44_sum, opt); }
+
 /* ------------------------------------------------------------------ downloads */
 static int dl(ll_ctx *ctx, void *dst, const void *src, size_t bytes)
 {

@@ -120,3 +120,67 @@ def test_small_map_is_left_alone(scene, api):
         m.set_map(scene["corner_map"][:65], scene["surf_map"][:60])
     assert e.value.code == -4
     m.close(); ctx.close()
+
+
+# ---- row-parallel over ranks (SURVEY 8e / BASELINE config 4): two processes share the box's one GPU, gloo carries the
+# all-reduce (RCCL needs one device per rank; the driver's multi-GPU runs use it through the same code path)
+def _row_parallel_worker(rank, world, port, rings, out):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    try:
+        import torch.distributed as dist
+        import lightloam_amd  # noqa: F401
+        from lightloam_amd import api, parallel, synth
+        from oracle import orc
+
+        class Req:
+            param = rings
+        sc = scene.__wrapped__(Req, orc, synth)
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        ctx = api.Context(api.default_params(rings, batch=1, max_points=4096))
+        cs, ss = sc["corner_stack"][rank::world], sc["surf_stack"][rank::world]          # this rank's share of the rows
+        m = api.Map(ctx, len(sc["corner_map"]) + 8, len(sc["surf_map"]) + 8, len(cs) + 8, len(ss) + 8)
+        m.set_map(sc["corner_map"], sc["surf_map"])
+        m.set_scan(cs, ss)
+        pose = parallel.map_optimize_row_parallel(m, sc["guess"])
+        m.close()
+        if rank == 0:
+            full = api.Map(ctx, len(sc["corner_map"]) + 8, len(sc["surf_map"]) + 8, len(sc["corner_stack"]) + 8, len(sc["surf_stack"]) + 8)
+            full.set_map(sc["corner_map"], sc["surf_map"]); full.set_scan(sc["corner_stack"], sc["surf_stack"])
+            ref, ran = full.optimize(sc["guess"])
+            full.close()
+            assert ran and np.abs(pose - ref).max() < 1e-7, (pose, ref)
+        import torch
+        got = [torch.zeros(7, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(got, torch.from_numpy(pose))
+        assert all((got[0] == g).all() for g in got)                                     # identical LM state everywhere
+        ctx.close()
+        out.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        out.put((rank, repr(e) + traceback.format_exc()))
+    finally:
+        try:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.destroy_process_group()
+        except Exception:
+            pass
+
+
+def test_row_parallel_two_ranks_match_one():
+    import multiprocessing as mp
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mpc = mp.get_context("spawn")
+    out = mpc.Queue()
+    procs = [mpc.Process(target=_row_parallel_worker, args=(r, 2, port, 16, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
