@@ -157,6 +157,42 @@ private:
     Context &c_;
 };
 
+/* ---- laserMapping's optimisation block (first stage) -------------------------------------------------
+ * What laserMapping.cpp:1822-2095 does once per frame, with the names it uses: the clouds gathered from the cube map,
+ * the scan's down-sized feature clouds, parameters[7] = (q_w_curr x,y,z,w, t_w_curr).  The cube bookkeeping around it
+ * (:1584-1808, :2101-2165) stays in the caller. */
+class MapOptimizer {
+public:
+    MapOptimizer(Context &c, int max_map_corner, int max_map_surf, int max_scan_corner, int max_scan_surf) {
+        c.check(ll_map_create(c.get(), max_map_corner, max_map_surf, max_scan_corner, max_scan_surf, &m_));
+    }
+    ~MapOptimizer() { ll_map_destroy(m_); }
+    MapOptimizer(const MapOptimizer &) = delete;
+    MapOptimizer &operator=(const MapOptimizer &) = delete;
+    /* kdtreeCornerFromMap->setInputCloud(laserCloudCornerFromMap); kdtreeSurfFromMap->setInputCloud(...) (:1826-1827) */
+    void setInputClouds(const std::vector<PointXYZI> &laserCloudCornerFromMap, const std::vector<PointXYZI> &laserCloudSurfFromMap) {
+        check(ll_map_set_map(m_, (const ll_point *)laserCloudCornerFromMap.data(), (int)laserCloudCornerFromMap.size(),
+                             (const ll_point *)laserCloudSurfFromMap.data(), (int)laserCloudSurfFromMap.size()));
+    }
+    /* laserCloudCornerStack / laserCloudSurfStack (:1813-1821) */
+    void setScan(const std::vector<PointXYZI> &laserCloudCornerStack, const std::vector<PointXYZI> &laserCloudSurfStack) {
+        check(ll_map_set_scan(m_, (const ll_point *)laserCloudCornerStack.data(), (int)laserCloudCornerStack.size(),
+                              (const ll_point *)laserCloudSurfStack.data(), (int)laserCloudSurfStack.size()));
+    }
+    /* the `if (laserCloudCornerFromMapNum > 10 && laserCloudSurfFromMapNum > 50)` block: iterCount 0..1, data association
+     * + ceres::Solve each.  Returns false where the reference prints "time Map corner and surf num are not enough". */
+    bool optimize(double parameters[7], int iterations = 2) {
+        int ran = 0;
+        check(ll_map_optimize(m_, parameters, iterations, nullptr, &ran));
+        return ran != 0;
+    }
+    void counts(int &corner_num, int &surf_num) { check(ll_map_get_counts(m_, &corner_num, &surf_num)); }
+    ll_map *get() const { return m_; }
+private:
+    void check(int rc) { if (rc != LL_OK) throw Error(rc, ll_map_last_error(m_)); }
+    ll_map *m_ = nullptr;
+};
+
 /* ---- I/O surface ---------------------------------------------------------------------------------- */
 
 /* KITTI velodyne .bin: float32 (x, y, z, reflectance) per point -- src/kittiHelper.cpp:22-32, same name */
