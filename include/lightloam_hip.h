@@ -221,6 +221,10 @@ int ll_map_lm_begin(ll_map *m, const double *neq44_sum, const ll_lm_options *opt
 int ll_map_lm_propose(ll_map *m, const ll_lm_options *opt);                               /* current pose <- candidate (or unchanged) */
 int ll_map_lm_accept(ll_map *m, const double *neq44_sum, const ll_lm_options *opt);       /* current pose <- accepted state */
 
+/* pcl::VoxelGrid<PointType>::filter on a whole cloud of any size (downSizeFilterCorner / downSizeFilterSurf,
+ * laserMapping.cpp:1813-1821, :2151-2165): centroids (x, y, z, intensity) per voxel, in voxel-index order.       */
+int ll_voxel_grid(ll_ctx *ctx, const ll_point *host_in, int n, float leaf_size, ll_point *host_out, int cap, int *n_out);
+
 /* ---------------------------------------------------------------- whole hot path
  * One pass: extract + associate + vote + normal equations + one GN step for slots [first, first+count),
  * everything device-resident, no host synchronisation inside.  `vote_enable` as above.                   */

@@ -25,7 +25,7 @@ EXPORTS = [
     "ll_lm_default_options", "ll_lm_solve_batch", "ll_odometry_frames",
     "ll_map_create", "ll_map_destroy", "ll_map_last_error", "ll_map_set_map", "ll_map_set_scan", "ll_map_associate",
     "ll_map_get_counts", "ll_map_download_edges", "ll_map_download_planes", "ll_map_normal_equations", "ll_map_optimize",
-    "ll_map_set_pose", "ll_map_get_pose", "ll_map_evaluate", "ll_map_lm_begin", "ll_map_lm_propose", "ll_map_lm_accept",
+    "ll_voxel_grid", "ll_map_set_pose", "ll_map_get_pose", "ll_map_evaluate", "ll_map_lm_begin", "ll_map_lm_propose", "ll_map_lm_accept",
 ]
 
 
@@ -267,6 +267,13 @@ class Context:
         names = (C.c_char_p * 16)(); ms = (C.c_double * 16)(); launches = (C.c_int * 16)()
         self._ck(self.lib.ll_profile_read(self.h, C.byref(n), names, ms, launches, int(bool(reset))))
         return {names[i].decode(): (ms[i], launches[i]) for i in range(n.value)}
+
+    def voxel_grid(self, points, leaf):
+        """pcl::VoxelGrid on a whole cloud (N x 4 float32) -> filtered cloud"""
+        pts = np.ascontiguousarray(points, np.float32)
+        out = np.zeros((max(len(pts), 1), 4), np.float32); n = C.c_int(0)
+        self._ck(self.lib.ll_voxel_grid(self.h, _ptr(pts), len(pts), C.c_float(leaf), _ptr(out), len(out), C.byref(n)))
+        return out[:n.value].copy()
 
     def algorithmic_bytes(self, first=0, count=1):
         b = [C.c_double(0) for _ in range(4)]

@@ -728,6 +728,39 @@ extern "C" int ll_map_lm_begin(ll_map *m, const double *neq44_sum, const ll_lm_o
 extern "C" int ll_map_lm_propose(ll_map *m, const ll_lm_options *opt) { return map_lm_stage(m, 1, nullptr, opt); }
 extern "C" int ll_map_lm_accept(ll_map *m, const double *neq44_sum, const ll_lm_options *opt) { return map_lm_stage(m, 2, neq44_sum, opt); }
 
+extern "C" int ll_voxel_grid(ll_ctx *ctx, const ll_point *host_in, int n, float leaf_size, ll_point *host_out, int cap, int *n_out)
+{
+    if (!ctx || !n_out || n < 0 || (n > 0 && !host_in) || !(leaf_size > 0.0f)) { if (ctx) ctx->err = "bad voxel grid arguments"; return LL_ERR_ARG; }
+    *n_out = 0;
+    if (n == 0) return LL_OK;
+    LL_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    void *work = nullptr; float4 *d_in = nullptr, *d_out = nullptr; int *d_n = nullptr;
+    int rc = LL_OK;
+    const int seg_off[2] = {0, n};
+    LLVoxWork W;
+    auto fail = [&](const char *what) { ctx->err = what; rc = LL_ERR_HIP; };
+    if (hipMalloc(&work, ll_vox_work_bytes(n, 1)) != hipSuccess || hipMalloc((void **)&d_in, (size_t)n * 16) != hipSuccess ||
+        hipMalloc((void **)&d_out, (size_t)n * 16) != hipSuccess || hipMalloc((void **)&d_n, sizeof(int)) != hipSuccess) fail("hipMalloc failed");
+    if (rc == LL_OK) {
+        ll_vox_work_carve(work, n, 1, &W);
+        if (hipMemcpyAsync(d_in, host_in, (size_t)n * 16, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(W.seg_off, seg_off, sizeof(seg_off), hipMemcpyHostToDevice, st) != hipSuccess) fail("upload failed");
+    }
+    if (rc == LL_OK) {
+        ll_voxel_grid_segments(d_in, n, 1, leaf_size, W, d_out, d_n, st);
+        int m = 0;
+        if (hipMemcpyAsync(&m, d_n, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) fail("voxel grid failed");
+        else if (m > cap) { ctx->err = "voxel grid output capacity too small"; rc = LL_ERR_CAPACITY; *n_out = m; }
+        else {
+            *n_out = m;
+            if (m > 0 && host_out && (hipMemcpyAsync(host_out, d_out, (size_t)m * 16, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) fail("download failed");
+        }
+    }
+    (void)hipFree(d_n); (void)hipFree(d_out); (void)hipFree(d_in); (void)hipFree(work);
+    return rc;
+}
+
 /* ------------------------------------------------------------------ downloads */
 static int dl(ll_ctx *ctx, void *dst, const void *src, size_t bytes)
 {

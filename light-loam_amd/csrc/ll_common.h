@@ -196,6 +196,19 @@ void ll_map_launch_build(const LLGrid3 &G, const float4 *pts, int n, int *tile_s
 void ll_map_launch_associate(const LLMapView &M, hipStream_t st);
 void ll_map_launch_normal_eq(const LLMapView &M, hipStream_t st);
 
+/* ---- whole-cloud VoxelGrid (ll_voxel.hip) ---- */
+struct LLVoxSeg;
+struct LLVoxWork {
+    int cap, max_seg;
+    int *segid, *bbox, *seg_off, *flag, *rank, *vals, *tmp_vals, *hist, *tile_sum, *seg_count;
+    unsigned long long *keys, *tmp_keys, *or_and;
+    LLVoxSeg *sp;
+};
+size_t ll_vox_work_bytes(int cap, int max_seg);
+void ll_vox_work_carve(void *base, int cap, int max_seg, LLVoxWork *W);
+void ll_voxel_grid_segments(const float4 *pts, int n, int nseg, float leaf, const LLVoxWork &W, float4 *out, int *n_out_dev, hipStream_t st);
+void ll_device_exscan(int *data, int n, int *tile_sum, hipStream_t st);
+
 struct LLProfiler;
 void ll_prof_mark(LLProfiler *p, int kernel_id, hipStream_t st);
 

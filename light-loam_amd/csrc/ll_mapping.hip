@@ -375,6 +375,16 @@ __global__ __launch_bounds__(1024) void k_map_normal_eq(LLMapView M)
 }
 
 /* ------------------------------------------------------------------ launchers */
+/* in-place exclusive scan of n ints (n <= 4096 * 4096); tile_sum: ceil(n / 4096) ints of scratch */
+void ll_device_exscan(int *data, int n, int *tile_sum, hipStream_t st)
+{
+    if (n <= 0) return;
+    const int nt = (n + LL_SCAN_TILE - 1) / LL_SCAN_TILE;
+    hipLaunchKernelGGL(k_scan_tiles, dim3(nt), dim3(1024), 0, st, data, n, tile_sum);
+    hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, st, tile_sum, nt);
+    hipLaunchKernelGGL(k_scan_add, dim3(nt), dim3(1024), 0, st, data, n, tile_sum);
+}
+
 void ll_map_launch_bbox(const float4 *pts, int n, int *bbox_dev, hipStream_t st)
 {
     const int init[6] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN};
@@ -403,10 +413,7 @@ void ll_map_launch_build(const LLGrid3 &G, const float4 *pts, int n, int *tile_s
     const int ns = G.ncell + 1;
     (void)hipMemsetAsync(G.start, 0, (size_t)ns * sizeof(int), st);
     if (n > 0) hipLaunchKernelGGL(k_map_count, dim3((n + LL_MAPB - 1) / LL_MAPB), dim3(LL_MAPB), 0, st, G, pts, n);
-    const int nt = (ns + LL_SCAN_TILE - 1) / LL_SCAN_TILE;
-    hipLaunchKernelGGL(k_scan_tiles, dim3(nt), dim3(1024), 0, st, G.start, ns, tile_sum);
-    hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, st, tile_sum, nt);
-    hipLaunchKernelGGL(k_scan_add, dim3(nt), dim3(1024), 0, st, G.start, ns, tile_sum);
+    ll_device_exscan(G.start, ns, tile_sum, st);
     (void)hipMemcpyAsync(G.cursor, G.start, (size_t)G.ncell * sizeof(int), hipMemcpyDeviceToDevice, st);
     if (n > 0) hipLaunchKernelGGL(k_map_scatter, dim3((n + LL_MAPB - 1) / LL_MAPB), dim3(LL_MAPB), 0, st, G, pts, n);
 }

@@ -1,0 +1,277 @@
+/*
+ * ll_voxel.hip -- pcl::VoxelGrid<PointXYZI>::filter for whole clouds of any size, many clouds per call.
+ * Replaces downSizeFilterCorner / downSizeFilterSurf .filter() of /root/reference/src/laserMapping.cpp (:1813-1821 on
+ * the scan, :2151-2165 on every cube of the 5 x 5 x 3 neighbourhood); the per-ring filter of scanRegistration stays in
+ * k_ring_features.
+ *
+ * The clouds ("segments") lie back to back in one array.  Per segment PCL computes the bounding box, the voxel index
+ * of every point ((floor(x/leaf) - min_b) . (1, div_x, div_x div_y)), sorts by index, and emits one centroid (x, y, z,
+ * intensity: f32 sums divided by the count) per distinct index, in index order.  Here:
+ *   k_vx_segid / k_vx_bbox / k_vx_params / k_vx_keys   segment of every point, bounding boxes by ordered-int atomics,
+ *                       PCL's box arithmetic per segment, 64-bit keys (segment << 32 | voxel index)
+ *   ll_sort_pairs       device-wide stable LSD radix sort (4-bit digits; tile histograms -> scan -> stable scatter with
+ *                       wave match-any ranking); digits that are equal for all keys are skipped
+ *   k_vx_heads / scan / k_vx_centroid   run heads -> output rank -> sums in INPUT order (the sort is stable; PCL's
+ *                       std::sort leaves the order inside a voxel unspecified, the oracle defines input order too)
+ * "Leaf size is too small" (more than INT_MAX voxels): the segment is passed through unchanged, as in PCL.
+ */
+#include "ll_common.h"
+#include <limits.h>
+
+#define LL_VB 256
+
+__device__ __forceinline__ int ll_vx_f2ord(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
+__device__ __forceinline__ float ll_vx_ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
+/* seg_off[nseg + 1]: ascending input offsets; segid[i] = the segment that holds point i */
+__global__ __launch_bounds__(LL_VB) void k_vx_segid(const int *seg_off, int nseg, int n, int *segid, int *bbox)
+{
+    const int i = blockIdx.x * LL_VB + threadIdx.x;
+    if (i < nseg * 6) bbox[i] = (i % 6 < 3) ? INT_MAX : INT_MIN;
+    if (i >= n) return;
+    int lo = 0, hi = nseg - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (seg_off[mid] <= i) lo = mid; else hi = mid - 1; }
+    segid[i] = lo;
+}
+
+__global__ __launch_bounds__(LL_VB) void k_vx_bbox(const float4 *pts, const int *segid, int n, int *bbox)
+{
+    const int i = blockIdx.x * LL_VB + threadIdx.x;
+    const bool in = i < n;
+    const float4 p = in ? pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int s = in ? segid[i] : -1;
+    /* most waves hold one segment: reduce in the wave, one set of atomics */
+    const int s0 = __builtin_amdgcn_readfirstlane(s);
+    if (__ballot(s != s0 && in) == 0ull && s0 >= 0) {
+        float mn[3] = {in ? p.x : INFINITY, in ? p.y : INFINITY, in ? p.z : INFINITY};
+        float mx[3] = {in ? p.x : -INFINITY, in ? p.y : -INFINITY, in ? p.z : -INFINITY};
+        for (int o = 32; o > 0; o >>= 1)
+            for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], o)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o)); }
+        if ((threadIdx.x & 63) == 0)
+            for (int k = 0; k < 3; ++k) { atomicMin(&bbox[s0 * 6 + k], ll_vx_f2ord(mn[k])); atomicMax(&bbox[s0 * 6 + 3 + k], ll_vx_f2ord(mx[k])); }
+    } else if (in) {
+        atomicMin(&bbox[s * 6 + 0], ll_vx_f2ord(p.x)); atomicMin(&bbox[s * 6 + 1], ll_vx_f2ord(p.y)); atomicMin(&bbox[s * 6 + 2], ll_vx_f2ord(p.z));
+        atomicMax(&bbox[s * 6 + 3], ll_vx_f2ord(p.x)); atomicMax(&bbox[s * 6 + 4], ll_vx_f2ord(p.y)); atomicMax(&bbox[s * 6 + 5], ll_vx_f2ord(p.z));
+    }
+}
+
+/* per segment: min_b[3] as floats, mul1, mul2, too_small  (voxel_grid.hpp applyFilter, PCL 1.10) */
+struct LLVoxSeg { float fb[3]; int mul1, mul2, too_small; };
+
+__global__ void k_vx_params(const int *bbox, const int *seg_off, int nseg, float inv, LLVoxSeg *sp)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nseg) return;
+    LLVoxSeg o;
+    o.fb[0] = o.fb[1] = o.fb[2] = 0.0f; o.mul1 = 1; o.mul2 = 1; o.too_small = 0;
+    if (seg_off[s + 1] > seg_off[s]) {
+        long long d[3]; int min_b[3], div_b[3];
+        for (int c = 0; c < 3; ++c) {
+            const float mn = ll_vx_ord2f(bbox[s * 6 + c]), mx = ll_vx_ord2f(bbox[s * 6 + 3 + c]);
+            d[c] = (long long)((mx - mn) * inv) + 1;
+            min_b[c] = (int)floorf(mn * inv);
+            div_b[c] = (int)floorf(mx * inv) - min_b[c] + 1;
+        }
+        o.too_small = d[0] * d[1] * d[2] > (long long)INT_MAX;
+        o.mul1 = div_b[0]; o.mul2 = div_b[0] * div_b[1];
+        for (int c = 0; c < 3; ++c) o.fb[c] = (float)min_b[c];
+    }
+    sp[s] = o;
+}
+
+__global__ __launch_bounds__(LL_VB) void k_vx_keys(const float4 *pts, const int *segid, const int *seg_off, const LLVoxSeg *sp, int n, float inv,
+                                                  unsigned long long *keys, int *vals)
+{
+    const int i = blockIdx.x * LL_VB + threadIdx.x;
+    if (i >= n) return;
+    const int s = segid[i];
+    const LLVoxSeg P = sp[s];
+    const float4 p = pts[i];
+    unsigned idx;
+    if (P.too_small) idx = (unsigned)(i - seg_off[s]);
+    else {
+        const int i0 = (int)(floorf(p.x * inv) - P.fb[0]);
+        const int i1 = (int)(floorf(p.y * inv) - P.fb[1]);
+        const int i2 = (int)(floorf(p.z * inv) - P.fb[2]);
+        idx = (unsigned)(i0 + i1 * P.mul1 + i2 * P.mul2);
+    }
+    keys[i] = ((unsigned long long)(unsigned)s << 32) | idx;
+    vals[i] = i;
+}
+
+/* ------------------------------------------------------------------ device-wide stable radix sort of (u64 key, i32 value) */
+#define LL_RS_TILE 4096           /* keys per workgroup: 4 rows of 1024 */
+#define LL_RS_ROWS 4
+
+__global__ __launch_bounds__(LL_VB) void k_rs_or_and(const unsigned long long *keys, int n, unsigned long long *or_and)
+{
+    unsigned long long o = 0ull, a = ~0ull;
+    for (int i = blockIdx.x * LL_VB + threadIdx.x; i < n; i += gridDim.x * LL_VB) { const unsigned long long k = keys[i]; o |= k; a &= k; }
+    for (int s = 32; s > 0; s >>= 1) { o |= __shfl_xor(o, s); a &= __shfl_xor(a, s); }
+    if ((threadIdx.x & 63) == 0) { atomicOr(&or_and[0], o); atomicAnd(&or_and[1], a); }
+}
+
+__global__ __launch_bounds__(1024) void k_rs_hist(const unsigned long long *keys, int n, int shift, int nblk, int *hist /* [16][nblk] */)
+{
+    __shared__ int h[16];
+    const int tid = threadIdx.x;
+    if (tid < 16) h[tid] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * LL_RS_TILE;
+#pragma unroll
+    for (int r = 0; r < LL_RS_ROWS; ++r) {
+        const int i = base + r * 1024 + tid;
+        const bool in = i < n;
+        const int d = in ? (int)((keys[i] >> shift) & 15ull) : 0;
+        unsigned mlo, mhi;
+        ll_match_any(d, 4, __ballot(in), mlo, mhi);
+        if (in && ll_match_rank(mlo, mhi) == 0) atomicAdd(&h[d], ll_match_count(mlo, mhi));
+    }
+    __syncthreads();
+    if (tid < 16) hist[tid * nblk + blockIdx.x] = h[tid];
+}
+
+__global__ __launch_bounds__(1024) void k_rs_scatter(const unsigned long long *keys, const int *vals, int n, int shift, int nblk,
+                                                     const int *hist_scanned, unsigned long long *keys_out, int *vals_out)
+{
+    __shared__ int cnt[16 * LL_RS_ROWS * 16];        /* [digit][row * 16 + wave] */
+    __shared__ int sc[16];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    cnt[tid] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * LL_RS_TILE;
+    unsigned long long k[LL_RS_ROWS]; int v[LL_RS_ROWS], rnk[LL_RS_ROWS];
+#pragma unroll
+    for (int r = 0; r < LL_RS_ROWS; ++r) {
+        const int i = base + r * 1024 + tid;
+        const bool in = i < n;
+        k[r] = in ? keys[i] : ~0ull; v[r] = in ? vals[i] : 0;
+        const int d = (int)((k[r] >> shift) & 15ull);
+        unsigned mlo, mhi;
+        ll_match_any(d, 4, __ballot(in), mlo, mhi);
+        rnk[r] = ll_match_rank(mlo, mhi);
+        if (in && rnk[r] == 0) cnt[d * (LL_RS_ROWS * 16) + r * 16 + wave] = ll_match_count(mlo, mhi);
+    }
+    __syncthreads();
+    const int mine = cnt[tid];
+    int total;
+    const int ex = ll_block_exscan_n<16>(mine, sc, total);       /* digit-major: earlier digits, then earlier (row, wave) */
+    cnt[tid] = ex;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < LL_RS_ROWS; ++r) {
+        const int i = base + r * 1024 + tid;
+        if (i >= n) continue;
+        const int d = (int)((k[r] >> shift) & 15ull);
+        const int within = cnt[d * (LL_RS_ROWS * 16) + r * 16 + wave] - cnt[d * (LL_RS_ROWS * 16)] + rnk[r];
+        const int pos = hist_scanned[d * nblk + blockIdx.x] + within;
+        keys_out[pos] = k[r]; vals_out[pos] = v[r];
+    }
+}
+
+/* sorts (keys, vals) by keys, stable; the result is in (keys, vals) again.  tmp_* hold n elements, hist 16 * ceil(n/4096)
+ * ints, tile_sum as for ll_device_exscan of that, or_and_host is pinned host memory for the varying-bit mask */
+void ll_sort_pairs(unsigned long long *keys, int *vals, unsigned long long *tmp_keys, int *tmp_vals, int n, int *hist, int *tile_sum,
+                   unsigned long long *or_and_dev, hipStream_t st)
+{
+    if (n <= 1) return;
+    const unsigned long long init[2] = {0ull, ~0ull};
+    unsigned long long oa[2];
+    (void)hipMemcpyAsync(or_and_dev, init, sizeof(init), hipMemcpyHostToDevice, st);
+    hipLaunchKernelGGL(k_rs_or_and, dim3(min(1024, (n + LL_VB - 1) / LL_VB)), dim3(LL_VB), 0, st, keys, n, or_and_dev);
+    (void)hipMemcpyAsync(oa, or_and_dev, sizeof(oa), hipMemcpyDeviceToHost, st);
+    (void)hipStreamSynchronize(st);
+    const unsigned long long vary = oa[0] ^ oa[1];                /* bits that differ between some two keys */
+    const int nblk = (n + LL_RS_TILE - 1) / LL_RS_TILE;
+    unsigned long long *ki = keys, *ko = tmp_keys; int *vi = vals, *vo = tmp_vals;
+    for (int shift = 0; shift < 64; shift += 4) {
+        if (((vary >> shift) & 15ull) == 0ull) continue;
+        hipLaunchKernelGGL(k_rs_hist, dim3(nblk), dim3(1024), 0, st, ki, n, shift, nblk, hist);
+        ll_device_exscan(hist, 16 * nblk, tile_sum, st);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(nblk), dim3(1024), 0, st, ki, vi, n, shift, nblk, hist, ko, vo);
+        unsigned long long *tk = ki; ki = ko; ko = tk;
+        int *tv = vi; vi = vo; vo = tv;
+    }
+    if (ki != keys) {
+        (void)hipMemcpyAsync(keys, ki, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToDevice, st);
+        (void)hipMemcpyAsync(vals, vi, (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, st);
+    }
+}
+
+/* ------------------------------------------------------------------ runs -> centroids */
+__global__ __launch_bounds__(LL_VB) void k_vx_heads(const unsigned long long *keys, int n, int nseg, int *flag, int *seg_count)
+{
+    const int i = blockIdx.x * LL_VB + threadIdx.x;
+    if (i < nseg) seg_count[i] = 0;
+    if (i >= n) return;
+    flag[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(LL_VB) void k_vx_centroid(const float4 *pts, const unsigned long long *keys, const int *vals, const int *flag,
+                                                      const int *rank, int n, float4 *out, int *seg_count)
+{
+    const int i = blockIdx.x * LL_VB + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    const unsigned long long key = keys[i];
+    /* CentroidPoint<PointXYZI>: f32 sums from zero in input order, divided by float(n) */
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f; int cn = 0;
+    for (int j = i; j < n && keys[j] == key; ++j) {
+        const float4 p = pts[vals[j]];
+        sx += p.x; sy += p.y; sz += p.z; si += p.w; ++cn;
+    }
+    const float fn = (float)cn;
+    out[rank[i]] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
+    atomicAdd(&seg_count[(int)(key >> 32)], 1);
+}
+
+/* workspace for up to cap points / max_seg segments: one device allocation carved into LLVoxWork (ll_common.h) */
+size_t ll_vox_work_bytes(int cap, int max_seg)
+{
+    const size_t nblk = ((size_t)cap + LL_RS_TILE - 1) / LL_RS_TILE + 1;
+    size_t b = 0;
+    b += (size_t)cap * sizeof(int) * 5;                             /* segid, flag, rank, vals, tmp_vals */
+    b += (size_t)cap * sizeof(unsigned long long) * 2;              /* keys, tmp_keys */
+    b += (size_t)max_seg * (6 + 1 + 1) * sizeof(int) + sizeof(int); /* bbox, seg_off (+1), seg_count */
+    b += (size_t)max_seg * sizeof(LLVoxSeg);
+    b += 16 * nblk * sizeof(int) + (16 * nblk / 4096 + 2) * sizeof(int) + ((size_t)cap / 4096 + 2) * sizeof(int);
+    b += 2 * sizeof(unsigned long long);
+    return b + 4096;
+}
+
+void ll_vox_work_carve(void *base, int cap, int max_seg, LLVoxWork *W)
+{
+    unsigned char *p = (unsigned char *)base;
+    auto take = [&](size_t bytes) { void *r = p; p += (bytes + 255) / 256 * 256; return r; };
+    const size_t nblk = ((size_t)cap + LL_RS_TILE - 1) / LL_RS_TILE + 1;
+    W->cap = cap; W->max_seg = max_seg;
+    W->keys = (unsigned long long *)take((size_t)cap * 8); W->tmp_keys = (unsigned long long *)take((size_t)cap * 8);
+    W->or_and = (unsigned long long *)take(16);
+    W->segid = (int *)take((size_t)cap * 4); W->flag = (int *)take((size_t)cap * 4); W->rank = (int *)take((size_t)cap * 4 + 4);
+    W->vals = (int *)take((size_t)cap * 4); W->tmp_vals = (int *)take((size_t)cap * 4);
+    W->bbox = (int *)take((size_t)max_seg * 24); W->seg_off = (int *)take((size_t)(max_seg + 1) * 4); W->seg_count = (int *)take((size_t)max_seg * 4);
+    W->sp = (LLVoxSeg *)take((size_t)max_seg * sizeof(LLVoxSeg));
+    W->hist = (int *)take(16 * nblk * 4);
+    W->tile_sum = (int *)take((16 * nblk / 4096 + 2 + (size_t)cap / 4096 + 2) * 4);
+}
+
+/* pts[0..n): nseg clouds back to back, seg_off (device, nseg + 1 ascending offsets, seg_off[nseg] = n).
+ * out: the filtered clouds back to back in segment order; seg_count (W.seg_count, device): points per filtered cloud;
+ * *n_out_dev (device int, may alias nothing else): total.  Everything is enqueued on st except the sort's one
+ * host read-back of the varying key bits. */
+void ll_voxel_grid_segments(const float4 *pts, int n, int nseg, float leaf, const LLVoxWork &W, float4 *out, int *n_out_dev, hipStream_t st)
+{
+    const float inv = 1.0f / leaf;                                   /* inverse_leaf_size_ = Array4f::Ones() / leaf_size_ */
+    const int nb = (max(n, nseg * 6) + LL_VB - 1) / LL_VB;
+    hipLaunchKernelGGL(k_vx_segid, dim3(max(nb, 1)), dim3(LL_VB), 0, st, W.seg_off, nseg, n, W.segid, W.bbox);
+    if (n <= 0) { (void)hipMemsetAsync(W.seg_count, 0, (size_t)nseg * sizeof(int), st); (void)hipMemsetAsync(n_out_dev, 0, sizeof(int), st); return; }
+    hipLaunchKernelGGL(k_vx_bbox, dim3((n + LL_VB - 1) / LL_VB), dim3(LL_VB), 0, st, pts, W.segid, n, W.bbox);
+    hipLaunchKernelGGL(k_vx_params, dim3((nseg + 63) / 64), dim3(64), 0, st, W.bbox, W.seg_off, nseg, inv, W.sp);
+    hipLaunchKernelGGL(k_vx_keys, dim3((n + LL_VB - 1) / LL_VB), dim3(LL_VB), 0, st, pts, W.segid, W.seg_off, W.sp, n, inv, W.keys, W.vals);
+    ll_sort_pairs(W.keys, W.vals, W.tmp_keys, W.tmp_vals, n, W.hist, W.tile_sum, W.or_and, st);
+    hipLaunchKernelGGL(k_vx_heads, dim3((max(n, nseg) + LL_VB - 1) / LL_VB), dim3(LL_VB), 0, st, W.keys, n, nseg, W.flag, W.seg_count);
+    (void)hipMemcpyAsync(W.rank, W.flag, (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, st);
+    (void)hipMemsetAsync(W.rank + n, 0, sizeof(int), st);
+    ll_device_exscan(W.rank, n + 1, W.tile_sum, st);                 /* rank[n] = number of voxels */
+    (void)hipMemcpyAsync(n_out_dev, W.rank + n, sizeof(int), hipMemcpyDeviceToDevice, st);
+    hipLaunchKernelGGL(k_vx_centroid, dim3((n + LL_VB - 1) / LL_VB), dim3(LL_VB), 0, st, pts, W.keys, W.vals, W.flag, W.rank, n, out, W.seg_count);
+}
