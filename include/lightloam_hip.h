@@ -225,6 +225,29 @@ int ll_map_lm_accept(ll_map *m, const double *neq44_sum, const ll_lm_options *op
  * laserMapping.cpp:1813-1821, :2151-2165): centroids (x, y, z, intensity) per voxel, in voxel-index order.       */
 int ll_voxel_grid(ll_ctx *ctx, const ll_point *host_in, int n, float leaf_size, ll_point *host_out, int cap, int *n_out);
 
+/* ---------------------------------------------------------------- laserMapping's cube map (second stage)
+ * The 21 x 21 x 11 cubes of 50 m that hold the map (laserMapping.cpp:45-53, :74-75), resident in HBM, and the per-frame
+ * body around the optimisation: ll_cubemap_prepare = :1584-1821 (centre cube of t_w_curr, the six shift loops, the
+ * 5 x 5 x 3 valid cubes gathered into laserCloudCornerFromMap / SurfFromMap, the scan's less-sharp / less-flat clouds
+ * down-sized to laserCloudCornerStack / SurfStack), ll_cubemap_optimize = :1822-2100, ll_cubemap_update = :2103-2165
+ * (the registered scan's points into their cubes, every valid cube down-sized).  line_res / plane_res =
+ * mapping_line_resolution / mapping_plane_resolution (:2363-2364, defaults 0.4 / 0.8).  pool_points: HBM points per
+ * cloud type for the cubes (two pools of that size each).                                                          */
+typedef struct ll_cubemap ll_cubemap;
+int  ll_cubemap_create(ll_ctx *ctx, float line_res, float plane_res, int max_scan_corner, int max_scan_surf, int pool_points, ll_cubemap **out);
+void ll_cubemap_destroy(ll_cubemap *cm);
+const char *ll_cubemap_last_error(const ll_cubemap *cm);
+int ll_cubemap_prepare(ll_cubemap *cm, const double *t_w3, const ll_point *host_corner_last, int n_corner, const ll_point *host_surf_last, int n_surf);
+int ll_cubemap_optimize(ll_cubemap *cm, double *pose_w7, int n_outer, const ll_lm_options *opt, int *ran);
+int ll_cubemap_update(ll_cubemap *cm, const double *pose_w7);
+/* the three calls in sequence with the reference's constants; pose_w7 in: the guess of transformAssociateToMap (:1581) */
+int ll_cubemap_process(ll_cubemap *cm, double *pose_w7, const ll_point *host_corner_last, int n_corner, const ll_point *host_surf_last, int n_surf, int *ran);
+/* cen3: laserCloudCenWidth / Height / Depth; counts4: corner / surf from map, corner / surf stack */
+int ll_cubemap_info(ll_cubemap *cm, int *cen3, int *counts4);
+/* which: 0 laserCloudCornerFromMap, 1 laserCloudSurfFromMap, 2 laserCloudCornerStack, 3 laserCloudSurfStack */
+int ll_cubemap_download_cloud(ll_cubemap *cm, int which, ll_point *out, int cap, int *n);
+int ll_cubemap_download_cube(ll_cubemap *cm, int surf, int cube_index, ll_point *out, int cap, int *n);
+
 /* ---------------------------------------------------------------- whole hot path
  * One pass: extract + associate + vote + normal equations + one GN step for slots [first, first+count),
  * everything device-resident, no host synchronisation inside.  `vote_enable` as above.                   */

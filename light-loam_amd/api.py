@@ -25,6 +25,8 @@ EXPORTS = [
     "ll_lm_default_options", "ll_lm_solve_batch", "ll_odometry_frames",
     "ll_map_create", "ll_map_destroy", "ll_map_last_error", "ll_map_set_map", "ll_map_set_scan", "ll_map_associate",
     "ll_map_get_counts", "ll_map_download_edges", "ll_map_download_planes", "ll_map_normal_equations", "ll_map_optimize",
+    "ll_cubemap_create", "ll_cubemap_destroy", "ll_cubemap_last_error", "ll_cubemap_prepare", "ll_cubemap_optimize", "ll_cubemap_update",
+    "ll_cubemap_process", "ll_cubemap_info", "ll_cubemap_download_cloud", "ll_cubemap_download_cube",
     "ll_voxel_grid", "ll_map_set_pose", "ll_map_get_pose", "ll_map_evaluate", "ll_map_lm_begin", "ll_map_lm_propose", "ll_map_lm_accept",
 ]
 
@@ -382,3 +384,69 @@ class Map:
     def lm_accept(self, neq44, opt=None):
         v = np.ascontiguousarray(neq44, np.float64)
         self._ck(self.lib.ll_map_lm_accept(self.h, _ptr(v), None if opt is None else C.byref(opt)))
+
+
+class CubeMap:
+    """One ll_cubemap: laserMapping's cube map + per-frame body (laserMapping.cpp:1584-2165) on the device of `ctx`."""
+
+    def __init__(self, ctx, max_scan_corner, max_scan_surf, pool_points=1 << 20, line_res=0.4, plane_res=0.8):
+        self.ctx = ctx; self.lib = ctx.lib
+        self.lib.ll_cubemap_last_error.restype = C.c_char_p
+        self.lib.ll_cubemap_last_error.argtypes = [C.c_void_p]
+        self.lib.ll_cubemap_destroy.argtypes = [C.c_void_p]
+        self.h = C.c_void_p()
+        rc = self.lib.ll_cubemap_create(ctx.h, C.c_float(line_res), C.c_float(plane_res), int(max_scan_corner), int(max_scan_surf),
+                                        int(pool_points), C.byref(self.h))
+        if rc != LL_OK:
+            raise LightLoamError(rc, ctx.lib.ll_last_error(ctx.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ll_cubemap_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != LL_OK:
+            raise LightLoamError(rc, self.lib.ll_cubemap_last_error(self.h).decode())
+
+    def prepare(self, t_w, corner_last, surf_last):
+        t = np.ascontiguousarray(t_w, np.float64)
+        c = np.ascontiguousarray(corner_last, np.float32); s_ = np.ascontiguousarray(surf_last, np.float32)
+        self._ck(self.lib.ll_cubemap_prepare(self.h, _ptr(t), _ptr(c), len(c), _ptr(s_), len(s_)))
+
+    def optimize(self, pose_w, n_outer=2, opt=None):
+        p = np.ascontiguousarray(pose_w, np.float64).copy(); ran = C.c_int(0)
+        self._ck(self.lib.ll_cubemap_optimize(self.h, _ptr(p), n_outer, None if opt is None else C.byref(opt), C.byref(ran)))
+        return p, bool(ran.value)
+
+    def update(self, pose_w):
+        p = np.ascontiguousarray(pose_w, np.float64)
+        self._ck(self.lib.ll_cubemap_update(self.h, _ptr(p)))
+
+    def process(self, pose_w, corner_last, surf_last):
+        p = np.ascontiguousarray(pose_w, np.float64).copy(); ran = C.c_int(0)
+        c = np.ascontiguousarray(corner_last, np.float32); s_ = np.ascontiguousarray(surf_last, np.float32)
+        self._ck(self.lib.ll_cubemap_process(self.h, _ptr(p), _ptr(c), len(c), _ptr(s_), len(s_), C.byref(ran)))
+        return p, bool(ran.value)
+
+    def info(self):
+        cen = (C.c_int * 3)(); cnt = (C.c_int * 4)()
+        self._ck(self.lib.ll_cubemap_info(self.h, cen, cnt))
+        return tuple(cen), tuple(cnt)
+
+    def cloud(self, which):
+        _, cnt = self.info()
+        out = np.zeros((max(cnt[which], 1), 4), np.float32); n = C.c_int(0)
+        self._ck(self.lib.ll_cubemap_download_cloud(self.h, which, _ptr(out), len(out), C.byref(n)))
+        return out[:n.value].copy()
+
+    def cube(self, surf, index, cap=1 << 18):
+        out = np.zeros((cap, 4), np.float32); n = C.c_int(0)
+        self._ck(self.lib.ll_cubemap_download_cube(self.h, int(surf), int(index), _ptr(out), len(out), C.byref(n)))
+        return out[:n.value].copy()

@@ -3,23 +3,10 @@
  * No CPU fallback anywhere: every stage is a HIP kernel launch on the ctx stream; if the device or the gfx950
  * code object is unusable, ll_create fails with LL_ERR_DEVICE.
  */
-#include "lightloam_hip.h"
-#include "ll_common.h"
-#include <string>
-#include <vector>
-#include <cstring>
+#include "ll_internal.h"
 #include <cstdio>
 #include <cmath>
 
-#define LL_PROF_EVENTS 8192
-struct LLProfiler {
-    bool on = false;
-    std::vector<hipEvent_t> ev;
-    std::vector<int> id;          /* kernel that STARTS at event i, LL_K_END for a closing mark */
-    int n = 0;
-    double total_ms[LL_K_COUNT] = {0};
-    int launches[LL_K_COUNT] = {0};
-};
 static const char *const kKernelNames[LL_K_COUNT] = {"k_classify", "k_offsets", "k_scatter", "k_ring_features", "k_compact",
                                                      "k_associate", "k_vote", "k_normal_equations", "k_gn_step", "k_build_grid", "k_first_kept"};
 
@@ -36,34 +23,7 @@ void ll_prof_mark(LLProfiler *p, int kernel_id, hipStream_t st)
     p->n++;
 }
 
-struct ll_ctx {
-    LLProfiler prof;
-    ll_params p;
-    LLView V;
-    hipStream_t stream = nullptr;
-    int device = 0;
-    std::vector<void *> allocs;
-    std::string err;
-    size_t feat_lds = 0;
-    float4 *h_stage = nullptr;      /* pinned staging for uploads */
-    size_t h_stage_pts = 0;
-    double *d_tmp_pose = nullptr, *d_rows = nullptr;
-    size_t rows_cap = 0;
-    std::vector<int> n_in_host;
-    hipEvent_t ev[16];
-    bool ev_ok = false;
-};
-
 static std::string g_create_err;
-
-#define LL_HIP(call)                                                                         \
-    do {                                                                                     \
-        hipError_t e_ = (call);                                                              \
-        if (e_ != hipSuccess) {                                                              \
-            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                    \
-            return LL_ERR_HIP;                                                               \
-        }                                                                                    \
-    } while (0)
 
 extern "C" int ll_abi_version(void) { return LL_ABI_VERSION; }
 
@@ -372,7 +332,7 @@ extern "C" void ll_lm_default_options(ll_lm_options *o)
     o->jacobi_scaling = 1;
 }
 
-static LLLmOpt to_dev_opt(const ll_lm_options *opt)
+LLLmOpt ll_to_dev_opt(const ll_lm_options *opt)
 {
     ll_lm_options d; ll_lm_default_options(&d);
     if (opt) d = *opt;
@@ -399,7 +359,7 @@ static void enqueue_lm(ll_ctx *ctx, int first, int count, const LLLmOpt &o)
 extern "C" int ll_lm_solve_batch(ll_ctx *ctx, int first, int count, const ll_lm_options *opt)
 {
     int rc = check_range(ctx, first, count); if (rc) return rc;
-    const LLLmOpt o = to_dev_opt(opt);
+    const LLLmOpt o = ll_to_dev_opt(opt);
     if (o.max_num_iterations < 0 || o.max_num_iterations > 64) { ctx->err = "max_num_iterations out of range"; return LL_ERR_ARG; }
     ctx->V.carry_slot = first;
     enqueue_lm(ctx, first, count, o);
@@ -412,7 +372,7 @@ extern "C" int ll_odometry_frames(ll_ctx *ctx, int first, int count, const doubl
 {
     int rc = check_range(ctx, first, count); if (rc) return rc;
     if (n_outer < 1 || n_outer > 16) { ctx->err = "n_outer out of range"; return LL_ERR_ARG; }
-    const LLLmOpt o = to_dev_opt(opt);
+    const LLLmOpt o = ll_to_dev_opt(opt);
     double ident[7] = {0, 0, 0, 1, 0, 0, 0};
     LL_HIP(hipMemcpyAsync(ctx->V.pose + (size_t)first * 7, host_pose0 ? host_pose0 : ident, 7 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     LL_HIP(hipStreamSynchronize(ctx->stream));
@@ -461,35 +421,6 @@ extern "C" int ll_hot_path_batch(ll_ctx *ctx, int first, int count, const double
 }
 
 /* ------------------------------------------------------------------ mapping stage (ll_mapping.hip) */
-struct ll_map {
-    ll_ctx *ctx = nullptr;
-    LLMapView M;
-    int cap_map[2] = {0, 0}, cap_stk[2] = {0, 0};
-    int max_cells = 0;
-    float4 *d_map[2] = {nullptr, nullptr}, *d_stk[2] = {nullptr, nullptr};
-    int *d_bbox = nullptr, *d_tile = nullptr;
-    std::vector<void *> allocs;
-    std::string err;
-};
-
-#define LLM_HIP(call)                                                                        \
-    do {                                                                                     \
-        hipError_t e_ = (call);                                                              \
-        if (e_ != hipSuccess) { m->err = std::string(#call) + ": " + hipGetErrorString(e_); return LL_ERR_HIP; } \
-    } while (0)
-
-template <typename T>
-static bool map_alloc(ll_map *m, T *&ptr, size_t count)
-{
-    void *p = nullptr;
-    const size_t bytes = (count ? count : 1) * sizeof(T);
-    if (hipMalloc(&p, bytes) != hipSuccess) { m->err = "hipMalloc failed (" + std::to_string(bytes) + " bytes)"; return false; }
-    if (hipMemset(p, 0, bytes) != hipSuccess) { m->err = "hipMemset failed"; (void)hipFree(p); return false; }
-    m->allocs.push_back(p);
-    ptr = (T *)p;
-    return true;
-}
-
 extern "C" void ll_map_destroy(ll_map *m)
 {
     if (!m) return;
@@ -541,17 +472,13 @@ static int map_upload(ll_map *m, float4 *dst, const ll_point *src, int n)
     return LL_OK;
 }
 
-extern "C" int ll_map_set_map(ll_map *m, const ll_point *corner, int n_corner, const ll_point *surf, int n_surf)
+/* search grids over the clouds that already sit in d_map[0 / 1] (uploaded by ll_map_set_map, gathered by the cube map) */
+int ll_map_rebuild(ll_map *m, int n_corner, int n_surf)
 {
-    if (!m) return LL_ERR_ARG;
-    if (n_corner < 0 || n_surf < 0 || (!corner && n_corner > 0) || (!surf && n_surf > 0)) { m->err = "bad map clouds"; return LL_ERR_ARG; }
-    if (n_corner > m->cap_map[0] || n_surf > m->cap_map[1]) { m->err = "map cloud larger than the capacity given to ll_map_create"; return LL_ERR_CAPACITY; }
-    LLM_HIP(hipSetDevice(m->ctx->device));
     hipStream_t st = m->ctx->stream;
-    const ll_point *src[2] = {corner, surf}; const int n[2] = {n_corner, n_surf};
+    const int n[2] = {n_corner, n_surf};
     int bbox[12];
     for (int w = 0; w < 2; ++w) {
-        int rc = map_upload(m, m->d_map[w], src[w], n[w]); if (rc) return rc;
         m->M.n_map[w] = n[w];
         ll_map_launch_bbox(m->d_map[w], n[w], m->d_bbox + 6 * w, st);
     }
@@ -562,7 +489,19 @@ extern "C" int ll_map_set_map(ll_map *m, const ll_point *corner, int n_corner, c
         ll_map_launch_build(m->M.grid[w], m->d_map[w], n[w], m->d_tile, st);
     }
     LLM_HIP(hipGetLastError());
-    LLM_HIP(hipStreamSynchronize(st));                          /* host buffers may be reused by the caller */
+    return LL_OK;
+}
+
+extern "C" int ll_map_set_map(ll_map *m, const ll_point *corner, int n_corner, const ll_point *surf, int n_surf)
+{
+    if (!m) return LL_ERR_ARG;
+    if (n_corner < 0 || n_surf < 0 || (!corner && n_corner > 0) || (!surf && n_surf > 0)) { m->err = "bad map clouds"; return LL_ERR_ARG; }
+    if (n_corner > m->cap_map[0] || n_surf > m->cap_map[1]) { m->err = "map cloud larger than the capacity given to ll_map_create"; return LL_ERR_CAPACITY; }
+    LLM_HIP(hipSetDevice(m->ctx->device));
+    int rc = map_upload(m, m->d_map[0], corner, n_corner); if (rc) return rc;
+    rc = map_upload(m, m->d_map[1], surf, n_surf); if (rc) return rc;
+    rc = ll_map_rebuild(m, n_corner, n_surf); if (rc) return rc;
+    LLM_HIP(hipStreamSynchronize(m->ctx->stream));              /* host buffers may be reused by the caller */
     return LL_OK;
 }
 
@@ -656,7 +595,7 @@ extern "C" int ll_map_optimize(ll_map *m, double *pose_w7, int n_outer, const ll
 {
     if (!m || !pose_w7) return LL_ERR_ARG;
     if (n_outer < 1 || n_outer > 16) { m->err = "n_outer out of range"; return LL_ERR_ARG; }
-    const LLLmOpt o = to_dev_opt(opt);
+    const LLLmOpt o = ll_to_dev_opt(opt);
     if (o.max_num_iterations < 0 || o.max_num_iterations > 64) { m->err = "max_num_iterations out of range"; return LL_ERR_ARG; }
     LLM_HIP(hipSetDevice(m->ctx->device));
     if (ran) *ran = 0;
@@ -710,7 +649,7 @@ extern "C" int ll_map_evaluate(ll_map *m, double *neq44)
 static int map_lm_stage(ll_map *m, int stage, const double *neq44_sum, const ll_lm_options *opt)
 {
     if (!m || (stage != 1 && !neq44_sum)) return LL_ERR_ARG;
-    const LLLmOpt o = to_dev_opt(opt);
+    const LLLmOpt o = ll_to_dev_opt(opt);
     LLM_HIP(hipSetDevice(m->ctx->device));
     hipStream_t st = m->ctx->stream;
     if (neq44_sum) LLM_HIP(hipMemcpyAsync(m->M.neq, neq44_sum, LL_NEQ_STRIDE * sizeof(double), hipMemcpyHostToDevice, st));

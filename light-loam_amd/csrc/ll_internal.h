@@ -1,0 +1,80 @@
+/*
+ * ll_internal.h -- what the C-ABI translation units (ll_api.hip, ll_cubemap.hip) share: the context structs behind the
+ * opaque handles of include/lightloam_hip.h and the error-return macros.
+ */
+#pragma once
+#include "lightloam_hip.h"
+#include "ll_common.h"
+#include <string>
+#include <vector>
+#include <cstring>
+
+#define LL_PROF_EVENTS 8192
+struct LLProfiler {
+    bool on = false;
+    std::vector<hipEvent_t> ev;
+    std::vector<int> id;          /* kernel that STARTS at event i, LL_K_END for a closing mark */
+    int n = 0;
+    double total_ms[LL_K_COUNT] = {0};
+    int launches[LL_K_COUNT] = {0};
+};
+struct ll_ctx {
+    LLProfiler prof;
+    ll_params p;
+    LLView V;
+    hipStream_t stream = nullptr;
+    int device = 0;
+    std::vector<void *> allocs;
+    std::string err;
+    size_t feat_lds = 0;
+    float4 *h_stage = nullptr;      /* pinned staging for uploads */
+    size_t h_stage_pts = 0;
+    double *d_tmp_pose = nullptr, *d_rows = nullptr;
+    size_t rows_cap = 0;
+    std::vector<int> n_in_host;
+    hipEvent_t ev[16];
+    bool ev_ok = false;
+};
+
+
+#define LL_HIP(call)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                    \
+            return LL_ERR_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+struct ll_map {
+    ll_ctx *ctx = nullptr;
+    LLMapView M;
+    int cap_map[2] = {0, 0}, cap_stk[2] = {0, 0};
+    int max_cells = 0;
+    float4 *d_map[2] = {nullptr, nullptr}, *d_stk[2] = {nullptr, nullptr};
+    int *d_bbox = nullptr, *d_tile = nullptr;
+    std::vector<void *> allocs;
+    std::string err;
+};
+
+#define LLM_HIP(call)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) { m->err = std::string(#call) + ": " + hipGetErrorString(e_); return LL_ERR_HIP; } \
+    } while (0)
+
+template <typename T>
+static inline bool map_alloc(ll_map *m, T *&ptr, size_t count)
+{
+    void *p = nullptr;
+    const size_t bytes = (count ? count : 1) * sizeof(T);
+    if (hipMalloc(&p, bytes) != hipSuccess) { m->err = "hipMalloc failed (" + std::to_string(bytes) + " bytes)"; return false; }
+    if (hipMemset(p, 0, bytes) != hipSuccess) { m->err = "hipMemset failed"; (void)hipFree(p); return false; }
+    m->allocs.push_back(p);
+    ptr = (T *)p;
+    return true;
+}
+
+
+LLLmOpt ll_to_dev_opt(const ll_lm_options *opt);
+int ll_map_rebuild(ll_map *m, int n_corner, int n_surf);      /* grids over the clouds already in d_map[] */

@@ -1212,3 +1212,153 @@ int orc_map_optimize(double q[4], double t[3],
     free(p_n); free(e_a); free(p_src); free(e_src);
     return 1;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* f2 (second stage)  the cube map around the optimisation: laserMapping.cpp:1584-1821, :2101-2165 */
+/* ------------------------------------------------------------------------------------------ */
+#define CM_W 21
+#define CM_H 21
+#define CM_D 11
+#define CM_N (CM_W * CM_H * CM_D)        /* 4851, :53 */
+typedef struct { orc_point *p; int n, cap; } cm_cloud;
+struct orc_cubemap {
+    cm_cloud corner[CM_N], surf[CM_N];   /* laserCloudCornerArray / laserCloudSurfArray (:74-75) */
+    int cen[3];                          /* laserCloudCenWidth / Height / Depth (:45-47) */
+    float line_res, plane_res;           /* :2363-2364 */
+    int valid[125], n_valid;             /* laserCloudValidInd (:56) */
+    cm_cloud from_map[2], stack[2];      /* laserCloudCornerFromMap / SurfFromMap, laserCloudCornerStack / SurfStack */
+};
+
+static void cm_push(cm_cloud *c, const orc_point *p, int n)
+{
+    if (c->n + n > c->cap) { c->cap = (c->n + n) * 2 + 16; c->p = (orc_point *)realloc(c->p, (size_t)c->cap * sizeof(orc_point)); }
+    if (n > 0) memcpy(c->p + c->n, p, (size_t)n * sizeof(orc_point));
+    c->n += n;
+}
+
+orc_cubemap *orc_cubemap_create(float line_res, float plane_res)
+{
+    orc_cubemap *m = (orc_cubemap *)calloc(1, sizeof(orc_cubemap));
+    m->cen[0] = 10; m->cen[1] = 10; m->cen[2] = 5;
+    m->line_res = line_res; m->plane_res = plane_res;
+    return m;
+}
+
+void orc_cubemap_destroy(orc_cubemap *m)
+{
+    if (!m) return;
+    for (int i = 0; i < CM_N; ++i) { free(m->corner[i].p); free(m->surf[i].p); }
+    for (int w = 0; w < 2; ++w) { free(m->from_map[w].p); free(m->stack[w].p); }
+    free(m);
+}
+
+/* one step of a shift loop (:1598-1778): along `axis`, every line of cubes moves by one towards +end (dir = +1: the
+ * cube at the far end wraps to index 0 and is cleared) or towards index 0 (dir = -1) */
+static void cm_shift(orc_cubemap *m, int axis, int dir)
+{
+    const int dim[3] = {CM_W, CM_H, CM_D}, stride[3] = {1, CM_W, CM_W * CM_H};
+    const int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
+    for (int u = 0; u < dim[a1]; ++u) for (int v = 0; v < dim[a2]; ++v) {
+        const int base = u * stride[a1] + v * stride[a2];
+        if (dir > 0) {
+            cm_cloud c = m->corner[base + (dim[axis] - 1) * stride[axis]], sf = m->surf[base + (dim[axis] - 1) * stride[axis]];
+            for (int i = dim[axis] - 1; i >= 1; --i) {
+                m->corner[base + i * stride[axis]] = m->corner[base + (i - 1) * stride[axis]];
+                m->surf[base + i * stride[axis]] = m->surf[base + (i - 1) * stride[axis]];
+            }
+            c.n = 0; sf.n = 0;
+            m->corner[base] = c; m->surf[base] = sf;
+        } else {
+            cm_cloud c = m->corner[base], sf = m->surf[base];
+            for (int i = 0; i < dim[axis] - 1; ++i) {
+                m->corner[base + i * stride[axis]] = m->corner[base + (i + 1) * stride[axis]];
+                m->surf[base + i * stride[axis]] = m->surf[base + (i + 1) * stride[axis]];
+            }
+            c.n = 0; sf.n = 0;
+            m->corner[base + (dim[axis] - 1) * stride[axis]] = c; m->surf[base + (dim[axis] - 1) * stride[axis]] = sf;
+        }
+    }
+}
+
+/* :1584-1821: centre cube of t_w_curr, shifts, the 5 x 5 x 3 valid cubes, the clouds gathered from them, the scan's
+ * feature clouds down-sized */
+void orc_cubemap_prepare(orc_cubemap *m, const double t_w[3], const orc_point *corner_last, int n_corner, const orc_point *surf_last, int n_surf)
+{
+    const int dim[3] = {CM_W, CM_H, CM_D};
+    int cc[3];
+    for (int k = 0; k < 3; ++k) {
+        cc[k] = (int)((t_w[k] + 25.0) / 50.0) + m->cen[k];                                  /* :1584-1586 */
+        if (t_w[k] + 25.0 < 0) cc[k]--;                                                     /* :1588-1593 */
+    }
+    for (int k = 0; k < 3; ++k) {
+        while (cc[k] < 3) { cm_shift(m, k, +1); cc[k]++; m->cen[k]++; }                     /* :1595-1625 and the J, K twins */
+        while (cc[k] >= dim[k] - 3) { cm_shift(m, k, -1); cc[k]--; m->cen[k]--; }           /* :1627-1657 */
+    }
+    m->n_valid = 0;
+    for (int i = cc[0] - 2; i <= cc[0] + 2; i++) for (int j = cc[1] - 2; j <= cc[1] + 2; j++) for (int k = cc[2] - 1; k <= cc[2] + 1; k++)   /* :1783-1801 */
+        if (i >= 0 && i < CM_W && j >= 0 && j < CM_H && k >= 0 && k < CM_D) m->valid[m->n_valid++] = i + CM_W * j + CM_W * CM_H * k;
+    m->from_map[0].n = 0; m->from_map[1].n = 0;
+    for (int i = 0; i < m->n_valid; ++i) {                                                  /* :1803-1808 */
+        cm_push(&m->from_map[0], m->corner[m->valid[i]].p, m->corner[m->valid[i]].n);
+        cm_push(&m->from_map[1], m->surf[m->valid[i]].p, m->surf[m->valid[i]].n);
+    }
+    const orc_point *in[2] = {corner_last, surf_last}; const int n_in[2] = {n_corner, n_surf};
+    const float leaf[2] = {m->line_res, m->plane_res};
+    for (int w = 0; w < 2; ++w) {                                                           /* :1813-1821 */
+        m->stack[w].n = 0;
+        cm_push(&m->stack[w], NULL, 0);
+        if (m->stack[w].cap < n_in[w] + 1) { m->stack[w].cap = n_in[w] + 16; m->stack[w].p = (orc_point *)realloc(m->stack[w].p, (size_t)m->stack[w].cap * sizeof(orc_point)); }
+        int n_out = 0;
+        orc_voxel_grid(in[w], n_in[w], leaf[w], m->stack[w].p, &n_out);
+        m->stack[w].n = n_out;
+    }
+}
+
+int orc_cubemap_optimize(orc_cubemap *m, double q[4], double t[3], int n_outer, double huber_delta, const orc_lm_options *opt)
+{
+    return orc_map_optimize(q, t, m->stack[0].p, m->stack[0].n, m->from_map[0].p, m->from_map[0].n,
+                            m->stack[1].p, m->stack[1].n, m->from_map[1].p, m->from_map[1].n, n_outer, huber_delta, opt);
+}
+
+/* :2103-2165: the registered scan's points into their cubes, then every valid cube down-sized */
+void orc_cubemap_update(orc_cubemap *m, const double q[4], const double t[3])
+{
+    for (int w = 0; w < 2; ++w) {
+        cm_cloud *arr = w ? m->surf : m->corner;
+        for (int i = 0; i < m->stack[w].n; ++i) {
+            orc_point sel;
+            orc_point_associate_to_map(q, t, &m->stack[w].p[i], &sel);
+            const float v[3] = {sel.x, sel.y, sel.z};
+            int c[3], ok = 1;
+            const int dim[3] = {CM_W, CM_H, CM_D};
+            for (int k = 0; k < 3; ++k) {
+                c[k] = (int)((v[k] + 25.0) / 50.0) + m->cen[k];                             /* :2108-2110 */
+                if (v[k] + 25.0 < 0) c[k]--;                                                /* :2112-2117 */
+                if (c[k] < 0 || c[k] >= dim[k]) ok = 0;
+            }
+            if (ok) cm_push(&arr[c[0] + CM_W * c[1] + CM_W * CM_H * c[2]], &sel, 1);        /* :2119-2125 */
+        }
+        const float leaf = w ? m->plane_res : m->line_res;
+        for (int i = 0; i < m->n_valid; ++i) {                                              /* :2151-2165 */
+            cm_cloud *c = &arr[m->valid[i]];
+            if (c->n == 0) continue;
+            orc_point *tmp = (orc_point *)malloc((size_t)c->n * sizeof(orc_point));
+            int n_out = 0;
+            orc_voxel_grid(c->p, c->n, leaf, tmp, &n_out);
+            memcpy(c->p, tmp, (size_t)n_out * sizeof(orc_point)); c->n = n_out;
+            free(tmp);
+        }
+    }
+}
+
+void orc_cubemap_get(const orc_cubemap *m, int which, const orc_point **p, int *n)
+{
+    const cm_cloud *c = which < 2 ? &m->from_map[which] : &m->stack[which - 2];
+    *p = c->p; *n = c->n;
+}
+void orc_cubemap_cube(const orc_cubemap *m, int surf, int cube, const orc_point **p, int *n)
+{
+    const cm_cloud *c = surf ? &m->surf[cube] : &m->corner[cube];
+    *p = c->p; *n = c->n;
+}
+void orc_cubemap_center(const orc_cubemap *m, int cen[3]) { cen[0] = m->cen[0]; cen[1] = m->cen[1]; cen[2] = m->cen[2]; }

@@ -160,6 +160,17 @@ int orc_map_optimize(double q[4], double t[3],
                      const orc_point *surf_stack, int n_ss, const orc_point *surf_map, int n_sm,
                      int n_outer, double huber_delta, const orc_lm_options *opt);
 
+/* ---- f2, second stage: the cube map around the optimisation (laserMapping.cpp:1584-1821, :2101-2165) ---- */
+typedef struct orc_cubemap orc_cubemap;
+orc_cubemap *orc_cubemap_create(float line_res /* 0.4 */, float plane_res /* 0.8 */);
+void orc_cubemap_destroy(orc_cubemap *m);
+void orc_cubemap_prepare(orc_cubemap *m, const double t_w[3], const orc_point *corner_last, int n_corner, const orc_point *surf_last, int n_surf);
+int orc_cubemap_optimize(orc_cubemap *m, double q[4], double t[3], int n_outer, double huber_delta, const orc_lm_options *opt);
+void orc_cubemap_update(orc_cubemap *m, const double q[4], const double t[3]);
+void orc_cubemap_get(const orc_cubemap *m, int which /* 0 corner from map, 1 surf from map, 2 corner stack, 3 surf stack */, const orc_point **p, int *n);
+void orc_cubemap_cube(const orc_cubemap *m, int surf, int cube, const orc_point **p, int *n);
+void orc_cubemap_center(const orc_cubemap *m, int cen[3]);
+
 #ifdef __cplusplus
 }
 #endif

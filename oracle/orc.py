@@ -310,3 +310,59 @@ def map_optimize(q, t, corner_stack, corner_map, surf_stack, surf_map, n_outer=2
     ran = lib().orc_map_optimize(_p(q), _p(t), _p(cs), len(cs), _p(cm), len(cm), _p(ss), len(ss), _p(sm), len(sm),
                                  n_outer, C.c_double(huber_delta), C.byref(opt))
     return q, t, bool(ran)
+
+
+class CubeMap:
+    """laserMapping's cube map (laserMapping.cpp:1584-1821, :2101-2165), restated"""
+
+    def __init__(self, line_res=0.4, plane_res=0.8):
+        L = lib()
+        L.orc_cubemap_create.restype = C.c_void_p
+        L.orc_cubemap_create.argtypes = [C.c_float, C.c_float]
+        for f in ("orc_cubemap_destroy", "orc_cubemap_prepare", "orc_cubemap_update", "orc_cubemap_get", "orc_cubemap_cube", "orc_cubemap_center"):
+            getattr(L, f).restype = None
+        L.orc_cubemap_destroy.argtypes = [C.c_void_p]
+        L.orc_cubemap_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orc_cubemap_optimize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p]
+        L.orc_cubemap_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_cubemap_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_cubemap_cube.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_cubemap_center.argtypes = [C.c_void_p, C.c_void_p]
+        self.L = L
+        self.h = L.orc_cubemap_create(line_res, plane_res)
+
+    def close(self):
+        if self.h:
+            self.L.orc_cubemap_destroy(self.h); self.h = None
+
+    def prepare(self, t_w, corner_last, surf_last):
+        t = _d(t_w, 3); c, s_ = _f4(corner_last), _f4(surf_last)
+        self.L.orc_cubemap_prepare(self.h, _p(t), _p(c), len(c), _p(s_), len(s_))
+
+    def optimize(self, q, t, n_outer=2, huber_delta=0.1, opt=None):
+        q = _d(q, 4).copy(); t = _d(t, 3).copy(); opt = opt or lm_options()
+        ran = self.L.orc_cubemap_optimize(self.h, _p(q), _p(t), n_outer, huber_delta, C.byref(opt))
+        return q, t, bool(ran)
+
+    def update(self, q, t):
+        q = _d(q, 4); t = _d(t, 3)
+        self.L.orc_cubemap_update(self.h, _p(q), _p(t))
+
+    def _view(self, fn, *args):
+        p = C.c_void_p(); n = C.c_int(0)
+        fn(self.h, *args, C.byref(p), C.byref(n))
+        if n.value == 0:
+            return np.zeros((0, 4), np.float32)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(n.value, 4)).copy()
+
+    def cloud(self, which):
+        """0 corner from map, 1 surf from map, 2 corner stack, 3 surf stack"""
+        return self._view(self.L.orc_cubemap_get, which)
+
+    def cube(self, surf, index):
+        return self._view(self.L.orc_cubemap_cube, int(surf), int(index))
+
+    def center(self):
+        c = (C.c_int * 3)()
+        self.L.orc_cubemap_center(self.h, c)
+        return tuple(c)
