@@ -193,6 +193,61 @@ private:
     ll_map *m_ = nullptr;
 };
 
+/* ---- laserMapping's per-frame body with the cube map on the device (second stage) ---------------------
+ * process() of laserMapping.cpp between transformAssociateToMap (:1581) and transformUpdate (:2101) plus the map update
+ * (:2103-2165): the 21 x 21 x 11 cube arrays, their shifting, laserCloudCornerFromMap / SurfFromMap, the down-sized
+ * scan, the optimisation, adding the registered scan and down-sizing the touched cubes.  What is left to the node: the
+ * message queues, the two transform helpers below, publishing. */
+class LaserMapping {
+public:
+    LaserMapping(Context &c, float lineRes = 0.4f, float planeRes = 0.8f, int max_scan_corner = 20000, int max_scan_surf = 200000,
+                 int pool_points = 1 << 22) {
+        c.check(ll_cubemap_create(c.get(), lineRes, planeRes, max_scan_corner, max_scan_surf, pool_points, &cm_));
+    }
+    ~LaserMapping() { ll_cubemap_destroy(cm_); }
+    LaserMapping(const LaserMapping &) = delete;
+    LaserMapping &operator=(const LaserMapping &) = delete;
+
+    /* transformAssociateToMap (:113-117): q_w_curr = q_wmap_wodom * q_wodom_curr, t_w_curr = q_wmap_wodom * t_wodom_curr + t_wmap_wodom */
+    void transformAssociateToMap(const double q_wodom_curr[4], const double t_wodom_curr[3]) {
+        qmul(q_wmap_wodom, q_wodom_curr, parameters);
+        double r[3]; qrot(q_wmap_wodom, t_wodom_curr, r);
+        for (int k = 0; k < 3; ++k) parameters[4 + k] = r[k] + t_wmap_wodom[k];
+    }
+    /* transformUpdate (:119-123): q_wmap_wodom = q_w_curr * q_wodom_curr^-1, t_wmap_wodom = t_w_curr - q_wmap_wodom * t_wodom_curr */
+    void transformUpdate(const double q_wodom_curr[4], const double t_wodom_curr[3]) {
+        const double n2 = q_wodom_curr[0] * q_wodom_curr[0] + q_wodom_curr[1] * q_wodom_curr[1] + q_wodom_curr[2] * q_wodom_curr[2] + q_wodom_curr[3] * q_wodom_curr[3];
+        const double inv[4] = {-q_wodom_curr[0] / n2, -q_wodom_curr[1] / n2, -q_wodom_curr[2] / n2, q_wodom_curr[3] / n2};
+        qmul(parameters, inv, q_wmap_wodom);
+        double r[3]; qrot(q_wmap_wodom, t_wodom_curr, r);
+        for (int k = 0; k < 3; ++k) t_wmap_wodom[k] = parameters[4 + k] - r[k];
+    }
+    /* :1584-2165 for one frame; parameters[] holds the guess on entry and the optimised q_w_curr, t_w_curr on return */
+    bool process(const std::vector<PointXYZI> &laserCloudCornerLast, const std::vector<PointXYZI> &laserCloudSurfLast) {
+        int ran = 0;
+        check(ll_cubemap_process(cm_, parameters, (const ll_point *)laserCloudCornerLast.data(), (int)laserCloudCornerLast.size(),
+                                 (const ll_point *)laserCloudSurfLast.data(), (int)laserCloudSurfLast.size(), &ran));
+        return ran != 0;
+    }
+    double parameters[7] = {0, 0, 0, 1, 0, 0, 0};                 /* :81-83 */
+    double q_wmap_wodom[4] = {0, 0, 0, 1}, t_wmap_wodom[3] = {0, 0, 0};   /* :88-89 */
+    ll_cubemap *get() const { return cm_; }
+private:
+    static void qmul(const double a[4], const double b[4], double o[4]) {
+        const double ax = a[0], ay = a[1], az = a[2], aw = a[3], bx = b[0], by = b[1], bz = b[2], bw = b[3];
+        o[0] = aw * bx + ax * bw + ay * bz - az * by; o[1] = aw * by - ax * bz + ay * bw + az * bx;
+        o[2] = aw * bz + ax * by - ay * bx + az * bw; o[3] = aw * bw - ax * bx - ay * by - az * bz;
+    }
+    static void qrot(const double q[4], const double v[3], double o[3]) {
+        const double ux = q[0], uy = q[1], uz = q[2], w = q[3];
+        double uvx = uy * v[2] - uz * v[1], uvy = uz * v[0] - ux * v[2], uvz = ux * v[1] - uy * v[0];
+        uvx += uvx; uvy += uvy; uvz += uvz;
+        o[0] = v[0] + w * uvx + (uy * uvz - uz * uvy); o[1] = v[1] + w * uvy + (uz * uvx - ux * uvz); o[2] = v[2] + w * uvz + (ux * uvy - uy * uvx);
+    }
+    void check(int rc) { if (rc != LL_OK) throw Error(rc, ll_cubemap_last_error(cm_)); }
+    ll_cubemap *cm_ = nullptr;
+};
+
 /* ---- I/O surface ---------------------------------------------------------------------------------- */
 
 /* KITTI velodyne .bin: float32 (x, y, z, reflectance) per point -- src/kittiHelper.cpp:22-32, same name */

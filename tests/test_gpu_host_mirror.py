@@ -92,3 +92,33 @@ def test_kitti_directory_tool_writes_the_reference_trajectory_format(tmp_path, s
         assert np.allclose(T[k + 1, [3, 7, 11]], tw, atol=2e-6 * max(1, np.abs(tw).max()))
     gt = synth.pose(cfg, n - 1)
     assert abs(T[-1, 3] - gt[0]) < 0.2 and abs(T[-1, 7] - gt[1]) < 0.2
+
+
+def test_kitti_tool_with_the_mapping_node(tmp_path, synth):
+    """the three-node chain (scanRegistration -> laserOdometry -> laserMapping) through the C++ host mirror: the written
+    trajectory is the mapped one (laserMapping.cpp:2284-2325) and stays on the synthetic ground truth."""
+    from lightloam_amd import build
+    lib_dir = os.path.dirname(build.lib_path())
+    exe = str(tmp_path / "ll_odometry_kitti")
+    subprocess.check_call(["g++", "-O2", "-std=c++14", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tools", "ll_odometry_kitti.cpp"), "-o", exe,
+                           "-L", lib_dir, "-llightloam_hip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
+    cfg = synth.default_cfg(16)
+    n = 12
+    d = tmp_path / "velodyne"; d.mkdir()
+    for k in range(n):
+        synth.scan(cfg, k).astype("<f4").tofile(d / f"{k:06d}.bin")
+    odo, mapped = tmp_path / "odo.txt", tmp_path / "map.txt"
+    for res, flag in ((odo, "0"), (mapped, "1")):
+        out = subprocess.run([exe, str(d), str(res), "16", "0.9", flag], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout + out.stderr
+    To, Tm = np.loadtxt(odo), np.loadtxt(mapped)
+    assert To.shape == Tm.shape == (n, 12)
+    assert np.allclose(Tm[0], [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0])
+    gt = np.array([synth.pose(cfg, k) for k in range(n)])
+    c, s_ = np.cos(gt[0, 2]), np.sin(gt[0, 2])
+    gt_xy = (gt[:, :2] - gt[0, :2]) @ np.array([[c, -s_], [s_, c]])
+    ate = lambda T: float(np.sqrt(np.mean(np.sum((T[:, [3, 7]] - gt_xy) ** 2, axis=1))))
+    travelled = float(np.linalg.norm(np.diff(gt_xy, axis=0), axis=1).sum())
+    assert ate(To) < 0.02 * travelled and ate(Tm) < 0.02 * travelled, (ate(To), ate(Tm), travelled)
+    assert np.abs(Tm[:, [3, 7]] - To[:, [3, 7]]).max() < 0.25                  # a refinement of the odometry, not a different path

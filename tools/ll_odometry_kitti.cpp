@@ -2,13 +2,18 @@
 // the way the reference's kittiHelper -> scanRegistration -> laserOdometry chain would process them, writing the
 // reference's trajectory-file format (laserMapping.cpp:2284-2325: 12 values of H_init^-1 * H per frame).
 //
-//   ll_odometry_kitti <scan_dir> <result_path> [scan_line = 64] [first-frame forward guess in metres = 0]
+//   ll_odometry_kitti <scan_dir> <result_path> [scan_line = 64] [first-frame forward guess in metres = 0] [mapping = 0]
+//
+// mapping = 1 adds the third node: every frame's odometry pose goes through laserMapping's scan-to-map refinement
+// (lightloam::LaserMapping, laserMapping.cpp:1581-2165) and the written trajectory is q_w_curr / t_w_curr, which is what
+// the reference's result file holds (:2284-2325).
 //
 // Build:  g++ -O2 -std=c++14 -I include tools/ll_odometry_kitti.cpp -L light-loam_amd -llightloam_hip -o ll_odometry_kitti
 #include <algorithm>
 #include <cstdlib>
 #include <dirent.h>
 #include <iostream>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -16,10 +21,11 @@
 
 int main(int argc, char **argv)
 {
-    if (argc < 3) { std::cerr << "usage: ll_odometry_kitti <scan_dir> <result_path> [scan_line] [first guess tx]\n"; return 2; }
+    if (argc < 3) { std::cerr << "usage: ll_odometry_kitti <scan_dir> <result_path> [scan_line] [first guess tx] [mapping]\n"; return 2; }
     const std::string dir = argv[1], result = argv[2];
     const int scan_line = argc > 3 ? std::atoi(argv[3]) : 64;
     const double tx0 = argc > 4 ? std::atof(argv[4]) : 0.0;
+    const bool mapping = argc > 5 && std::atoi(argv[5]) != 0;
     std::vector<std::string> files;
     if (DIR *d = opendir(dir.c_str())) {
         while (dirent *e = readdir(d)) {
@@ -46,6 +52,31 @@ int main(int argc, char **argv)
         TrajectoryWriter out(result);
         WorldPose w;
         out.append(w);
+        std::unique_ptr<LaserMapping> lm;
+        std::vector<PointXYZI> cloud, sharp, lessSharp, flat, lessFlat;
+        auto map_frame = [&](int k) {                                         // laserMapping's process() for frame k
+            ll_scan_info info;
+            ctx.check(ll_get_scan_info(ctx.get(), k, &info));
+            sharp.resize(info.n_sharp); lessSharp.resize(info.n_less_sharp); flat.resize(info.n_flat); lessFlat.resize(info.n_less_flat);
+            ctx.check(ll_download_features(ctx.get(), k, (ll_point *)sharp.data(), (int)sharp.size(), (ll_point *)lessSharp.data(), (int)lessSharp.size(),
+                                           (ll_point *)flat.data(), (int)flat.size(), (ll_point *)lessFlat.data(), (int)lessFlat.size()));
+            lm->transformAssociateToMap(w.q, w.t);                            // :1581
+            lm->process(lessSharp, lessFlat);                                 // :1584-2165
+            lm->transformUpdate(w.q, w.t);                                    // :2101
+            WorldPose m;
+            for (int i = 0; i < 4; ++i) m.q[i] = lm->parameters[i];
+            for (int i = 0; i < 3; ++i) m.t[i] = lm->parameters[4 + i];
+            return m;
+        };
+        if (mapping) {
+            lm.reset(new LaserMapping(ctx, 0.4f, 0.8f, scan_line * 120 + 64, 400000, 1 << 22));
+            std::remove(result.c_str());
+            TrajectoryWriter mapped(result);
+            mapped.append(map_frame(0));
+            for (int k = 0; k < n - 1; ++k) { w.compose(&rel[(size_t)k * 7], &rel[(size_t)k * 7 + 4]); mapped.append(map_frame(k + 1)); }
+            std::cout << "wrote " << n << " mapped poses to " << result << "; final position " << lm->parameters[4] << " " << lm->parameters[5] << " " << lm->parameters[6] << "\n";
+            return 0;
+        }
         for (int k = 0; k < n - 1; ++k) { w.compose(&rel[(size_t)k * 7], &rel[(size_t)k * 7 + 4]); out.append(w); }
         std::cout << "wrote " << n << " poses to " << result << "; final position " << w.t[0] << " " << w.t[1] << " " << w.t[2] << "\n";
     } catch (const lightloam::Error &e) {
