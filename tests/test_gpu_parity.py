@@ -291,3 +291,53 @@ def test_vote_disabled_keeps_all(case, odo):
     cnt, sel, w = ctx.vote_result(1)
     assert sel.all() and (w == 1.0).all()
     ctx.vote(1, 2, True)
+
+
+def test_random_irregular_scans_stress(api, orc):
+    """96 random scans with a different length for every ring (0..400 points), smooth stretches, jumps, exact duplicates
+    and NaN returns: labels and the four feature clouds bit-exact.  Exercises every branch of the per-segment pick
+    (segments shorter than the five-point mark reach, forward-mark imports, ties, empty rings) in one batch."""
+    rng = np.random.default_rng(20260101)
+    scans = []
+    for s in range(96):
+        rings = []
+        for k in range(16):
+            n = int(rng.choice([0, 3, 9, 11, 12, 17, 30, 47, 64, 65, 129, 250, 400], p=[.04, .04, .06, .06, .06, .1, .12, .12, .1, .1, .08, .06, .06]))
+            if n == 0:
+                continue
+            base = rng.uniform(0.6, 12.0)
+            r = base * (1.0 + rng.uniform(0.0005, 0.01) * np.cumsum(rng.standard_normal(n)))
+            r = np.where(rng.random(n) < rng.uniform(0.0, 0.3), r * rng.uniform(1.2, 2.0), r)      # jumps: corners
+            if rng.random() < 0.3:
+                r = np.round(r * 8) / 8                                                         # plateaus: exact ties
+            ring = _vlp16_ring(-15 + 2 * k, n, np.abs(r) + 0.35, phase=rng.random())
+            if rng.random() < 0.2 and n > 4:
+                ring[rng.integers(0, n, 2)] = np.nan                                            # removeNaNFromPointCloud
+            if rng.random() < 0.2 and n > 6:
+                j = rng.integers(1, n - 1); ring[j] = ring[j - 1]                                # a repeated return
+            rings.append(ring)
+        if not rings:
+            rings.append(_vlp16_ring(1, 40, 5.0))
+        scans.append(_ring_scan(rings))
+    P = orc.params(16, minimum_range=0.3)
+    ctx = api.Context(api.default_params(16, batch=len(scans), max_points=max(map(len, scans)) + 8, minimum_range=0.3))
+    for k, sc in enumerate(scans):
+        ctx.upload_scan(k, sc)
+    ctx.extract(0, len(scans))
+    checked = 0
+    for k, sc in enumerate(scans):
+        ref = orc.extract(sc, P)
+        info = ctx.scan_info(k)
+        if ref["rc"] != 0:
+            assert info.status != 0
+            continue
+        assert info.status == 0, (k, info.status)
+        lab = ctx.labels(k)
+        n = len(lab)
+        assert n == len(ref["label"]) and (lab[5:n - 5].astype(np.int32) == ref["label"][5:n - 5]).all(), f"scan {k} labels"
+        f = ctx.features(k)
+        for name in ("sharp", "less_sharp", "flat", "less_flat"):
+            assert_bit_equal(f[name], ref[name], f"scan {k} {name}")
+        checked += 1
+    assert checked > 80
+    ctx.close()
