@@ -213,7 +213,9 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 (features, association, vote) + f64 (residuals, Jacobians, normal equations)",
             "data": "synthetic",
-            "config": {"workload": "HDL-64E / KITTI-shape scan (64 rings x 2048 azimuths, min_range 5 m), feature extraction "
+            "config": {"workload": ("HDL-64E / KITTI-shape scan (64 rings x 2048 azimuths, min_range 5 m)" if args.rings == 64 else
+                                    "dense 128-ring scan (128 rings x 2048 azimuths over [-25, +15] deg, linear ring model)" if args.rings == 128 else
+                                    "%d-ring synthetic scan" % args.rings) + ", feature extraction "
                                    "+ graph-match + one GN iteration per scan pair, inputs resident in HBM",
                        "scans_per_gpu_per_step": args.batch, "chunk": args.chunk or args.batch,
                        "points_per_scan_in": int(info.n_in), "points_per_scan_kept": int(info.n),
