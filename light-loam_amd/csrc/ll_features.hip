@@ -39,14 +39,14 @@ __device__ __forceinline__ bool ll_xcd_map2(int id, int per_scan, int count, int
 #define LL_NLIST 176      /* per segment slots: sharp[6][2] lsharp[6][20] flat[6][4] + counters[6][3] */
 
 struct FeatLds {
-    unsigned *k32;             /* [mr] sort key: curvature bits / voxel index */
-    unsigned short *k16;       /* [mr] payload: local index / input order */
+    unsigned *k32;             /* [mr] phases 1-3: curvature bits per slot; phase 4: sort key (voxel index) */
+    unsigned short *k16;       /* [mr] phases 2-3: suppression extents per slot; phase 4: sort payload (local index) */
     float *tx, *ty, *tz;       /* [LL_FTILE + 16] phase 1; afterwards the region is the pick's per-wave scratch */
     unsigned *picked, *gapf;   /* bitmaps over local index */
     int8_t *lab;               /* [mr] */
     int *lists;                /* [LL_NLIST] */
     int *cnt;                  /* [16 * ROWS * 4 + 1] radix counters */
-    int *sc;                   /* [64] scan scratch, bounds, segment table */
+    int *sc;                   /* [64] scan scratch [0..15], per-wave bounds [32..55], finished-segment mask [60] */
 };
 
 /* the curvature tile; afterwards four per-wave scratch rows of 64 * SR u16 (SR = ceil(ROWS * 256 / 384)) for the pick */
@@ -211,7 +211,6 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features
     const int Lseg = active ? (E - S) : 0;                            /* indices S .. E-1 are in segments */
     const float4 *cloud = V.cloud + (size_t)s * V.NP;
     FeatLds L = ll_carve(ll_smem, V.max_ring);
-    int *segb = L.sc + 16;                                            /* segment bounds (slots) for sort + pick */
     float *fs = (float *)(L.sc + 32);                                 /* 24 floats: per-wave bounds */
 
     const int nwords = (nr + 31) / 32 + 1;
@@ -219,7 +218,6 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features
     for (int i = tid; i < nr; i += LL_BLOCK) L.lab[i] = 0;
     if (tid < 3 * LL_SEGS) L.lists[156 + tid] = 0;                    /* per segment: n_sharp, n_lsharp, n_flat */
     if (tid == 0) L.sc[60] = 0;                                       /* segments finished (bit j) */
-    if (tid <= LL_SEGS) segb[tid] = Lseg * tid / LL_SEGS;             /* sp_j - S, int math of :253-254 */
     __syncthreads();
 
     LL_PHASE_BEGIN();
