@@ -186,6 +186,9 @@ extern __shared__ __attribute__((aligned(16))) unsigned char ll_smem[];
 #define LL_PHASE_BEGIN() long long ll_t0 = (tid == 0) ? (long long)__builtin_amdgcn_s_memtime() : 0
 #define LL_PHASE(i) do { __syncthreads(); if (tid == 0) { const long long t1 = (long long)__builtin_amdgcn_s_memtime(); \
     atomicAdd(&V.dbg[i], (unsigned long long)(t1 - ll_t0)); ll_t0 = t1; } } while (0)
+#elif defined(LL_PHASE_STOP)   /* tools/phase_valu.py: the kernel returns after phase LL_PHASE_STOP (instruction counts per phase by difference) */
+#define LL_PHASE_BEGIN() do {} while (0)
+#define LL_PHASE(i) do { if ((i) == LL_PHASE_STOP) return; } while (0)
 #else
 #define LL_PHASE_BEGIN() do {} while (0)
 #define LL_PHASE(i) do {} while (0)
