@@ -67,3 +67,36 @@ def test_download_capacity_checks(api, scans):
     rc = ctx.lib.ll_download_cloud(ctx.h, 0, small.ctypes.data_as(C.c_void_p), 10, None, None)
     assert rc == -4
     ctx.close()
+
+
+def test_mapping_objects_validate_their_arguments(api, scans):
+    ctx = api.Context(api.default_params(16, batch=1, max_points=4096))
+    with pytest.raises(api.LightLoamError) as e:
+        api.Map(ctx, 0, 10, 10, 10)                                              # capacities must be positive
+    assert e.value.code == -2
+    m = api.Map(ctx, 100, 100, 50, 50)
+    pts = np.zeros((60, 4), np.float32)
+    with pytest.raises(api.LightLoamError) as e:
+        m.set_scan(pts, pts)                                                     # 60 > 50
+    assert e.value.code == -4
+    # an optimisation with nothing in the map: not run, pose returned unchanged, no residual blocks
+    m.set_map(np.zeros((0, 4), np.float32), np.zeros((0, 4), np.float32))
+    m.set_scan(pts[:10], pts[:10])
+    pose, ran = m.optimize([0, 0, 0, 1, 1, 2, 3.0])
+    assert not ran and (pose == [0, 0, 0, 1, 1, 2, 3.0]).all()
+    m.associate([0, 0, 0, 1, 0, 0, 0.0])
+    assert m.counts() == (0, 0)
+    H, g, cost = m.normal_equations()
+    assert not H.any() and not g.any() and cost == 0.0
+    m.close()
+    with pytest.raises(api.LightLoamError) as e:
+        api.CubeMap(ctx, 100, 100, pool_points=10)                               # pool too small to be a pool
+    assert e.value.code == -2
+    cm = api.CubeMap(ctx, 4096, 16384, pool_points=1 << 16)
+    with pytest.raises(api.LightLoamError) as e:
+        cm.prepare([0, 0, 0.0], np.zeros((5000, 4), np.float32), pts)           # 5000 > 4096
+    assert e.value.code == -4
+    # an empty scan goes through: nothing is added, nothing optimised
+    pose, ran = cm.process([0, 0, 0, 1, 0, 0, 0.0], np.zeros((0, 4), np.float32), np.zeros((0, 4), np.float32))
+    assert not ran and cm.info() == ((10, 10, 5), (0, 0, 0, 0))
+    cm.close(); ctx.close()
