@@ -134,8 +134,7 @@ extern "C" int ll_create(int device, const ll_params *p, ll_ctx **out)
          dev_alloc(ctx, V.tile_first_kept, BT) && dev_alloc(ctx, V.tile_last_kept, BT);
     ok = ok && dev_alloc(ctx, V.hdr, B) && dev_alloc(ctx, V.ring_off, (size_t)B * (R + 1));
     ok = ok && dev_alloc(ctx, V.cloud, BN, false) && dev_alloc(ctx, V.label, BN) && dev_alloc(ctx, V.curv, p->write_curvature ? BN : 1);
-    ok = ok && dev_alloc(ctx, V.sharp_slot, (size_t)B * V.cap_sharp, false) && dev_alloc(ctx, V.lsharp_slot, (size_t)B * V.cap_lsharp, false) &&
-         dev_alloc(ctx, V.flat_slot, (size_t)B * V.cap_flat, false) && dev_alloc(ctx, V.lflat_slot, BN, false) && dev_alloc(ctx, V.ring_feat_cnt, (size_t)B * R * 4);
+    ok = ok && dev_alloc(ctx, V.ring_pub, (size_t)B * R);
     ok = ok && dev_alloc(ctx, V.sharp, (size_t)B * V.cap_sharp, false) && dev_alloc(ctx, V.lsharp, (size_t)B * V.cap_lsharp, false) &&
          dev_alloc(ctx, V.flat, (size_t)B * V.cap_flat, false) && dev_alloc(ctx, V.lflat, BN, false);
     ok = ok && dev_alloc(ctx, V.carry_corner, V.cap_lsharp) && dev_alloc(ctx, V.carry_surf, NP) && dev_alloc(ctx, V.carry_cnt, 2);

@@ -73,7 +73,8 @@ struct LLView {
     ScanHdr *hdr; int *ring_off;
     float4 *cloud; int8_t *label; float *curv;
     /* features */
-    float4 *sharp_slot, *lsharp_slot, *flat_slot, *lflat_slot; int *ring_feat_cnt;   /* [B][R][4] */
+    unsigned long long *ring_pub;  /* [B][R] look-back word of every ring: launch tag << 40 | its four feature counts */
+    int epoch;                     /* the tag of the current k_ring_features launch (1 .. 2^24 - 2) */
     float4 *sharp, *lsharp, *flat, *lflat;
     /* targets */
     float4 *carry_corner, *carry_surf; int *carry_cnt;    /* carry_cnt[2] */

@@ -18,7 +18,8 @@
  *   phase 4  less-flat points (label <= 0) compacted in index order with their coordinates in registers, voxel index
  *            per PCL's formula, stable LSD radix sort (4-bit digits, match-any ranking) by (voxel, input order),
  *            voxel runs summed left to right in f32 by the thread that owns the run head
- *   phase 5  labels + feature slots out; k_compact turns per-ring slots into the published clouds.
+ *   phase 5  labels out; feature points straight into the published clouds: the ring's offsets come from a decoupled
+ *            look-back over the earlier rings' counts (no separate compaction pass).
  * The kernel is VALU-bound (~80 % VALU busy at six workgroups per CU): LDS is kept at ~26 KB for a 2304-point
  * ring capacity, VGPRs at 80.  ROWS = sort records per thread (capacity 256 * ROWS).
  * HBM traffic per ring point: 16 B read (+ L2-hot re-reads for voxel keys and centroids), 1 B label, features.
@@ -36,6 +37,11 @@ __device__ __forceinline__ bool ll_xcd_map2(int id, int per_scan, int count, int
 }
 
 #define LL_FTILE 512      /* points per curvature tile */
+#ifdef LL_PHASE_STOP
+#define LL_LOOKBACK_SPINS 1            /* instruction-count builds return early and never publish: do not wait for them */
+#else
+#define LL_LOOKBACK_SPINS (1 << 24)    /* bounded so that a logic error ends in wrong results, not in a hung GPU */
+#endif
 #define LL_NLIST 176      /* per segment slots: sharp[6][2] lsharp[6][20] flat[6][4] + counters[6][3] */
 
 struct FeatLds {
@@ -203,12 +209,36 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features
     const int s = first + sl;
     const int tid = threadIdx.x, lane = tid & 63;
     const ScanHdr h = V.hdr[s];
-    int *fcnt = V.ring_feat_cnt + ((size_t)s * V.R + r) * 4;
-    if (h.status != 0) { if (tid < 4) fcnt[tid] = 0; return; }
+    if (h.status != 0) return;                                        /* every ring of the scan takes this exit: nobody waits */
     const int N = h.n;
     const int off = V.ring_off[(size_t)s * (V.R + 1) + r];
     const int nr = V.ring_off[(size_t)s * (V.R + 1) + r + 1] - off;
-    if (nr <= 0) { if (tid < 4) fcnt[tid] = 0; return; }
+    /* One 64-bit word per ring carries the four counts AND the launch tag, written and polled with relaxed atomics: no
+     * release / acquire fence is needed (at agent scope those write back / invalidate the whole L2 on this chip). */
+    unsigned long long *ring_pub = V.ring_pub + (size_t)s * V.R;
+    const unsigned long long tag = (unsigned long long)V.epoch << 40;
+    auto ll_pub = [&](int c0, int c1, int c2, int c3) {
+        __hip_atomic_store(&ring_pub[r], tag | ((unsigned long long)c3 << 16) | ((unsigned long long)c1 << 9) | ((unsigned long long)c2 << 4) | (unsigned long long)c0,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto ll_poll = [&](int q, int v[4]) {
+        unsigned long long w; int spins = 0;
+        while (((w = __hip_atomic_load(&ring_pub[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 40) != (unsigned long long)V.epoch && ++spins < LL_LOOKBACK_SPINS)
+            __builtin_amdgcn_s_sleep(16);
+        v[0] += (int)(w & 15u); v[2] += (int)((w >> 4) & 31u); v[1] += (int)((w >> 9) & 127u); v[3] += (int)((w >> 16) & 0xffffffu);
+    };
+    if (nr <= 0) {                                                    /* empty ring: publish zero counts for the rings behind it */
+        if (tid == 0) {
+            ll_pub(0, 0, 0, 0);
+            if (r == V.R - 1) {                                       /* the scan's totals are the last ring's offsets */
+                int tot[4] = {0, 0, 0, 0};
+                for (int q = 0; q < r; ++q) ll_poll(q, tot);
+                ScanHdr *hh = &V.hdr[s];
+                hh->n_sharp = tot[0]; hh->n_less_sharp = tot[1]; hh->n_flat = tot[2]; hh->n_less_flat = tot[3];
+            }
+        }
+        return;
+    }
     const int S = off + 5, E = off + nr - 6;                          /* scanStartInd / scanEndInd (:218-220) */
     const bool active = (E - S >= 6);                                 /* :248 */
     const int Lseg = active ? (E - S) : 0;                            /* indices S .. E-1 are in segments */
@@ -222,6 +252,28 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features
     if (tid < 3 * LL_SEGS) L.lists[156 + tid] = 0;                    /* per segment: n_sharp, n_lsharp, n_flat */
     if (tid == 0) L.sc[60] = 0;                                       /* segments finished (bit j) */
     __syncthreads();
+
+    /* Decoupled look-back over the rings of the scan (they run on one XCD, dispatched in ring order): publish this
+     * ring's four feature counts, wait for every earlier ring's, return their sums = this ring's offsets in the four
+     * published clouds (ring, segment, pick order; scanRegistration.cpp:273-279, :325, :376).  Called exactly once. */
+    auto publish_and_prefix = [&](int c0, int c1, int c2, int c3, int *outp) __attribute__((always_inline)) {
+        if (tid == 0) ll_pub(c0, c1, c2, c3);
+        int v[4] = {0, 0, 0, 0};
+        for (int q = tid; q < r; q += LL_BLOCK) ll_poll(q, v);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) for (int o = 32; o > 0; o >>= 1) v[c] += __shfl_xor(v[c], o);
+        __syncthreads();
+        if (lane == 0) for (int c = 0; c < 4; ++c) L.sc[32 + (tid >> 6) * 4 + c] = v[c];
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { int t = 0; for (int w = 0; w < LL_BLOCK / 64; ++w) t += L.sc[32 + w * 4 + c]; outp[c] = t; }
+        __syncthreads();
+    };
+    int roff[4] = {0, 0, 0, 0}; bool looked_back = false;           /* this ring's offsets in sharp / less-sharp / flat / less-flat */
+    auto seg_totals = [&](int &ns_, int &nls_, int &nf_) __attribute__((always_inline)) {
+        ns_ = 0; nls_ = 0; nf_ = 0;
+        for (int j = 0; j < LL_SEGS; ++j) { ns_ += L.lists[156 + j * 3]; nls_ += L.lists[157 + j * 3]; nf_ += L.lists[158 + j * 3]; }
+    };
 
     LL_PHASE_BEGIN();
     /* ---------------- phase 1: curvature + gap flags + sort records ---------------- */
@@ -541,7 +593,8 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features
                     }
             }
             int o = ll_block_exscan(__popc(headm), L.sc, n_lf_out);
-            float4 *out = V.lflat_slot + (size_t)s * V.NP + off;
+            { int a_, b_, c_; seg_totals(a_, b_, c_); publish_and_prefix(a_, b_, c_, n_lf_out, roff); looked_back = true; }
+            float4 *out = V.lflat + (size_t)s * V.NP + roff[3];
             /* CentroidPoint<PointXYZI>: f32 sums from zero in input order, divided by float(n) */
             float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f; int cn = 0;
 #pragma unroll
@@ -568,59 +621,33 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features
     /* ---------------- phase 5: labels + feature slots ---------------- */
     int8_t *label = V.label + (size_t)s * V.NP + off;
     for (int i = tid; i < nr; i += LL_BLOCK) label[i] = L.lab[i];
-    /* per-segment lists -> the ring's slots in (segment, pick order) */
+    /* per-segment lists -> the published clouds at this ring's offsets, in (segment, pick order) */
     int ns = 0, nls = 0, nf = 0;
+    seg_totals(ns, nls, nf);
+    if (!looked_back) publish_and_prefix(ns, nls, nf, n_lf_out, roff);          /* rings without a less-flat point */
     {
         const int js = tid / LL_SHARP_PER_SEG, jl = tid / LL_LSHARP_PER_SEG, jf = tid / LL_FLAT_PER_SEG;
         int os = 0, ol = 0, of = 0;
         for (int j = 0; j < LL_SEGS; ++j) {
-            const int a = L.lists[156 + j * 3], b = L.lists[157 + j * 3], c = L.lists[158 + j * 3];
-            if (j < js) os += a;
-            if (j < jl) ol += b;
-            if (j < jf) of += c;
-            ns += a; nls += b; nf += c;
+            if (j < js) os += L.lists[156 + j * 3];
+            if (j < jl) ol += L.lists[157 + j * 3];
+            if (j < jf) of += L.lists[158 + j * 3];
         }
-        const size_t ring_id = (size_t)s * V.R + r;
         if (js < LL_SEGS && tid % LL_SHARP_PER_SEG < L.lists[156 + js * 3])
-            V.sharp_slot[ring_id * 12 + os + tid % LL_SHARP_PER_SEG] = cloud[off + L.lists[tid]];
+            V.sharp[(size_t)s * V.cap_sharp + roff[0] + os + tid % LL_SHARP_PER_SEG] = cloud[off + L.lists[tid]];
         if (jl < LL_SEGS && tid % LL_LSHARP_PER_SEG < L.lists[157 + jl * 3])
-            V.lsharp_slot[ring_id * 120 + ol + tid % LL_LSHARP_PER_SEG] = cloud[off + L.lists[12 + tid]];
+            V.lsharp[(size_t)s * V.cap_lsharp + roff[1] + ol + tid % LL_LSHARP_PER_SEG] = cloud[off + L.lists[12 + tid]];
         if (jf < LL_SEGS && tid % LL_FLAT_PER_SEG < L.lists[158 + jf * 3])
-            V.flat_slot[ring_id * 24 + of + tid % LL_FLAT_PER_SEG] = cloud[off + L.lists[132 + tid]];
+            V.flat[(size_t)s * V.cap_flat + roff[2] + of + tid % LL_FLAT_PER_SEG] = cloud[off + L.lists[132 + tid]];
     }
-    if (tid == 0) { fcnt[0] = ns; fcnt[1] = nls; fcnt[2] = nf; fcnt[3] = n_lf_out; }
+    if (r == V.R - 1 && tid == 0) {                                            /* the scan's totals */
+        ScanHdr *hh = &V.hdr[s];
+        hh->n_sharp = roff[0] + ns; hh->n_less_sharp = roff[1] + nls; hh->n_flat = roff[2] + nf; hh->n_less_flat = roff[3] + n_lf_out;
+    }
     LL_PHASE(6);
 #ifdef LL_PHASE_TIMING
     if (tid == 0) atomicAdd(&V.dbg[15], 1ull);
 #endif
-}
-
-/* per-ring slots -> clouds in publication order (ring, segment, pick order; :273-279, :325, :376) */
-__global__ __launch_bounds__(128) void k_compact(LLView V, int first, int count)
-{
-    int sl, r;
-    if (!ll_xcd_map2(blockIdx.x, V.R, count, sl, r)) return;
-    const int s = first + sl;
-    const int tid = threadIdx.x;
-    __shared__ int pre[4], mine[4];
-    const int *fc = V.ring_feat_cnt + (size_t)s * V.R * 4;
-    if (tid < 4) {
-        int run = 0;
-        for (int q = 0; q < r; ++q) run += fc[q * 4 + tid];
-        pre[tid] = run; mine[tid] = fc[r * 4 + tid];
-    }
-    __syncthreads();
-    const size_t ring_id = (size_t)s * V.R + r;
-    for (int i = tid; i < mine[0]; i += 128) V.sharp[(size_t)s * V.cap_sharp + pre[0] + i] = V.sharp_slot[ring_id * 12 + i];
-    for (int i = tid; i < mine[1]; i += 128) V.lsharp[(size_t)s * V.cap_lsharp + pre[1] + i] = V.lsharp_slot[ring_id * 120 + i];
-    for (int i = tid; i < mine[2]; i += 128) V.flat[(size_t)s * V.cap_flat + pre[2] + i] = V.flat_slot[ring_id * 24 + i];
-    const int off = V.ring_off[(size_t)s * (V.R + 1) + r];
-    for (int i = tid; i < mine[3]; i += 128) V.lflat[(size_t)s * V.NP + pre[3] + i] = V.lflat_slot[(size_t)s * V.NP + off + i];
-    if (r == V.R - 1 && tid == 0) {
-        ScanHdr *h = &V.hdr[s];
-        h->n_sharp = pre[0] + mine[0]; h->n_less_sharp = pre[1] + mine[1];
-        h->n_flat = pre[2] + mine[2]; h->n_less_flat = pre[3] + mine[3];
-    }
 }
 
 template <int ROWS>
@@ -638,12 +665,14 @@ void ll_launch_features(const LLView &V, int first, int count, size_t lds_bytes,
 {
     const int groups = (count + 7) / 8;
     const int grid = 8 * V.R * groups;
+    static int epoch = 0;                                      /* 24-bit tag of this launch in the rings' look-back words, never 0 */
+    LLView Ve = V;
+    epoch = epoch % 0xFFFFFE + 1;
+    Ve.epoch = epoch;
     ll_prof_mark(prof, LL_K_RING_FEATURES, st);
     const int rows = (V.max_ring + 255) / 256;                 /* sort records per thread */
-    if (rows <= 9) ll_launch_ring_features<9>(V, first, count, grid, lds_bytes, st);
-    else if (rows <= 18) ll_launch_ring_features<18>(V, first, count, grid, lds_bytes, st);
-    else ll_launch_ring_features<36>(V, first, count, grid, lds_bytes, st);
-    ll_prof_mark(prof, LL_K_COMPACT, st);
-    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(128), 0, st, V, first, count);
+    if (rows <= 9) ll_launch_ring_features<9>(Ve, first, count, grid, lds_bytes, st);
+    else if (rows <= 18) ll_launch_ring_features<18>(Ve, first, count, grid, lds_bytes, st);
+    else ll_launch_ring_features<36>(Ve, first, count, grid, lds_bytes, st);
     ll_prof_mark(prof, LL_K_END, st);
 }
