@@ -135,6 +135,15 @@ extern "C" int ll_create(int device, const ll_params *p, ll_ctx **out)
     ok = ok && dev_alloc(ctx, V.hdr, B) && dev_alloc(ctx, V.ring_off, (size_t)B * (R + 1));
     ok = ok && dev_alloc(ctx, V.cloud, BN, false) && dev_alloc(ctx, V.label, BN) && dev_alloc(ctx, V.curv, p->write_curvature ? BN : 1);
     ok = ok && dev_alloc(ctx, V.ring_pub, (size_t)B * R);
+    {   /* ring thresholds of this sensor model (ll_exact_math.h), computed once with the same exact arithmetic */
+        int *thr_dev = nullptr;
+        std::vector<int32_t> thr((size_t)R + 1);
+        ll_ring_thresholds(V.ring_model, R, V.lower_bound, V.factor, thr.data());
+        ok = ok && dev_alloc(ctx, thr_dev, (size_t)R + 1, false);
+        if (ok && (hipMemcpyAsync(thr_dev, thr.data(), ((size_t)R + 1) * sizeof(int), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                   hipStreamSynchronize(ctx->stream) != hipSuccess)) { g_create_err = "threshold upload failed"; ok = false; }
+        V.ring_thr = thr_dev;
+    }
     ok = ok && dev_alloc(ctx, V.sharp, (size_t)B * V.cap_sharp, false) && dev_alloc(ctx, V.lsharp, (size_t)B * V.cap_lsharp, false) &&
          dev_alloc(ctx, V.flat, (size_t)B * V.cap_flat, false) && dev_alloc(ctx, V.lflat, BN, false);
     ok = ok && dev_alloc(ctx, V.carry_corner, V.cap_lsharp) && dev_alloc(ctx, V.carry_surf, NP) && dev_alloc(ctx, V.carry_cnt, 2);

@@ -60,6 +60,7 @@ struct LLView {
     /* configuration */
     int B, NP, T, R, ring_model, max_ring, write_curv;
     float thres, lower_bound, factor;
+    const int *ring_thr;           /* [R + 1] ll_ring_thresholds: keys of the smallest t = z / sqrt(x^2 + y^2) of every ring */
     double curv_thr, gap_thr;      /* 0.1 / 0.05 as double: the reference compares f32 against double literals */
     float leaf, inv_leaf;
     float nn_max;                  /* 25 */
@@ -109,13 +110,6 @@ struct LLLmOpt {
 void ll_launch_lm_begin(const LLView &V, int first, int count, const LLLmOpt &o, hipStream_t st);
 void ll_launch_lm_propose(const LLView &V, int first, int count, const LLLmOpt &o, hipStream_t st);
 void ll_launch_lm_accept(const LLView &V, int first, int count, const LLLmOpt &o, hipStream_t st);
-
-__device__ __forceinline__ int ll_trunc_to_int(double v)
-{
-    /* x86-64 cvttsd2si semantics: NaN / out of range -> INT_MIN ("integer indefinite") */
-    if (!(v > -2147483649.0 && v < 2147483648.0)) return (int)0x80000000;
-    return (int)v;
-}
 
 /* Match-any over a wave: afterwards (mlo, mhi) = the lanes of `among` whose low `bits` bits of v equal this lane's.
  * Per bit one ballot and, per mask half, one three-input bit operation  m & ~(ballot ^ y), y = the lane's bit as 0 / ~0

@@ -70,6 +70,46 @@ LL_HD float ll_div_pi_f32(float a)
     return (float)__builtin_fma(rem, rpi, q);
 }
 
+/* x86-64 cvttsd2si semantics of the reference's int(double): NaN / out of range -> INT_MIN ("integer indefinite") */
+LL_HD int ll_trunc_to_int(double v)
+{
+    if (!(v > -2147483649.0 && v < 2147483648.0)) return (int)0x80000000;
+    return (int)v;
+}
+
+/* scanRegistration.cpp:139-168 as a function of t = z / sqrt(x*x + y*y): the UNCLAMPED ring number
+ *   angle = atan(t) * 180 / M_PI (f32 atan, f32 product, f64 division, f32 store), then the 16 / 32 / 64-ring formula
+ * (ring_model 1: the 64-ring linear formula for any ring count).  Every step is monotone non-decreasing in t -- ll_atanf
+ * is (checked over all floats by tests/test_exact_math.py) -- so the ring of a point is found by comparing t with R + 1
+ * precomputed thresholds instead of evaluating this chain per point (ll_ring_thresholds / k_classify). */
+LL_HD int ll_ring_of_t(float t, int ring_model, int R, float lower_bound, float factor)
+{
+    const float angle = ll_div_pi_f32(ll_atanf(t) * 180.0f);
+    if (ring_model == 0 && R == 16) return ll_trunc_to_int((double)((angle + 15.0f) / 2.0f) + 0.5);        /* :144 */
+    if (ring_model == 0 && R == 32) return ll_trunc_to_int(((double)angle + 92.0 / 3.0) * 3.0 / 4.0);       /* :153 */
+    return ll_trunc_to_int((double)((angle - lower_bound) * factor) + 0.5);                                  /* :162 */
+}
+
+/* order-preserving int key of a float (-inf .. -0 < +0 .. +inf; NaNs beyond the infinities) */
+LL_HD int32_t ll_float_key(float f) { const int32_t i = (int32_t)ll_f2u(f); return i >= 0 ? i : (int32_t)(i ^ 0x7fffffff); }
+LL_HD float ll_key_float(int32_t k) { return ll_u2f((uint32_t)(k >= 0 ? k : (k ^ 0x7fffffff))); }
+
+/* thr[k], k = 0 .. R: key of the smallest float t with ll_ring_of_t(t) >= k (INT32_MAX if there is none).
+ * A point's ring is  #{k : key(t) >= thr[k]} - 1  when that is in 0 .. R-1, else the point is rejected (:164-168). */
+LL_HD void ll_ring_thresholds(int ring_model, int R, float lower_bound, float factor, int32_t *thr)
+{
+    const int32_t kmin = ll_float_key(ll_u2f(0xff800000u)), kmax = ll_float_key(ll_u2f(0x7f800000u));      /* -inf, +inf */
+    for (int k = 0; k <= R; ++k) {
+        if (ll_ring_of_t(ll_key_float(kmax), ring_model, R, lower_bound, factor) < k) { thr[k] = 0x7fffffff; continue; }
+        int32_t lo = kmin, hi = kmax;                                  /* invariant: ring(hi) >= k; find the smallest such key */
+        while (lo < hi) {
+            const int32_t mid = (int32_t)(((int64_t)lo + (int64_t)hi) >> 1);
+            if (ll_ring_of_t(ll_key_float(mid), ring_model, R, lower_bound, factor) >= k) hi = mid; else lo = mid + 1;
+        }
+        thr[k] = lo;
+    }
+}
+
 LL_HD float ll_atan2f(float y, float x)
 {
     const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f,

@@ -32,16 +32,18 @@ __device__ __forceinline__ bool ll_keep(const float4 p, float thres)
     return !(p.x * p.x + p.y * p.y + p.z * p.z < thres * thres);
 }
 
-__device__ __forceinline__ int ll_scan_id(const LLView &V, const float4 p)
+/* scanID of a point (:139-168): the chain atan -> degrees -> ring formula -> int() is monotone in t = z / sqrt(x^2 + y^2), so
+ * the ring is the number of precomputed thresholds (ll_ring_thresholds, exact for this context's parameters) not above t,
+ * minus one -- a binary search over <= 129 keys in LDS instead of an arctangent, an f64 division and f64 arithmetic. */
+__device__ __forceinline__ int ll_scan_id(const int *thr, int R, const float4 p)
 {
-    /* float angle = atan(z / sqrt(x*x + y*y)) * 180 / M_PI  (:139): f32 atan, f32 product, f64 division, f32 store
-     * (ll_div_pi_f32: the same f64 quotient without the division sequence, checked over all 2^32 floats) */
-    const float angle = ll_div_pi_f32(ll_atanf(p.z / sqrtf(p.x * p.x + p.y * p.y)) * 180.0f);
-    int id;
-    if (V.ring_model == 0 && V.R == 16)       id = ll_trunc_to_int((double)((angle + 15.0f) / 2.0f) + 0.5);       /* :144 */
-    else if (V.ring_model == 0 && V.R == 32)  id = ll_trunc_to_int(((double)angle + 92.0 / 3.0) * 3.0 / 4.0);      /* :153 */
-    else                                      id = ll_trunc_to_int((double)((angle - V.lower_bound) * V.factor) + 0.5); /* :162 */
-    return (id > V.R - 1 || id < 0) ? -1 : id;
+    const float t = p.z / sqrtf(p.x * p.x + p.y * p.y);
+    if (t != t) return -1;                                  /* 0 / 0: the reference's int(NaN) is INT_MIN -> rejected */
+    const int key = ll_float_key(t);
+    int lo = 0, hi = R + 1;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (thr[mid] <= key) lo = mid + 1; else hi = mid; }
+    const int id = lo - 1;
+    return (id > R - 1 || id < 0) ? -1 : id;
 }
 
 /* first kept point of each scan -> startOri (:114).  One workgroup per scan, 4 points per thread per round, stops at
@@ -91,6 +93,8 @@ __global__ __launch_bounds__(LL_BLOCK) void k_classify(LLView V, int first, int 
 
     __shared__ int sh_first_p, sh_fk, sh_lk;
     __shared__ int hist[LL_MAX_RINGS];
+    __shared__ int thr[LL_MAX_RINGS + 1];
+    if (tid <= V.R) thr[tid] = V.ring_thr[tid];
     if (tid == 0) { sh_first_p = INT_MAX; sh_fk = INT_MAX; sh_lk = -1; }
     if (tid < LL_MAX_RINGS) hist[tid] = 0;
     __syncthreads();
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(LL_BLOCK) void k_classify(LLView V, int first, int 
         int id = -1; float o = 0.0f; bool firstp = false;
         if (kept) {
             o = -ll_atan2f(p.y, p.x);                                                 /* :177 (also start/endOri source) */
-            id = ll_scan_id(V, p);
+            id = ll_scan_id(thr, V.R, p);
             if (id >= 0) {
                 /* the !halfPassed branch (:180-192) evaluated as if the flag were still false */
                 float a = o;

@@ -44,6 +44,49 @@ long long em_check_div_pi(unsigned long long first, unsigned long long stride)
     return bad;
 }
 
+// ll_atanf must be monotone non-decreasing over the floats in value order (-inf .. +inf): what k_classify's ring
+// thresholds rest on.  Returns the number of adjacent pairs (stride 1) that decrease.
+long long em_check_atanf_monotone(void)
+{
+    long long bad = 0;
+#pragma omp parallel for reduction(+ : bad) schedule(static)
+    for (long long k = (long long)ll_float_key(ll_u2f(0xff800000u)); k < (long long)ll_float_key(ll_u2f(0x7f800000u)); ++k) {
+        const float a = ll_atanf(ll_key_float((int32_t)k)), b = ll_atanf(ll_key_float((int32_t)(k + 1)));
+        if (b < a) bad++;
+    }
+    return bad;
+}
+
+// ring by thresholds == ring by the direct formula, for every float t (bit patterns first, first+stride, ...) and the
+// four sensor models the library is used with; returns the number of mismatches
+long long em_check_ring_thresholds(unsigned long long first, unsigned long long stride)
+{
+    struct M { int model, R; float lb, ub; } models[] = {{0, 16, -15.f, 15.f}, {0, 32, -30.67f, 10.67f}, {0, 64, -24.9f, 2.f}, {1, 128, -25.f, 15.f}, {1, 40, -16.f, 7.f}};
+    long long bad = 0;
+    for (const M &m : models) {
+        const float factor = (float)(m.R - 1) / (m.ub - m.lb);
+        int32_t thr[129];
+        ll_ring_thresholds(m.model, m.R, m.lb, factor, thr);
+        for (int k = 0; k < m.R; ++k) if (thr[k] > thr[k + 1]) bad++;
+#pragma omp parallel for reduction(+ : bad) schedule(static)
+        for (long long i = (long long)first; i < (1LL << 32); i += (long long)stride) {
+            const float t = ll_u2f((uint32_t)i);
+            int want = ll_ring_of_t(t, m.model, m.R, m.lb, factor);
+            want = (want > m.R - 1 || want < 0) ? -1 : want;
+            int got = -1;
+            if (t == t) {
+                const int32_t key = ll_float_key(t);
+                int lo = 0, hi = m.R + 1;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (thr[mid] <= key) lo = mid + 1; else hi = mid; }
+                got = lo - 1;
+                if (got > m.R - 1 || got < 0) got = -1;
+            }
+            if (got != want) bad++;
+        }
+    }
+    return bad;
+}
+
 // atan2f on n pseudo-random pairs in four regimes (raw bit patterns, lidar-range values, mixed exponents, tiny y)
 long long em_check_atan2f(long long n, unsigned long long seed)
 {

@@ -27,6 +27,9 @@ def em():
     lib.em_check_atan2f_specials.restype = C.c_longlong
     lib.em_check_div_pi.restype = C.c_longlong
     lib.em_check_div_pi.argtypes = [C.c_ulonglong, C.c_ulonglong]
+    lib.em_check_atanf_monotone.restype = C.c_longlong
+    lib.em_check_ring_thresholds.restype = C.c_longlong
+    lib.em_check_ring_thresholds.argtypes = [C.c_ulonglong, C.c_ulonglong]
     lib.em_check_vote.restype = C.c_longlong
     lib.em_check_vote.argtypes = [C.c_ulonglong, C.c_ulonglong]
     return lib
@@ -52,6 +55,24 @@ def test_div_pi_stratified(em):
 @pytest.mark.slow
 def test_div_pi_exhaustive(em):
     assert em.em_check_div_pi(0, 1) == 0
+
+
+@pytest.mark.slow
+def test_atanf_is_monotone_over_all_floats(em):
+    """k_classify finds a point's ring by comparing t = z / sqrt(x^2 + y^2) with precomputed thresholds; that is the
+    reference's atan -> degrees -> formula -> int() chain only because every step, ll_atanf included, is monotone."""
+    assert em.em_check_atanf_monotone() == 0
+
+
+def test_ring_thresholds_equal_the_formula_stratified(em):
+    """five sensor models x every 97th float: the threshold search returns exactly the formula's ring"""
+    assert em.em_check_ring_thresholds(13, 97) == 0
+
+
+@pytest.mark.skipif(not os.environ.get("LIGHTLOAM_EXHAUSTIVE"), reason="5 models x 2^32 floats, ~5 min on 8 cores: set LIGHTLOAM_EXHAUSTIVE=1 "
+                    "(passed on 2026-10-01 for the header as committed)")
+def test_ring_thresholds_equal_the_formula_exhaustive(em):
+    assert em.em_check_ring_thresholds(0, 1) == 0
 
 
 def test_atan2f_special_values(em):
