@@ -99,3 +99,35 @@ def test_lm_options_are_the_ceres_defaults(api):
     api.load_library().ll_lm_default_options(__import__("ctypes").byref(o))
     assert (o.max_num_iterations, o.initial_radius, o.min_relative_decrease, o.jacobi_scaling) == (4, 1e4, 1e-3, 1)
     assert (o.function_tolerance, o.gradient_tolerance, o.parameter_tolerance) == (1e-6, 1e-10, 1e-8)
+
+
+def test_forty_frame_s64_drive_ate(api, orc, synth):
+    """north_star's accuracy clause on a longer KITTI-shape drive: 40 frames (36 m, a 4 deg turn), device odometry vs the
+    oracle's, both against the synthetic ground truth."""
+    rings, nframes = 64, 40
+    cfg = synth.default_cfg(rings)
+    scans = [synth.scan(cfg, k) for k in range(nframes)]
+    P = orc.params(rings)
+    ex = [orc.extract(s, P) for s in scans]
+    pose0 = np.array([0, 0, 0, 1.0, 0.9, 0.0, 0.0])
+    orc.set_nn_mode(1)
+    q = pose0[:4].copy(); t = pose0[4:].copy(); rel_o = []
+    for k in range(1, nframes):
+        q, t = orc.odometry_frame(q, t, ex[k], ex[k - 1], vote=k > 5)
+        rel_o.append(np.concatenate([q, t]))
+    orc.set_nn_mode(0)
+    ctx = api.Context(api.default_params(rings, batch=nframes, max_points=max(map(len, scans))))
+    for k, s in enumerate(scans):
+        ctx.upload_scan(k, s)
+    ctx.extract(0, nframes)
+    ctx.set_target_from_slot(0)
+    rel_d = ctx.odometry_frames(1, nframes - 1, pose0=pose0, n_outer=3, first_frame_index=1)
+    ctx.close()
+    gt = np.array([synth.pose(cfg, k) for k in range(nframes)])
+    c, s_ = np.cos(gt[0, 2]), np.sin(gt[0, 2])
+    gt_xy = (gt[:, :2] - gt[0, :2]) @ np.array([[c, -s_], [s_, c]])
+    ate_o, ate_d = ate(integrate(np.array(rel_o)), gt_xy), ate(integrate(rel_d), gt_xy)
+    travelled = float(np.linalg.norm(np.diff(gt_xy, axis=0), axis=1).sum())
+    assert travelled > 30 and ate_o < 0.02 * travelled, (ate_o, travelled)
+    assert abs(ate_d - ate_o) <= 0.01 * ate_o + 1e-9, (ate_d, ate_o)              # ATE within 1 % of the CPU path
+    assert np.abs(rel_d - np.array(rel_o)).max() < 1e-5
