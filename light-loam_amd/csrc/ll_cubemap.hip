@@ -315,8 +315,7 @@ extern "C" int ll_cubemap_update(ll_cubemap *cm, const double *pose_w7)
         size_t need = (size_t)n_out;
         for (int c = 0; c < CM_N; ++c) if (!is_valid[c] && addcnt[c] > 0) need += (size_t)cm->cnt[w][c] + (size_t)addcnt[c];
         /* the valid cubes' old clouds are dead from here on: do not carry them through a compaction */
-        std::vector<int> old_cnt(cm->n_valid);
-        for (int v = 0; v < cm->n_valid; ++v) { old_cnt[v] = cm->cnt[w][cm->valid[v]]; cm->cnt[w][cm->valid[v]] = 0; }
+        for (int v = 0; v < cm->n_valid; ++v) cm->cnt[w][cm->valid[v]] = 0;
         rc = cm_reserve(cm, w, need); if (rc) return rc;
         float4 *pool = cm->pool[w][cm->cur[w]];
         if (n_out > 0) CM_HIP(hipMemcpyAsync(pool + cm->top[w], cm->d_out, (size_t)n_out * sizeof(float4), hipMemcpyDeviceToDevice, st));
@@ -332,7 +331,6 @@ extern "C" int ll_cubemap_update(ll_cubemap *cm, const double *pose_w7)
         rc = cm_run_ops(cm, grow, pool, cm->d_tp, cm->d_vals, pool); if (rc) return rc;
         cm->top[w] = at;
         CM_HIP(hipStreamSynchronize(st));
-        (void)old_cnt;
     }
     CM_HIP(hipGetLastError());
     return LL_OK;
