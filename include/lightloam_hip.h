@@ -242,6 +242,9 @@ int ll_cubemap_optimize(ll_cubemap *cm, double *pose_w7, int n_outer, const ll_l
 int ll_cubemap_update(ll_cubemap *cm, const double *pose_w7);
 /* the three calls in sequence with the reference's constants; pose_w7 in: the guess of transformAssociateToMap (:1581) */
 int ll_cubemap_process(ll_cubemap *cm, double *pose_w7, const ll_point *host_corner_last, int n_corner, const ll_point *host_surf_last, int n_surf, int *ran);
+/* the same for the scan that sits in an extracted slot of the owning ll_ctx: its less-sharp / less-flat clouds go from the
+ * slot to the map stage device-to-device (the laser_cloud_corner_last / laser_cloud_surf_last topics, laserOdometry.cpp:898-910) */
+int ll_cubemap_process_slot(ll_cubemap *cm, double *pose_w7, int slot, int *ran);
 /* cen3: laserCloudCenWidth / Height / Depth; counts4: corner / surf from map, corner / surf stack */
 int ll_cubemap_info(ll_cubemap *cm, int *cen3, int *counts4);
 /* which: 0 laserCloudCornerFromMap, 1 laserCloudSurfFromMap, 2 laserCloudCornerStack, 3 laserCloudSurfStack */

@@ -229,6 +229,12 @@ public:
                                  (const ll_point *)laserCloudSurfLast.data(), (int)laserCloudSurfLast.size(), &ran));
         return ran != 0;
     }
+    /* the same for the scan in an extracted slot of the context: nothing crosses the PCIe bus */
+    bool process_slot(int slot) {
+        int ran = 0;
+        check(ll_cubemap_process_slot(cm_, parameters, slot, &ran));
+        return ran != 0;
+    }
     double parameters[7] = {0, 0, 0, 1, 0, 0, 0};                 /* :81-83 */
     double q_wmap_wodom[4] = {0, 0, 0, 1}, t_wmap_wodom[3] = {0, 0, 0};   /* :88-89 */
     ll_cubemap *get() const { return cm_; }

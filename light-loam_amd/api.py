@@ -26,7 +26,7 @@ EXPORTS = [
     "ll_map_create", "ll_map_destroy", "ll_map_last_error", "ll_map_set_map", "ll_map_set_scan", "ll_map_associate",
     "ll_map_get_counts", "ll_map_download_edges", "ll_map_download_planes", "ll_map_normal_equations", "ll_map_optimize",
     "ll_cubemap_create", "ll_cubemap_destroy", "ll_cubemap_last_error", "ll_cubemap_prepare", "ll_cubemap_optimize", "ll_cubemap_update",
-    "ll_cubemap_process", "ll_cubemap_info", "ll_cubemap_download_cloud", "ll_cubemap_download_cube",
+    "ll_cubemap_process", "ll_cubemap_process_slot", "ll_cubemap_info", "ll_cubemap_download_cloud", "ll_cubemap_download_cube",
     "ll_voxel_grid", "ll_map_set_pose", "ll_map_get_pose", "ll_map_evaluate", "ll_map_lm_begin", "ll_map_lm_propose", "ll_map_lm_accept",
 ]
 
@@ -433,6 +433,11 @@ class CubeMap:
         p = np.ascontiguousarray(pose_w, np.float64).copy(); ran = C.c_int(0)
         c = np.ascontiguousarray(corner_last, np.float32); s_ = np.ascontiguousarray(surf_last, np.float32)
         self._ck(self.lib.ll_cubemap_process(self.h, _ptr(p), _ptr(c), len(c), _ptr(s_), len(s_), C.byref(ran)))
+        return p, bool(ran.value)
+
+    def process_slot(self, pose_w, slot):
+        p = np.ascontiguousarray(pose_w, np.float64).copy(); ran = C.c_int(0)
+        self._ck(self.lib.ll_cubemap_process_slot(self.h, _ptr(p), int(slot), C.byref(ran)))
         return p, bool(ran.value)
 
     def info(self):

@@ -210,7 +210,7 @@ static int cm_reserve(ll_cubemap *cm, int w, size_t need)
     return LL_OK;
 }
 
-extern "C" int ll_cubemap_prepare(ll_cubemap *cm, const double *t_w3, const ll_point *corner_last, int n_corner, const ll_point *surf_last, int n_surf)
+static int cm_prepare(ll_cubemap *cm, const double *t_w3, const ll_point *corner_last, int n_corner, const ll_point *surf_last, int n_surf, bool on_device)
 {
     if (!cm || !t_w3) return LL_ERR_ARG;
     if (n_corner < 0 || n_surf < 0 || (!corner_last && n_corner > 0) || (!surf_last && n_surf > 0)) { cm->err = "bad scan clouds"; return LL_ERR_ARG; }
@@ -250,7 +250,7 @@ extern "C" int ll_cubemap_prepare(ll_cubemap *cm, const double *t_w3, const ll_p
         int n_out = 0;
         if (n_in[w] > 0) {
             const int seg_off[2] = {0, n_in[w]};
-            CM_HIP(hipMemcpyAsync(cm->d_last, src[w], (size_t)n_in[w] * sizeof(ll_point), hipMemcpyHostToDevice, st));
+            CM_HIP(hipMemcpyAsync(cm->d_last, src[w], (size_t)n_in[w] * sizeof(ll_point), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
             CM_HIP(hipMemcpyAsync(cm->W.seg_off, seg_off, sizeof(seg_off), hipMemcpyHostToDevice, st));
             ll_voxel_grid_segments(cm->d_last, n_in[w], 1, cm->leaf[w], cm->W, cm->map->d_stk[w], cm->d_nout, st);
             CM_HIP(hipMemcpyAsync(&n_out, cm->d_nout, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -260,6 +260,30 @@ extern "C" int ll_cubemap_prepare(ll_cubemap *cm, const double *t_w3, const ll_p
     }
     CM_HIP(hipGetLastError());
     return LL_OK;
+}
+
+extern "C" int ll_cubemap_prepare(ll_cubemap *cm, const double *t_w3, const ll_point *corner_last, int n_corner, const ll_point *surf_last, int n_surf)
+{
+    return cm_prepare(cm, t_w3, corner_last, n_corner, surf_last, n_surf, false);
+}
+
+/* the scan of an extracted slot of the owning context: its less-sharp / less-flat clouds never leave the device
+ * (what laserOdometry publishes as laser_cloud_corner_last / laser_cloud_surf_last, laserOdometry.cpp:898-910) */
+extern "C" int ll_cubemap_process_slot(ll_cubemap *cm, double *pose_w7, int slot, int *ran)
+{
+    if (!cm || !pose_w7) return LL_ERR_ARG;
+    ll_ctx *ctx = cm->ctx;
+    if (slot < 0 || slot >= ctx->p.batch) { cm->err = "slot out of range"; return LL_ERR_ARG; }
+    ScanHdr h;
+    CM_HIP(hipMemcpyAsync(&h, ctx->V.hdr + slot, sizeof(ScanHdr), hipMemcpyDeviceToHost, ctx->stream));
+    CM_HIP(hipStreamSynchronize(ctx->stream));
+    if (h.status != 0) { cm->err = "the slot holds no extracted scan"; return LL_ERR_STATE; }
+    const LLView &V = ctx->V;
+    int rc = cm_prepare(cm, pose_w7 + 4, (const ll_point *)(V.lsharp + (size_t)slot * V.cap_lsharp), h.n_less_sharp,
+                        (const ll_point *)(V.lflat + (size_t)slot * V.NP), h.n_less_flat, true);
+    if (rc) return rc;
+    rc = ll_cubemap_optimize(cm, pose_w7, 2, nullptr, ran); if (rc) return rc;
+    return ll_cubemap_update(cm, pose_w7);
 }
 
 extern "C" int ll_cubemap_optimize(ll_cubemap *cm, double *pose_w7, int n_outer, const ll_lm_options *opt, int *ran)

@@ -90,3 +90,26 @@ def test_free_running_mapping_matches_oracle(api, orc, frames):
         a, b = dc.cube(s, i), oc.cube(s, i)
         assert abs(len(a) - len(b)) <= max(2, len(b) // 500)
     dc.close(); ctx.close(); oc.close()
+
+
+def test_process_slot_equals_process_with_downloaded_clouds(api, synth):
+    """the device-to-device feed (slot -> map stage) gives exactly what the host round trip gives"""
+    cfg = synth.default_cfg(16)
+    n = 5
+    scans = [synth.scan(cfg, k) for k in range(n)]
+    ctx = api.Context(api.default_params(16, batch=n, max_points=max(map(len, scans))))
+    for k, s in enumerate(scans):
+        ctx.upload_scan(k, s)
+    ctx.extract(0, n)
+    a = api.CubeMap(ctx, 4096, 32768, pool_points=1 << 18)
+    b = api.CubeMap(ctx, 4096, 32768, pool_points=1 << 18)
+    for k in range(n):
+        guess = _pose7(synth.pose(cfg, k)); guess[4:] += [0.05, 0.02, -0.01]
+        f = ctx.features(k)
+        pa, ra = a.process(guess, f["less_sharp"], f["less_flat"])
+        pb, rb = b.process_slot(guess, k)
+        assert ra == rb and (pa == pb).all()
+    assert a.info() == b.info()
+    for which in range(4):
+        assert_bit_equal(a.cloud(which), b.cloud(which), f"cloud {which}")
+    a.close(); b.close(); ctx.close()

@@ -53,15 +53,9 @@ int main(int argc, char **argv)
         WorldPose w;
         out.append(w);
         std::unique_ptr<LaserMapping> lm;
-        std::vector<PointXYZI> cloud, sharp, lessSharp, flat, lessFlat;
         auto map_frame = [&](int k) {                                         // laserMapping's process() for frame k
-            ll_scan_info info;
-            ctx.check(ll_get_scan_info(ctx.get(), k, &info));
-            sharp.resize(info.n_sharp); lessSharp.resize(info.n_less_sharp); flat.resize(info.n_flat); lessFlat.resize(info.n_less_flat);
-            ctx.check(ll_download_features(ctx.get(), k, (ll_point *)sharp.data(), (int)sharp.size(), (ll_point *)lessSharp.data(), (int)lessSharp.size(),
-                                           (ll_point *)flat.data(), (int)flat.size(), (ll_point *)lessFlat.data(), (int)lessFlat.size()));
             lm->transformAssociateToMap(w.q, w.t);                            // :1581
-            lm->process(lessSharp, lessFlat);                                 // :1584-2165
+            lm->process_slot(k);                                              // :1584-2165, fed device-to-device from the slot
             lm->transformUpdate(w.q, w.t);                                    // :2101
             WorldPose m;
             for (int i = 0; i < 4; ++i) m.q[i] = lm->parameters[i];
