@@ -202,6 +202,10 @@ int ll_map_download_planes(ll_map *m, int *src, double *norm3, double *d, int ca
 /* H (6x6 row-major over the manifold tangent + t), g, cost of the current blocks at pose_w (NULL = current pose),
  * HuberLoss(0.1) + EigenQuaternionManifold as :1863-1866                                                            */
 int ll_map_normal_equations(ll_map *m, const double *pose_w7, double *H36, double *g6, double *cost);
+/* What ceres::CostFunction::Evaluate would return for the current blocks at pose_w (NULL = current pose): residuals,
+ * jacobians[0] rows x 4 (ambient x,y,z,w), jacobians[1] rows x 3, row-major, loss NOT applied; rows = 3*n_edge + n_plane,
+ * edges first -- for callers that keep ceres::Solve (:2073-2082) and only replace the data association.              */
+int ll_map_residual_jacobian(ll_map *m, const double *pose_w7, double *r, double *Jq, double *Jt, int cap_rows);
 /* The whole block :1822-2095: if the map holds > 10 corner and > 50 surf points, n_outer (2, :1832) x { associate,
  * ceres::Solve restated (LM, <= 4 iterations; opt NULL = ll_lm_default_options) }.  pose_w7 in/out; *ran = 0 when the
  * map is too small (the reference then keeps the odometry guess, :2096-2100).                                        */

@@ -24,7 +24,7 @@ EXPORTS = [
     "ll_residual_jacobian", "ll_hot_path_batch", "ll_algorithmic_bytes", "ll_profile_enable", "ll_profile_read", "ll_set_pose_guess", "ll_debug_counters", "ll_vote_host", "ll_debug_calibration_copy",
     "ll_lm_default_options", "ll_lm_solve_batch", "ll_odometry_frames",
     "ll_map_create", "ll_map_destroy", "ll_map_last_error", "ll_map_set_map", "ll_map_set_scan", "ll_map_associate",
-    "ll_map_get_counts", "ll_map_download_edges", "ll_map_download_planes", "ll_map_normal_equations", "ll_map_optimize",
+    "ll_map_residual_jacobian", "ll_map_get_counts", "ll_map_download_edges", "ll_map_download_planes", "ll_map_normal_equations", "ll_map_optimize",
     "ll_cubemap_create", "ll_cubemap_destroy", "ll_cubemap_last_error", "ll_cubemap_prepare", "ll_cubemap_optimize", "ll_cubemap_update",
     "ll_cubemap_process", "ll_cubemap_process_slot", "ll_cubemap_info", "ll_cubemap_download_cloud", "ll_cubemap_download_cube",
     "ll_voxel_grid", "ll_map_set_pose", "ll_map_get_pose", "ll_map_evaluate", "ll_map_lm_begin", "ll_map_lm_propose", "ll_map_lm_accept",
@@ -352,6 +352,14 @@ class Map:
         H = np.zeros((6, 6)); g = np.zeros(6); cost = C.c_double(0)
         self._ck(self.lib.ll_map_normal_equations(self.h, _ptr(p), _ptr(H), _ptr(g), C.byref(cost)))
         return H, g, cost.value
+
+    def residual_jacobian(self, pose_w=None):
+        ne, npl = self.counts()
+        rows = 3 * ne + npl
+        p = None if pose_w is None else np.ascontiguousarray(pose_w, np.float64)
+        r = np.zeros(max(rows, 1)); Jq = np.zeros((max(rows, 1), 4)); Jt = np.zeros((max(rows, 1), 3))
+        self._ck(self.lib.ll_map_residual_jacobian(self.h, _ptr(p), _ptr(r), _ptr(Jq), _ptr(Jt), len(r)))
+        return r[:rows], Jq[:rows], Jt[:rows]
 
     def optimize(self, pose_w, n_outer=2, opt=None):
         p = np.ascontiguousarray(pose_w, np.float64).copy()

@@ -629,6 +629,30 @@ extern "C" int ll_map_optimize(ll_map *m, double *pose_w7, int n_outer, const ll
     return LL_OK;
 }
 
+extern "C" int ll_map_residual_jacobian(ll_map *m, const double *pose_w7, double *r, double *Jq, double *Jt, int cap_rows)
+{
+    if (!m) return LL_ERR_ARG;
+    int ne = 0, np = 0;
+    int rc = ll_map_get_counts(m, &ne, &np); if (rc) return rc;
+    const size_t rows = (size_t)3 * ne + np;
+    if ((size_t)cap_rows < rows) { m->err = "row capacity too small"; return LL_ERR_CAPACITY; }
+    if (rows == 0) return LL_OK;
+    rc = map_set_pose(m, pose_w7); if (rc) return rc;
+    hipStream_t st = m->ctx->stream;
+    double *d = nullptr;
+    LLM_HIP(hipMalloc((void **)&d, rows * 8 * sizeof(double)));
+    double *dr = d, *dJq = d + rows, *dJt = dJq + rows * 4;
+    ll_map_launch_rows(m->M, dr, dJq, dJt, st);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && r) e = hipMemcpyAsync(r, dr, rows * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && Jq) e = hipMemcpyAsync(Jq, dJq, rows * 4 * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && Jt) e = hipMemcpyAsync(Jt, dJt, rows * 3 * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    if (e != hipSuccess) { m->err = std::string("ll_map_residual_jacobian: ") + hipGetErrorString(e); return LL_ERR_HIP; }
+    return LL_OK;
+}
+
 extern "C" int ll_map_set_pose(ll_map *m, const double *pose_w7)
 {
     if (!m || !pose_w7) return LL_ERR_ARG;

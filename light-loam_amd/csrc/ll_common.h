@@ -190,6 +190,7 @@ void ll_map_bbox_to_grid(const int bbox_host[6], int n, int max_cells, LLGrid3 *
 void ll_map_launch_build(const LLGrid3 &G, const float4 *pts, int n, int *tile_sum, hipStream_t st);
 void ll_map_launch_associate(const LLMapView &M, hipStream_t st);
 void ll_map_launch_normal_eq(const LLMapView &M, hipStream_t st);
+void ll_map_launch_rows(const LLMapView &M, double *r, double *Jq, double *Jt, hipStream_t st);
 
 /* ---- whole-cloud VoxelGrid (ll_voxel.hip) ---- */
 struct LLVoxSeg;

@@ -374,6 +374,34 @@ __global__ __launch_bounds__(1024) void k_map_normal_eq(LLMapView M)
     }
 }
 
+/* what ceres::CostFunction::Evaluate returns for the blocks (loss not applied): edges first (3 rows each), then planes */
+__global__ __launch_bounds__(LL_MAPB) void k_map_rows(LLMapView M, double *r_out, double *Jq_out, double *Jt_out)
+{
+    Pose P;
+    for (int k = 0; k < 4; ++k) P.q[k] = M.pose[k];
+    for (int k = 0; k < 3; ++k) P.t[k] = M.pose[4 + k];
+    const int n_e = M.counts[0], n_p = M.counts[1];
+    const int gtid = blockIdx.x * LL_MAPB + threadIdx.x, gsz = gridDim.x * LL_MAPB;
+    for (int i = gtid; i < n_e; i += gsz) {
+        double r[3], Jq[3][4], Jt[3][3];
+        ll_edge_d(P, M.stk[0][M.src[0][i]], &M.fa[(size_t)i * 3], &M.fb[(size_t)i * 3], r, Jq, Jt);
+        for (int row = 0; row < 3; ++row) {
+            const size_t R0 = (size_t)3 * i + row;
+            r_out[R0] = r[row];
+            for (int k = 0; k < 4; ++k) Jq_out[R0 * 4 + k] = Jq[row][k];
+            for (int k = 0; k < 3; ++k) Jt_out[R0 * 3 + k] = Jt[row][k];
+        }
+    }
+    for (int i = gtid; i < n_p; i += gsz) {
+        double r, Jq[4], Jt[3];
+        ll_plane_norm(P, M.stk[1][M.src[1][i]], &M.fn[(size_t)i * 3], M.fd[i], r, Jq, Jt);
+        const size_t R0 = (size_t)3 * n_e + i;
+        r_out[R0] = r;
+        for (int k = 0; k < 4; ++k) Jq_out[R0 * 4 + k] = Jq[k];
+        for (int k = 0; k < 3; ++k) Jt_out[R0 * 3 + k] = Jt[k];
+    }
+}
+
 /* ------------------------------------------------------------------ launchers */
 /* in-place exclusive scan of n ints (n <= 4096 * 4096); tile_sum: ceil(n / 4096) ints of scratch */
 void ll_device_exscan(int *data, int n, int *tile_sum, hipStream_t st)
@@ -428,4 +456,9 @@ void ll_map_launch_associate(const LLMapView &M, hipStream_t st)
 void ll_map_launch_normal_eq(const LLMapView &M, hipStream_t st)
 {
     hipLaunchKernelGGL(k_map_normal_eq, dim3(1), dim3(1024), 0, st, M);
+}
+
+void ll_map_launch_rows(const LLMapView &M, double *r, double *Jq, double *Jt, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_map_rows, dim3(64), dim3(LL_MAPB), 0, st, M, r, Jq, Jt);
 }

@@ -96,6 +96,24 @@ def test_normal_equations_match_oracle(scene, dev, orc):
     close(H, Ho, "H'"); close(g, go, "g'"); close(cost, co, "cost'")
 
 
+def test_residual_jacobian_rows_match_the_functors(scene, dev, orc):
+    """what ceres::CostFunction::Evaluate would return per block (LidarEdgeFactor, LidarPlaneNormFactor), loss not applied"""
+    q, t = scene["guess"][:4], scene["guess"][4:]
+    e_src, e_a, e_b, p_src, p_n, p_d = orc.map_associate(q, t, scene["corner_stack"], scene["corner_map"], scene["surf_stack"], scene["surf_map"])
+    dev.associate(scene["guess"])
+    r, Jq, Jt = dev.residual_jacobian(scene["guess"])
+    ne = len(e_src)
+    assert len(r) == 3 * ne + len(p_src)
+    src, a, b = dev.edges()                                       # the device's own line points (a / b may be swapped vs the oracle)
+    for i in range(0, ne, max(1, ne // 50)):
+        ro, Jqo, Jto = orc.edge_factor(q, t, scene["corner_stack"][src[i], :3], a[i], b[i])
+        close(r[3 * i:3 * i + 3], ro, "edge r"); close(Jq[3 * i:3 * i + 3], Jqo, "edge Jq"); close(Jt[3 * i:3 * i + 3], Jto, "edge Jt")
+    for i in range(0, len(p_src), max(1, len(p_src) // 50)):
+        ro, Jqo, Jto = orc.plane_norm_factor(q, t, scene["surf_stack"][p_src[i], :3], p_n[i], p_d[i])
+        row = 3 * ne + i
+        close(r[row:row + 1], ro, "plane r"); close(Jq[row:row + 1], Jqo, "plane Jq"); close(Jt[row:row + 1], Jto, "plane Jt")
+
+
 def test_optimize_matches_oracle_and_ground_truth(scene, dev, orc):
     q, t, ran = orc.map_optimize(scene["guess"][:4], scene["guess"][4:], scene["corner_stack"], scene["corner_map"], scene["surf_stack"], scene["surf_map"])
     assert ran
