@@ -360,6 +360,29 @@ private:
     Context &c_; int slot_;
     mutable std::vector<double> jq_, jt_;
 };
+
+/* the same for the mapping blocks of a MapOptimizer after ll_map_associate (LidarEdgeFactor + LidarPlaneNormFactor rows,
+ * laserMapping.cpp:1918-1919, :2033-2034); parameter blocks (4, 3) = parameters, parameters + 4 (:1871-1872) */
+class BatchedMapCost : public ceres::CostFunction {
+public:
+    BatchedMapCost(MapOptimizer &m, int rows) : m_(m) {
+        set_num_residuals(rows);
+        mutable_parameter_block_sizes()->push_back(4);
+        mutable_parameter_block_sizes()->push_back(3);
+        jq_.resize((size_t)rows * 4); jt_.resize((size_t)rows * 3);
+    }
+    bool Evaluate(double const *const *parameters, double *residuals, double **jacobians) const override {
+        const double pose[7] = {parameters[0][0], parameters[0][1], parameters[0][2], parameters[0][3],
+                                parameters[1][0], parameters[1][1], parameters[1][2]};
+        if (ll_map_residual_jacobian(m_.get(), pose, residuals, jq_.data(), jt_.data(), num_residuals()) != LL_OK) return false;
+        if (jacobians && jacobians[0]) std::copy(jq_.begin(), jq_.end(), jacobians[0]);
+        if (jacobians && jacobians[1]) std::copy(jt_.begin(), jt_.end(), jacobians[1]);
+        return true;
+    }
+private:
+    MapOptimizer &m_;
+    mutable std::vector<double> jq_, jt_;
+};
 }  // namespace lightloam
 #endif
 
