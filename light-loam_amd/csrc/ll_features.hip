@@ -225,6 +225,9 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features
         unsigned long long w; int spins = 0;
         while (((w = __hip_atomic_load(&ring_pub[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 40) != (unsigned long long)V.epoch && ++spins < LL_LOOKBACK_SPINS)
             __builtin_amdgcn_s_sleep(16);
+#ifndef LL_PHASE_STOP
+        if (spins >= LL_LOOKBACK_SPINS) V.hdr[s].status = -7;     /* LL_ERR_STATE: an earlier ring never published -- fail loudly, not wrongly */
+#endif
         v[0] += (int)(w & 15u); v[2] += (int)((w >> 4) & 31u); v[1] += (int)((w >> 9) & 127u); v[3] += (int)((w >> 16) & 0xffffffu);
     };
     if (nr <= 0) {                                                    /* empty ring: publish zero counts for the rings behind it */
