@@ -409,6 +409,7 @@ void ll_device_exscan(int *data, int n, int *tile_sum, hipStream_t st)
     if (n <= 0) return;
     const int nt = (n + LL_SCAN_TILE - 1) / LL_SCAN_TILE;
     hipLaunchKernelGGL(k_scan_tiles, dim3(nt), dim3(1024), 0, st, data, n, tile_sum);
+    if (nt == 1) return;                                         /* one tile: already the whole scan */
     hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, st, tile_sum, nt);
     hipLaunchKernelGGL(k_scan_add, dim3(nt), dim3(1024), 0, st, data, n, tile_sum);
 }
