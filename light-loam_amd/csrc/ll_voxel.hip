@@ -169,12 +169,91 @@ __global__ __launch_bounds__(1024) void k_rs_scatter(const unsigned long long *k
     }
 }
 
+/* the same sort for n <= 8192 pairs in ONE launch: one 1024-thread workgroup, keys and values in LDS between the
+ * passes, digits that do not vary found on the device (no host read-back).  104 KB of dynamic LDS. */
+#define LL_RSS_ROWS 8
+#define LL_RSS_MAX (LL_RSS_ROWS * 1024)
+extern __shared__ __attribute__((aligned(16))) unsigned char ll_rss_smem[];
+__global__ __launch_bounds__(1024) void k_rs_small(unsigned long long *keys, int *vals, int n)
+{
+    unsigned long long *lk = (unsigned long long *)ll_rss_smem;           /* [LL_RSS_MAX] */
+    int *lv = (int *)(lk + LL_RSS_MAX);                                     /* [LL_RSS_MAX] */
+    int *cnt = lv + LL_RSS_MAX;                                             /* [16][LL_RSS_ROWS * 16] */
+    __shared__ int sc[16];
+    __shared__ unsigned long long oa[2];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nrows = (n + 1023) >> 10;
+    unsigned long long k[LL_RSS_ROWS]; int v[LL_RSS_ROWS];
+    unsigned long long o = 0ull, a = ~0ull;
+#pragma unroll
+    for (int r = 0; r < LL_RSS_ROWS; ++r) {
+        const int i = r * 1024 + tid;
+        k[r] = ~0ull; v[r] = 0;
+        if (r < nrows && i < n) { k[r] = keys[i]; v[r] = vals[i]; o |= k[r]; a &= k[r]; }
+    }
+    if (tid == 0) { oa[0] = 0ull; oa[1] = ~0ull; }
+    __syncthreads();
+    for (int s_ = 32; s_ > 0; s_ >>= 1) { o |= __shfl_xor(o, s_); a &= __shfl_xor(a, s_); }
+    if ((tid & 63) == 0) { atomicOr(&oa[0], o); atomicAnd(&oa[1], a); }
+    __syncthreads();
+    const unsigned long long vary = oa[0] ^ oa[1];
+    for (int shift = 0; shift < 64; shift += 4) {
+        if (((vary >> shift) & 15ull) == 0ull) continue;
+        cnt[tid] = 0; cnt[1024 + tid] = 0;
+        __syncthreads();
+        int rnk[LL_RSS_ROWS];
+#pragma unroll
+        for (int r = 0; r < LL_RSS_ROWS; ++r) {
+            rnk[r] = 0;
+            if (r < nrows) {                                               /* the padding (all-ones keys) takes part and stays last */
+                const int d = (int)((k[r] >> shift) & 15ull);
+                unsigned mlo, mhi;
+                ll_match_any(d, 4, ~0ull, mlo, mhi);
+                rnk[r] = ll_match_rank(mlo, mhi);
+                if (rnk[r] == 0) cnt[d * (LL_RSS_ROWS * 16) + r * 16 + wave] = ll_match_count(mlo, mhi);
+            }
+        }
+        __syncthreads();
+        {   /* exclusive scan of the 2048 digit-major counters: two consecutive ones per thread */
+            const int c0 = cnt[2 * tid], c1 = cnt[2 * tid + 1];
+            int total;
+            const int ex = ll_block_exscan_n<16>(c0 + c1, sc, total);
+            cnt[2 * tid] = ex; cnt[2 * tid + 1] = ex + c0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < LL_RSS_ROWS; ++r)
+            if (r < nrows) {
+                const int d = (int)((k[r] >> shift) & 15ull);
+                const int pos = cnt[d * (LL_RSS_ROWS * 16) + r * 16 + wave] + rnk[r];
+                lk[pos] = k[r]; lv[pos] = v[r];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < LL_RSS_ROWS; ++r)
+            if (r < nrows) { k[r] = lk[r * 1024 + tid]; v[r] = lv[r * 1024 + tid]; }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < LL_RSS_ROWS; ++r) {
+        const int i = r * 1024 + tid;
+        if (r < nrows && i < n) { keys[i] = k[r]; vals[i] = v[r]; }
+    }
+}
+
 /* sorts (keys, vals) by keys, stable; the result is in (keys, vals) again.  tmp_* hold n elements, hist 16 * ceil(n/4096)
  * ints, tile_sum as for ll_device_exscan of that, or_and_host is pinned host memory for the varying-bit mask */
 void ll_sort_pairs(unsigned long long *keys, int *vals, unsigned long long *tmp_keys, int *tmp_vals, int n, int *hist, int *tile_sum,
                    unsigned long long *or_and_dev, hipStream_t st)
 {
     if (n <= 1) return;
+    if (n <= LL_RSS_MAX) {
+        const size_t lds = (size_t)LL_RSS_MAX * 12 + 16 * LL_RSS_ROWS * 16 * sizeof(int);
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_rs_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+        hipLaunchKernelGGL(k_rs_small, dim3(1), dim3(1024), lds, st, keys, vals, n);
+        return;
+    }
     const unsigned long long init[2] = {0ull, ~0ull};
     unsigned long long oa[2];
     (void)hipMemcpyAsync(or_and_dev, init, sizeof(init), hipMemcpyHostToDevice, st);
