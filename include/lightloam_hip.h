@@ -225,6 +225,23 @@ int ll_map_lm_begin(ll_map *m, const double *neq44_sum, const ll_lm_options *opt
 int ll_map_lm_propose(ll_map *m, const ll_lm_options *opt);                               /* current pose <- candidate (or unchanged) */
 int ll_map_lm_accept(ll_map *m, const double *neq44_sum, const ll_lm_options *opt);       /* current pose <- accepted state */
 
+/* Tile-parallel use over several GPUs: the map -- not the scan -- is split; every rank holds the points
+ * of ITS cubes (ll_cubemap_set_shard, or ll_map_set_map + ll_map_set_map_ids for a hand-made split) and the whole scan.
+ *     repeat n_outer x { ll_map_knn_partial -> all-gather of the candidates -> ll_map_associate_merged -> ll_map_solve }
+ * ll_map_knn_partial: the five nearest of this rank's points per stack point, nn = 5 x (x, y, z, squared distance) floats,
+ * id = 5 global ids (INFINITY / INT_MAX in unused slots); buffers of n_stack * 5 entries, HOST OR DEVICE memory (the
+ * all-gather is RCCL on device buffers over xGMI, 100 B per stack point and rank).  ll_map_associate_merged: the buffers
+ * of all parts back to back ([part][stack point][5], host or device); keeps the five smallest (distance, id) -- the
+ * global ids number the points in the order of the unsplit search cloud, so ties fall exactly as in ll_map_associate --
+ * and runs the line / plane fit: every rank ends with the residual blocks ll_map_associate would give on the whole map.
+ * ll_map_solve: one ceres::Solve restated on those blocks (replicated: <= a few thousand rows; identical on all ranks).
+ * ll_map_set_map_ids: ids ascending in the order of the unsplit cloud; both NULL = back to positions.                  */
+int ll_map_set_map_ids(ll_map *m, const int *corner_gid, const int *surf_gid);
+int ll_map_knn_partial(ll_map *m, const double *pose_w7, float *corner_nn, int *corner_id, float *surf_nn, int *surf_id);
+int ll_map_associate_merged(ll_map *m, const double *pose_w7, int n_parts, const float *corner_nn, const int *corner_id,
+                            const float *surf_nn, const int *surf_id);
+int ll_map_solve(ll_map *m, double *pose_w7, const ll_lm_options *opt);
+
 /* pcl::VoxelGrid<PointType>::filter on a whole cloud of any size (downSizeFilterCorner / downSizeFilterSurf,
  * laserMapping.cpp:1813-1821, :2151-2165): centroids (x, y, z, intensity) per voxel, in voxel-index order.       */
 int ll_voxel_grid(ll_ctx *ctx, const ll_point *host_in, int n, float leaf_size, ll_point *host_out, int cap, int *n_out);
@@ -249,6 +266,13 @@ int ll_cubemap_process(ll_cubemap *cm, double *pose_w7, const ll_point *host_cor
 /* the same for the scan that sits in an extracted slot of the owning ll_ctx: its less-sharp / less-flat clouds go from the
  * slot to the map stage device-to-device (the laser_cloud_corner_last / laser_cloud_surf_last topics, laserOdometry.cpp:898-910) */
 int ll_cubemap_process_slot(ll_cubemap *cm, double *pose_w7, int slot, int *ran);
+/* Tile shard: this cube map keeps only the cubes owned by `rank` of `world` (ownership is a function of the cube's
+ * position in the world, so the shift loops never move a cube between ranks); call before the first scan.  prepare and
+ * update work as before on the owned cubes (prepare also numbers the gathered points for ll_map_knn_partial);
+ * ll_cubemap_optimize / _process refuse (LL_ERR_STATE): the search goes through ll_cubemap_map() and the calls above.
+ * The union of the ranks' cubes is the unsplit cube map, cube by cube and bit for bit.                               */
+int ll_cubemap_set_shard(ll_cubemap *cm, int rank, int world);
+ll_map *ll_cubemap_map(ll_cubemap *cm);                       /* the inner ll_map (owned by the cube map) */
 /* cen3: laserCloudCenWidth / Height / Depth; counts4: corner / surf from map, corner / surf stack */
 int ll_cubemap_info(ll_cubemap *cm, int *cen3, int *counts4);
 /* which: 0 laserCloudCornerFromMap, 1 laserCloudSurfFromMap, 2 laserCloudCornerStack, 3 laserCloudSurfStack */

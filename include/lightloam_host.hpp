@@ -235,6 +235,40 @@ public:
         check(ll_cubemap_process_slot(cm_, parameters, slot, &ran));
         return ran != 0;
     }
+    /* ---- tile-parallel over the GPUs of a node: one LaserMapping per rank, each keeping the cubes it
+     * owns.  all_gather(send, recv, bytes): `bytes` from every rank into recv, rank-major (ncclAllGather / MPI_Allgather;
+     * the buffers handed over are host memory).  Every rank passes the same scan and ends with the same parameters[]. */
+    void set_shard(int rank, int world) { check(ll_cubemap_set_shard(cm_, rank, world)); world_ = world; }
+    template <class AllGather>
+    bool process_tile_parallel(const std::vector<PointXYZI> &laserCloudCornerLast, const std::vector<PointXYZI> &laserCloudSurfLast,
+                               AllGather &&all_gather, const ll_lm_options *opt = nullptr) {
+        check(ll_cubemap_prepare(cm_, parameters + 4, (const ll_point *)laserCloudCornerLast.data(), (int)laserCloudCornerLast.size(),
+                                 (const ll_point *)laserCloudSurfLast.data(), (int)laserCloudSurfLast.size()));
+        int cnt[4];
+        check(ll_cubemap_info(cm_, nullptr, cnt));
+        std::vector<int> all_cnt((size_t)2 * world_);
+        all_gather(cnt, all_cnt.data(), 2 * sizeof(int));
+        long tot[2] = {0, 0};
+        for (int r = 0; r < world_; ++r) { tot[0] += all_cnt[2 * r]; tot[1] += all_cnt[2 * r + 1]; }
+        const bool ran = tot[0] > 10 && tot[1] > 50;                                      /* :1822 */
+        if (ran) {
+            ll_map *m = ll_cubemap_map(cm_);
+            const size_t nc = (size_t)cnt[2] * 5, ns = (size_t)cnt[3] * 5;
+            std::vector<float> cn(nc * 4 + 4), sn(ns * 4 + 4), acn(cn.size() * world_), asn(sn.size() * world_);
+            std::vector<int> ci(nc + 1), si(ns + 1), aci(ci.size() * world_), asi(si.size() * world_);
+            for (int it = 0; it < 2; ++it) {                                              /* :1832 */
+                mcheck(m, ll_map_knn_partial(m, parameters, cn.data(), ci.data(), sn.data(), si.data()));
+                /* gather exactly the used part so that the parts sit back to back */
+                acn.resize(nc * 4 * world_); asn.resize(ns * 4 * world_); aci.resize(nc * world_); asi.resize(ns * world_);
+                if (nc) { all_gather(cn.data(), acn.data(), nc * 4 * sizeof(float)); all_gather(ci.data(), aci.data(), nc * sizeof(int)); }
+                if (ns) { all_gather(sn.data(), asn.data(), ns * 4 * sizeof(float)); all_gather(si.data(), asi.data(), ns * sizeof(int)); }
+                mcheck(m, ll_map_associate_merged(m, parameters, world_, acn.data(), aci.data(), asn.data(), asi.data()));
+                mcheck(m, ll_map_solve(m, parameters, opt));
+            }
+        }
+        check(ll_cubemap_update(cm_, parameters));
+        return ran;
+    }
     double parameters[7] = {0, 0, 0, 1, 0, 0, 0};                 /* :81-83 */
     double q_wmap_wodom[4] = {0, 0, 0, 1}, t_wmap_wodom[3] = {0, 0, 0};   /* :88-89 */
     ll_cubemap *get() const { return cm_; }
@@ -251,7 +285,9 @@ private:
         o[0] = v[0] + w * uvx + (uy * uvz - uz * uvy); o[1] = v[1] + w * uvy + (uz * uvx - ux * uvz); o[2] = v[2] + w * uvz + (ux * uvy - uy * uvx);
     }
     void check(int rc) { if (rc != LL_OK) throw Error(rc, ll_cubemap_last_error(cm_)); }
+    static void mcheck(ll_map *m, int rc) { if (rc != LL_OK) throw Error(rc, ll_map_last_error(m)); }
     ll_cubemap *cm_ = nullptr;
+    int world_ = 1;
 };
 
 /* ---- I/O surface ---------------------------------------------------------------------------------- */

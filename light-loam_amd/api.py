@@ -27,6 +27,7 @@ EXPORTS = [
     "ll_map_residual_jacobian", "ll_map_get_counts", "ll_map_download_edges", "ll_map_download_planes", "ll_map_normal_equations", "ll_map_optimize",
     "ll_cubemap_create", "ll_cubemap_destroy", "ll_cubemap_last_error", "ll_cubemap_prepare", "ll_cubemap_optimize", "ll_cubemap_update",
     "ll_cubemap_process", "ll_cubemap_process_slot", "ll_cubemap_info", "ll_cubemap_download_cloud", "ll_cubemap_download_cube",
+    "ll_map_set_map_ids", "ll_map_knn_partial", "ll_map_associate_merged", "ll_map_solve", "ll_cubemap_set_shard", "ll_cubemap_map",
     "ll_voxel_grid", "ll_map_set_pose", "ll_map_get_pose", "ll_map_evaluate", "ll_map_lm_begin", "ll_map_lm_propose", "ll_map_lm_accept",
 ]
 
@@ -286,11 +287,15 @@ class Context:
 class Map:
     """One ll_map: laserMapping's scan-to-submap optimisation (laserMapping.cpp:1822-2095) on the device of `ctx`."""
 
-    def __init__(self, ctx, max_map_corner, max_map_surf, max_scan_corner, max_scan_surf):
+    def __init__(self, ctx, max_map_corner, max_map_surf, max_scan_corner, max_scan_surf, _borrowed=None):
         self.ctx = ctx; self.lib = ctx.lib
         self.lib.ll_map_last_error.restype = C.c_char_p
         self.lib.ll_map_last_error.argtypes = [C.c_void_p]
         self.lib.ll_map_destroy.argtypes = [C.c_void_p]
+        self._owned = _borrowed is None
+        if _borrowed is not None:                      # the inner map of a CubeMap: the cube map destroys it
+            self.h = _borrowed
+            return
         self.h = C.c_void_p()
         rc = self.lib.ll_map_create(ctx.h, int(max_map_corner), int(max_map_surf), int(max_scan_corner), int(max_scan_surf), C.byref(self.h))
         if rc != LL_OK:
@@ -298,7 +303,8 @@ class Map:
 
     def close(self):
         if getattr(self, "h", None):
-            self.lib.ll_map_destroy(self.h)
+            if self._owned:
+                self.lib.ll_map_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -367,6 +373,34 @@ class Map:
         self._ck(self.lib.ll_map_optimize(self.h, _ptr(p), n_outer, None if opt is None else C.byref(opt), C.byref(ran)))
         return p, bool(ran.value)
 
+    # ---- tile-parallel search: this map holds a shard of the cubes, the candidates are all-gathered
+    def set_map_ids(self, corner_gid, surf_gid):
+        c = None if corner_gid is None else np.ascontiguousarray(corner_gid, np.int32)
+        s_ = None if surf_gid is None else np.ascontiguousarray(surf_gid, np.int32)
+        self._ck(self.lib.ll_map_set_map_ids(self.h, _ptr(c), _ptr(s_)))
+
+    def knn_partial(self, pose_w=None, n_stack=None):
+        """-> corner_nn [n, 5, 4] f32 (x, y, z, d2), corner_id [n, 5] i32, surf_nn, surf_id of this rank's points."""
+        nc, ns = n_stack if n_stack is not None else self._n_stack
+        p = None if pose_w is None else np.ascontiguousarray(pose_w, np.float64)
+        cn = np.zeros((nc, 5, 4), np.float32); ci = np.zeros((nc, 5), np.int32)
+        sn = np.zeros((ns, 5, 4), np.float32); si = np.zeros((ns, 5), np.int32)
+        self._ck(self.lib.ll_map_knn_partial(self.h, _ptr(p), _ptr(cn), _ptr(ci), _ptr(sn), _ptr(si)))
+        return cn, ci, sn, si
+
+    def associate_merged(self, corner_nn, corner_id, surf_nn, surf_id, pose_w=None):
+        """The candidates of all parts, arrays [parts, n, 5(, 4)] -> the residual blocks of the whole map."""
+        cn = np.ascontiguousarray(corner_nn, np.float32); ci = np.ascontiguousarray(corner_id, np.int32)
+        sn = np.ascontiguousarray(surf_nn, np.float32); si = np.ascontiguousarray(surf_id, np.int32)
+        assert cn.ndim == 4 and sn.ndim == 4 and cn.shape[0] == sn.shape[0] == ci.shape[0] == si.shape[0]
+        p = None if pose_w is None else np.ascontiguousarray(pose_w, np.float64)
+        self._ck(self.lib.ll_map_associate_merged(self.h, _ptr(p), int(cn.shape[0]), _ptr(cn), _ptr(ci), _ptr(sn), _ptr(si)))
+
+    def solve(self, pose_w, opt=None):
+        p = np.ascontiguousarray(pose_w, np.float64).copy()
+        self._ck(self.lib.ll_map_solve(self.h, _ptr(p), None if opt is None else C.byref(opt)))
+        return p
+
     # ---- row-parallel stepping (SURVEY 8e): the caller sums `evaluate()` over ranks between the LM stages
     def set_pose(self, pose_w):
         p = np.ascontiguousarray(pose_w, np.float64)
@@ -422,6 +456,16 @@ class CubeMap:
     def _ck(self, rc):
         if rc != LL_OK:
             raise LightLoamError(rc, self.lib.ll_cubemap_last_error(self.h).decode())
+
+    def set_shard(self, rank, world):
+        """Keep only the cubes of `rank` out of `world` (tile-parallel mapping); before the first scan."""
+        self._ck(self.lib.ll_cubemap_set_shard(self.h, int(rank), int(world)))
+
+    def map(self):
+        """The inner Map (borrowed): knn_partial / associate_merged / solve / edges / planes on the gathered clouds."""
+        self.lib.ll_cubemap_map.restype = C.c_void_p
+        self.lib.ll_cubemap_map.argtypes = [C.c_void_p]
+        return Map(self.ctx, 0, 0, 0, 0, _borrowed=C.c_void_p(self.lib.ll_cubemap_map(self.h)))
 
     def prepare(self, t_w, corner_last, surf_last):
         t = np.ascontiguousarray(t_w, np.float64)

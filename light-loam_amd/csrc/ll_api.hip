@@ -464,6 +464,8 @@ extern "C" int ll_map_create(ll_ctx *ctx, int max_map_corner, int max_map_surf, 
          map_alloc(m, M.fa, (size_t)m->cap_stk[0] * 3) && map_alloc(m, M.fb, (size_t)m->cap_stk[0] * 3);
     ok = ok && map_alloc(m, M.qn, (size_t)m->cap_stk[1] * 3) && map_alloc(m, M.qd, (size_t)m->cap_stk[1]) &&
          map_alloc(m, M.fn, (size_t)m->cap_stk[1] * 3) && map_alloc(m, M.fd, (size_t)m->cap_stk[1]);
+    for (int w = 0; w < 2 && ok; ++w)
+        ok = ok && map_alloc(m, M.nn_pt[w], (size_t)m->cap_stk[w] * 5) && map_alloc(m, M.nn_id[w], (size_t)m->cap_stk[w] * 5);
     ok = ok && map_alloc(m, M.counts, 2) && map_alloc(m, M.pose, 7) && map_alloc(m, M.neq, LL_NEQ_STRIDE) && map_alloc(m, M.lm, LL_LM_STRIDE);
     ok = ok && map_alloc(m, m->d_bbox, 12) && map_alloc(m, m->d_tile, (size_t)(m->max_cells + 1 + 4095) / 4096 + 1);
     if (!ok) { ctx->err = m->err; ll_map_destroy(m); return LL_ERR_HIP; }
@@ -599,6 +601,111 @@ extern "C" int ll_map_normal_equations(ll_map *m, const double *pose_w7, double 
     return LL_OK;
 }
 
+/* ---- tile-parallel mapping: the map's cubes are spread over the ranks; every rank searches its own
+ * points, the candidates are all-gathered by the caller (RCCL on device buffers, gloo on host buffers -- the copies
+ * below take either), and every rank forms the same residual blocks from the merged five nearest. ---- */
+int ll_map_use_ids(ll_map *m, bool on)
+{
+    for (int w = 0; w < 2; ++w) {
+        if (on && !m->d_gid[w] && !map_alloc(m, m->d_gid[w], (size_t)m->cap_map[w])) return LL_ERR_HIP;
+        m->M.gid[w] = on ? m->d_gid[w] : nullptr;
+    }
+    return LL_OK;
+}
+
+extern "C" int ll_map_set_map_ids(ll_map *m, const int *corner_gid, const int *surf_gid)
+{
+    if (!m) return LL_ERR_ARG;
+    LLM_HIP(hipSetDevice(m->ctx->device));
+    if (!corner_gid && !surf_gid) return ll_map_use_ids(m, false);
+    if (!corner_gid || !surf_gid) { m->err = "give the ids of both clouds or of neither"; return LL_ERR_ARG; }
+    int rc = ll_map_use_ids(m, true); if (rc) return rc;
+    const int *src[2] = {corner_gid, surf_gid};
+    for (int w = 0; w < 2; ++w)
+        if (m->M.n_map[w] > 0) LLM_HIP(hipMemcpyAsync(m->d_gid[w], src[w], (size_t)m->M.n_map[w] * sizeof(int), hipMemcpyDefault, m->ctx->stream));
+    LLM_HIP(hipStreamSynchronize(m->ctx->stream));
+    return LL_OK;
+}
+
+extern "C" int ll_map_knn_partial(ll_map *m, const double *pose_w7, float *corner_nn, int *corner_id, float *surf_nn, int *surf_id)
+{
+    if (!m) return LL_ERR_ARG;
+    if ((m->M.n_stk[0] > 0 && (!corner_nn || !corner_id)) || (m->M.n_stk[1] > 0 && (!surf_nn || !surf_id))) { m->err = "null candidate buffers"; return LL_ERR_ARG; }
+    LLM_HIP(hipSetDevice(m->ctx->device));
+    int rc = map_set_pose(m, pose_w7); if (rc) return rc;
+    hipStream_t st = m->ctx->stream;
+    ll_map_launch_knn_partial(m->M, st);
+    LLM_HIP(hipGetLastError());
+    float *nn[2] = {corner_nn, surf_nn}; int *id[2] = {corner_id, surf_id};
+    for (int w = 0; w < 2; ++w) {
+        const size_t n = (size_t)m->M.n_stk[w] * 5;
+        if (n == 0) continue;
+        LLM_HIP(hipMemcpyAsync(nn[w], m->M.nn_pt[w], n * sizeof(float4), hipMemcpyDefault, st));
+        LLM_HIP(hipMemcpyAsync(id[w], m->M.nn_id[w], n * sizeof(int), hipMemcpyDefault, st));
+    }
+    LLM_HIP(hipStreamSynchronize(st));
+    return LL_OK;
+}
+
+extern "C" int ll_map_associate_merged(ll_map *m, const double *pose_w7, int n_parts, const float *corner_nn, const int *corner_id,
+                                       const float *surf_nn, const int *surf_id)
+{
+    if (!m) return LL_ERR_ARG;
+    if (n_parts < 1 || n_parts > 64) { m->err = "n_parts out of range"; return LL_ERR_ARG; }
+    if ((m->M.n_stk[0] > 0 && (!corner_nn || !corner_id)) || (m->M.n_stk[1] > 0 && (!surf_nn || !surf_id))) { m->err = "null candidate buffers"; return LL_ERR_ARG; }
+    LLM_HIP(hipSetDevice(m->ctx->device));
+    if (n_parts > m->cap_parts) {
+        for (int w = 0; w < 2; ++w) {
+            m->d_all_pt[w] = nullptr; m->d_all_id[w] = nullptr;   /* the smaller buffers stay in allocs until destroy */
+            if (!map_alloc(m, m->d_all_pt[w], (size_t)n_parts * m->cap_stk[w] * 5) || !map_alloc(m, m->d_all_id[w], (size_t)n_parts * m->cap_stk[w] * 5)) return LL_ERR_HIP;
+        }
+        m->cap_parts = n_parts;
+    }
+    int rc = map_set_pose(m, pose_w7); if (rc) return rc;
+    hipStream_t st = m->ctx->stream;
+    const float *nn[2] = {corner_nn, surf_nn}; const int *id[2] = {corner_id, surf_id};
+    for (int w = 0; w < 2; ++w) {
+        const size_t n = (size_t)n_parts * m->M.n_stk[w] * 5;
+        if (n == 0) continue;
+        LLM_HIP(hipMemcpyAsync(m->d_all_pt[w], nn[w], n * sizeof(float4), hipMemcpyDefault, st));
+        LLM_HIP(hipMemcpyAsync(m->d_all_id[w], id[w], n * sizeof(int), hipMemcpyDefault, st));
+    }
+    const float4 *pt_all[2] = {m->d_all_pt[0], m->d_all_pt[1]}; const int *id_all[2] = {m->d_all_id[0], m->d_all_id[1]};
+    ll_map_launch_associate_merged(m->M, n_parts, pt_all, id_all, st);
+    LLM_HIP(hipGetLastError());
+    LLM_HIP(hipStreamSynchronize(st));                          /* the caller's buffers may be reused */
+    return LL_OK;
+}
+
+/* one ceres::Solve (:2072-2082) on the residual blocks the last association left behind */
+static void map_lm_solve(ll_map *m, const LLLmOpt &o)
+{
+    hipStream_t st = m->ctx->stream;
+    LLView Vm = m->ctx->V;                                    /* the LM kernels on a one-slot view of the map's state */
+    Vm.pose = m->M.pose; Vm.neq = m->M.neq; Vm.lm = m->M.lm;
+    ll_map_launch_normal_eq(m->M, st);
+    ll_launch_lm_begin(Vm, 0, 1, o, st);
+    for (int k = 0; k < o.max_num_iterations; ++k) {
+        ll_launch_lm_propose(Vm, 0, 1, o, st);
+        ll_map_launch_normal_eq(m->M, st);
+        ll_launch_lm_accept(Vm, 0, 1, o, st);
+    }
+}
+
+extern "C" int ll_map_solve(ll_map *m, double *pose_w7, const ll_lm_options *opt)
+{
+    if (!m || !pose_w7) return LL_ERR_ARG;
+    const LLLmOpt o = ll_to_dev_opt(opt);
+    if (o.max_num_iterations < 0 || o.max_num_iterations > 64) { m->err = "max_num_iterations out of range"; return LL_ERR_ARG; }
+    LLM_HIP(hipSetDevice(m->ctx->device));
+    int rc = map_set_pose(m, pose_w7); if (rc) return rc;
+    map_lm_solve(m, o);
+    LLM_HIP(hipGetLastError());
+    LLM_HIP(hipMemcpyAsync(pose_w7, m->M.pose, 7 * sizeof(double), hipMemcpyDeviceToHost, m->ctx->stream));
+    LLM_HIP(hipStreamSynchronize(m->ctx->stream));
+    return LL_OK;
+}
+
 extern "C" int ll_map_optimize(ll_map *m, double *pose_w7, int n_outer, const ll_lm_options *opt, int *ran)
 {
     if (!m || !pose_w7) return LL_ERR_ARG;
@@ -610,17 +717,10 @@ extern "C" int ll_map_optimize(ll_map *m, double *pose_w7, int n_outer, const ll
     if (!(m->M.n_map[0] > 10 && m->M.n_map[1] > 50)) return LL_OK;           /* :1822 */
     int rc = map_set_pose(m, pose_w7); if (rc) return rc;
     hipStream_t st = m->ctx->stream;
-    LLView Vm = m->ctx->V;                                    /* the LM kernels on a one-slot view of the map's state */
-    Vm.pose = m->M.pose; Vm.neq = m->M.neq; Vm.lm = m->M.lm;
+    if (m->M.gid[0]) { m->err = "the map holds a tile shard: search with ll_map_knn_partial / ll_map_associate_merged"; return LL_ERR_STATE; }
     for (int it = 0; it < n_outer; ++it) {                                     /* :1832 */
         ll_map_launch_associate(m->M, st);
-        ll_map_launch_normal_eq(m->M, st);
-        ll_launch_lm_begin(Vm, 0, 1, o, st);
-        for (int k = 0; k < o.max_num_iterations; ++k) {
-            ll_launch_lm_propose(Vm, 0, 1, o, st);
-            ll_map_launch_normal_eq(m->M, st);
-            ll_launch_lm_accept(Vm, 0, 1, o, st);
-        }
+        map_lm_solve(m, o);
     }
     LLM_HIP(hipGetLastError());
     LLM_HIP(hipMemcpyAsync(pose_w7, m->M.pose, 7 * sizeof(double), hipMemcpyDeviceToHost, st));

@@ -10,7 +10,7 @@
  *   ring_off   int    [B][R+1]     ring r occupies laserCloud[ring_off[r], ring_off[r+1])
  *   cloud      float4 [B][NP]      laserCloud: ring-major, (x, y, z, intensity)
  *   label      int8   [B][NP]      cloudLabel   curv float [B][NP] (optional)
- *   *_slot     per-ring fixed-capacity feature slots written by the ring kernel, then compacted into
+ *   ring_pub   u64 [B][R]          look-back words: the ring kernel writes its features straight at their final offsets in
  *   sharp / less_sharp / flat / less_flat float4 [B][cap] in the reference's publication order.
  *   carry_*    target clouds for the first slot of a batch (previous batch's last scan).
  *   corr / vote / neq / pose arrays for the odometry stages.
@@ -184,11 +184,15 @@ struct LLMapView {
     int *counts;                                 /* [2] edge blocks, plane blocks */
     double *pose, *neq, *lm;                     /* one slot: parameters[7], normal equations [44], LM state */
     double huber;
+    const int *gid[2];                           /* tile shard: global id per map point (nullptr: position in the cloud) */
+    float4 *nn_pt[2]; int *nn_id[2];             /* tile shard: per stack point 5 x (x, y, z, distance) and 5 global ids */
 };
 void ll_map_launch_bbox(const float4 *pts, int n, int *bbox_dev, hipStream_t st);
 void ll_map_bbox_to_grid(const int bbox_host[6], int n, int max_cells, LLGrid3 *G);
 void ll_map_launch_build(const LLGrid3 &G, const float4 *pts, int n, int *tile_sum, hipStream_t st);
 void ll_map_launch_associate(const LLMapView &M, hipStream_t st);
+void ll_map_launch_knn_partial(const LLMapView &M, hipStream_t st);
+void ll_map_launch_associate_merged(const LLMapView &M, int n_parts, const float4 *const pt_all[2], const int *const id_all[2], hipStream_t st);
 void ll_map_launch_normal_eq(const LLMapView &M, hipStream_t st);
 void ll_map_launch_rows(const LLMapView &M, double *r, double *Jq, double *Jt, hipStream_t st);
 

@@ -25,7 +25,16 @@
 #define CM_N (CM_W * CM_H * CM_D)     /* 4851 (:53) */
 #define CM_MAX_OPS 16384
 
-struct CmOp { int kind, src, cnt, dst; };   /* kind 0: pool[src + i]; kind 1: points[index[src + i]] */
+struct CmOp { int kind, src, cnt, dst, tag; };   /* kind 0: pool[src + i]; kind 1: points[index[src + i]]; tag + i: global id */
+
+/* tile-parallel mapping: the rank that keeps a cube, from the cube's position in the WORLD (array index
+ * minus the running centre, which the shifts preserve) so that ownership never changes when the array shifts */
+__host__ __device__ __forceinline__ int cm_owner(int wi, int wj, int wk, int world)
+{
+    const int h = (wi + 1024) + 3 * (wj + 1024) + 5 * (wk + 1024);
+    return h % world;
+}
+#define CM_GID_SHIFT 20                  /* global id = position in the valid list << 20 | position in the cube */
 
 struct ll_cubemap {
     ll_ctx *ctx = nullptr;
@@ -38,6 +47,7 @@ struct ll_cubemap {
     int cur[2] = {0, 0};
     std::vector<int> off[2], cnt[2];
     int valid[125]; int n_valid = 0;
+    int rank = 0, world = 1;                      /* tile shard: this map keeps the cubes with cm_owner() == rank */
     float4 *d_last = nullptr, *d_tp = nullptr, *d_work = nullptr, *d_out = nullptr;
     int cap_work = 0;
     CmOp *d_ops = nullptr;
@@ -56,17 +66,19 @@ struct ll_cubemap {
     } while (0)
 
 /* ------------------------------------------------------------------ kernels */
-__global__ __launch_bounds__(256) void k_cm_copy(const float4 *pool, const float4 *points, const int *index, const CmOp *ops, int nops, float4 *dst)
+__global__ __launch_bounds__(256) void k_cm_copy(const float4 *pool, const float4 *points, const int *index, const CmOp *ops, int nops, float4 *dst, int *gid)
 {
     const int o = blockIdx.y;
     if (o >= nops) return;
     const CmOp op = ops[o];
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < op.cnt; i += gridDim.x * 256)
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < op.cnt; i += gridDim.x * 256) {
         dst[op.dst + i] = op.kind == 0 ? pool[op.src + i] : points[index[op.src + i]];
+        if (gid) gid[op.dst + i] = op.tag + i;
+    }
 }
 
 /* pointAssociateToMap (:125-134) + the cube of the result (:2108-2125).  key = cube index, or CM_N when outside the map */
-__global__ __launch_bounds__(256) void k_cm_assign(const float4 *stack, int n, const double *pose, int cenx, int ceny, int cenz,
+__global__ __launch_bounds__(256) void k_cm_assign(const float4 *stack, int n, const double *pose, int cenx, int ceny, int cenz, int rank, int world,
                                                    float4 *tp, unsigned long long *keys, int *vals, int *addcnt)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -85,7 +97,10 @@ __global__ __launch_bounds__(256) void k_cm_assign(const float4 *stack, int n, c
     if ((double)sy + 25.0 < 0) cj--;
     if ((double)sz + 25.0 < 0) ck--;
     int cube = CM_N;
-    if (ci >= 0 && ci < CM_W && cj >= 0 && cj < CM_H && ck >= 0 && ck < CM_D) { cube = ci + CM_W * cj + CM_W * CM_H * ck; atomicAdd(&addcnt[cube], 1); }
+    if (ci >= 0 && ci < CM_W && cj >= 0 && cj < CM_H && ck >= 0 && ck < CM_D &&
+        (world == 1 || cm_owner(ci - cenx, cj - ceny, ck - cenz, world) == rank)) {          /* another rank's cube: not kept here */
+        cube = ci + CM_W * cj + CM_W * CM_H * ck; atomicAdd(&addcnt[cube], 1);
+    }
     keys[i] = (unsigned long long)cube;
     vals[i] = i;
 }
@@ -155,7 +170,7 @@ extern "C" int ll_cubemap_create(ll_ctx *ctx, float line_res, float plane_res, i
     return LL_OK;
 }
 
-static int cm_run_ops(ll_cubemap *cm, const std::vector<CmOp> &ops, const float4 *pool, const float4 *points, const int *index, float4 *dst)
+static int cm_run_ops(ll_cubemap *cm, const std::vector<CmOp> &ops, const float4 *pool, const float4 *points, const int *index, float4 *dst, int *gid = nullptr)
 {
     hipStream_t st = cm->ctx->stream;
     for (size_t o0 = 0; o0 < ops.size(); o0 += CM_MAX_OPS) {
@@ -163,7 +178,7 @@ static int cm_run_ops(ll_cubemap *cm, const std::vector<CmOp> &ops, const float4
         int mx = 1;
         for (int i = 0; i < n; ++i) mx = std::max(mx, ops[o0 + i].cnt);
         CM_HIP(hipMemcpyAsync(cm->d_ops, ops.data() + o0, (size_t)n * sizeof(CmOp), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_cm_copy, dim3(std::min(64, (mx + 255) / 256), n), dim3(256), 0, st, pool, points, index, cm->d_ops, n, dst);
+        hipLaunchKernelGGL(k_cm_copy, dim3(std::min(64, (mx + 255) / 256), n), dim3(256), 0, st, pool, points, index, cm->d_ops, n, dst, gid);
         CM_HIP(hipStreamSynchronize(st));                      /* ops is host memory that goes out of scope */
     }
     return LL_OK;
@@ -194,7 +209,7 @@ static int cm_compact(ll_cubemap *cm, int w)
     std::vector<CmOp> ops;
     size_t top = 0;
     for (int c = 0; c < CM_N; ++c)
-        if (cm->cnt[w][c] > 0) { ops.push_back({0, cm->off[w][c], cm->cnt[w][c], (int)top}); top += (size_t)cm->cnt[w][c]; }
+        if (cm->cnt[w][c] > 0) { ops.push_back({0, cm->off[w][c], cm->cnt[w][c], (int)top, 0}); top += (size_t)cm->cnt[w][c]; }
     const int other = cm->cur[w] ^ 1;
     int rc = cm_run_ops(cm, ops, cm->pool[w][cm->cur[w]], nullptr, nullptr, cm->pool[w][other]); if (rc) return rc;
     size_t k = 0;
@@ -236,10 +251,11 @@ static int cm_prepare(ll_cubemap *cm, const double *t_w3, const ll_point *corner
         std::vector<CmOp> ops; size_t tot = 0;
         for (int v = 0; v < cm->n_valid; ++v) {
             const int c = cm->valid[v];
-            if (cm->cnt[w][c] > 0) { ops.push_back({0, cm->off[w][c], cm->cnt[w][c], (int)tot}); tot += (size_t)cm->cnt[w][c]; }
+            if (cm->cnt[w][c] >= (1 << CM_GID_SHIFT) && cm->world > 1) { cm->err = "a cube holds more points than a tile shard can number"; return LL_ERR_CAPACITY; }
+            if (cm->cnt[w][c] > 0) { ops.push_back({0, cm->off[w][c], cm->cnt[w][c], (int)tot, v << CM_GID_SHIFT}); tot += (size_t)cm->cnt[w][c]; }
         }
         if (tot > (size_t)cm->map->cap_map[w]) { cm->err = "the valid cubes hold more points than the search cloud capacity"; return LL_ERR_CAPACITY; }
-        int rc = cm_run_ops(cm, ops, cm->pool[w][cm->cur[w]], nullptr, nullptr, cm->map->d_map[w]); if (rc) return rc;
+        int rc = cm_run_ops(cm, ops, cm->pool[w][cm->cur[w]], nullptr, nullptr, cm->map->d_map[w], cm->world > 1 ? cm->map->d_gid[w] : nullptr); if (rc) return rc;
         n_from[w] = (int)tot;
     }
     int rc = ll_map_rebuild(cm->map, n_from[0], n_from[1]);
@@ -261,6 +277,22 @@ static int cm_prepare(ll_cubemap *cm, const double *t_w3, const ll_point *corner
     CM_HIP(hipGetLastError());
     return LL_OK;
 }
+
+/* keep only the cubes of rank `rank` out of `world` (before the first scan); the searches then go through
+ * ll_map_knn_partial / ll_map_associate_merged on ll_cubemap_map() */
+extern "C" int ll_cubemap_set_shard(ll_cubemap *cm, int rank, int world)
+{
+    if (!cm) return LL_ERR_ARG;
+    if (world < 1 || world > 64 || rank < 0 || rank >= world) { cm->err = "bad shard"; return LL_ERR_ARG; }
+    for (int w = 0; w < 2; ++w) if (cm->top[w] != 0) { cm->err = "the cube map already holds points"; return LL_ERR_STATE; }
+    CM_HIP(hipSetDevice(cm->ctx->device));
+    const int rc = ll_map_use_ids(cm->map, world > 1);
+    if (rc) { cm->err = cm->map->err; return rc; }
+    cm->rank = rank; cm->world = world;
+    return LL_OK;
+}
+
+extern "C" ll_map *ll_cubemap_map(ll_cubemap *cm) { return cm ? cm->map : nullptr; }
 
 extern "C" int ll_cubemap_prepare(ll_cubemap *cm, const double *t_w3, const ll_point *corner_last, int n_corner, const ll_point *surf_last, int n_surf)
 {
@@ -306,7 +338,7 @@ extern "C" int ll_cubemap_update(ll_cubemap *cm, const double *pose_w7)
         const int ns = m->M.n_stk[w];
         CM_HIP(hipMemsetAsync(cm->d_addcnt, 0, (CM_N + 1) * sizeof(int), st));
         if (ns > 0) {
-            hipLaunchKernelGGL(k_cm_assign, dim3((ns + 255) / 256), dim3(256), 0, st, m->d_stk[w], ns, m->M.pose, cm->cen[0], cm->cen[1], cm->cen[2],
+            hipLaunchKernelGGL(k_cm_assign, dim3((ns + 255) / 256), dim3(256), 0, st, m->d_stk[w], ns, m->M.pose, cm->cen[0], cm->cen[1], cm->cen[2], cm->rank, cm->world,
                                cm->d_tp, cm->d_keys, cm->d_vals, cm->d_addcnt);
             ll_sort_pairs(cm->d_keys, cm->d_vals, cm->WS.keys, cm->WS.vals, ns, cm->WS.hist, cm->WS.tile_sum, cm->WS.or_and, st);   /* by cube, stack order kept */
         }
@@ -321,8 +353,8 @@ extern "C" int ll_cubemap_update(ll_cubemap *cm, const double *pose_w7)
             const int c = cm->valid[v];
             is_valid[c] = 1;
             seg_off[v] = (int)tot;
-            if (cm->cnt[w][c] > 0) { ops.push_back({0, cm->off[w][c], cm->cnt[w][c], (int)tot}); tot += (size_t)cm->cnt[w][c]; }
-            if (addcnt[c] > 0) { ops.push_back({1, goff[c], addcnt[c], (int)tot}); tot += (size_t)addcnt[c]; }
+            if (cm->cnt[w][c] > 0) { ops.push_back({0, cm->off[w][c], cm->cnt[w][c], (int)tot, 0}); tot += (size_t)cm->cnt[w][c]; }
+            if (addcnt[c] > 0) { ops.push_back({1, goff[c], addcnt[c], (int)tot, 0}); tot += (size_t)addcnt[c]; }
         }
         seg_off[cm->n_valid] = (int)tot;
         if (tot > (size_t)cm->cap_work) { cm->err = "the valid cubes hold more points than the filter workspace"; return LL_ERR_CAPACITY; }
@@ -348,8 +380,8 @@ extern "C" int ll_cubemap_update(ll_cubemap *cm, const double *pose_w7)
         std::vector<CmOp> grow;
         for (int c = 0; c < CM_N; ++c)
             if (!is_valid[c] && addcnt[c] > 0) {
-                if (cm->cnt[w][c] > 0) grow.push_back({0, cm->off[w][c], cm->cnt[w][c], (int)at});
-                grow.push_back({1, goff[c], addcnt[c], (int)(at + (size_t)cm->cnt[w][c])});
+                if (cm->cnt[w][c] > 0) grow.push_back({0, cm->off[w][c], cm->cnt[w][c], (int)at, 0});
+                grow.push_back({1, goff[c], addcnt[c], (int)(at + (size_t)cm->cnt[w][c]), 0});
                 cm->off[w][c] = (int)at; cm->cnt[w][c] += addcnt[c]; at += (size_t)cm->cnt[w][c];
             }
         rc = cm_run_ops(cm, grow, pool, cm->d_tp, cm->d_vals, pool); if (rc) return rc;

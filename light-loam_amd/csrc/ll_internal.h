@@ -53,6 +53,10 @@ struct ll_map {
     int max_cells = 0;
     float4 *d_map[2] = {nullptr, nullptr}, *d_stk[2] = {nullptr, nullptr};
     int *d_bbox = nullptr, *d_tile = nullptr;
+    /* tile-parallel search: global ids of a shard's map points, this rank's candidates, everybody's candidates */
+    int *d_gid[2] = {nullptr, nullptr};
+    float4 *d_all_pt[2] = {nullptr, nullptr}; int *d_all_id[2] = {nullptr, nullptr};
+    int cap_parts = 0;
     std::vector<void *> allocs;
     std::string err;
 };
@@ -78,3 +82,4 @@ static inline bool map_alloc(ll_map *m, T *&ptr, size_t count)
 
 LLLmOpt ll_to_dev_opt(const ll_lm_options *opt);
 int ll_map_rebuild(ll_map *m, int n_corner, int n_surf);      /* grids over the clouds already in d_map[] */
+int ll_map_use_ids(ll_map *m, bool on);                       /* search ties by d_gid[] (a tile shard) or by position */

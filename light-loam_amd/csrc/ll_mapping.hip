@@ -200,102 +200,173 @@ __device__ __forceinline__ void ll_qr_solve_5x3(double A[5][3], double b[5], dou
         for (int c = 0; c < 3; ++c) if (perm[k] == c) x[c] = z[k];
 }
 
+/* pointAssociateToMap (:125-134) of stack point po */
+__device__ __forceinline__ void ll_map_to_world(const double *pose, const float4 po, float &sx, float &sy, float &sz)
+{
+    const double ux = pose[0], uy = pose[1], uz = pose[2], w = pose[3];
+    const double v[3] = {(double)po.x, (double)po.y, (double)po.z};
+    double uvx = uy * v[2] - uz * v[1], uvy = uz * v[0] - ux * v[2], uvz = ux * v[1] - uy * v[0];
+    uvx += uvx; uvy += uvy; uvz += uvz;
+    sx = (float)(((v[0] + w * uvx) + (uy * uvz - uz * uvy)) + pose[4]);
+    sy = (float)(((v[1] + w * uvy) + (uz * uvx - ux * uvz)) + pose[5]);
+    sz = (float)(((v[2] + w * uvz) + (ux * uvy - uy * uvx)) + pose[6]);
+}
+
+/* insertion of (d, j[, p]) into five slots kept ascending by (distance, index) */
+template <bool WITH_PT>
+__device__ __forceinline__ void ll_five_insert(float bd[5], int bi[5], float4 bp[5], int &nb, float d, int j, const float4 &p)
+{
+    if (d < bd[4] || (d == bd[4] && j < bi[4])) {
+        bd[4] = d; bi[4] = j;
+        if (WITH_PT) bp[4] = p;
+#pragma unroll
+        for (int s = 4; s > 0; --s)
+            if (bd[s] < bd[s - 1] || (bd[s] == bd[s - 1] && bi[s] < bi[s - 1])) {
+                const float td = bd[s]; bd[s] = bd[s - 1]; bd[s - 1] = td;
+                const int ti = bi[s]; bi[s] = bi[s - 1]; bi[s - 1] = ti;
+                if (WITH_PT) { const float4 tp = bp[s]; bp[s] = bp[s - 1]; bp[s - 1] = tp; }
+            }
+        if (nb < 5) ++nb;
+    }
+}
+
+/* exact K = 5 over the 27 cells around the query, ascending (distance, index).  gid == nullptr: index = position in the
+ * search cloud; otherwise the caller's global id of the point (a tile shard of a larger cloud, same tie order). */
+template <bool WITH_PT>
+__device__ __forceinline__ void ll_map_search5(const LLGrid3 &G, int n_map, const int *gid, float sx, float sy, float sz,
+                                               float bd[5], int bi[5], float4 bp[5], int &nb)
+{
+    nb = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { bd[k] = INFINITY; bi[k] = INT_MAX; if (WITH_PT) bp[k] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    if (n_map <= 0) return;
+    int cx = (int)floorf((sx - G.org[0]) / G.cell), cy = (int)floorf((sy - G.org[1]) / G.cell), cz = (int)floorf((sz - G.org[2]) / G.cell);
+    cx = min(max(cx, 0), G.dim[0] - 1); cy = min(max(cy, 0), G.dim[1] - 1); cz = min(max(cz, 0), G.dim[2] - 1);
+    for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = cy + dy, zz = cz + dz;
+        if (yy < 0 || zz < 0 || yy >= G.dim[1] || zz >= G.dim[2]) continue;
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, G.dim[0] - 1);
+        const int row = (zz * G.dim[1] + yy) * G.dim[0];
+        const int st = G.start[row + x0], en = G.start[row + x1 + 1];          /* the three x-cells are contiguous */
+        for (int k = st; k < en; ++k) {
+            const float4 p = G.pts[k];
+            float diff = sx - p.x; float d = diff * diff;                  /* FLANN L2_Simple: a = query, b = data */
+            diff = sy - p.y; d += diff * diff;
+            diff = sz - p.z; d += diff * diff;
+            int j = __float_as_int(p.w);
+            if (WITH_PT && gid) j = gid[j];
+            ll_five_insert<WITH_PT>(bd, bi, bp, nb, d, j, p);
+        }
+    }
+}
+
+/* the five neighbours of stack point i -> line (eigen test, :1888-1930) or plane (QR fit, :1960-2000) */
+template <bool CORNER>
+__device__ __forceinline__ void ll_map_fit(const LLMapView &M, int i, const double P5[5][3])
+{
+    const int which = CORNER ? 0 : 1;
+    unsigned char ok = 0;
+    if (CORNER) {
+        double c[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < 5; ++j) for (int k = 0; k < 3; ++k) c[k] = c[k] + P5[j][k];              /* :1888-1895 */
+        for (int k = 0; k < 3; ++k) c[k] = c[k] / 5.0;
+        double cov[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {                                                                  /* :1898-1903 */
+            const double z[3] = {P5[j][0] - c[0], P5[j][1] - c[1], P5[j][2] - c[2]};
+            for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) cov[a][b] = cov[a][b] + z[a] * z[b];
+        }
+        double w[3], V[3][3];
+        ll_sym_eig3(cov, w, V);
+        if (w[2] > 3 * w[1]) {                                                                         /* :1911 */
+            ok = 1;
+            for (int k = 0; k < 3; ++k) { M.qa[(size_t)i * 3 + k] = 0.1 * V[k][2] + c[k]; M.qb[(size_t)i * 3 + k] = -0.1 * V[k][2] + c[k]; }
+        }
+    } else {
+        double A[5][3], b[5] = {-1.0, -1.0, -1.0, -1.0, -1.0}, nrm[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < 5; ++j) for (int k = 0; k < 3; ++k) A[j][k] = P5[j][k];
+        ll_qr_solve_5x3(A, b, nrm);                                                                     /* :1972 */
+        const double len = sqrt((nrm[0] * nrm[0] + nrm[1] * nrm[1]) + nrm[2] * nrm[2]);
+        const double nd = 1 / len;                                                                     /* :1973 */
+        if (len * len > 0.0) { nrm[0] /= len; nrm[1] /= len; nrm[2] /= len; }                        /* :1974 */
+        bool valid = true;
+#pragma unroll
+        for (int j = 0; j < 5; ++j)                                                                    /* :1980-1990 */
+            if (fabs(nrm[0] * P5[j][0] + nrm[1] * P5[j][1] + nrm[2] * P5[j][2] + nd) > 0.2) valid = false;
+        if (valid) {
+            ok = 1;
+            for (int k = 0; k < 3; ++k) M.qn[(size_t)i * 3 + k] = nrm[k];
+            M.qd[i] = nd;
+        }
+    }
+    M.ok[which][i] = ok;
+}
+
 template <bool CORNER>
 __global__ __launch_bounds__(LL_MAPB) void k_map_knn(LLMapView M)
 {
     const int which = CORNER ? 0 : 1;
     const int i = blockIdx.x * LL_MAPB + threadIdx.x;
     if (i >= M.n_stk[which]) return;
-    const LLGrid3 &G = M.grid[which];
-    const float4 po = M.stk[which][i];
-    /* pointAssociateToMap */
     float sx, sy, sz;
-    {
-        const double *pose = M.pose;
-        const double ux = pose[0], uy = pose[1], uz = pose[2], w = pose[3];
-        const double v[3] = {(double)po.x, (double)po.y, (double)po.z};
-        double uvx = uy * v[2] - uz * v[1], uvy = uz * v[0] - ux * v[2], uvz = ux * v[1] - uy * v[0];
-        uvx += uvx; uvy += uvy; uvz += uvz;
-        sx = (float)(((v[0] + w * uvx) + (uy * uvz - uz * uvy)) + pose[4]);
-        sy = (float)(((v[1] + w * uvy) + (uz * uvx - ux * uvz)) + pose[5]);
-        sz = (float)(((v[2] + w * uvz) + (ux * uvy - uy * uvx)) + pose[6]);
-    }
-    /* exact K = 5 over the 27 cells around the query, ascending (distance, index) */
-    float bd[5]; int bi[5]; int nb = 0;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) { bd[k] = INFINITY; bi[k] = INT_MAX; }
-    if (M.n_map[which] > 0) {
-        int cx = (int)floorf((sx - G.org[0]) / G.cell), cy = (int)floorf((sy - G.org[1]) / G.cell), cz = (int)floorf((sz - G.org[2]) / G.cell);
-        cx = min(max(cx, 0), G.dim[0] - 1); cy = min(max(cy, 0), G.dim[1] - 1); cz = min(max(cz, 0), G.dim[2] - 1);
-        for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) {
-            const int yy = cy + dy, zz = cz + dz;
-            if (yy < 0 || zz < 0 || yy >= G.dim[1] || zz >= G.dim[2]) continue;
-            const int x0 = max(cx - 1, 0), x1 = min(cx + 1, G.dim[0] - 1);
-            const int row = (zz * G.dim[1] + yy) * G.dim[0];
-            const int st = G.start[row + x0], en = G.start[row + x1 + 1];          /* the three x-cells are contiguous */
-            for (int k = st; k < en; ++k) {
-                const float4 p = G.pts[k];
-                float diff = sx - p.x; float d = diff * diff;                  /* FLANN L2_Simple: a = query, b = data */
-                diff = sy - p.y; d += diff * diff;
-                diff = sz - p.z; d += diff * diff;
-                const int j = __float_as_int(p.w);
-                if (d < bd[4] || (d == bd[4] && j < bi[4])) {
-                    /* insertion into the sorted five */
-                    bd[4] = d; bi[4] = j;
-#pragma unroll
-                    for (int s = 4; s > 0; --s)
-                        if (bd[s] < bd[s - 1] || (bd[s] == bd[s - 1] && bi[s] < bi[s - 1])) {
-                            const float td = bd[s]; bd[s] = bd[s - 1]; bd[s - 1] = td;
-                            const int ti = bi[s]; bi[s] = bi[s - 1]; bi[s - 1] = ti;
-                        }
-                    if (nb < 5) ++nb;
-                }
-            }
-        }
-    }
-    unsigned char ok = 0;
-    if (nb == 5 && bd[4] < 1.0f) {
+    ll_map_to_world(M.pose, M.stk[which][i], sx, sy, sz);
+    float bd[5]; int bi[5]; int nb; float4 unused[1];
+    ll_map_search5<false>(M.grid[which], M.n_map[which], nullptr, sx, sy, sz, bd, bi, unused, nb);
+    if (nb == 5 && bd[4] < 1.0f) {                                                                     /* :1885, :1958 */
         const float4 *cloud = M.map[which];
         double P5[5][3];
 #pragma unroll
         for (int j = 0; j < 5; ++j) { const float4 p = cloud[bi[j]]; P5[j][0] = p.x; P5[j][1] = p.y; P5[j][2] = p.z; }
-        if (CORNER) {
-            double c[3] = {0.0, 0.0, 0.0};
+        ll_map_fit<CORNER>(M, i, P5);
+    } else M.ok[which][i] = 0;
+}
+
+/* tile-parallel mapping: this rank's search clouds are the points of ITS cubes; per stack point the five
+ * nearest of them go out as (x, y, z, distance) + global id, INFINITY / INT_MAX in the unused slots */
+template <bool CORNER>
+__global__ __launch_bounds__(LL_MAPB) void k_map_knn_partial(LLMapView M)
+{
+    const int which = CORNER ? 0 : 1;
+    const int i = blockIdx.x * LL_MAPB + threadIdx.x;
+    if (i >= M.n_stk[which]) return;
+    float sx, sy, sz;
+    ll_map_to_world(M.pose, M.stk[which][i], sx, sy, sz);
+    float bd[5]; int bi[5]; float4 bp[5]; int nb;
+    ll_map_search5<true>(M.grid[which], M.n_map[which], M.gid[which], sx, sy, sz, bd, bi, bp, nb);
 #pragma unroll
-            for (int j = 0; j < 5; ++j) for (int k = 0; k < 3; ++k) c[k] = c[k] + P5[j][k];              /* :1888-1895 */
-            for (int k = 0; k < 3; ++k) c[k] = c[k] / 5.0;
-            double cov[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {                                                                  /* :1898-1903 */
-                const double z[3] = {P5[j][0] - c[0], P5[j][1] - c[1], P5[j][2] - c[2]};
-                for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) cov[a][b] = cov[a][b] + z[a] * z[b];
-            }
-            double w[3], V[3][3];
-            ll_sym_eig3(cov, w, V);
-            if (w[2] > 3 * w[1]) {                                                                         /* :1911 */
-                ok = 1;
-                for (int k = 0; k < 3; ++k) { M.qa[(size_t)i * 3 + k] = 0.1 * V[k][2] + c[k]; M.qb[(size_t)i * 3 + k] = -0.1 * V[k][2] + c[k]; }
-            }
-        } else {
-            double A[5][3], b[5] = {-1.0, -1.0, -1.0, -1.0, -1.0}, nrm[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-            for (int j = 0; j < 5; ++j) for (int k = 0; k < 3; ++k) A[j][k] = P5[j][k];
-            ll_qr_solve_5x3(A, b, nrm);                                                                     /* :1972 */
-            const double len = sqrt((nrm[0] * nrm[0] + nrm[1] * nrm[1]) + nrm[2] * nrm[2]);
-            const double nd = 1 / len;                                                                     /* :1973 */
-            if (len * len > 0.0) { nrm[0] /= len; nrm[1] /= len; nrm[2] /= len; }                        /* :1974 */
-            bool valid = true;
-#pragma unroll
-            for (int j = 0; j < 5; ++j)                                                                    /* :1980-1990 */
-                if (fabs(nrm[0] * P5[j][0] + nrm[1] * P5[j][1] + nrm[2] * P5[j][2] + nd) > 0.2) valid = false;
-            if (valid) {
-                ok = 1;
-                for (int k = 0; k < 3; ++k) M.qn[(size_t)i * 3 + k] = nrm[k];
-                M.qd[i] = nd;
-            }
-        }
+    for (int j = 0; j < 5; ++j) {
+        M.nn_pt[which][(size_t)i * 5 + j] = make_float4(bp[j].x, bp[j].y, bp[j].z, bd[j]);
+        M.nn_id[which][(size_t)i * 5 + j] = bi[j];
     }
-    M.ok[which][i] = ok;
+}
+
+/* the candidates of all ranks ([part][stack point][5]) -> the five nearest overall -> the same fit as k_map_knn */
+template <bool CORNER>
+__global__ __launch_bounds__(LL_MAPB) void k_map_fit_merged(LLMapView M, int n_parts, const float4 *pt_all, const int *id_all)
+{
+    const int which = CORNER ? 0 : 1;
+    const int n = M.n_stk[which];
+    const int i = blockIdx.x * LL_MAPB + threadIdx.x;
+    if (i >= n) return;
+    float bd[5]; int bi[5]; float4 bp[5]; int nb = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { bd[k] = INFINITY; bi[k] = INT_MAX; bp[k] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    for (int part = 0; part < n_parts; ++part)
+        for (int j = 0; j < 5; ++j) {
+            const size_t at = ((size_t)part * n + i) * 5 + j;
+            const float4 p = pt_all[at];
+            const int id = id_all[at];
+            if (id == INT_MAX) break;                                   /* a part's slots are filled front to back */
+            ll_five_insert<true>(bd, bi, bp, nb, p.w, id, p);
+        }
+    if (nb == 5 && bd[4] < 1.0f) {
+        double P5[5][3];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { P5[j][0] = bp[j].x; P5[j][1] = bp[j].y; P5[j][2] = bp[j].z; }
+        ll_map_fit<CORNER>(M, i, P5);
+    } else M.ok[which][i] = 0;
 }
 
 /* per-query results -> residual blocks in stack order; one 1024-thread workgroup */
@@ -451,6 +522,19 @@ void ll_map_launch_associate(const LLMapView &M, hipStream_t st)
 {
     if (M.n_stk[0] > 0) hipLaunchKernelGGL(k_map_knn<true>, dim3((M.n_stk[0] + LL_MAPB - 1) / LL_MAPB), dim3(LL_MAPB), 0, st, M);
     if (M.n_stk[1] > 0) hipLaunchKernelGGL(k_map_knn<false>, dim3((M.n_stk[1] + LL_MAPB - 1) / LL_MAPB), dim3(LL_MAPB), 0, st, M);
+    hipLaunchKernelGGL(k_map_compact, dim3(1), dim3(1024), 0, st, M);
+}
+
+void ll_map_launch_knn_partial(const LLMapView &M, hipStream_t st)
+{
+    if (M.n_stk[0] > 0) hipLaunchKernelGGL(k_map_knn_partial<true>, dim3((M.n_stk[0] + LL_MAPB - 1) / LL_MAPB), dim3(LL_MAPB), 0, st, M);
+    if (M.n_stk[1] > 0) hipLaunchKernelGGL(k_map_knn_partial<false>, dim3((M.n_stk[1] + LL_MAPB - 1) / LL_MAPB), dim3(LL_MAPB), 0, st, M);
+}
+
+void ll_map_launch_associate_merged(const LLMapView &M, int n_parts, const float4 *const pt_all[2], const int *const id_all[2], hipStream_t st)
+{
+    if (M.n_stk[0] > 0) hipLaunchKernelGGL(k_map_fit_merged<true>, dim3((M.n_stk[0] + LL_MAPB - 1) / LL_MAPB), dim3(LL_MAPB), 0, st, M, n_parts, pt_all[0], id_all[0]);
+    if (M.n_stk[1] > 0) hipLaunchKernelGGL(k_map_fit_merged<false>, dim3((M.n_stk[1] + LL_MAPB - 1) / LL_MAPB), dim3(LL_MAPB), 0, st, M, n_parts, pt_all[1], id_all[1]);
     hipLaunchKernelGGL(k_map_compact, dim3(1), dim3(1024), 0, st, M);
 }
 

@@ -3,6 +3,9 @@
 Two ways the hot path spreads over the GPUs of a node:
   * scan-parallel  -- scans (or scan pairs) are independent work items: block-partition them over ranks, no
                       data-path collective at all; only the timing barrier / max-over-ranks in bench.py.
+  * tile-parallel  -- the MAP of laserMapping is split: every rank keeps the cubes it owns, searches its own points for
+                      the five nearest of every stack point, and the candidates (100 B per stack point and rank) are
+                      all-gathered; every rank then merges them and solves the same small problem.
   * row-parallel   -- the residual rows of ONE scan pair are split over ranks (laserMapping-size problems); every
                       Gauss-Newton iteration ends with an all-reduce of the 28 unique doubles of the normal equations
                       (21 upper-triangular entries of J^T J, 6 of J^T r, the cost) over xGMI: 224 bytes, latency-bound.
@@ -78,3 +81,48 @@ def map_optimize_row_parallel(m, pose_w, n_outer=2, max_num_iterations=4, opt=No
             m.lm_propose(opt)
             m.lm_accept(reduced(), opt)
     return m.pose()
+
+
+def _all_gather_np(a, group=None, device=None):
+    """numpy array -> [world, ...] stacked over the ranks of `group` (RCCL when `device` is a GPU device, else gloo)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if device is not None:
+        t = t.to(device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(out, t, group=group)
+    return np.stack([o.cpu().numpy() for o in out])
+
+
+def map_optimize_tile_parallel(m, pose_w, n_stack, n_map_total, n_outer=2, opt=None, group=None, device=None, gather=None):
+    """laserMapping's optimisation (laserMapping.cpp:1822-2095) with the MAP split over the ranks of `group`: `m` holds this
+    rank's shard of the search clouds (api.Map.set_map + set_map_ids, or the inner map of a sharded api.CubeMap) and the
+    whole scan.  Per outer iteration: K = 5 search on the local points, all-gather of the candidates, merge + line / plane
+    fit, Levenberg-Marquardt on the (replicated) residual blocks.  n_map_total = (corner, surf) points of the whole map
+    (the reference's > 10 / > 50 test, :1822).  `gather` replaces the torch.distributed all-gather (tests).
+    Returns (pose, ran) -- bit-identical on every rank and to api.Map.optimize on the unsplit map."""
+    pose = np.ascontiguousarray(pose_w, np.float64).copy()
+    if not (n_map_total[0] > 10 and n_map_total[1] > 50):
+        return pose, False
+    if gather is None:
+        gather = lambda a: _all_gather_np(a, group, device)
+    for _ in range(n_outer):
+        cn, ci, sn, si = m.knn_partial(pose, n_stack)
+        m.associate_merged(gather(cn), gather(ci), gather(sn), gather(si), pose)
+        pose = m.solve(pose, opt)
+    return pose, True
+
+
+def cubemap_process_tile_parallel(cm, pose_w, corner_last, surf_last, opt=None, group=None, device=None, gather=None):
+    """One laserMapping frame (api.CubeMap.process) on a cube map sharded with CubeMap.set_shard(rank, world): every rank
+    gets the whole scan, keeps and searches only its cubes.  Collectives per frame: one all-gather of the two gathered
+    cloud sizes and, per outer iteration, the candidate all-gather."""
+    cm.prepare(np.asarray(pose_w, np.float64)[4:7], corner_last, surf_last)
+    _, cnt = cm.info()
+    if gather is None:
+        gather = lambda a: _all_gather_np(a, group, device)
+    tot = gather(np.array(cnt[:2], np.int64)).sum(axis=0)
+    pose, ran = map_optimize_tile_parallel(cm.map(), pose_w, (cnt[2], cnt[3]), (int(tot[0]), int(tot[1])), 2, opt, group, device, gather)
+    cm.update(pose)
+    return pose, ran

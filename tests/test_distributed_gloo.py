@@ -4,6 +4,9 @@
  * row-parallel GN: each rank accumulates the normal equations of ITS share of the residual blocks (here with the CPU
    oracle -- this is a test of the sharding + all-reduce logic, no GPU involved), the 28-double all-reduce must
    reproduce the single-process H, g, cost, and the GN step computed from it must be identical on both ranks.
+ * tile-parallel mapping: each rank finds the five nearest map points among ITS share of the map (numpy here, the
+   device's ll_map_knn_partial on the GPU box -- tests/test_gpu_tile_parallel.py), parallel._all_gather_np stacks the
+   candidates [rank][query][5]; the five smallest (distance, id) of the stack must be the whole map's five nearest.
 """
 import os
 import sys
@@ -52,9 +55,32 @@ def _worker(rank, world, port, out):
         gathered = [torch.zeros(6, dtype=torch.float64) for _ in range(world)]
         dist.all_gather(gathered, torch.from_numpy(d))
         assert all((gathered[0] == x).all() for x in gathered)      # every rank takes the identical step
+
+        # ---- tile-parallel K = 5 search: shard the map, all-gather the candidates, merge
+        rng = np.random.default_rng(5)                                  # same stream on both ranks
+        cloud = rng.uniform(-3, 3, (400, 3)).astype(np.float32)
+        cloud[100:110] = cloud[90:100]                                  # exact duplicates: distance ties across ranks
+        qs = rng.uniform(-3, 3, (64, 3)).astype(np.float32)
+        owner = rng.integers(0, world, len(cloud))
+        ids = np.flatnonzero(owner == rank).astype(np.int32)
+
+        def five(points, gid):
+            d = ((qs[:, None, :] - points[None, :, :]) ** 2).astype(np.float32)
+            d = (d[:, :, 0] + d[:, :, 1]) + d[:, :, 2]
+            order = np.lexsort((np.broadcast_to(gid, d.shape), d), axis=1)[:, :5]
+            return np.take_along_axis(d, order, 1), gid[order]
+        d_loc, id_loc = five(cloud[ids], ids)
+        d_all = parallel._all_gather_np(d_loc); id_all = parallel._all_gather_np(id_loc)
+        assert d_all.shape == (world, 64, 5) and id_all.dtype == np.int32
+        assert (d_all[rank] == d_loc).all() and (id_all[rank] == id_loc).all()          # rank-major, own part in place
+        dm = d_all.transpose(1, 0, 2).reshape(64, -1); im = id_all.transpose(1, 0, 2).reshape(64, -1)
+        order = np.lexsort((im, dm), axis=1)[:, :5]
+        d_ref, id_ref = five(cloud, np.arange(len(cloud), dtype=np.int32))
+        assert (np.take_along_axis(im, order, 1) == id_ref).all() and (np.take_along_axis(dm, order, 1) == d_ref).all()
         out.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
-        out.put((rank, repr(e)))
+        import traceback
+        out.put((rank, repr(e) + traceback.format_exc()))
     finally:
         dist.destroy_process_group()
 

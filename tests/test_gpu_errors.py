@@ -100,3 +100,40 @@ def test_mapping_objects_validate_their_arguments(api, scans):
     pose, ran = cm.process([0, 0, 0, 1, 0, 0, 0.0], np.zeros((0, 4), np.float32), np.zeros((0, 4), np.float32))
     assert not ran and cm.info() == ((10, 10, 5), (0, 0, 0, 0))
     cm.close(); ctx.close()
+
+
+def test_tile_parallel_entry_points_validate_their_arguments(api):
+    import ctypes as C
+    ctx = api.Context(api.default_params(16, batch=1, max_points=4096))
+    m = api.Map(ctx, 100, 100, 50, 50)
+    pts = np.random.default_rng(0).uniform(-1, 1, (40, 4)).astype(np.float32)
+    m.set_map(pts, pts); m.set_scan(pts[:10], pts[:10])
+    lib = ctx.lib
+    pose = np.array([0, 0, 0, 1, 0, 0, 0.0])
+    P = pose.ctypes.data_as(C.c_void_p)
+    assert lib.ll_map_knn_partial(m.h, P, None, None, None, None) == -2          # stack points but nowhere to put the candidates
+    cn, ci, sn, si = m.knn_partial(pose)
+    for parts in (0, 65):
+        assert lib.ll_map_associate_merged(m.h, P, parts, cn.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p),
+                                           sn.ctypes.data_as(C.c_void_p), si.ctypes.data_as(C.c_void_p)) == -2
+    with pytest.raises(api.LightLoamError) as e:
+        m.set_map_ids(np.arange(40, dtype=np.int32), None)                       # ids of one cloud only
+    assert e.value.code == -2
+    # without ids a Map numbers its points by position: one part == the plain association
+    m.associate(pose); want = m.counts(), m.edges(), m.planes()
+    m.associate_merged(cn[None], ci[None], sn[None], si[None], pose)
+    assert m.counts() == want[0]
+    # an empty stack needs no buffers at all
+    m.set_scan(np.zeros((0, 4), np.float32), np.zeros((0, 4), np.float32))
+    assert lib.ll_map_knn_partial(m.h, P, None, None, None, None) == 0
+    assert lib.ll_map_associate_merged(m.h, P, 2, None, None, None, None) == 0 and m.counts() == (0, 0)
+    m.close()
+    cm = api.CubeMap(ctx, 4096, 16384, pool_points=1 << 16)
+    for rank, world in ((0, 0), (2, 2), (-1, 2), (0, 65)):
+        with pytest.raises(api.LightLoamError) as e:
+            cm.set_shard(rank, world)
+        assert e.value.code == -2
+    cm.set_shard(1, 2); cm.set_shard(0, 1)                                       # allowed while the map is empty; (0, 1) = unsplit again
+    pose2, ran = cm.process(pose, np.zeros((0, 4), np.float32), np.zeros((0, 4), np.float32))
+    assert not ran
+    cm.close(); ctx.close()

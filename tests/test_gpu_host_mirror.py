@@ -100,7 +100,7 @@ def test_kitti_tool_with_the_mapping_node(tmp_path, synth):
     from lightloam_amd import build
     lib_dir = os.path.dirname(build.lib_path())
     exe = str(tmp_path / "ll_odometry_kitti")
-    subprocess.check_call(["g++", "-O2", "-std=c++14", "-I", os.path.join(ROOT, "include"),
+    subprocess.check_call(["g++", "-O2", "-std=c++14", "-pthread", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tools", "ll_odometry_kitti.cpp"), "-o", exe,
                            "-L", lib_dir, "-llightloam_hip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
     cfg = synth.default_cfg(16)
@@ -108,10 +108,12 @@ def test_kitti_tool_with_the_mapping_node(tmp_path, synth):
     d = tmp_path / "velodyne"; d.mkdir()
     for k in range(n):
         synth.scan(cfg, k).astype("<f4").tofile(d / f"{k:06d}.bin")
-    odo, mapped = tmp_path / "odo.txt", tmp_path / "map.txt"
-    for res, flag in ((odo, "0"), (mapped, "1")):
+    odo, mapped, tiled = tmp_path / "odo.txt", tmp_path / "map.txt", tmp_path / "map3.txt"
+    for res, flag in ((odo, "0"), (mapped, "1"), (tiled, "3")):
         out = subprocess.run([exe, str(d), str(res), "16", "0.9", flag], capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stdout + out.stderr
+    # the map split over three ranks (LaserMapping::process_tile_parallel) writes the same file
+    assert tiled.read_bytes() == mapped.read_bytes()
     To, Tm = np.loadtxt(odo), np.loadtxt(mapped)
     assert To.shape == Tm.shape == (n, 12)
     assert np.allclose(Tm[0], [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0])

@@ -6,15 +6,20 @@
 //
 // mapping = 1 adds the third node: every frame's odometry pose goes through laserMapping's scan-to-map refinement
 // (lightloam::LaserMapping, laserMapping.cpp:1581-2165) and the written trajectory is q_w_curr / t_w_curr, which is what
-// the reference's result file holds (:2284-2325).
+// the reference's result file holds (:2284-2325).  mapping = G >= 2 runs that node with the map split over G ranks
+// (lightloam::LaserMapping::process_tile_parallel; G threads stand in for G processes) and writes the same file.
 //
-// Build:  g++ -O2 -std=c++14 -I include tools/ll_odometry_kitti.cpp -L light-loam_amd -llightloam_hip -o ll_odometry_kitti
+// Build:  g++ -O2 -std=c++14 -pthread -I include tools/ll_odometry_kitti.cpp -L light-loam_amd -llightloam_hip -o ll_odometry_kitti
 #include <algorithm>
+#include <condition_variable>
 #include <cstdlib>
+#include <cstring>
 #include <dirent.h>
 #include <iostream>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "lightloam_host.hpp"
@@ -62,6 +67,66 @@ int main(int argc, char **argv)
             for (int i = 0; i < 3; ++i) m.t[i] = lm->parameters[4 + i];
             return m;
         };
+        const int tiles = argc > 5 ? std::atoi(argv[5]) : 0;
+        if (tiles >= 2) {
+            // mapping = G >= 2: the map split over G ranks, here G threads of this process, each with its
+            // own context and LaserMapping shard; the all-gather is a barrier + memcpy (ncclAllGather between processes).
+            // The trajectory written is rank 0's -- and must be the one mapping = 1 writes, byte for byte.
+            std::vector<std::vector<PointXYZI>> corner(n), surf(n);
+            for (int k = 0; k < n; ++k) {
+                ll_scan_info info;
+                ctx.check(ll_get_scan_info(ctx.get(), k, &info));
+                corner[k].resize(info.n_less_sharp); surf[k].resize(info.n_less_flat);
+                ctx.check(ll_download_features(ctx.get(), k, nullptr, 0, (ll_point *)corner[k].data(), info.n_less_sharp, nullptr, 0,
+                                               (ll_point *)surf[k].data(), info.n_less_flat));
+            }
+            std::vector<WorldPose> odo(n);
+            for (int k = 1; k < n; ++k) { w.compose(&rel[(size_t)(k - 1) * 7], &rel[(size_t)(k - 1) * 7 + 4]); odo[k] = w; }
+            struct Exchange {
+                std::mutex mu; std::condition_variable cv; int arrived = 0, generation = 0, world = 0;
+                const void *send[64];
+                void barrier(std::unique_lock<std::mutex> &lk) {
+                    const int gen = generation;
+                    if (++arrived == world) { arrived = 0; ++generation; cv.notify_all(); }
+                    else cv.wait(lk, [&] { return generation != gen; });
+                }
+                void all_gather(int rank, const void *s, void *recv, size_t bytes) {
+                    std::unique_lock<std::mutex> lk(mu);
+                    send[rank] = s;
+                    barrier(lk);
+                    for (int r = 0; r < world; ++r) std::memcpy((char *)recv + (size_t)r * bytes, send[r], bytes);
+                    barrier(lk);                                       // nobody reuses its send buffer before all have copied
+                }
+            } ex;
+            ex.world = tiles;
+            std::vector<std::string> errors(tiles);
+            std::vector<std::vector<WorldPose>> mapped_of(tiles, std::vector<WorldPose>(n));
+            std::vector<std::thread> th;
+            for (int r = 0; r < tiles; ++r)
+                th.emplace_back([&, r] {
+                    try {
+                        Context c(scan_line, 1);
+                        LaserMapping shard(c, 0.4f, 0.8f, scan_line * 120 + 64, 400000, 1 << 22);
+                        shard.set_shard(r, tiles);
+                        for (int k = 0; k < n; ++k) {
+                            shard.transformAssociateToMap(odo[k].q, odo[k].t);
+                            shard.process_tile_parallel(corner[k], surf[k], [&](const void *s_, void *d_, size_t b) { ex.all_gather(r, s_, d_, b); });
+                            shard.transformUpdate(odo[k].q, odo[k].t);
+                            for (int i = 0; i < 4; ++i) mapped_of[r][k].q[i] = shard.parameters[i];
+                            for (int i = 0; i < 3; ++i) mapped_of[r][k].t[i] = shard.parameters[4 + i];
+                        }
+                    } catch (const std::exception &e) { errors[r] = e.what(); std::cerr << "rank " << r << ": " << e.what() << "\n"; std::_Exit(1); }
+                });
+            for (auto &t : th) t.join();
+            for (int r = 1; r < tiles; ++r)
+                for (int k = 0; k < n; ++k)
+                    if (std::memcmp(&mapped_of[r][k], &mapped_of[0][k], sizeof(WorldPose)) != 0) { std::cerr << "ranks disagree at frame " << k << "\n"; return 1; }
+            std::remove(result.c_str());
+            TrajectoryWriter mapped(result);
+            for (int k = 0; k < n; ++k) mapped.append(mapped_of[0][k]);
+            std::cout << "wrote " << n << " mapped poses (map split over " << tiles << " ranks) to " << result << "\n";
+            return 0;
+        }
         if (mapping) {
             lm.reset(new LaserMapping(ctx, 0.4f, 0.8f, scan_line * 120 + 64, 400000, 1 << 22));
             std::remove(result.c_str());
