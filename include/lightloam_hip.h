@@ -241,6 +241,12 @@ int ll_map_knn_partial(ll_map *m, const double *pose_w7, float *corner_nn, int *
 int ll_map_associate_merged(ll_map *m, const double *pose_w7, int n_parts, const float *corner_nn, const int *corner_id,
                             const float *surf_nn, const int *surf_id);
 int ll_map_solve(ll_map *m, double *pose_w7, const ll_lm_options *opt);
+/* BASELINE config 4 in full -- tiles for the search AND rows for the solve: after ll_map_associate_merged every rank holds
+ * all residual blocks; with a row shard set, ll_map_evaluate / ll_map_normal_equations sum only the blocks i with
+ * i % world == rank, and the LM runs through evaluate -> all-reduce(JtJ, Jtr, cost) -> ll_map_lm_begin / _accept as in the
+ * row-parallel scheme above (result within f64 summation-order rounding of one GPU; identical on all ranks).  (0, 1) =
+ * all blocks.  ll_map_solve / ll_map_optimize refuse while a row shard is set.                                        */
+int ll_map_set_row_shard(ll_map *m, int rank, int world);
 
 /* pcl::VoxelGrid<PointType>::filter on a whole cloud of any size (downSizeFilterCorner / downSizeFilterSurf,
  * laserMapping.cpp:1813-1821, :2151-2165): centroids (x, y, z, intensity) per voxel, in voxel-index order.       */

@@ -27,7 +27,7 @@ EXPORTS = [
     "ll_map_residual_jacobian", "ll_map_get_counts", "ll_map_download_edges", "ll_map_download_planes", "ll_map_normal_equations", "ll_map_optimize",
     "ll_cubemap_create", "ll_cubemap_destroy", "ll_cubemap_last_error", "ll_cubemap_prepare", "ll_cubemap_optimize", "ll_cubemap_update",
     "ll_cubemap_process", "ll_cubemap_process_slot", "ll_cubemap_info", "ll_cubemap_download_cloud", "ll_cubemap_download_cube",
-    "ll_map_set_map_ids", "ll_map_knn_partial", "ll_map_associate_merged", "ll_map_solve", "ll_cubemap_set_shard", "ll_cubemap_map",
+    "ll_map_set_map_ids", "ll_map_knn_partial", "ll_map_associate_merged", "ll_map_solve", "ll_map_set_row_shard", "ll_cubemap_set_shard", "ll_cubemap_map",
     "ll_voxel_grid", "ll_map_set_pose", "ll_map_get_pose", "ll_map_evaluate", "ll_map_lm_begin", "ll_map_lm_propose", "ll_map_lm_accept",
 ]
 
@@ -395,6 +395,10 @@ class Map:
         assert cn.ndim == 4 and sn.ndim == 4 and cn.shape[0] == sn.shape[0] == ci.shape[0] == si.shape[0]
         p = None if pose_w is None else np.ascontiguousarray(pose_w, np.float64)
         self._ck(self.lib.ll_map_associate_merged(self.h, _ptr(p), int(cn.shape[0]), _ptr(cn), _ptr(ci), _ptr(sn), _ptr(si)))
+
+    def set_row_shard(self, rank, world):
+        """evaluate() / normal_equations() sum the residual blocks i with i % world == rank ((0, 1): all of them)."""
+        self._ck(self.lib.ll_map_set_row_shard(self.h, int(rank), int(world)))
 
     def solve(self, pose_w, opt=None):
         p = np.ascontiguousarray(pose_w, np.float64).copy()

@@ -692,11 +692,20 @@ static void map_lm_solve(ll_map *m, const LLLmOpt &o)
     }
 }
 
+extern "C" int ll_map_set_row_shard(ll_map *m, int rank, int world)
+{
+    if (!m) return LL_ERR_ARG;
+    if (world < 1 || world > 64 || rank < 0 || rank >= world) { m->err = "bad row shard"; return LL_ERR_ARG; }
+    m->M.row_rank = rank; m->M.row_world = world;
+    return LL_OK;
+}
+
 extern "C" int ll_map_solve(ll_map *m, double *pose_w7, const ll_lm_options *opt)
 {
     if (!m || !pose_w7) return LL_ERR_ARG;
     const LLLmOpt o = ll_to_dev_opt(opt);
     if (o.max_num_iterations < 0 || o.max_num_iterations > 64) { m->err = "max_num_iterations out of range"; return LL_ERR_ARG; }
+    if (m->M.row_world > 1) { m->err = "the map sums a row shard: step with ll_map_evaluate + all-reduce + ll_map_lm_*"; return LL_ERR_STATE; }
     LLM_HIP(hipSetDevice(m->ctx->device));
     int rc = map_set_pose(m, pose_w7); if (rc) return rc;
     map_lm_solve(m, o);
@@ -717,6 +726,7 @@ extern "C" int ll_map_optimize(ll_map *m, double *pose_w7, int n_outer, const ll
     if (!(m->M.n_map[0] > 10 && m->M.n_map[1] > 50)) return LL_OK;           /* :1822 */
     int rc = map_set_pose(m, pose_w7); if (rc) return rc;
     hipStream_t st = m->ctx->stream;
+    if (m->M.row_world > 1) { m->err = "the map sums a row shard: step with ll_map_evaluate + all-reduce + ll_map_lm_*"; return LL_ERR_STATE; }
     if (m->M.gid[0]) { m->err = "the map holds a tile shard: search with ll_map_knn_partial / ll_map_associate_merged"; return LL_ERR_STATE; }
     for (int it = 0; it < n_outer; ++it) {                                     /* :1832 */
         ll_map_launch_associate(m->M, st);

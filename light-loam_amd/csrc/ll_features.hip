@@ -192,12 +192,18 @@ extern __shared__ __attribute__((aligned(16))) unsigned char ll_smem[];
 #define LL_PHASE_BEGIN() long long ll_t0 = (tid == 0) ? (long long)__builtin_amdgcn_s_memtime() : 0
 #define LL_PHASE(i) do { __syncthreads(); if (tid == 0) { const long long t1 = (long long)__builtin_amdgcn_s_memtime(); \
     atomicAdd(&V.dbg[i], (unsigned long long)(t1 - ll_t0)); ll_t0 = t1; } } while (0)
+#define LL_WAIT_BEGIN() const long long ll_w0 = (tid == 0) ? (long long)__builtin_amdgcn_s_memtime() : 0
+#define LL_WAIT_END() do { if (tid == 0) atomicAdd(&V.dbg[7], (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - ll_w0)); } while (0)
 #elif defined(LL_PHASE_STOP)   /* tools/phase_valu.py: the kernel returns after phase LL_PHASE_STOP (instruction counts per phase by difference) */
 #define LL_PHASE_BEGIN() do {} while (0)
 #define LL_PHASE(i) do { if ((i) == LL_PHASE_STOP) return; } while (0)
+#define LL_WAIT_BEGIN() do {} while (0)
+#define LL_WAIT_END() do {} while (0)
 #else
 #define LL_PHASE_BEGIN() do {} while (0)
 #define LL_PHASE(i) do {} while (0)
+#define LL_WAIT_BEGIN() do {} while (0)
+#define LL_WAIT_END() do {} while (0)
 #endif
 
 /* 2nd launch bound = waves per SIMD: six 256-thread workgroups per CU for the common 2304-point capacity (<= 80 VGPRs) */
@@ -596,7 +602,7 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features
                     }
             }
             int o = ll_block_exscan(__popc(headm), L.sc, n_lf_out);
-            { int a_, b_, c_; seg_totals(a_, b_, c_); publish_and_prefix(a_, b_, c_, n_lf_out, roff); looked_back = true; }
+            { int a_, b_, c_; seg_totals(a_, b_, c_); LL_WAIT_BEGIN(); publish_and_prefix(a_, b_, c_, n_lf_out, roff); LL_WAIT_END(); looked_back = true; }
             float4 *out = V.lflat + (size_t)s * V.NP + roff[3];
             /* CentroidPoint<PointXYZI>: f32 sums from zero in input order, divided by float(n) */
             float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f; int cn = 0;

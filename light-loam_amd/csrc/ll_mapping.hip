@@ -404,7 +404,8 @@ __global__ __launch_bounds__(1024) void k_map_normal_eq(LLMapView M)
     double acc[LL_NACC];
 #pragma unroll
     for (int k = 0; k < LL_NACC; ++k) acc[k] = 0.0;
-    for (int i = tid; i < n_e; i += 1024) {
+    const int rw = M.row_world > 1 ? M.row_world : 1, rr = M.row_world > 1 ? M.row_rank : 0;   /* this rank's share of the blocks */
+    for (int i = rr + rw * tid; i < n_e; i += 1024 * rw) {
         double r[3], Jq[3][4], Jt[3][3];
         ll_edge_d(P, M.stk[0][M.src[0][i]], &M.fa[(size_t)i * 3], &M.fb[(size_t)i * 3], r, Jq, Jt);
         const double sc = ll_huber_scale(r[0] * r[0] + r[1] * r[1] + r[2] * r[2], M.huber, acc[27]);
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(1024) void k_map_normal_eq(LLMapView M)
             ll_acc_row(acc, J, r[row] * sc);
         }
     }
-    for (int i = tid; i < n_p; i += 1024) {
+    for (int i = rr + rw * tid; i < n_p; i += 1024 * rw) {
         double r, Jq[4], Jt[3], J[6];
         ll_plane_norm(P, M.stk[1][M.src[1][i]], &M.fn[(size_t)i * 3], M.fd[i], r, Jq, Jt);
         const double sc = ll_huber_scale(r * r, M.huber, acc[27]);
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(1024) void k_map_normal_eq(LLMapView M)
         for (int a = 0; a < 6; ++a) for (int b = a; b < 6; ++b) { out[a * 6 + b] = tot[k]; out[b * 6 + a] = tot[k]; ++k; }
         for (int a = 0; a < 6; ++a) out[36 + a] = tot[21 + a];
         out[42] = tot[27];
-        out[43] = (double)(3 * n_e + n_p);
+        out[43] = (double)(3 * ((n_e - rr + rw - 1) / rw) + (n_p - rr + rw - 1) / rw);   /* rows summed here */
     }
 }
 

@@ -95,26 +95,59 @@ def _all_gather_np(a, group=None, device=None):
     return np.stack([o.cpu().numpy() for o in out])
 
 
-def map_optimize_tile_parallel(m, pose_w, n_stack, n_map_total, n_outer=2, opt=None, group=None, device=None, gather=None):
+def _lm_all_reduced(m, max_num_iterations, opt, group, device):
+    """One ceres::Solve restated with the normal equations summed over the ranks (every rank evaluates its row shard)."""
+    import torch
+    import torch.distributed as dist
+
+    def reduced():
+        buf = torch.from_numpy(m.evaluate())
+        if device is not None:
+            buf = buf.to(device)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        return buf.cpu().numpy()
+
+    m.lm_begin(reduced(), opt)
+    for _ in range(max_num_iterations):
+        m.lm_propose(opt)
+        m.lm_accept(reduced(), opt)
+
+
+def map_optimize_tile_parallel(m, pose_w, n_stack, n_map_total, n_outer=2, opt=None, group=None, device=None, gather=None,
+                               row_parallel=False):
     """laserMapping's optimisation (laserMapping.cpp:1822-2095) with the MAP split over the ranks of `group`: `m` holds this
     rank's shard of the search clouds (api.Map.set_map + set_map_ids, or the inner map of a sharded api.CubeMap) and the
     whole scan.  Per outer iteration: K = 5 search on the local points, all-gather of the candidates, merge + line / plane
     fit, Levenberg-Marquardt on the (replicated) residual blocks.  n_map_total = (corner, surf) points of the whole map
     (the reference's > 10 / > 50 test, :1822).  `gather` replaces the torch.distributed all-gather (tests).
-    Returns (pose, ran) -- bit-identical on every rank and to api.Map.optimize on the unsplit map."""
+    Returns (pose, ran) -- bit-identical on every rank and to api.Map.optimize on the unsplit map.
+    row_parallel=True (BASELINE config 4 to the letter): the Levenberg-Marquardt evaluations are split too -- every rank sums
+    the residual blocks i with i % world == rank and the normal equations are all-reduced (RCCL over xGMI); the pose then
+    agrees with one GPU to f64 summation-order rounding and is still identical on every rank."""
     pose = np.ascontiguousarray(pose_w, np.float64).copy()
     if not (n_map_total[0] > 10 and n_map_total[1] > 50):
         return pose, False
     if gather is None:
         gather = lambda a: _all_gather_np(a, group, device)
-    for _ in range(n_outer):
-        cn, ci, sn, si = m.knn_partial(pose, n_stack)
-        m.associate_merged(gather(cn), gather(ci), gather(sn), gather(si), pose)
-        pose = m.solve(pose, opt)
+    if row_parallel:
+        import torch.distributed as dist
+        m.set_row_shard(dist.get_rank(group), dist.get_world_size(group))
+    try:
+        for _ in range(n_outer):
+            cn, ci, sn, si = m.knn_partial(pose, n_stack)
+            m.associate_merged(gather(cn), gather(ci), gather(sn), gather(si), pose)
+            if row_parallel:
+                _lm_all_reduced(m, 4 if opt is None else opt.max_num_iterations, opt, group, device)
+                pose = m.pose()
+            else:
+                pose = m.solve(pose, opt)
+    finally:
+        if row_parallel:
+            m.set_row_shard(0, 1)
     return pose, True
 
 
-def cubemap_process_tile_parallel(cm, pose_w, corner_last, surf_last, opt=None, group=None, device=None, gather=None):
+def cubemap_process_tile_parallel(cm, pose_w, corner_last, surf_last, opt=None, group=None, device=None, gather=None, row_parallel=False):
     """One laserMapping frame (api.CubeMap.process) on a cube map sharded with CubeMap.set_shard(rank, world): every rank
     gets the whole scan, keeps and searches only its cubes.  Collectives per frame: one all-gather of the two gathered
     cloud sizes and, per outer iteration, the candidate all-gather."""
@@ -123,6 +156,6 @@ def cubemap_process_tile_parallel(cm, pose_w, corner_last, surf_last, opt=None, 
     if gather is None:
         gather = lambda a: _all_gather_np(a, group, device)
     tot = gather(np.array(cnt[:2], np.int64)).sum(axis=0)
-    pose, ran = map_optimize_tile_parallel(cm.map(), pose_w, (cnt[2], cnt[3]), (int(tot[0]), int(tot[1])), 2, opt, group, device, gather)
+    pose, ran = map_optimize_tile_parallel(cm.map(), pose_w, (cnt[2], cnt[3]), (int(tot[0]), int(tot[1])), 2, opt, group, device, gather, row_parallel)
     cm.update(pose)
     return pose, ran

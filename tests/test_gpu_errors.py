@@ -123,6 +123,10 @@ def test_tile_parallel_entry_points_validate_their_arguments(api):
     m.associate(pose); want = m.counts(), m.edges(), m.planes()
     m.associate_merged(cn[None], ci[None], sn[None], si[None], pose)
     assert m.counts() == want[0]
+    for rank, world in ((0, 0), (2, 2), (-1, 2), (0, 65)):
+        with pytest.raises(api.LightLoamError) as e:
+            m.set_row_shard(rank, world)
+        assert e.value.code == -2
     # an empty stack needs no buffers at all
     m.set_scan(np.zeros((0, 4), np.float32), np.zeros((0, 4), np.float32))
     assert lib.ll_map_knn_partial(m.h, P, None, None, None, None) == 0

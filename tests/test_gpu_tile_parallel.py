@@ -156,6 +156,7 @@ def _tile_parallel_worker(rank, world, port, out):
     sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     try:
+        import numpy as np
         import torch
         import torch.distributed as dist
         import lightloam_amd  # noqa: F401
@@ -167,6 +168,8 @@ def _tile_parallel_worker(rank, world, port, out):
         ctx = api.Context(api.default_params(16, batch=1, max_points=4096))
         cm = api.CubeMap(ctx, 4096, 32768, pool_points=1 << 18)
         cm.set_shard(rank, world)
+        cm_rows = api.CubeMap(ctx, 4096, 32768, pool_points=1 << 18)              # tiles for the search AND rows for the solve
+        cm_rows.set_shard(rank, world)
         whole = api.CubeMap(ctx, 4096, 32768, pool_points=1 << 18) if rank == 0 else None
         for k in range(5):
             f = orc.extract(synth.scan(cfg, k), P)
@@ -179,6 +182,25 @@ def _tile_parallel_worker(rank, world, port, out):
             got = [torch.zeros(7, dtype=torch.float64) for _ in range(world)]
             dist.all_gather(got, torch.from_numpy(pose))
             assert all((got[0] == g).all() for g in got)
+            # BASELINE config 4 to the letter: all-reduce of JtJ / Jtr between the ranks' row shards
+            pose_r, ran_r = parallel.cubemap_process_tile_parallel(cm_rows, guess, f["less_sharp"], f["less_flat"], row_parallel=True)
+            assert ran_r == ran and np.abs(pose_r - pose).max() < 1e-7, (k, pose_r, pose)
+            dist.all_gather(got, torch.from_numpy(pose_r))
+            assert all((got[0] == g).all() for g in got)
+            if ran:
+                m = cm_rows.map()
+                full_rows = m.evaluate()[43]
+                m.set_row_shard(rank, world); mine = m.evaluate()[43]; m.set_row_shard(0, 1)
+                t = torch.tensor([mine]); dist.all_reduce(t)
+                assert t.item() == full_rows and 0 < mine < full_rows                # the shards partition the rows
+                m.set_row_shard(rank, world)
+                try:
+                    m.solve(pose_r)
+                    raise AssertionError("a row shard must refuse the single-rank solve")
+                except api.LightLoamError as e:
+                    assert e.code == -7
+                m.set_row_shard(0, 1)
+        cm_rows.close()
         cm.close()
         if whole is not None:
             whole.close()

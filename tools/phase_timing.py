@@ -33,6 +33,7 @@ print(f"k_ring_features phase timing over {buf[15]} workgroups (s_memtime cycles
 for i, nm in enumerate(names):
     print(f"  {nm:32s} {buf[i] / n:10.0f}  {100.0 * buf[i] / max(1, tot):5.1f}%")
 print(f"  {'total':32s} {tot / n:10.0f}")
+print(f"  {'(look-back publish + wait, inside p4c)':32s} {buf[7] / n:10.0f}  {100.0 * buf[7] / max(1, tot):5.1f}%")
 g = max(1, buf[14])
 print(f"k_build_grid phase timing over {buf[14]} workgroups:")
 for i, nm in ((8, "zero + histogram"), (9, "scan + cell starts"), (10, "scatter to cell order"), (11, "ring tables + validity")):

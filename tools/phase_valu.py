@@ -11,7 +11,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 stop = int(sys.argv[1])
-out = os.path.join(ROOT, "gpurun_out", f"liblightloam_hip_stop{stop}.so")
+out = os.path.join(ROOT, os.environ.get("LL_PHASE_DIR", "gpurun_out"), f"liblightloam_hip_stop{stop}.so")   # LL_PHASE_DIR=_phase: pre-built on the CPU box, travels with the snapshot
 os.makedirs(os.path.dirname(out), exist_ok=True)
 os.environ["LIGHTLOAM_HIP_LIB"] = out
 import lightloam_amd  # noqa: E402,F401
