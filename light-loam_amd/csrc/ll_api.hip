@@ -143,6 +143,13 @@ extern "C" int ll_create(int device, const ll_params *p, ll_ctx **out)
         if (ok && (hipMemcpyAsync(thr_dev, thr.data(), ((size_t)R + 1) * sizeof(int), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
                    hipStreamSynchronize(ctx->stream) != hipSuccess)) { g_create_err = "threshold upload failed"; ok = false; }
         V.ring_thr = thr_dev;
+        std::vector<int32_t> lut(LL_RING_LUT_MAX);
+        V.lut_nb = ll_ring_lut_build(thr.data(), R, lut.data(), &V.lut_t0, &V.lut_scale);
+        int *lut_dev = nullptr;
+        ok = ok && dev_alloc(ctx, lut_dev, LL_RING_LUT_MAX, false);
+        if (ok && (hipMemcpyAsync(lut_dev, lut.data(), LL_RING_LUT_MAX * sizeof(int), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                   hipStreamSynchronize(ctx->stream) != hipSuccess)) { g_create_err = "threshold upload failed"; ok = false; }
+        V.ring_lut = lut_dev;
     }
     ok = ok && dev_alloc(ctx, V.sharp, (size_t)B * V.cap_sharp, false) && dev_alloc(ctx, V.lsharp, (size_t)B * V.cap_lsharp, false) &&
          dev_alloc(ctx, V.flat, (size_t)B * V.cap_flat, false) && dev_alloc(ctx, V.lflat, BN, false);

@@ -49,6 +49,7 @@ struct ScanHdr {
     int status;
     int max_ring;
     int n_sharp, n_less_sharp, n_flat, n_less_flat;
+    float so_lo_up, so_hi_dn;      /* ll_f32_ceil(startOri - pi/2), ll_f32_floor(startOri + 3pi/2): the wrap tests of :181-188 in f32 */
 };
 
 struct PairHdr {
@@ -61,6 +62,7 @@ struct LLView {
     int B, NP, T, R, ring_model, max_ring, write_curv;
     float thres, lower_bound, factor;
     const int *ring_thr;           /* [R + 1] ll_ring_thresholds: keys of the smallest t = z / sqrt(x^2 + y^2) of every ring */
+    const int *ring_lut; int lut_nb; float lut_t0, lut_scale;   /* ll_ring_lut_build: first guess per t bucket (lut_nb = 0: unused) */
     double curv_thr, gap_thr;      /* 0.1 / 0.05 as double: the reference compares f32 against double literals */
     float leaf, inv_leaf;
     float nn_max;                  /* 25 */

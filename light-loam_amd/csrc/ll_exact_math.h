@@ -110,6 +110,57 @@ LL_HD void ll_ring_thresholds(int ring_model, int R, float lower_bound, float fa
     }
 }
 
+/* A first guess for the threshold search: t is cut into nb equal buckets between the first and the last threshold,
+ * lut[b] = the ring of the smallest t that falls into bucket b, and a point's ring is lut[b] plus the number of the next
+ * two thresholds not above t.  The bucket function is a chain of monotone f32 operations, so every bucket is an interval
+ * of floats and ll_ring_lut_build can check -- exactly, at context creation -- that no bucket spans more than three
+ * rings; if one does (exotic ring parameters) it returns false and k_classify keeps the binary search. */
+#define LL_RING_LUT_MAX 1024
+LL_HD int ll_ring_bucket(float t, float t0, float scale, int nb)
+{
+    const float u = (t - t0) * scale;
+    int b = (int)(u < 0.0f ? 0.0f : (u > (float)(nb - 1) ? (float)(nb - 1) : u));        /* NaN never gets here */
+    return b;
+}
+LL_HD int ll_ring_count(const int32_t *thr, int R, int32_t key)                           /* #{k <= R : thr[k] <= key} - 1 */
+{
+    int lo = 0, hi = R + 1;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (thr[mid] <= key) lo = mid + 1; else hi = mid; }
+    return lo - 1;
+}
+/* out: lut[nb] (rings as ints), t0, scale; returns nb, or 0 when the guess cannot be used */
+LL_HD int ll_ring_lut_build(const int32_t *thr, int R, int32_t *lut, float *t0_out, float *scale_out)
+{
+    const int32_t kinf_lo = ll_float_key(ll_u2f(0xff800000u)), kinf_hi = ll_float_key(ll_u2f(0x7f800000u));
+    if (thr[0] <= kinf_lo || thr[R] >= kinf_hi || thr[0] >= thr[R]) return 0;             /* unbounded or empty ring range */
+    int nb = 8 * R; if (nb > LL_RING_LUT_MAX) nb = LL_RING_LUT_MAX;
+    const float t0 = ll_key_float(thr[0]), t1 = ll_key_float(thr[R]);
+    const float scale = (float)(nb - 1) / (t1 - t0);
+    if (!(scale > 0.0f) || !(scale < 3.0e38f)) return 0;
+    int32_t first_key = kinf_lo;                                                           /* smallest key of bucket b */
+    for (int b = 0; b < nb; ++b) {
+        /* the smallest key whose bucket is >= b + 1 (monotone bucket function: binary search over all finite floats) */
+        int32_t lo = first_key, hi = kinf_hi;
+        while (lo < hi) {
+            const int32_t mid = (int32_t)(((int64_t)lo + (int64_t)hi) >> 1);
+            if (ll_ring_bucket(ll_key_float(mid), t0, scale, nb) >= b + 1) hi = mid; else lo = mid + 1;
+        }
+        const int32_t last_key = (b == nb - 1) ? kinf_hi : lo - 1;                        /* the last bucket runs to +inf */
+        if (last_key < first_key) { lut[b] = b ? lut[b - 1] : 0; first_key = lo; continue; }   /* no float lands here */
+        /* rings below 0 (t under the first threshold) are rejected before the guess is used: start at the first threshold */
+        const int32_t fk = first_key < thr[0] ? thr[0] : first_key;
+        int g = ll_ring_count(thr, R, fk);
+        if (g < 0) g = 0;
+        if (g > R - 1) g = R - 1;                                                          /* thr[g + 2] stays inside the padded array */
+        const int top = ll_ring_count(thr, R, last_key);
+        if (last_key >= thr[0] && top > g + 2) return 0;
+        lut[b] = g;
+        first_key = lo;
+    }
+    *t0_out = t0; *scale_out = scale;
+    return nb;
+}
+
 LL_HD float ll_atan2f(float y, float x)
 {
     const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f,
@@ -146,6 +197,60 @@ LL_HD float ll_atan2f(float y, float x)
     if (m == 1) return ll_u2f(ll_f2u(z) ^ 0x80000000u);
     if (m == 2) return pi - (z - pi_lo);
     return (z - pi_lo) - pi;
+}
+
+/* ll_atan2f for the common case, specials behind one rarely taken branch: both operands finite and non-zero, the
+ * quotient's exponent within +-60 and |y / x| inside ll_atanf's regular range [2^-29, 2^25).  What is left is the
+ * division, the reduction + polynomial of ll_atanf for a positive argument, and the quadrant fix -- the same f32
+ * operations in the same order (tests/test_exact_math.py compares the two functions over edge cases and a random sweep). */
+LL_HD float ll_atan2f_finite(float y, float x)
+{
+    const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    const int32_t hx = (int32_t)ll_f2u(x), hy = (int32_t)ll_f2u(y);
+    const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    const int k = (iy - ix) >> 23;
+    const float q = ll_u2f(ll_f2u(y / x) & 0x7fffffffu);
+    const int32_t iq = (int32_t)ll_f2u(q);
+    if (ix == 0 || iy == 0 || hx == 0x3f800000 || k > 60 || k < -60 || iq < 0x31000000 || iq >= 0x4c000000) return ll_atan2f(y, x);
+    /* ll_atanf(q), q > 0 in the regular range */
+    const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f,
+                aT3 = -1.1111110449e-01f, aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f,
+                aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f, aT8 = 4.9768779427e-02f,
+                aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
+    const bool r0 = iq < 0x3f300000, r1 = iq < 0x3f980000, r2 = iq < 0x401c0000, small = iq < 0x3ee00000;
+    float num = r0 ? 2.0f * q - 1.0f : (r1 ? q - 1.0f : (r2 ? q - 1.5f : -1.0f));
+    float den = r0 ? 2.0f + q        : (r1 ? q + 1.0f : (r2 ? 1.0f + 1.5f * q : q));
+    const float hi = r0 ? 4.6364760399e-01f : (r1 ? 7.8539812565e-01f : (r2 ? 9.8279368877e-01f : 1.5707962513e+00f));
+    const float lo = r0 ? 5.0121582440e-09f : (r1 ? 3.7748947079e-08f : (r2 ? 3.4473217170e-08f : 7.5497894159e-08f));
+    num = small ? q : num; den = small ? 1.0f : den;
+    const float t = num / den;
+    const float z2 = t * t;
+    const float w = z2 * z2;
+    const float s1 = z2 * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    const float rs = t - t * (s1 + s2);
+    const float rr = hi - ((t * (s1 + s2) - lo) - t);
+    const float z = small ? rs : rr;
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);              /* 2*sign(x) + sign(y) */
+    if (m == 0) return z;
+    if (m == 1) return ll_u2f(ll_f2u(z) ^ 0x80000000u);
+    if (m == 2) return pi - (z - pi_lo);
+    return (z - pi_lo) - pi;
+}
+
+/* the smallest float >= c / the largest float <= c: for a float a,  a < c  <=>  a < ll_f32_ceil(c)  and
+ * a > c  <=>  a > ll_f32_floor(c), which turns the reference's float-against-double comparisons into f32 compares */
+LL_HD float ll_f32_ceil(double c)
+{
+    float f = (float)c;
+    if ((double)f < c) { const uint32_t b = ll_f2u(f); f = (f == 0.0f) ? ll_u2f(1u) : ll_u2f(f > 0.0f ? b + 1u : b - 1u); }
+    return f;
+}
+LL_HD float ll_f32_floor(double c)
+{
+    float f = (float)c;
+    if ((double)f > c) { const uint32_t b = ll_f2u(f); f = (f == 0.0f) ? ll_u2f(0x80000001u) : ll_u2f(f > 0.0f ? b - 1u : b + 1u); }
+    return f;
 }
 
 /* graph vote predicate: std::exp(-(gap*gap)/1.0f) < 0.96f  (laserOdometry.cpp:239-242).

@@ -34,15 +34,24 @@ __device__ __forceinline__ bool ll_keep(const float4 p, float thres)
 
 /* scanID of a point (:139-168): the chain atan -> degrees -> ring formula -> int() is monotone in t = z / sqrt(x^2 + y^2), so
  * the ring is the number of precomputed thresholds (ll_ring_thresholds, exact for this context's parameters) not above t,
- * minus one -- a binary search over <= 129 keys in LDS instead of an arctangent, an f64 division and f64 arithmetic. */
-__device__ __forceinline__ int ll_scan_id(const int *thr, int R, const float4 p)
+ * minus one.  thr: R + 2 keys in LDS (the last one INT_MAX).  With a bucket table (ll_ring_lut_build) the count starts at
+ * the bucket's first ring and needs two comparisons; without one it is a binary search over the R + 1 keys. */
+template <bool LUT>
+__device__ __forceinline__ int ll_scan_id(const int *thr, const int *lut, int nb, float t0, float scale, int R, const float4 p)
 {
     const float t = p.z / sqrtf(p.x * p.x + p.y * p.y);
     if (t != t) return -1;                                  /* 0 / 0: the reference's int(NaN) is INT_MIN -> rejected */
     const int key = ll_float_key(t);
-    int lo = 0, hi = R + 1;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (thr[mid] <= key) lo = mid + 1; else hi = mid; }
-    const int id = lo - 1;
+    int id;
+    if (LUT) {
+        const int g = lut[ll_ring_bucket(t, t0, scale, nb)];
+        id = g + (key >= thr[g + 1] ? 1 : 0) + (key >= thr[g + 2] ? 1 : 0);
+        if (key < thr[0]) id = -1;
+    } else {
+        int lo = 0, hi = R + 1;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (thr[mid] <= key) lo = mid + 1; else hi = mid; }
+        id = lo - 1;
+    }
     return (id > R - 1 || id < 0) ? -1 : id;
 }
 
@@ -77,9 +86,12 @@ __global__ __launch_bounds__(LL_BLOCK) void k_first_kept(LLView V, int first, in
         float start_ori = 0.0f;
         if (fk != INT_MAX) { const float4 p0 = raw[fk]; start_ori = -ll_atan2f(p0.y, p0.x); }
         V.hdr[s].start_ori = start_ori; V.hdr[s].first_kept = fk;
+        V.hdr[s].so_lo_up = ll_f32_ceil((double)start_ori - M_PI / 2);
+        V.hdr[s].so_hi_dn = ll_f32_floor((double)start_ori + M_PI * 3 / 2);
     }
 }
 
+template <bool LUT>
 __global__ __launch_bounds__(LL_BLOCK) void k_classify(LLView V, int first, int count)
 {
     int sl, tile;
@@ -93,19 +105,20 @@ __global__ __launch_bounds__(LL_BLOCK) void k_classify(LLView V, int first, int 
 
     __shared__ int sh_first_p, sh_fk, sh_lk;
     __shared__ int hist[LL_MAX_RINGS];
-    __shared__ int thr[LL_MAX_RINGS + 1];
+    __shared__ int thr[LL_MAX_RINGS + 2];
+    __shared__ int lut[LUT ? LL_RING_LUT_MAX : 1];
     if (tid <= V.R) thr[tid] = V.ring_thr[tid];
-    if (tid == 0) { sh_first_p = INT_MAX; sh_fk = INT_MAX; sh_lk = -1; }
+    if (tid == 0) { sh_first_p = INT_MAX; sh_fk = INT_MAX; sh_lk = -1; thr[V.R + 1] = INT_MAX; }
     if (tid < LL_MAX_RINGS) hist[tid] = 0;
+    if (LUT) for (int i = tid; i < V.lut_nb; i += LL_BLOCK) lut[i] = V.ring_lut[i];
     __syncthreads();
-    const float start_ori = V.hdr[s].start_ori;                      /* k_first_kept */
+    const ScanHdr h0 = V.hdr[s];                                      /* k_first_kept */
+    const float start_ori = h0.start_ori, so_lo_up = h0.so_lo_up, so_hi_dn = h0.so_hi_dn;
 
     float *ori = V.ori + (size_t)s * V.NP;
     int8_t *ring = V.ring + (size_t)s * V.NP;
     const int lane = tid & 63;
     int bits = 0; while ((1 << bits) < V.R) ++bits;
-    /* the constants of the halfPassed predicate, hoisted (f64) */
-    const double so_lo = (double)start_ori - M_PI / 2, so_hi = (double)start_ori + M_PI * 3 / 2;
 #pragma unroll
     for (int k = 0; k < LL_TILE / LL_BLOCK; ++k) {
         const int i = base + k * LL_BLOCK + tid;
@@ -115,14 +128,15 @@ __global__ __launch_bounds__(LL_BLOCK) void k_classify(LLView V, int first, int 
         const bool kept = in && ll_keep(p, V.thres);
         int id = -1; float o = 0.0f; bool firstp = false;
         if (kept) {
-            o = -ll_atan2f(p.y, p.x);                                                 /* :177 (also start/endOri source) */
-            id = ll_scan_id(thr, V.R, p);
+            o = -ll_atan2f_finite(p.y, p.x);                                          /* :177 (also start/endOri source) */
+            id = ll_scan_id<LUT>(thr, lut, V.lut_nb, V.lut_t0, V.lut_scale, V.R, p);
             if (id >= 0) {
-                /* the !halfPassed branch (:180-192) evaluated as if the flag were still false */
+                /* the !halfPassed branch (:180-192) evaluated as if the flag were still false; the float-against-double
+                 * comparisons in f32 against the rounded-outward bounds of k_first_kept (ll_f32_ceil / ll_f32_floor) */
                 float a = o;
-                if ((double)a < so_lo)        a = (float)((double)a + 2 * M_PI);
-                else if ((double)a > so_hi)   a = (float)((double)a - 2 * M_PI);
-                firstp = (double)(a - start_ori) > M_PI;
+                const bool below = a < so_lo_up, above = a > so_hi_dn;
+                if (below || above) a = (float)((double)a + (below ? 2 * M_PI : -(2 * M_PI)));
+                firstp = (a - start_ori) >= 3.14159274101257324f;                     /* (double)(a - startOri) > M_PI */
             }
         }
         if (in) { ori[i] = o; ring[i] = (int8_t)id; }
@@ -289,7 +303,8 @@ void ll_launch_organize(const LLView &V, int first, int count, hipStream_t st, L
     ll_prof_mark(prof, LL_K_FIRST, st);
     hipLaunchKernelGGL(k_first_kept, dim3(count), dim3(LL_BLOCK), 0, st, V, first, count);
     ll_prof_mark(prof, LL_K_CLASSIFY, st);
-    hipLaunchKernelGGL(k_classify, dim3(grid), dim3(LL_BLOCK), 0, st, V, first, count);
+    if (V.lut_nb > 0) hipLaunchKernelGGL(k_classify<true>, dim3(grid), dim3(LL_BLOCK), 0, st, V, first, count);
+    else hipLaunchKernelGGL(k_classify<false>, dim3(grid), dim3(LL_BLOCK), 0, st, V, first, count);
     ll_prof_mark(prof, LL_K_OFFSETS, st);
     hipLaunchKernelGGL(k_offsets, dim3(count), dim3(LL_BLOCK), 0, st, V, first, count);
     ll_prof_mark(prof, LL_K_SCATTER, st);

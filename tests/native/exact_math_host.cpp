@@ -65,8 +65,10 @@ long long em_check_ring_thresholds(unsigned long long first, unsigned long long 
     long long bad = 0;
     for (const M &m : models) {
         const float factor = (float)(m.R - 1) / (m.ub - m.lb);
-        int32_t thr[129];
+        int32_t thr[130], lut[LL_RING_LUT_MAX]; float t0 = 0.f, scale = 0.f;
         ll_ring_thresholds(m.model, m.R, m.lb, factor, thr);
+        thr[m.R + 1] = 0x7fffffff;
+        const int nb = ll_ring_lut_build(thr, m.R, lut, &t0, &scale);
         for (int k = 0; k < m.R; ++k) if (thr[k] > thr[k + 1]) bad++;
 #pragma omp parallel for reduction(+ : bad) schedule(static)
         for (long long i = (long long)first; i < (1LL << 32); i += (long long)stride) {
@@ -82,7 +84,52 @@ long long em_check_ring_thresholds(unsigned long long first, unsigned long long 
                 if (got > m.R - 1 || got < 0) got = -1;
             }
             if (got != want) bad++;
+            if (nb > 0 && t == t) {                                   // the bucket-table path of k_classify
+                const int32_t key = ll_float_key(t);
+                const int g = lut[ll_ring_bucket(t, t0, scale, nb)];
+                int id = g + (key >= thr[g + 1] ? 1 : 0) + (key >= thr[g + 2] ? 1 : 0);
+                if (key < thr[0]) id = -1;
+                if (id > m.R - 1 || id < 0) id = -1;
+                if (id != want) bad++;
+            }
         }
+    }
+    return bad;
+}
+
+// how many of the five models get a bucket table (all of them should)
+long long em_ring_lut_models(void)
+{
+    struct M { int model, R; float lb, ub; } models[] = {{0, 16, -15.f, 15.f}, {0, 32, -30.67f, 10.67f}, {0, 64, -24.9f, 2.f}, {1, 128, -25.f, 15.f}, {1, 40, -16.f, 7.f}};
+    long long n = 0;
+    for (const M &m : models) {
+        const float factor = (float)(m.R - 1) / (m.ub - m.lb);
+        int32_t thr[130], lut[LL_RING_LUT_MAX]; float t0, scale;
+        ll_ring_thresholds(m.model, m.R, m.lb, factor, thr);
+        if (ll_ring_lut_build(thr, m.R, lut, &t0, &scale) > 0) n++;
+    }
+    return n;
+}
+
+// a < c  <=>  a < ll_f32_ceil(c)   and   a > c  <=>  a > ll_f32_floor(c)   for floats a around doubles c
+long long em_check_f32_bounds(long long n, unsigned long long seed)
+{
+    long long bad = 0;
+    uint64_t s = seed;
+    for (long long i = 0; i < n; i++) {
+        const float base = (i & 1) ? ll_u2f(pcg(&s)) : (float)((int32_t)pcg(&s) * (8.0 / 2147483648.0));
+        if (base != base || base - base != 0.0f) continue;
+        const double c = (i & 2) ? (double)base : (double)base + ((int32_t)pcg(&s) * (1.0 / 2147483648.0)) * (double)base * 1e-7 + ((i & 4) ? 1e-50 : 0.0);
+        const float up = ll_f32_ceil(c), dn = ll_f32_floor(c);
+        if (!((double)up >= c) || !((double)dn <= c)) bad++;
+        const uint32_t ub = ll_f2u(up);
+        for (int d = -3; d <= 3; d++) {                               // floats next to the bound
+            const float a = ll_key_float(ll_float_key(up) + d);
+            if (a != a) continue;
+            if (((double)a < c) != (a < up)) bad++;
+            if (((double)a > c) != (a > dn)) bad++;
+        }
+        (void)ub;
     }
     return bad;
 }
@@ -105,6 +152,10 @@ long long em_check_atan2f(long long n, unsigned long long seed)
             }
             const float a = atan2f(y, x), b = ll_atan2f(y, x);
             if (ll_f2u(a) != ll_f2u(b) && !(a != a && b != b)) bad++;
+            if (y - y == 0.0f && x - x == 0.0f) {                     // finite operands: the fast path k_classify uses
+                const float c = ll_atan2f_finite(y, x);
+                if (ll_f2u(a) != ll_f2u(c)) bad++;
+            }
         }
     }
     return bad;
@@ -121,6 +172,7 @@ long long em_check_atan2f_specials(void)
             const float y = ll_u2f(sp[i]), x = ll_u2f(sp[j]);
             const float a = atan2f(y, x), b = ll_atan2f(y, x);
             if (ll_f2u(a) != ll_f2u(b) && !(a != a && b != b)) bad++;
+            if (y - y == 0.0f && x - x == 0.0f && ll_f2u(a) != ll_f2u(ll_atan2f_finite(y, x))) bad++;
         }
     return bad;
 }

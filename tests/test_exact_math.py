@@ -30,6 +30,9 @@ def em():
     lib.em_check_atanf_monotone.restype = C.c_longlong
     lib.em_check_ring_thresholds.restype = C.c_longlong
     lib.em_check_ring_thresholds.argtypes = [C.c_ulonglong, C.c_ulonglong]
+    lib.em_ring_lut_models.restype = C.c_longlong
+    lib.em_check_f32_bounds.restype = C.c_longlong
+    lib.em_check_f32_bounds.argtypes = [C.c_longlong, C.c_ulonglong]
     lib.em_check_vote.restype = C.c_longlong
     lib.em_check_vote.argtypes = [C.c_ulonglong, C.c_ulonglong]
     return lib
@@ -73,6 +76,17 @@ def test_ring_thresholds_equal_the_formula_stratified(em):
                     "(passed on 2026-10-01 for the header as committed)")
 def test_ring_thresholds_equal_the_formula_exhaustive(em):
     assert em.em_check_ring_thresholds(0, 1) == 0
+
+
+def test_every_sensor_model_gets_a_bucket_table(em):
+    """k_classify's first guess (ll_ring_lut_build) validates itself at context creation; the stratified sweep above also
+    runs every float through the table path and compares with the formula"""
+    assert em.em_ring_lut_models() == 5
+
+
+def test_float_against_double_comparisons_in_f32(em):
+    """the halfPassed wrap tests compare a float with a double (:181-188); ll_f32_ceil / ll_f32_floor move the bound to f32"""
+    assert em.em_check_f32_bounds(2_000_000, 99) == 0
 
 
 def test_atan2f_special_values(em):
