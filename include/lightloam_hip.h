@@ -252,6 +252,20 @@ int ll_map_set_row_shard(ll_map *m, int rank, int world);
  * laserMapping.cpp:1813-1821, :2151-2165): centroids (x, y, z, intensity) per voxel, in voxel-index order.       */
 int ll_voxel_grid(ll_ctx *ctx, const ll_point *host_in, int n, float leaf_size, ll_point *host_out, int cap, int *n_out);
 
+/* ---------------------------------------------------------------- lidarFactor.hpp functors on caller-supplied blocks
+ * For a node that keeps its own association code and ceres::Problem and only wants the functors evaluated on the device
+ * (include/lightloam_lidarFactor.hpp keeps LidarEdgeFactor::Create / LidarPlaneFactor_modify::Create /
+ * LidarPlaneNormFactor::Create as they are called at laserOdometry.cpp:615, :783 and laserMapping.cpp:1918, :2033).
+ * ll_factor_blocks_set: the blocks of one problem, f64 --
+ *     edge9   [n_edge][9]   curr_point, last_point_a, last_point_b                         (lidarFactor.hpp:9-52,  3 rows each)
+ *     plane13 [n_plane][13] curr_point, last_point_j, last_point_l, last_point_m, weight   (:203-251, 1 row each)
+ *     pnorm7  [n_pnorm][7]  curr_point, plane_unit_norm, negative_OA_dot_norm              (:253-285, 1 row each)
+ * all with s = 1 (the reference never passes anything else: DISTORTION 0, laserOdometry.cpp:23, :81-84).
+ * ll_factor_blocks_evaluate: residuals [rows], jacobians w.r.t. q (x, y, z, w) [rows][4] and t [rows][3], row-major,
+ * rows = 3 n_edge + n_plane + n_pnorm in that order; loss functions are the caller's (Ceres applies them).         */
+int ll_factor_blocks_set(ll_ctx *ctx, int n_edge, const double *edge9, int n_plane, const double *plane13, int n_pnorm, const double *pnorm7);
+int ll_factor_blocks_evaluate(ll_ctx *ctx, const double q[4], const double t[3], double *r, double *Jq, double *Jt, int cap_rows);
+
 /* ---------------------------------------------------------------- laserMapping's cube map (second stage)
  * The 21 x 21 x 11 cubes of 50 m that hold the map (laserMapping.cpp:45-53, :74-75), resident in HBM, and the per-frame
  * body around the optimisation: ll_cubemap_prepare = :1584-1821 (centre cube of t_w_curr, the six shift loops, the

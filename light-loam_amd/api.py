@@ -28,6 +28,7 @@ EXPORTS = [
     "ll_cubemap_create", "ll_cubemap_destroy", "ll_cubemap_last_error", "ll_cubemap_prepare", "ll_cubemap_optimize", "ll_cubemap_update",
     "ll_cubemap_process", "ll_cubemap_process_slot", "ll_cubemap_info", "ll_cubemap_download_cloud", "ll_cubemap_download_cube",
     "ll_map_set_map_ids", "ll_map_knn_partial", "ll_map_associate_merged", "ll_map_solve", "ll_map_set_row_shard", "ll_cubemap_set_shard", "ll_cubemap_map",
+    "ll_factor_blocks_set", "ll_factor_blocks_evaluate",
     "ll_voxel_grid", "ll_map_set_pose", "ll_map_get_pose", "ll_map_evaluate", "ll_map_lm_begin", "ll_map_lm_propose", "ll_map_lm_accept",
 ]
 
@@ -277,6 +278,21 @@ class Context:
         out = np.zeros((max(len(pts), 1), 4), np.float32); n = C.c_int(0)
         self._ck(self.lib.ll_voxel_grid(self.h, _ptr(pts), len(pts), C.c_float(leaf), _ptr(out), len(out), C.byref(n)))
         return out[:n.value].copy()
+
+    def factor_blocks_set(self, edge9=None, plane13=None, pnorm7=None):
+        """lidarFactor.hpp blocks of one problem: edge [n, 9], plane [n, 13], plane-norm [n, 7] (f64)."""
+        e = np.ascontiguousarray(edge9 if edge9 is not None else np.zeros((0, 9)), np.float64).reshape(-1, 9)
+        p = np.ascontiguousarray(plane13 if plane13 is not None else np.zeros((0, 13)), np.float64).reshape(-1, 13)
+        n = np.ascontiguousarray(pnorm7 if pnorm7 is not None else np.zeros((0, 7)), np.float64).reshape(-1, 7)
+        self._fb_rows = 3 * len(e) + len(p) + len(n)
+        self._ck(self.lib.ll_factor_blocks_set(self.h, len(e), _ptr(e), len(p), _ptr(p), len(n), _ptr(n)))
+
+    def factor_blocks_evaluate(self, q, t):
+        q = np.ascontiguousarray(q, np.float64); t = np.ascontiguousarray(t, np.float64)
+        rows = self._fb_rows
+        r = np.zeros(max(rows, 1)); Jq = np.zeros((max(rows, 1), 4)); Jt = np.zeros((max(rows, 1), 3))
+        self._ck(self.lib.ll_factor_blocks_evaluate(self.h, _ptr(q), _ptr(t), _ptr(r), _ptr(Jq), _ptr(Jt), len(r)))
+        return r[:rows], Jq[:rows], Jt[:rows]
 
     def algorithmic_bytes(self, first=0, count=1):
         b = [C.c_double(0) for _ in range(4)]

@@ -435,6 +435,58 @@ extern "C" int ll_hot_path_batch(ll_ctx *ctx, int first, int count, const double
     return LL_OK;
 }
 
+/* ------------------------------------------------------------------ lidarFactor.hpp functors on caller-supplied blocks (ll_functors.hip) */
+extern "C" int ll_factor_blocks_set(ll_ctx *ctx, int n_edge, const double *edge9, int n_plane, const double *plane13, int n_pnorm, const double *pnorm7)
+{
+    if (!ctx) return LL_ERR_ARG;
+    if (n_edge < 0 || n_plane < 0 || n_pnorm < 0 || (n_edge > 0 && !edge9) || (n_plane > 0 && !plane13) || (n_pnorm > 0 && !pnorm7) ||
+        (long long)n_edge + n_plane + n_pnorm > (1 << 24)) { ctx->err = "bad residual blocks"; return LL_ERR_ARG; }
+    LL_HIP(hipSetDevice(ctx->device));
+    const size_t need = (size_t)n_edge * 9 + (size_t)n_plane * 13 + (size_t)n_pnorm * 7;
+    if (need > ctx->fb_cap) {
+        double *p = nullptr;
+        if (!dev_alloc(ctx, p, need + need / 2 + 64, false)) return LL_ERR_HIP;      /* the smaller buffer stays in allocs until destroy */
+        ctx->d_fb = p; ctx->fb_cap = need + need / 2 + 64;
+    }
+    hipStream_t st = ctx->stream;
+    double *d = ctx->d_fb;
+    if (n_edge) LL_HIP(hipMemcpyAsync(d, edge9, (size_t)n_edge * 9 * sizeof(double), hipMemcpyHostToDevice, st));
+    d += (size_t)n_edge * 9;
+    if (n_plane) LL_HIP(hipMemcpyAsync(d, plane13, (size_t)n_plane * 13 * sizeof(double), hipMemcpyHostToDevice, st));
+    d += (size_t)n_plane * 13;
+    if (n_pnorm) LL_HIP(hipMemcpyAsync(d, pnorm7, (size_t)n_pnorm * 7 * sizeof(double), hipMemcpyHostToDevice, st));
+    LL_HIP(hipStreamSynchronize(st));
+    ctx->fb_n[0] = n_edge; ctx->fb_n[1] = n_plane; ctx->fb_n[2] = n_pnorm;
+    return LL_OK;
+}
+
+extern "C" int ll_factor_blocks_evaluate(ll_ctx *ctx, const double *q4, const double *t3, double *r, double *Jq, double *Jt, int cap_rows)
+{
+    if (!ctx || !q4 || !t3) return LL_ERR_ARG;
+    const int ne = ctx->fb_n[0], np = ctx->fb_n[1], nn = ctx->fb_n[2];
+    const size_t rows = (size_t)3 * ne + np + nn;
+    if ((size_t)cap_rows < rows) { ctx->err = "row capacity too small"; return LL_ERR_CAPACITY; }
+    if (rows == 0) return LL_OK;
+    LL_HIP(hipSetDevice(ctx->device));
+    if (rows * 8 > ctx->fb_out_cap) {
+        double *p = nullptr;
+        if (!dev_alloc(ctx, p, rows * 8 + rows * 4 + 64, false)) return LL_ERR_HIP;
+        ctx->d_fb_out = p; ctx->fb_out_cap = rows * 8 + rows * 4 + 64;
+    }
+    hipStream_t st = ctx->stream;
+    const double pose[7] = {q4[0], q4[1], q4[2], q4[3], t3[0], t3[1], t3[2]};
+    LL_HIP(hipMemcpyAsync(ctx->d_tmp_pose, pose, sizeof(pose), hipMemcpyHostToDevice, st));
+    double *dr = ctx->d_fb_out, *dJq = dr + rows, *dJt = dJq + rows * 4;
+    const double *edge = ctx->d_fb, *plane = edge + (size_t)ne * 9, *pnorm = plane + (size_t)np * 13;
+    ll_launch_factor_blocks(ctx->d_tmp_pose, ne, edge, np, plane, nn, pnorm, dr, dJq, dJt, st);
+    LL_HIP(hipGetLastError());
+    if (r) LL_HIP(hipMemcpyAsync(r, dr, rows * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (Jq) LL_HIP(hipMemcpyAsync(Jq, dJq, rows * 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (Jt) LL_HIP(hipMemcpyAsync(Jt, dJt, rows * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+    LL_HIP(hipStreamSynchronize(st));
+    return LL_OK;
+}
+
 /* ------------------------------------------------------------------ mapping stage (ll_mapping.hip) */
 extern "C" void ll_map_destroy(ll_map *m)
 {

@@ -199,6 +199,9 @@ void ll_map_launch_associate_merged(const LLMapView &M, int n_parts, const float
 void ll_map_launch_normal_eq(const LLMapView &M, hipStream_t st);
 void ll_map_launch_rows(const LLMapView &M, double *r, double *Jq, double *Jt, hipStream_t st);
 
+void ll_launch_factor_blocks(const double *pose, int n_e, const double *edge, int n_p, const double *plane, int n_n, const double *pnorm,
+                             double *r, double *Jq, double *Jt, hipStream_t st);                        /* ll_functors.hip */
+
 /* ---- whole-cloud VoxelGrid (ll_voxel.hip) ---- */
 struct LLVoxSeg;
 struct LLVoxWork {

@@ -37,10 +37,9 @@ __device__ __forceinline__ void ll_to_local(const Pose &P, const double Ja[4], d
 }
 
 /* LidarEdgeFactor (lidarFactor.hpp:9-52): r[3], ambient Jq[3][4], Jt[3][3]; a, b = the two points of the line in f64 */
-__device__ __forceinline__ void ll_edge_d(const Pose &P, const float4 c, const double a[3], const double b[3],
-                                          double r[3], double Jq[3][4], double Jt[3][3])
+__device__ __forceinline__ void ll_edge_dd(const Pose &P, const double cp[3], const double a[3], const double b[3],
+                                           double r[3], double Jq[3][4], double Jt[3][3])
 {
-    const double cp[3] = {c.x, c.y, c.z};
     double lp[3], A[3][4];
     ll_lp_and_jac(P, cp, lp, A);
     const double pa[3] = {lp[0] - a[0], lp[1] - a[1], lp[2] - a[2]}, pb[3] = {lp[0] - b[0], lp[1] - b[1], lp[2] - b[2]};
@@ -56,6 +55,13 @@ __device__ __forceinline__ void ll_edge_d(const Pose &P, const float4 c, const d
     }
 }
 
+__device__ __forceinline__ void ll_edge_d(const Pose &P, const float4 c, const double a[3], const double b[3],
+                                          double r[3], double Jq[3][4], double Jt[3][3])
+{
+    const double cp[3] = {c.x, c.y, c.z};
+    ll_edge_dd(P, cp, a, b, r, Jq, Jt);
+}
+
 __device__ __forceinline__ void ll_edge(const Pose &P, const float4 c, const float4 a4, const float4 b4,
                                         double r[3], double Jq[3][4], double Jt[3][3])
 {
@@ -64,9 +70,8 @@ __device__ __forceinline__ void ll_edge(const Pose &P, const float4 c, const flo
 }
 
 /* LidarPlaneNormFactor (lidarFactor.hpp:253-285): r = n . (q * cp + t) + d */
-__device__ __forceinline__ void ll_plane_norm(const Pose &P, const float4 c, const double n[3], double d, double &r, double Jq[4], double Jt[3])
+__device__ __forceinline__ void ll_plane_norm_dd(const Pose &P, const double cp[3], const double n[3], double d, double &r, double Jq[4], double Jt[3])
 {
-    const double cp[3] = {c.x, c.y, c.z};
     double lp[3], A[3][4];
     ll_lp_and_jac(P, cp, lp, A);
     r = (n[0] * lp[0] + (n[1] * lp[1] + n[2] * lp[2])) + d;                                                  /* :270 */
@@ -74,13 +79,18 @@ __device__ __forceinline__ void ll_plane_norm(const Pose &P, const float4 c, con
     for (int k = 0; k < 3; ++k) Jt[k] = n[k];
 }
 
-/* LidarPlaneFactor_modify (lidarFactor.hpp:203-251) */
-__device__ __forceinline__ void ll_plane(const Pose &P, const float4 c, const float4 j4, const float4 l4, const float4 m4,
-                                         double weight, double &r, double Jq[4], double Jt[3])
+__device__ __forceinline__ void ll_plane_norm(const Pose &P, const float4 c, const double n[3], double d, double &r, double Jq[4], double Jt[3])
 {
-    const double cp[3] = {c.x, c.y, c.z}, j[3] = {j4.x, j4.y, j4.z};
-    const double a[3] = {j[0] - (double)l4.x, j[1] - (double)l4.y, j[2] - (double)l4.z};
-    const double b[3] = {j[0] - (double)m4.x, j[1] - (double)m4.y, j[2] - (double)m4.z};
+    const double cp[3] = {c.x, c.y, c.z};
+    ll_plane_norm_dd(P, cp, n, d, r, Jq, Jt);
+}
+
+/* LidarPlaneFactor_modify (lidarFactor.hpp:203-251) */
+__device__ __forceinline__ void ll_plane_dd(const Pose &P, const double cp[3], const double j[3], const double l[3], const double m[3],
+                                            double weight, double &r, double Jq[4], double Jt[3])
+{
+    const double a[3] = {j[0] - l[0], j[1] - l[1], j[2] - l[2]};
+    const double b[3] = {j[0] - m[0], j[1] - m[1], j[2] - m[2]};
     double n[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};     /* :210 */
     const double z = (n[0] * n[0] + n[1] * n[1]) + n[2] * n[2];
     if (z > 0.0) { const double nn = sqrt(z); n[0] /= nn; n[1] /= nn; n[2] /= nn; }                      /* :211 normalize() */
@@ -90,6 +100,13 @@ __device__ __forceinline__ void ll_plane(const Pose &P, const float4 c, const fl
     r = (d[0] * n[0] + (d[1] * n[1] + d[2] * n[2])) * weight;                                              /* :233 */
     for (int k = 0; k < 4; ++k) Jq[k] = (n[0] * A[0][k] + n[1] * A[1][k] + n[2] * A[2][k]) * weight;
     for (int k = 0; k < 3; ++k) Jt[k] = n[k] * weight;
+}
+
+__device__ __forceinline__ void ll_plane(const Pose &P, const float4 c, const float4 j4, const float4 l4, const float4 m4,
+                                         double weight, double &r, double Jq[4], double Jt[3])
+{
+    const double cp[3] = {c.x, c.y, c.z}, j[3] = {j4.x, j4.y, j4.z}, l[3] = {l4.x, l4.y, l4.z}, m[3] = {m4.x, m4.y, m4.z};
+    ll_plane_dd(P, cp, j, l, m, weight, r, Jq, Jt);
 }
 
 /* ceres HuberLoss(a) + Corrector (rho'' <= 0 branch): scale = sqrt(rho'), cost += rho/2 */

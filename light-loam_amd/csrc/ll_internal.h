@@ -34,6 +34,10 @@ struct ll_ctx {
     std::vector<int> n_in_host;
     hipEvent_t ev[16];
     bool ev_ok = false;
+    /* caller-supplied residual blocks (ll_factor_blocks_set / _evaluate) */
+    double *d_fb = nullptr, *d_fb_out = nullptr;
+    size_t fb_cap = 0, fb_out_cap = 0;
+    int fb_n[3] = {0, 0, 0};
 };
 
 
