@@ -216,6 +216,7 @@ extern "C" int ll_extract_batch(ll_ctx *ctx, int first, int count)
 {
     int rc = check_range(ctx, first, count); if (rc) return rc;
     ll_launch_organize(ctx->V, first, count, ctx->stream, &ctx->prof);
+    ll_next_epoch(ctx);
     ll_launch_features(ctx->V, first, count, ctx->feat_lds, ctx->stream, &ctx->prof);
     ll_launch_build_grid(ctx->V, first, count, 0, ctx->stream, &ctx->prof);
     LL_HIP(hipGetLastError());
@@ -425,6 +426,7 @@ extern "C" int ll_hot_path_batch(ll_ctx *ctx, int first, int count, const double
     for (int c0 = 0; c0 < count; c0 += chunk) {
         const int f = first + c0, n = (count - c0 < chunk) ? count - c0 : chunk;
         ll_launch_organize(ctx->V, f, n, ctx->stream, &ctx->prof);
+        ll_next_epoch(ctx);
         ll_launch_features(ctx->V, f, n, ctx->feat_lds, ctx->stream, &ctx->prof);
         ll_launch_build_grid(ctx->V, f, n, 0, ctx->stream, &ctx->prof);
         ll_launch_associate(ctx->V, f, n, ctx->stream, &ctx->prof);

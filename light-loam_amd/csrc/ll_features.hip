@@ -674,10 +674,7 @@ void ll_launch_features(const LLView &V, int first, int count, size_t lds_bytes,
 {
     const int groups = (count + 7) / 8;
     const int grid = 8 * V.R * groups;
-    static int epoch = 0;                                      /* 24-bit tag of this launch in the rings' look-back words, never 0 */
-    LLView Ve = V;
-    epoch = epoch % 0xFFFFFE + 1;
-    Ve.epoch = epoch;
+    const LLView &Ve = V;                                      /* V.epoch: the caller's per-context launch tag (ll_next_epoch) */
     ll_prof_mark(prof, LL_K_RING_FEATURES, st);
     const int rows = (V.max_ring + 255) / 256;                 /* sort records per thread */
     if (rows <= 9) ll_launch_ring_features<9>(Ve, first, count, grid, lds_bytes, st);
