@@ -476,7 +476,9 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
     }
 }
 
-__global__ __launch_bounds__(LL_BLOCK) void k_associate(LLView V, int first, int count, int qb_corner, int qb_plane)
+/* 2nd launch bound = waves per SIMD.  Left alone the compiler spends 106 SGPRs and lands on 7; asked for 8 it fits in 78
+ * with the same 60 VGPRs and no scratch -- the kernel is latency-bound, one more wave per SIMD is worth 17 % (A/B, one box). */
+__global__ __launch_bounds__(LL_BLOCK, 8) void k_associate(LLView V, int first, int count, int qb_corner, int qb_plane)
 {
     const int per = qb_corner + qb_plane;
     const int sl = blockIdx.x / per, item = blockIdx.x % per;
