@@ -118,6 +118,7 @@ extern "C" int ll_create(int device, const ll_params *p, ll_ctx **out)
      * the same number, so the defaults are mapped back to the exact double literals */
     V.curv_thr = (p->curv_threshold == 0.1f) ? 0.1 : (double)p->curv_threshold;
     V.gap_thr = (p->gap_sq_threshold == 0.05f) ? 0.05 : (double)p->gap_sq_threshold;
+    V.curv_gt = ll_f32_floor(V.curv_thr); V.curv_lt = ll_f32_ceil(V.curv_thr); V.gap_gt = ll_f32_floor(V.gap_thr);
     V.leaf = p->leaf_size; V.inv_leaf = 1.0f / p->leaf_size;
     V.nn_max = p->nn_dist_sq_max; V.nearby = (double)p->nearby_scan;
     V.huber = (p->huber_delta == 0.1f) ? 0.1 : (double)p->huber_delta;

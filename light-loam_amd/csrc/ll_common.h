@@ -64,6 +64,8 @@ struct LLView {
     const int *ring_thr;           /* [R + 1] ll_ring_thresholds: keys of the smallest t = z / sqrt(x^2 + y^2) of every ring */
     const int *ring_lut; int lut_nb; float lut_t0, lut_scale;   /* ll_ring_lut_build: first guess per t bucket (lut_nb = 0: unused) */
     double curv_thr, gap_thr;      /* 0.1 / 0.05 as double: the reference compares f32 against double literals */
+    float curv_gt, curv_lt, gap_gt; /* the same comparisons in f32: c > curv_thr <=> c > curv_gt = ll_f32_floor(curv_thr), c < curv_thr <=>
+                                     * c < curv_lt = ll_f32_ceil(curv_thr), g > gap_thr <=> g > gap_gt = ll_f32_floor(gap_thr) (ll_exact_math.h) */
     float leaf, inv_leaf;
     float nn_max;                  /* 25 */
     double nearby;                 /* 2.5 */

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features
             const int g = off + li, t = li - c0 + 5;
             if (g >= 1) {                                             /* gap to the previous point (:290-293) */
                 const float dx = L.tx[t] - L.tx[t - 1], dy = L.ty[t] - L.ty[t - 1], dz = L.tz[t] - L.tz[t - 1];
-                if ((double)(dx * dx + dy * dy + dz * dz) > V.gap_thr) atomicOr(&L.gapf[li >> 5], 1u << (li & 31));
+                if (dx * dx + dy * dy + dz * dz > V.gap_gt) atomicOr(&L.gapf[li >> 5], 1u << (li & 31));   /* (double)g > 0.05 */
             }
             if (g >= 5 && g < N - 5) {                                /* :225-235, strict left-to-right */
                 const float *X = L.tx + t, *Y = L.ty + t, *Z = L.tz + t;
@@ -379,9 +379,9 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features
                 if (q < len) {
                     cb[k] = L.k32[sp + q];
                     exw[k >> 2] |= (unsigned)L.k16[sp + q] << ((k & 3) * 8);
-                    const double cv = (double)ll_u2f(cb[k]);              /* f32 curvature against the double literal 0.1 */
-                    if (cv > V.curv_thr) candc |= 1u << k;                /* :266 */
-                    if (cv < V.curv_thr) candf |= 1u << k;                /* :321 */
+                    const float cv = ll_u2f(cb[k]);                       /* f32 curvature against the double literal 0.1, in f32 */
+                    if (cv > V.curv_gt) candc |= 1u << k;                 /* :266 */
+                    if (cv < V.curv_lt) candf |= 1u << k;                 /* :321 */
                 }
             }
             bool imported = (j == 0);
