@@ -299,7 +299,7 @@ extern "C" int ll_vote_host(ll_ctx *ctx, const ll_point *src, const ll_point *tg
 {
     if (!ctx || n < 0 || (n > 0 && (!src || !tgt))) return LL_ERR_ARG;
     if (n == 0) return LL_OK;
-    if ((size_t)n * 24 + 16 > 160 * 1024) { ctx->err = "ll_vote_host: more than 6826 correspondences do not fit one workgroup's LDS"; return LL_ERR_CAPACITY; }
+    if ((size_t)n * 28 + 16 > 160 * 1024) { ctx->err = "ll_vote_host: more than 5850 correspondences do not fit one workgroup's LDS"; return LL_ERR_CAPACITY; }
     /* scratch: src, tgt (float4), count (int), weight (float), selected (u8) */
     const size_t bytes = (size_t)n * (16 + 16 + 4 + 4 + 1) + 64;
     void *d = nullptr;

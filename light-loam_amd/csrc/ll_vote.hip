@@ -5,7 +5,7 @@
  *
  * One workgroup per scan pair.  Per-query association results are compacted in query order (the order the
  * reference appends them).  The vote is the reference's dense all-pairs test inside each of 10 (planes) or 5
- * (corners) contiguous regions: thread i counts the j of its region with | |src_i-src_j| - |tgt_i-tgt_j| |^2 >= T,
+ * (corners) contiguous regions: every pair (i, j) of a region with | |src_i-src_j| - |tgt_i-tgt_j| |^2 >= T counts for both,
  * where "std::exp(-gap^2) < 0.96f" is replaced by the bit-exact threshold of ll_exact_math.h.  src/tgt points are
  * staged once in LDS and broadcast-read.  Selection: count <= 0.9f*m, weight 5 if count <= 50 else 1 (:299-322).
  * Output is per correspondence (count, selected, weight); the reference's output ORDER (ascending count, std::sort
@@ -32,30 +32,50 @@ __device__ __forceinline__ int ll_block_compact(int n, int *sc, F emit, const in
     return total;
 }
 
-/* the vote proper on LDS-staged src (S3) / tgt (T3) xyz triples; returns this thread's number of selected entries */
+/* the vote proper on LDS-staged src (S3) / tgt (T3) xyz triples; returns this thread's number of selected entries.
+ * Every unordered pair of a region is evaluated ONCE, like the reference's i < j loop (:228-252): entry i of a region of m
+ * takes the partners at circular offsets 1 .. (m - 1) / 2 (and, for even m, the lower half takes offset m / 2), which
+ * gives every lane the same trip count; an incompatible pair bumps the entry's own register count and the partner's
+ * count in LDS (cntL, n_p ints, zeroed here).  Counts are integers, so the summation order does not matter. */
 __device__ __forceinline__ int ll_vote_core(const float *S3, const float *T3, int n_p, int number_of_region, int enable,
-                                            int *vc, uint8_t *vs, float *vw)
+                                            int *vc, uint8_t *vs, float *vw, int *cntL)
 {
     const int chunk = n_p / number_of_region;                     /* cor_size_all / number_of_region (:202) */
+    for (int i = threadIdx.x; i < n_p; i += LL_BLOCK) cntL[i] = 0;
+    __syncthreads();
+    if (enable) {
+        for (int i = threadIdx.x; i < n_p; i += LL_BLOCK) {
+            const int rg = (chunk > 0) ? min(i / chunk, number_of_region - 1) : number_of_region - 1;
+            const int b0 = chunk * rg, b1 = (rg == number_of_region - 1) ? n_p : chunk * (rg + 1);
+            const int m = b1 - b0;
+            const float ax = S3[3 * i], ay = S3[3 * i + 1], az = S3[3 * i + 2];
+            const float bx = T3[3 * i], by = T3[3 * i + 1], bz = T3[3 * i + 2];
+            const int half = (m - 1) / 2;
+            const int nd = half + (((m & 1) == 0 && (i - b0) < m / 2) ? 1 : 0);        /* even m: offset m / 2 once per pair */
+            int cnt = 0;
+            int j = i;
+            for (int d = 1; d <= nd; ++d) {
+                ++j; if (j >= b1) j -= m;
+                /* Distance() (:153-162): f32 sqrt of dx*dx + dy*dy + dz*dz; the squares make the operand order irrelevant
+                 * bit-for-bit, so (i, j) and (j, i) are the same test */
+                float dx = ax - S3[3 * j], dy = ay - S3[3 * j + 1], dz = az - S3[3 * j + 2];
+                const float s1 = sqrtf(dx * dx + dy * dy + dz * dz);
+                dx = bx - T3[3 * j]; dy = by - T3[3 * j + 1]; dz = bz - T3[3 * j + 2];
+                const float s2 = sqrtf(dx * dx + dy * dy + dz * dz);
+                const float gap = fabsf(s1 - s2);
+                if (ll_vote_incompatible(gap * gap)) { ++cnt; atomicAdd(&cntL[j], 1); }
+            }
+            if (cnt) atomicAdd(&cntL[i], cnt);
+        }
+    }
+    __syncthreads();
     int my_sel = 0;
     for (int i = threadIdx.x; i < n_p; i += LL_BLOCK) {
         int cnt = 0, sel = 1; float w = 1.0f;
         if (enable) {
             const int rg = (chunk > 0) ? min(i / chunk, number_of_region - 1) : number_of_region - 1;
             const int b0 = chunk * rg, b1 = (rg == number_of_region - 1) ? n_p : chunk * (rg + 1);
-            const float ax = S3[3 * i], ay = S3[3 * i + 1], az = S3[3 * i + 2];
-            const float bx = T3[3 * i], by = T3[3 * i + 1], bz = T3[3 * i + 2];
-            for (int j = b0; j < b1; ++j) {
-                if (j == i) continue;
-                /* Distance() (:153-162): f32 sqrt of dx*dx + dy*dy + dz*dz; the reference evaluates (i, j) with i < j
-                 * only -- the squares make the operand order irrelevant bit-for-bit */
-                float dx = ax - S3[3 * j], dy = ay - S3[3 * j + 1], dz = az - S3[3 * j + 2];
-                const float s1 = sqrtf(dx * dx + dy * dy + dz * dz);
-                dx = bx - T3[3 * j]; dy = by - T3[3 * j + 1]; dz = bz - T3[3 * j + 2];
-                const float s2 = sqrtf(dx * dx + dy * dy + dz * dz);
-                const float gap = fabsf(s1 - s2);
-                cnt += ll_vote_incompatible(gap * gap) ? 1 : 0;
-            }
+            cnt = cntL[i];
             const float num_selected = 0.90f * (float)(b1 - b0);                 /* :299-300 */
             sel = !((float)cnt > num_selected);                                   /* :312 */
             w = ((float)cnt <= 50.0f) ? 5.0f : 1.0f;                              /* :317-322 */
@@ -101,7 +121,8 @@ __global__ __launch_bounds__(LL_BLOCK) void k_vote(LLView V, int first, int coun
     }
     __syncthreads();
     const int my_sel = ll_vote_core(S3, T3, n_p, 10 /* plane case (:186-187) */, enable,
-                                    V.v_count + (size_t)s * V.cap_flat, V.v_sel + (size_t)s * V.cap_flat, V.v_w + (size_t)s * V.cap_flat);
+                                    V.v_count + (size_t)s * V.cap_flat, V.v_sel + (size_t)s * V.cap_flat, V.v_w + (size_t)s * V.cap_flat,
+                                    (int *)(T3 + 3 * (size_t)V.cap_flat));
     if (my_sel) atomicAdd(&nsel_sh, my_sel);
     __syncthreads();
     if (tid == 0) {
@@ -121,12 +142,12 @@ __global__ __launch_bounds__(LL_BLOCK) void k_vote_points(const float4 *src, con
         T3[3 * i] = b.x; T3[3 * i + 1] = b.y; T3[3 * i + 2] = b.z;
     }
     __syncthreads();
-    (void)ll_vote_core(S3, T3, n, regions, 1, vc, vs, vw);
+    (void)ll_vote_core(S3, T3, n, regions, 1, vc, vs, vw, (int *)(T3 + 3 * (size_t)n));
 }
 
 void ll_launch_vote(const LLView &V, int first, int count, int enable, hipStream_t st, LLProfiler *prof)
 {
-    const size_t lds = (size_t)V.cap_flat * 24;
+    const size_t lds = (size_t)V.cap_flat * 28;                   /* src + tgt triples + one count per correspondence */
     static size_t attr_bytes = 0;
     if (lds > attr_bytes) { (void)hipFuncSetAttribute((const void *)k_vote, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_bytes = lds; }
     ll_prof_mark(prof, LL_K_VOTE, st);
@@ -136,7 +157,7 @@ void ll_launch_vote(const LLView &V, int first, int count, int enable, hipStream
 
 void ll_launch_vote_points(const float4 *src, const float4 *tgt, int n, int regions, int *vc, uint8_t *vs, float *vw, hipStream_t st)
 {
-    const size_t lds = (size_t)n * 24 + 16;
+    const size_t lds = (size_t)n * 28 + 16;
     static size_t attr_bytes = 0;
     if (lds > attr_bytes) { (void)hipFuncSetAttribute((const void *)k_vote_points, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_bytes = lds; }
     hipLaunchKernelGGL(k_vote_points, dim3(1), dim3(LL_BLOCK), lds, st, src, tgt, n, regions, vc, vs, vw);
