@@ -31,8 +31,8 @@ struct CmOp { int kind, src, cnt, dst, tag; };   /* kind 0: pool[src + i]; kind 
  * minus the running centre, which the shifts preserve) so that ownership never changes when the array shifts */
 __host__ __device__ __forceinline__ int cm_owner(int wi, int wj, int wk, int world)
 {
-    const int h = (wi + 1024) + 3 * (wj + 1024) + 5 * (wk + 1024);
-    return h % world;
+    const int h = (wi + 3 * wj + 5 * wk) % world;            /* any distance from the origin: the remainder is folded to 0 .. world - 1 */
+    return h < 0 ? h + world : h;
 }
 #define CM_GID_SHIFT 20                  /* global id = position in the valid list << 20 | position in the cube */
 
