@@ -506,11 +506,8 @@ __global__ __launch_bounds__(LL_BLOCK, 8) void k_associate(LLView V, int first, 
 
 void ll_launch_build_grid(const LLView &V, int first, int count, int carry, hipStream_t st, LLProfiler *prof)
 {
-    static bool attr_set = false;
-    if (!attr_set) {   /* 68 KiB histogram + static LDS exceeds the default dynamic-LDS limit */
-        (void)hipFuncSetAttribute((const void *)k_build_grid, hipFuncAttributeMaxDynamicSharedMemorySize, (LL_GRID_NC + LL_GRID_NC / 16) * sizeof(int));
-        attr_set = true;
-    }
+    static size_t attr_bytes[LL_MAX_DEVICES] = {0};   /* 68 KiB histogram + static LDS exceeds the default dynamic-LDS limit */
+    ll_ensure_dynamic_lds(k_build_grid, (LL_GRID_NC + LL_GRID_NC / 16) * sizeof(int), attr_bytes);
     ll_prof_mark(prof, LL_K_GRID, st);
     hipLaunchKernelGGL(k_build_grid, dim3(2 * (carry ? 1 : count)), dim3(LL_GB), (LL_GRID_NC + LL_GRID_NC / 16) * sizeof(int), st, V, first, carry ? 1 : count, carry);
     ll_prof_mark(prof, LL_K_END, st);

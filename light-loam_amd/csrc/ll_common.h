@@ -217,6 +217,17 @@ void ll_vox_work_carve(void *base, int cap, int max_seg, LLVoxWork *W);
 void ll_voxel_grid_segments(const float4 *pts, int n, int nseg, float leaf, const LLVoxWork &W, float4 *out, int *n_out_dev, hipStream_t st);
 void ll_device_exscan(int *data, int n, int *tile_sum, hipStream_t st);
 
+/* raise a kernel's dynamic-LDS limit once per (kernel, device): the cache is per device, so contexts on several GPUs of
+ * one process each get the attribute (a race between host threads only repeats the call) */
+#define LL_MAX_DEVICES 64
+template <typename K>
+static inline void ll_ensure_dynamic_lds(K kernel, size_t bytes, size_t (&cache)[LL_MAX_DEVICES])
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= LL_MAX_DEVICES) dev = 0;
+    if (bytes > cache[dev]) { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); cache[dev] = bytes; }
+}
+
 struct LLProfiler;
 void ll_prof_mark(LLProfiler *p, int kernel_id, hipStream_t st);
 

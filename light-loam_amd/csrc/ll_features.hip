@@ -662,11 +662,8 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features
 template <int ROWS>
 static void ll_launch_ring_features(const LLView &V, int first, int count, int grid, size_t lds_bytes, hipStream_t st)
 {
-    static size_t attr_bytes = 0;
-    if (lds_bytes > attr_bytes) {
-        (void)hipFuncSetAttribute((const void *)k_ring_features<ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        attr_bytes = lds_bytes;
-    }
+    static size_t attr_bytes[LL_MAX_DEVICES] = {0};
+    ll_ensure_dynamic_lds(k_ring_features<ROWS>, lds_bytes, attr_bytes);
     hipLaunchKernelGGL(k_ring_features<ROWS>, dim3(grid), dim3(LL_BLOCK), lds_bytes, st, V, first, count);
 }
 

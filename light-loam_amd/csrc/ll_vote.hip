@@ -148,8 +148,8 @@ __global__ __launch_bounds__(LL_BLOCK) void k_vote_points(const float4 *src, con
 void ll_launch_vote(const LLView &V, int first, int count, int enable, hipStream_t st, LLProfiler *prof)
 {
     const size_t lds = (size_t)V.cap_flat * 28;                   /* src + tgt triples + one count per correspondence */
-    static size_t attr_bytes = 0;
-    if (lds > attr_bytes) { (void)hipFuncSetAttribute((const void *)k_vote, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_bytes = lds; }
+    static size_t attr_bytes[LL_MAX_DEVICES] = {0};
+    ll_ensure_dynamic_lds(k_vote, lds, attr_bytes);
     ll_prof_mark(prof, LL_K_VOTE, st);
     hipLaunchKernelGGL(k_vote, dim3(count), dim3(LL_BLOCK), lds, st, V, first, count, enable);
     ll_prof_mark(prof, LL_K_END, st);
@@ -158,7 +158,7 @@ void ll_launch_vote(const LLView &V, int first, int count, int enable, hipStream
 void ll_launch_vote_points(const float4 *src, const float4 *tgt, int n, int regions, int *vc, uint8_t *vs, float *vw, hipStream_t st)
 {
     const size_t lds = (size_t)n * 28 + 16;
-    static size_t attr_bytes = 0;
-    if (lds > attr_bytes) { (void)hipFuncSetAttribute((const void *)k_vote_points, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_bytes = lds; }
+    static size_t attr_bytes[LL_MAX_DEVICES] = {0};
+    ll_ensure_dynamic_lds(k_vote_points, lds, attr_bytes);
     hipLaunchKernelGGL(k_vote_points, dim3(1), dim3(LL_BLOCK), lds, st, src, tgt, n, regions, vc, vs, vw);
 }

@@ -249,8 +249,8 @@ void ll_sort_pairs(unsigned long long *keys, int *vals, unsigned long long *tmp_
     if (n <= 1) return;
     if (n <= LL_RSS_MAX) {
         const size_t lds = (size_t)LL_RSS_MAX * 12 + 16 * LL_RSS_ROWS * 16 * sizeof(int);
-        static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_rs_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+        static size_t attr_bytes[LL_MAX_DEVICES] = {0};
+        ll_ensure_dynamic_lds(k_rs_small, lds, attr_bytes);
         hipLaunchKernelGGL(k_rs_small, dim3(1), dim3(1024), lds, st, keys, vals, n);
         return;
     }
