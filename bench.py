@@ -124,7 +124,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4096, help="scans resident per GPU and processed per step")
+    ap.add_argument("--batch", type=int, default=8192, help="scans resident per GPU and processed per step (8192 S64 scans: 100 GB of the 288)")
     ap.add_argument("--chunk", type=int, default=0, help="scans per launch sequence inside a step (0 = whole batch)")
     ap.add_argument("--rings", type=int, default=64)
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic poses the batch cycles through")
