@@ -873,7 +873,8 @@ static int lm_step(const double H[36], const double g[6], const double scale[6],
     }
     for (int i = 0; i < 6; ++i) {
         double d = A[i * 6 + i];                         /* diag(J^T J) of the SCALED Jacobian */
-        if (d < min_diag) d = min_diag; if (d > max_diag) d = max_diag;
+        if (d < min_diag) d = min_diag;
+        if (d > max_diag) d = max_diag;
         A[i * 6 + i] += d / radius;                      /* lm_diagonal^2 = clamp(diag) / radius */
     }
     return orc_gn_solve(A, b, step_scaled);
