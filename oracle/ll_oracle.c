@@ -368,7 +368,8 @@ static void grid_cell_of(const nn_grid *g, const orc_point *p, int c[3])
     const float v[3] = {p->x, p->y, p->z};
     for (int k = 0; k < 3; ++k) {
         int i = (int)floorf((v[k] - g->mn[k]) / g->cell);
-        if (i < 0) i = 0; if (i >= g->dim[k]) i = g->dim[k] - 1;
+        if (i < 0) i = 0;
+        if (i >= g->dim[k]) i = g->dim[k] - 1;
         c[k] = i;
     }
 }
