@@ -341,3 +341,52 @@ def test_random_irregular_scans_stress(api, orc):
         checked += 1
     assert checked > 80
     ctx.close()
+
+
+def test_two_contexts_on_two_host_threads(api, synth):
+    """One ll_ctx per host thread is the contract (the reference nodes are single-threaded spinners); two contexts driven
+    concurrently from two threads must not disturb each other: same features, correspondences counts and poses as the same
+    work run alone.  (The look-back launch tag and the scratch buffers are per context; ctypes releases the GIL in calls.)"""
+    import threading
+    cfg = synth.default_cfg(16)
+    n = 24
+    scans = [synth.scan(cfg, k % 6) for k in range(n)]
+    P = lambda: api.default_params(16, batch=n, max_points=max(map(len, scans)))
+
+    def work(ctx, rounds, out):
+        try:
+            for _ in range(rounds):
+                ctx.set_target_from_slot(0)
+                ctx.hot_path(1, n - 1, None, vote=True)
+            ctx.synchronize()
+            out.append(([ctx.features(k) for k in (1, n // 2, n - 1)], [ctx.pose(k).copy() for k in range(1, n)]))
+        except Exception as e:  # pragma: no cover
+            out.append(e)
+
+    def fresh():
+        ctx = api.Context(P())
+        for k, s in enumerate(scans):
+            ctx.upload_scan(k, s)
+        ctx.extract(0, 1)
+        return ctx
+
+    alone = []
+    c0 = fresh(); work(c0, 1, alone); c0.close()
+    assert not isinstance(alone[0], Exception), alone[0]
+    ctxs = [fresh(), fresh()]
+    outs = [[], []]
+    th = [threading.Thread(target=work, args=(ctxs[i], 6, outs[i])) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for o in outs:
+        assert o and not isinstance(o[0], Exception), o
+        feats, poses = o[0]
+        for fa, fb in zip(feats, alone[0][0]):
+            for key in ("sharp", "less_sharp", "flat", "less_flat"):
+                assert_bit_equal(fa[key], fb[key], key)
+        for pa, pb in zip(poses, alone[0][1]):
+            assert (pa == pb).all()
+    for c in ctxs:
+        c.close()
