@@ -47,16 +47,22 @@ __device__ __forceinline__ bool ll_xcd_map2(int id, int per_scan, int count, int
 struct FeatLds {
     unsigned *k32;             /* [mr] phases 1-3: curvature bits per slot; phase 4: sort key (voxel index) */
     unsigned short *k16;       /* [mr] phases 2-3: suppression extents per slot; phase 4: sort payload (local index) */
-    float *tx, *ty, *tz;       /* [LL_FTILE + 16] phase 1; afterwards the region is the pick's per-wave scratch */
+    float *tx, *ty, *tz;       /* [LL_FTILE + 16] phase 1; afterwards the region is the pick's per-wave scratch, then the radix counters */
     unsigned *picked, *gapf;   /* bitmaps over local index */
     int8_t *lab;               /* [mr] */
     int *lists;                /* [LL_NLIST] */
-    int *cnt;                  /* [16 * ROWS * 4 + 1] radix counters */
+    int *cnt;                  /* [32 * ROWS * 4 + 1] radix counters (= the tile region) */
     int *sc;                   /* [64] scan scratch [0..15], per-wave bounds [32..55], finished-segment mask [60] */
 };
 
 /* the curvature tile; afterwards four per-wave scratch rows of 64 * SR u16 (SR = ceil(ROWS * 256 / 384)) for the pick */
-static size_t ll_feat_tile_bytes(size_t rows) { const size_t t = 3 * 4 * (size_t)(LL_FTILE + 16), w = 4 * 64 * ((rows * 256 + 383) / 384) * 2; return t > w ? t : w; }
+static size_t ll_feat_tile_bytes(size_t rows)
+{
+    const size_t t = 3 * 4 * (size_t)(LL_FTILE + 16), w = 4 * 64 * ((rows * 256 + 383) / 384) * 2;
+    const size_t c = 4 * (32 * rows * 4 + 4);                   /* phase 4: the radix counters (5-bit digits) live here too */
+    const size_t m = t > w ? t : w;
+    return m > c ? m : c;
+}
 
 size_t ll_features_lds_bytes(int max_ring)
 {
@@ -67,7 +73,6 @@ size_t ll_features_lds_bytes(int max_ring)
     b += 2 * 4 * (mr / 32 + 2);              /* bitmaps */
     b += mr;                                 /* labels */
     b += 4 * LL_NLIST;
-    b += 4 * (16 * rows * 4 + 4);            /* radix counters */
     b += 4 * 64;
     return (b + 15) / 16 * 16 + 64;
 }
@@ -76,8 +81,8 @@ __device__ __forceinline__ FeatLds ll_carve(unsigned char *base, int max_ring)
 {
     const size_t mr = (size_t)((max_ring + 255) / 256 * 256);
     const size_t rows = (mr / 256 <= 9) ? 9 : (mr / 256 <= 18) ? 18 : 36;     /* the ROWS instantiation that will run */
-    const size_t tile = 3 * 4 * (size_t)(LL_FTILE + 16), wscr = 4 * 64 * ((rows * 256 + 383) / 384) * 2;
-    const size_t tile_bytes = tile > wscr ? tile : wscr;
+    const size_t tile = 3 * 4 * (size_t)(LL_FTILE + 16), wscr = 4 * 64 * ((rows * 256 + 383) / 384) * 2, cbytes = 4 * (32 * rows * 4 + 4);
+    const size_t tile_bytes = (tile > wscr ? tile : wscr) > cbytes ? (tile > wscr ? tile : wscr) : cbytes;
     FeatLds L;
     unsigned char *p = base;
     L.k32 = (unsigned *)p; p += 4 * mr;
@@ -86,7 +91,7 @@ __device__ __forceinline__ FeatLds ll_carve(unsigned char *base, int max_ring)
     L.picked = (unsigned *)p; p += 4 * (mr / 32 + 2);
     L.gapf = (unsigned *)p; p += 4 * (mr / 32 + 2);
     L.lists = (int *)p; p += 4 * LL_NLIST;
-    L.cnt = (int *)p; p += 4 * (16 * rows * 4 + 4);
+    L.cnt = (int *)L.tx;                      /* radix counters of phase 4 share the tile region */
     L.sc = (int *)p; p += 4 * 64;
     L.k16 = (unsigned short *)p; p += 2 * mr;
     L.lab = (int8_t *)p;
@@ -105,8 +110,7 @@ template <int ROWS>
 __device__ __forceinline__ void ll_radix_sort(unsigned *k32, unsigned short *k16, int n, int *cnt, int *sc, int tid)
 {
     constexpr int SLOTS = ROWS * (LL_BLOCK / 64);               /* (row, wave) pairs */
-    constexpr int NCNT = 16 * SLOTS;
-    constexpr int PER = (NCNT + LL_BLOCK - 1) / LL_BLOCK;       /* counters per thread in the scan */
+    constexpr int NCNT_MAX = 32 * SLOTS;                        /* cnt: NCNT_MAX + 1 ints */
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      /* uniform: scalar registers / branches */
     const int nrows = (n + LL_BLOCK - 1) / LL_BLOCK;            /* uniform */
     unsigned e32[ROWS]; unsigned short e16[ROWS];
@@ -119,13 +123,25 @@ __device__ __forceinline__ void ll_radix_sort(unsigned *k32, unsigned short *k16
         if (k < nrows && g < n) { e32[k] = k32[g]; e16[k] = k16[g]; vary |= e32[k] ^ hi0; }
     }
     for (int o = 32; o > 0; o >>= 1) vary |= __shfl_xor(vary, o);
-    if (tid == 0) cnt[NCNT] = 0;
+    if (tid == 0) cnt[NCNT_MAX] = 0;
     __syncthreads();
-    if (lane == 0 && vary) atomicOr((unsigned *)&cnt[NCNT], vary);
+    if (lane == 0 && vary) atomicOr((unsigned *)&cnt[NCNT_MAX], vary);
     __syncthreads();
-    vary = (unsigned)cnt[NCNT];
-    for (int sh = 0; sh < 32; sh += 4) {
-        if (((vary >> sh) & 15u) == 0u) continue;
+    vary = (unsigned)cnt[NCNT_MAX];
+    __syncthreads();                                            /* cnt[] is zeroed next */
+    if (vary == 0u) return;                                     /* one voxel (or none): already in order */
+    /* The keys differ only in bits [lo, hi): ceil((hi - lo) / 5) passes, the first n5 of them over 5-bit digits and the
+     * rest over 4-bit digits, so that 21 .. 25 varying bits take five passes instead of six.  A digit whose bits do not
+     * vary is skipped. */
+    const int lo = __ffs((int)vary) - 1, hi = 32 - __clz((int)vary);
+    const int w = hi - lo, npass = (w + 4) / 5;
+    const int n5 = max(0, w - 4 * npass);
+    auto pass = [&](auto bits_tag, int sh) __attribute__((always_inline)) {
+        constexpr int BITS = decltype(bits_tag)::value;
+        constexpr int NCNT = (1 << BITS) * SLOTS;
+        constexpr int PER = (NCNT + LL_BLOCK - 1) / LL_BLOCK;   /* counters per thread in the scan */
+        constexpr unsigned DM = (1u << BITS) - 1u;
+        if (((vary >> sh) & DM) == 0u) return;
         for (int i = tid; i < NCNT; i += LL_BLOCK) cnt[i] = 0;
         __syncthreads();
         int rnk[ROWS];
@@ -133,9 +149,9 @@ __device__ __forceinline__ void ll_radix_sort(unsigned *k32, unsigned short *k16
         for (int k = 0; k < ROWS; ++k) {
             rnk[k] = 0;
             if (k < nrows) {
-                const int d = (int)((e32[k] >> sh) & 15u);
+                const int d = (int)((e32[k] >> sh) & DM);
                 unsigned mlo, mhi;
-                ll_match_any(d, 4, ~0ull, mlo, mhi);
+                ll_match_any(d, BITS, ~0ull, mlo, mhi);
                 rnk[k] = ll_match_rank(mlo, mhi);
                 if (rnk[k] == 0) cnt[d * SLOTS + k * (LL_BLOCK / 64) + wave] = ll_match_count(mlo, mhi);
             }
@@ -155,7 +171,7 @@ __device__ __forceinline__ void ll_radix_sort(unsigned *k32, unsigned short *k16
 #pragma unroll
         for (int k = 0; k < ROWS; ++k) {
             if (k < nrows) {
-                const int d = (int)((e32[k] >> sh) & 15u);
+                const int d = (int)((e32[k] >> sh) & DM);
                 const int pos = cnt[d * SLOTS + k * (LL_BLOCK / 64) + wave] + rnk[k];
                 k32[pos] = e32[k]; k16[pos] = e16[k];
             }
@@ -165,6 +181,11 @@ __device__ __forceinline__ void ll_radix_sort(unsigned *k32, unsigned short *k16
         for (int k = 0; k < ROWS; ++k) {
             if (k < nrows) { const int g = k * LL_BLOCK + tid; e32[k] = k32[g]; e16[k] = k16[g]; }
         }
+    };
+    int sh = lo;
+    for (int p = 0; p < npass; ++p) {
+        if (p < n5) { pass(std::integral_constant<int, 5>{}, sh); sh += 5; }
+        else { pass(std::integral_constant<int, 4>{}, sh); sh += 4; }
     }
 }
 
