@@ -99,93 +99,98 @@ __device__ __forceinline__ FeatLds ll_carve(unsigned char *base, int max_ring)
 }
 
 /* Stable least-significant-digit radix sort of the records (k32[g], k16[g]), g < n <= 256*ROWS, by k32; one workgroup.
- * 4-bit digits.  Record g lives in row g / 256 of thread g % 256 (registers); its destination is
- *   #(records with a smaller digit) + #(same digit, earlier (row, wave)) + rank inside its wave,
- * the first two from one workgroup exclusive scan over the digit-major table cnt[digit][row*4 + wave], the last from a
- * wave match-any.  Digits that are equal for every key are skipped (their pass would be the identity).  The last row
- * is padded with all-ones keys that take part like records (they stay at the end, no per-record guards); rows beyond
- * it are skipped.  Keys must be < 0xffffffff.  Stability makes the result ordered by (k32, original position):
- * exactly the (voxel, input order) order the oracle defines. */
+ * Record g lives in wave g / (64 * nrows), row (g / 64) % nrows, lane g % 64 (nrows = rows per wave), so that the order
+ * (wave, row, lane) is the input order.  Its destination is
+ *   #(records with a smaller digit) + #(same digit, earlier wave) + #(same digit, same wave, earlier row) + rank in its row:
+ * every wave counts into its own 2^BITS counters, one row after the other (a wave's LDS operations execute in order, so
+ * the counter a row reads already holds the rows before it), the rank inside the row comes from a wave match-any, and one
+ * workgroup exclusive scan over the digit-major (digit, wave) table turns the counters into bases.  Wave-private counters
+ * make the table small enough for digits of up to 8 bits: the keys differ only in bits [lo, hi), which takes
+ * ceil((hi - lo) / 8) passes of 5..8-bit digits (three for the usual 17..24 varying bits of a ring's voxel indices).
+ * The last row is padded with all-ones keys that take part like records (they stay at the end, no per-record guards);
+ * rows beyond it are skipped.  Keys must be < 0xffffffff.  Stability makes the result ordered by (k32, original
+ * position): exactly the (voxel, input order) order the oracle defines. */
 template <int ROWS>
 __device__ __forceinline__ void ll_radix_sort(unsigned *k32, unsigned short *k16, int n, int *cnt, int *sc, int tid)
 {
-    constexpr int SLOTS = ROWS * (LL_BLOCK / 64);               /* (row, wave) pairs */
-    constexpr int NCNT_MAX = 32 * SLOTS;                        /* cnt: NCNT_MAX + 1 ints */
+    constexpr int NW = LL_BLOCK / 64;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      /* uniform: scalar registers / branches */
-    const int nrows = (n + LL_BLOCK - 1) / LL_BLOCK;            /* uniform */
+    const int nrows = (n + LL_BLOCK - 1) / LL_BLOCK;            /* rows per wave, uniform */
+    const int wbase = wave * nrows * 64;                        /* the wave's first record */
+    const int myrows = max(0, min(nrows, (n - wbase + 63) >> 6));   /* rows of this wave that hold a record */
     unsigned e32[ROWS]; unsigned short e16[ROWS];
     unsigned vary = 0;
     const unsigned hi0 = (n > 0) ? k32[0] : 0u;
 #pragma unroll
     for (int k = 0; k < ROWS; ++k) {
-        const int g = k * LL_BLOCK + tid;
+        const int g = wbase + k * 64 + lane;
         e32[k] = 0xffffffffu; e16[k] = 0;
-        if (k < nrows && g < n) { e32[k] = k32[g]; e16[k] = k16[g]; vary |= e32[k] ^ hi0; }
+        if (k < myrows && g < n) { e32[k] = k32[g]; e16[k] = k16[g]; vary |= e32[k] ^ hi0; }
     }
     for (int o = 32; o > 0; o >>= 1) vary |= __shfl_xor(vary, o);
-    if (tid == 0) cnt[NCNT_MAX] = 0;
+    if (tid == 0) sc[16] = 0;
     __syncthreads();
-    if (lane == 0 && vary) atomicOr((unsigned *)&cnt[NCNT_MAX], vary);
+    if (lane == 0 && vary) atomicOr((unsigned *)&sc[16], vary);
     __syncthreads();
-    vary = (unsigned)cnt[NCNT_MAX];
-    __syncthreads();                                            /* cnt[] is zeroed next */
+    vary = (unsigned)sc[16];
     if (vary == 0u) return;                                     /* one voxel (or none): already in order */
-    /* The keys differ only in bits [lo, hi): ceil((hi - lo) / 5) passes, the first n5 of them over 5-bit digits and the
-     * rest over 4-bit digits, so that 21 .. 25 varying bits take five passes instead of six.  A digit whose bits do not
-     * vary is skipped. */
     const int lo = __ffs((int)vary) - 1, hi = 32 - __clz((int)vary);
-    const int w = hi - lo, npass = (w + 4) / 5;
-    const int n5 = max(0, w - 4 * npass);
     auto pass = [&](auto bits_tag, int sh) __attribute__((always_inline)) {
         constexpr int BITS = decltype(bits_tag)::value;
-        constexpr int NCNT = (1 << BITS) * SLOTS;
-        constexpr int PER = (NCNT + LL_BLOCK - 1) / LL_BLOCK;   /* counters per thread in the scan */
-        constexpr unsigned DM = (1u << BITS) - 1u;
-        if (((vary >> sh) & DM) == 0u) return;
-        for (int i = tid; i < NCNT; i += LL_BLOCK) cnt[i] = 0;
-        __syncthreads();
+        constexpr int ND = 1 << BITS;
+        constexpr unsigned DM = (unsigned)ND - 1u;
+        for (int i = tid; i < NW * ND; i += LL_BLOCK) cnt[i] = 0;
+        __syncthreads();                                        /* also: every thread holds its records in registers */
+        int *wc = cnt + wave * ND;                              /* this wave's counters */
         int rnk[ROWS];
 #pragma unroll
         for (int k = 0; k < ROWS; ++k) {
             rnk[k] = 0;
-            if (k < nrows) {
+            if (k < myrows) {
                 const int d = (int)((e32[k] >> sh) & DM);
                 unsigned mlo, mhi;
                 ll_match_any(d, BITS, ~0ull, mlo, mhi);
-                rnk[k] = ll_match_rank(mlo, mhi);
-                if (rnk[k] == 0) cnt[d * SLOTS + k * (LL_BLOCK / 64) + wave] = ll_match_count(mlo, mhi);
+                const int r = ll_match_rank(mlo, mhi);
+                const int pre = wc[d];                          /* records of the earlier rows of this wave with digit d */
+                rnk[k] = pre + r;
+                if (r == 0) wc[d] = pre + ll_match_count(mlo, mhi);
             }
         }
         __syncthreads();
-        {   /* exclusive scan of the digit-major table: PER consecutive counters per thread */
-            const int i0 = tid * PER;
-            int v[PER]; int s = 0;
+        {   /* exclusive scan of the (digit, wave) table in digit-major order: thread d owns digit d */
+            int v[NW]; int s = 0;
 #pragma unroll
-            for (int u = 0; u < PER; ++u) { v[u] = (i0 + u < NCNT) ? cnt[i0 + u] : 0; s += v[u]; }
+            for (int w = 0; w < NW; ++w) { v[w] = (tid < ND) ? cnt[w * ND + tid] : 0; s += v[w]; }
             int total;
             int run = ll_block_exscan(s, sc, total);
+            if (tid < ND) {
 #pragma unroll
-            for (int u = 0; u < PER; ++u) { if (i0 + u < NCNT) cnt[i0 + u] = run; run += v[u]; }
+                for (int w = 0; w < NW; ++w) { cnt[w * ND + tid] = run; run += v[w]; }
+            }
         }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < ROWS; ++k) {
-            if (k < nrows) {
+            if (k < myrows) {
                 const int d = (int)((e32[k] >> sh) & DM);
-                const int pos = cnt[d * SLOTS + k * (LL_BLOCK / 64) + wave] + rnk[k];
+                const int pos = wc[d] + rnk[k];
                 k32[pos] = e32[k]; k16[pos] = e16[k];
             }
         }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < ROWS; ++k) {
-            if (k < nrows) { const int g = k * LL_BLOCK + tid; e32[k] = k32[g]; e16[k] = k16[g]; }
+            if (k < myrows) { const int g = wbase + k * 64 + lane; e32[k] = k32[g]; e16[k] = k16[g]; }
         }
     };
-    int sh = lo;
-    for (int p = 0; p < npass; ++p) {
-        if (p < n5) { pass(std::integral_constant<int, 5>{}, sh); sh += 5; }
-        else { pass(std::integral_constant<int, 4>{}, sh); sh += 4; }
+    int sh = lo, rem = hi - lo;
+    for (int left = (rem + 7) / 8; left > 0; --left) {
+        const int bits = max(5, (rem + left - 1) / left);       /* spread the varying bits evenly over the passes */
+        if (bits <= 5) pass(std::integral_constant<int, 5>{}, sh);
+        else if (bits == 6) pass(std::integral_constant<int, 6>{}, sh);
+        else if (bits == 7) pass(std::integral_constant<int, 7>{}, sh);
+        else pass(std::integral_constant<int, 8>{}, sh);
+        sh += bits; rem -= bits;
     }
 }
 
