@@ -288,11 +288,12 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features
     if (tid == 0) L.sc[60] = 0;                                       /* segments finished (bit j) */
     __syncthreads();
 
-    /* Decoupled look-back over the rings of the scan (they run on one XCD, dispatched in ring order): publish this
-     * ring's four feature counts, wait for every earlier ring's, return their sums = this ring's offsets in the four
-     * published clouds (ring, segment, pick order; scanRegistration.cpp:273-279, :325, :376).  Called exactly once. */
-    auto publish_and_prefix = [&](int c0, int c1, int c2, int c3, int *outp) __attribute__((always_inline)) {
-        if (tid == 0) ll_pub(c0, c1, c2, c3);
+    /* Decoupled look-back over the rings of the scan (they run on one XCD, dispatched in ring order): publish() this
+     * ring's four feature counts as soon as they are known, go on with everything that does not need the offsets, then
+     * prefix() waits for every earlier ring's counts and returns their sums = this ring's offsets in the four published
+     * clouds (ring, segment, pick order; scanRegistration.cpp:273-279, :325, :376).  Each is called exactly once. */
+    auto publish = [&](int c0, int c1, int c2, int c3) __attribute__((always_inline)) { if (tid == 0) ll_pub(c0, c1, c2, c3); };
+    auto prefix = [&](int *outp) __attribute__((always_inline)) {
         int v[4] = {0, 0, 0, 0};
         for (int q = tid; q < r; q += LL_BLOCK) ll_poll(q, v);
 #pragma unroll
@@ -305,6 +306,25 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features
         __syncthreads();
     };
     int roff[4] = {0, 0, 0, 0}; bool looked_back = false;           /* this ring's offsets in sharp / less-sharp / flat / less-flat */
+    /* the picked points of the per-segment lists, fetched before the look-back wait: thread t holds entry t of each list
+     * and its position (segment, pick order) among the ring's sharp / less-sharp / flat points, -1 = no entry */
+    float4 fpt[3]; int fpos[3] = {-1, -1, -1};
+    auto gather_lists = [&]() __attribute__((always_inline)) {
+        const int js = tid / LL_SHARP_PER_SEG, jl = tid / LL_LSHARP_PER_SEG, jf = tid / LL_FLAT_PER_SEG;
+        int os = 0, ol = 0, of = 0;
+        for (int j = 0; j < LL_SEGS; ++j) {
+            if (j < js) os += L.lists[156 + j * 3];
+            if (j < jl) ol += L.lists[157 + j * 3];
+            if (j < jf) of += L.lists[158 + j * 3];
+        }
+        if (js < LL_SEGS && tid % LL_SHARP_PER_SEG < L.lists[156 + js * 3]) { fpos[0] = os + tid % LL_SHARP_PER_SEG; fpt[0] = cloud[off + L.lists[tid]]; }
+        if (jl < LL_SEGS && tid % LL_LSHARP_PER_SEG < L.lists[157 + jl * 3]) { fpos[1] = ol + tid % LL_LSHARP_PER_SEG; fpt[1] = cloud[off + L.lists[12 + tid]]; }
+        if (jf < LL_SEGS && tid % LL_FLAT_PER_SEG < L.lists[158 + jf * 3]) { fpos[2] = of + tid % LL_FLAT_PER_SEG; fpt[2] = cloud[off + L.lists[132 + tid]]; }
+    };
+    auto write_labels = [&]() __attribute__((always_inline)) {
+        int8_t *label = V.label + (size_t)s * V.NP + off;
+        for (int i = tid; i < nr; i += LL_BLOCK) label[i] = L.lab[i];
+    };
     auto seg_totals = [&](int &ns_, int &nls_, int &nf_) __attribute__((always_inline)) {
         ns_ = 0; nls_ = 0; nf_ = 0;
         for (int j = 0; j < LL_SEGS; ++j) { ns_ += L.lists[156 + j * 3]; nls_ += L.lists[157 + j * 3]; nf_ += L.lists[158 + j * 3]; }
@@ -436,6 +456,13 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features
                 unsigned myrec = 0;                                       /* lane n: pick n+1 as li | extents << 16 */
                 /* non-negative float bits order like the floats; the flats maximise the complement */
                 unsigned mk[SR];
+                if (pass == 1) {
+                    /* what the corner picks of this segment marked (exported to the bitmap below, together with any
+                     * forward marks of earlier segments that are already there -- those are the reference's too) */
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+                    for (int k = 0; k < SR; ++k) if (k * 64 + lane < len && ll_bit(L.picked, li0 + k * 64)) sup |= 1u << k;
+                }
 #pragma unroll
                 for (int k = 0; k < SR; ++k) mk[k] = (pass == 1 && ((candf & ~sup) >> k) & 1u) ? ~cb[k] : 0u;
                 /* one pick loop, instantiated for the row count it scans (NR rows of `key`): the corner pass over the
@@ -492,14 +519,13 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features
                         if (lane == npick - 1) myrec = (unsigned)sel | ((unsigned)e << 16);
                         if (!CORNER && npick >= LL_FLAT_PER_SEG) break;   /* :328-331: labelled, but no marking */
                         const int slo = sel - (e & 15), shi = sel + (e >> 4);
-                        /* rows are 64 apart and a pick marks at most 11 consecutive indices: per lane at most one row is hit */
-                        const int dd = shi - li0;
-                        const int kl = (dd >= 0 && (dd & 63) <= shi - slo) ? (dd >> 6) : -1;
-                        if (kl >= 0) sup |= 1u << kl;
-                        if (CORNER) {
+                        if (CORNER) {                                     /* the marks themselves go to the bitmap after the pass */
 #pragma unroll
                             for (int r = 0; r < NR; ++r) key[r] = ((unsigned)(cli[r] - slo) <= (unsigned)(shi - slo)) ? 0u : key[r];
                         } else {
+                            /* rows are 64 apart and a pick marks at most 11 consecutive indices: per lane at most one row is hit */
+                            const int dd = shi - li0;
+                            const int kl = (dd >= 0 && (dd & 63) <= shi - slo) ? (dd >> 6) : -1;
 #pragma unroll
                             for (int k = 0; k < NR; ++k) key[k] = (kl == k) ? 0u : key[k];
                         }
@@ -520,7 +546,10 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features
                         else L.lab[sel] = 1;
                         L.lists[12 + j * LL_LSHARP_PER_SEG + lane] = sel;
                     } else { L.lab[sel] = -1; L.lists[132 + j * LL_FLAT_PER_SEG + lane] = sel; }
-                    const int shi = sel + (e >> 4), f0 = max(sel - (e & 15), ep + 6);      /* marks beyond this segment */
+                    /* marks into the bitmap: a corner pick's whole range from this segment's first index on (the flat pass
+                     * reads it back; never below sp + 5 -- an earlier segment may still be running and must not see marks the
+                     * reference makes after it), a flat pick's only beyond this segment */
+                    const int shi = sel + (e >> 4), f0 = max(sel - (e & 15), pass == 0 ? sp + 5 : ep + 6);
                     if ((pass == 0 || lane < LL_FLAT_PER_SEG - 1) && shi >= f0) {
                         const unsigned long long bits = ((1ull << (shi - f0 + 1)) - 1ull) << (f0 & 31);
                         atomicOr(&L.picked[f0 >> 5], (unsigned)bits);
@@ -628,53 +657,72 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features
                     }
             }
             int o = ll_block_exscan(__popc(headm), L.sc, n_lf_out);
-            { int a_, b_, c_; seg_totals(a_, b_, c_); LL_WAIT_BEGIN(); publish_and_prefix(a_, b_, c_, n_lf_out, roff); LL_WAIT_END(); looked_back = true; }
-            float4 *out = V.lflat + (size_t)s * V.NP + roff[3];
-            /* CentroidPoint<PointXYZI>: f32 sums from zero in input order, divided by float(n) */
+            LL_PHASE(12);
+            { int a_, b_, c_; seg_totals(a_, b_, c_); publish(a_, b_, c_, n_lf_out); }   /* the counts go out now, the wait comes last */
+            /* CentroidPoint<PointXYZI>: f32 sums from zero in input order, divided by float(n).  A run that ends inside the
+             * thread's range leaves its centroid in the registers of its last point (bit u of endm); nothing is stored until
+             * the offsets are known */
             float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f; int cn = 0;
+            unsigned endm = 0;
 #pragma unroll
             for (int u = 0; u < ROWS; ++u)
                 if (b0 + u < b1) {
                     if ((headm >> u) & 1u) {
-                        if (cn) { const float fn = (float)cn; out[o++] = make_float4(sx / fn, sy / fn, sz / fn, si / fn); }
+                        if (u > 0 && cn) {
+                            const float fn = (float)cn;
+                            pt[u > 0 ? u - 1 : 0] = make_float4(sx / fn, sy / fn, sz / fn, si / fn); endm |= 1u << (u > 0 ? u - 1 : 0);
+                        }
                         sx = 0.0f; sy = 0.0f; sz = 0.0f; si = 0.0f; cn = 0;
                     } else if (!cn) continue;                                        /* tail of an earlier thread's run */
                     sx += pt[u].x; sy += pt[u].y; sz += pt[u].z; si += pt[u].w; ++cn;
                 }
-            if (cn) {
-                const unsigned vid = L.k32[b1 - 1];
-                for (int e = b1; e < m && L.k32[e] == vid; ++e) {
-                    const float4 q = cloud[off + L.k16[e]];
-                    sx += q.x; sy += q.y; sz += q.z; si += q.w; ++cn;
+            LL_PHASE(13);
+            /* The run that is open at the end of the range goes on with the next thread's points up to that thread's first
+             * head: they sit in the next lane's registers (never overwritten above: a thread's leading points belong to
+             * no run of its own) and come over by a one-lane wave shift.  Whatever lies beyond -- a next thread without a
+             * head, or the next wave -- is fetched from the cloud. */
+            {
+#define LL_SHL1(x) __builtin_amdgcn_update_dpp(0, (int)(x), 0x130, 0xf, 0xf, false)      /* wave_shl:1: lane i <- lane i + 1 */
+                const unsigned hm_n = (unsigned)LL_SHL1(headm);
+                const int cnt_n = LL_SHL1(b1 - b0);
+                const int c_n = (lane == 63) ? 0 : (hm_n ? __ffs((int)hm_n) - 1 : cnt_n);   /* leading non-head points of the next lane */
+#pragma unroll
+                for (int u = 0; u < ROWS; ++u)
+                    if (u < perm) {
+                        const float qx = __int_as_float(LL_SHL1(__float_as_int(pt[u].x))), qy = __int_as_float(LL_SHL1(__float_as_int(pt[u].y)));
+                        const float qz = __int_as_float(LL_SHL1(__float_as_int(pt[u].z))), qw = __int_as_float(LL_SHL1(__float_as_int(pt[u].w)));
+                        if (cn && u < c_n) { sx += qx; sy += qy; sz += qz; si += qw; ++cn; }
+                    }
+#undef LL_SHL1
+                float4 last = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (cn) {
+                    const unsigned vid = L.k32[b1 - 1];
+                    for (int e = b1 + c_n; e < m && L.k32[e] == vid; ++e) {
+                        const float4 q = cloud[off + L.k16[e]];
+                        sx += q.x; sy += q.y; sz += q.z; si += q.w; ++cn;
+                    }
+                    const float fn = (float)cn; last = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
                 }
-                const float fn = (float)cn; out[o++] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
+                LL_PHASE(5);
+                write_labels(); gather_lists();
+                prefix(roff); looked_back = true;
+                LL_PHASE(7);
+                float4 *out = V.lflat + (size_t)s * V.NP + roff[3];
+#pragma unroll
+                for (int u = 0; u < ROWS; ++u) if ((endm >> u) & 1u) out[o++] = pt[u];
+                if (cn) out[o] = last;
             }
         }
     }
 
-    LL_PHASE(5);
     /* ---------------- phase 5: labels + feature slots ---------------- */
-    int8_t *label = V.label + (size_t)s * V.NP + off;
-    for (int i = tid; i < nr; i += LL_BLOCK) label[i] = L.lab[i];
     /* per-segment lists -> the published clouds at this ring's offsets, in (segment, pick order) */
     int ns = 0, nls = 0, nf = 0;
     seg_totals(ns, nls, nf);
-    if (!looked_back) publish_and_prefix(ns, nls, nf, n_lf_out, roff);          /* rings without a less-flat point */
-    {
-        const int js = tid / LL_SHARP_PER_SEG, jl = tid / LL_LSHARP_PER_SEG, jf = tid / LL_FLAT_PER_SEG;
-        int os = 0, ol = 0, of = 0;
-        for (int j = 0; j < LL_SEGS; ++j) {
-            if (j < js) os += L.lists[156 + j * 3];
-            if (j < jl) ol += L.lists[157 + j * 3];
-            if (j < jf) of += L.lists[158 + j * 3];
-        }
-        if (js < LL_SEGS && tid % LL_SHARP_PER_SEG < L.lists[156 + js * 3])
-            V.sharp[(size_t)s * V.cap_sharp + roff[0] + os + tid % LL_SHARP_PER_SEG] = cloud[off + L.lists[tid]];
-        if (jl < LL_SEGS && tid % LL_LSHARP_PER_SEG < L.lists[157 + jl * 3])
-            V.lsharp[(size_t)s * V.cap_lsharp + roff[1] + ol + tid % LL_LSHARP_PER_SEG] = cloud[off + L.lists[12 + tid]];
-        if (jf < LL_SEGS && tid % LL_FLAT_PER_SEG < L.lists[158 + jf * 3])
-            V.flat[(size_t)s * V.cap_flat + roff[2] + of + tid % LL_FLAT_PER_SEG] = cloud[off + L.lists[132 + tid]];
-    }
+    if (!looked_back) { publish(ns, nls, nf, n_lf_out); write_labels(); gather_lists(); prefix(roff); }   /* rings without a less-flat point */
+    if (fpos[0] >= 0) V.sharp[(size_t)s * V.cap_sharp + roff[0] + fpos[0]] = fpt[0];
+    if (fpos[1] >= 0) V.lsharp[(size_t)s * V.cap_lsharp + roff[1] + fpos[1]] = fpt[1];
+    if (fpos[2] >= 0) V.flat[(size_t)s * V.cap_flat + roff[2] + fpos[2]] = fpt[2];
     if (r == V.R - 1 && tid == 0) {                                            /* the scan's totals */
         ScanHdr *hh = &V.hdr[s];
         hh->n_sharp = roff[0] + ns; hh->n_less_sharp = roff[1] + nls; hh->n_flat = roff[2] + nf; hh->n_less_flat = roff[3] + n_lf_out;

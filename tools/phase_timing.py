@@ -25,15 +25,15 @@ buf = (C.c_ulonglong * 16)()
 ctx._ck(ctx.lib.ll_debug_counters(ctx.h, buf, 1))
 ctx.extract(0, B)
 ctx._ck(ctx.lib.ll_debug_counters(ctx.h, buf, 1))
-names = ["p1 curvature+keys", "p2 suppression extents", "p3 per-segment pick", "p4a compact+bounds+voxel keys", "p4b voxel sort",
-         "p4c heads+centroids", "p5 outputs"]
+names = [(0, "p1 curvature+keys"), (1, "p2 suppression extents"), (2, "p3 per-segment pick"), (3, "p4a compact+bounds+voxel keys"),
+         (4, "p4b voxel sort"), (12, "p4c gather + run heads + scan"), (7, "p4d look-back publish + wait"), (13, "p4e centroid sums (own range)"),
+         (5, "p4f runs continued into later threads"), (6, "p5 outputs")]
 n = max(1, buf[15])
-tot = sum(buf[i] for i in range(7))
+tot = sum(buf[i] for i, _ in names)
 print(f"k_ring_features phase timing over {buf[15]} workgroups (s_memtime cycles per workgroup, thread 0 wall):")
-for i, nm in enumerate(names):
-    print(f"  {nm:32s} {buf[i] / n:10.0f}  {100.0 * buf[i] / max(1, tot):5.1f}%")
-print(f"  {'total':32s} {tot / n:10.0f}")
-print(f"  {'(look-back publish + wait, inside p4c)':32s} {buf[7] / n:10.0f}  {100.0 * buf[7] / max(1, tot):5.1f}%")
+for i, nm in names:
+    print(f"  {nm:40s} {buf[i] / n:10.0f}  {100.0 * buf[i] / max(1, tot):5.1f}%")
+print(f"  {'total':40s} {tot / n:10.0f}")
 g = max(1, buf[14])
 print(f"k_build_grid phase timing over {buf[14]} workgroups:")
 for i, nm in ((8, "zero + histogram"), (9, "scan + cell starts"), (10, "scatter to cell order"), (11, "ring tables + validity")):
