@@ -263,19 +263,20 @@ __device__ __forceinline__ float ll_walk_d2(const float4 p, float sx, float sy, 
     return (p.x - sx) * (p.x - sx) + (p.y - sy) * (p.y - sy) + (p.z - sz) * (p.z - sz);
 }
 
-/* e-th cell (0 <= e < 8*ring, or the centre for ring 0) of the Chebyshev ring `ring`: top row, bottom row, then the
- * two side cells of every inner row */
-__device__ __forceinline__ void ll_ring_cell(int ring, int e, int &dx, int &dy)
+/* e-th entry (0 <= e < 4*ring, or the centre cell for ring 0) of the Chebyshev ring `ring`: the top row, the bottom row
+ * (2*ring + 1 cells each, CONTIGUOUS in the cell-ordered point array, so a row is one range), then the two side cells of
+ * every inner row.  Returns the cell range [x0, x1] of row yy. */
+__device__ __forceinline__ void ll_ring_entry(int ring, int e, int cx, int cy, int &x0, int &x1, int &yy)
 {
-    if (ring == 0) { dx = 0; dy = 0; return; }
-    const int w = 2 * ring + 1;
-    if (e < w) { dx = e - ring; dy = -ring; }
-    else if (e < 2 * w) { dx = e - w - ring; dy = ring; }
-    else { const int t = e - 2 * w; dy = -ring + 1 + (t >> 1); dx = (t & 1) ? ring : -ring; }
+    if (ring == 0) { x0 = cx; x1 = cx; yy = cy; return; }
+    if (e < 2) { x0 = cx - ring; x1 = cx + ring; yy = e ? cy + ring : cy - ring; return; }
+    const int t = e - 2;
+    yy = cy - ring + 1 + (t >> 1);
+    x0 = x1 = (t & 1) ? cx + ring : cx - ring;
 }
 
 #define LL_SCAN_UN 2              /* point loads a lane keeps in flight while scanning a cell */
-#define LL_RING_CELLS 24          /* cell bounds fetched per round; wider rings take several rounds */
+#define LL_RING_CELLS 24          /* entries (rows / side cells) whose bounds are fetched per round; wider rings take several rounds */
 
 /* visit the cells around (qx, qy) in Chebyshev rings; scan(cell_start, cell_end) scans one cell, bound() is the current
  * pruning radius^2 (shrinks as candidates are found), sync() shares the best inside the 8-lane group.
@@ -288,17 +289,18 @@ __device__ __forceinline__ void ll_grid_search(const int *gstart, float qx, floa
     const int cx = ll_cell_coord(qx), cy = ll_cell_coord(qy);
     for (int ring = 0; ring <= rmax; ++ring) {
         if (ring >= 2) { const float lbr = (float)(ring - 1) * LL_GRID_CELL - 1e-3f; if (lbr * lbr > bound()) break; }
-        const int ncell = ring == 0 ? 1 : 8 * ring;
+        const int ncell = ring == 0 ? 1 : 4 * ring;                   /* entries: two rows + the side cells */
         for (int e0 = 0; e0 < ncell; e0 += LL_RING_CELLS) {           /* wide rings go through the table in chunks */
             const int ne = min(LL_RING_CELLS, ncell - e0);
             const float bnd = bound();
             for (int e = sub; e < ne; e += 8) {
-                int dx, dy; ll_ring_cell(ring, e0 + e, dx, dy);
-                const int xx = cx + dx, yy = cy + dy;
+                int x0, x1, yy; ll_ring_entry(ring, e0 + e, cx, cy, x0, x1, yy);
+                const int xa = max(x0, 0), xb = min(x1, LL_GRID_G - 1);
                 int st = 0, en = 0; float lb = 0.0f;
-                if (xx >= 0 && xx < LL_GRID_G && yy >= 0 && yy < LL_GRID_G) {
-                    lb = ll_cell_lb2(qx, qy, xx, yy);
-                    if (!(lb > bnd)) { const int c = yy * LL_GRID_G + xx; st = gstart[c]; en = gstart[c + 1]; }
+                if (xa <= xb && yy >= 0 && yy < LL_GRID_G) {
+                    /* a row passes through the query's column: only its distance in y counts */
+                    lb = ll_cell_lb2(qx, qy, x0 == x1 ? xa : cx, yy);
+                    if (!(lb > bnd)) { st = gstart[yy * LL_GRID_G + xa]; en = gstart[yy * LL_GRID_G + xb + 1]; }
                 }
                 cellb[3 * e] = st; cellb[3 * e + 1] = en; cellb[3 * e + 2] = __float_as_int(lb);
             }
