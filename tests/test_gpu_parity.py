@@ -284,6 +284,31 @@ def test_pick_on_short_rings(api, orc, n_az):
     assert len(ref["sharp"]) > 0 and len(ref["flat"]) > 0
 
 
+@pytest.mark.parametrize("n_az,spread", [(1800, 0.02), (2200, 0.004), (2304, 0.0005), (600, 0.05)])
+def test_voxel_runs_across_lanes_and_waves(api, orc, n_az, spread):
+    """Rings whose consecutive points pile up in a few 0.2 m voxels: runs of 10 .. 2000 points of one voxel, so that a
+    centroid's left-to-right f32 sum continues through the next lane's registers (wave shift), through lanes that own no
+    run head at all, and across the four waves of the workgroup (the cloud fallback) -- bit-exact against the oracle,
+    which sums in input order.  One ring also revisits its voxels (two arcs over the same cells) so that a voxel's points
+    are not adjacent before the sort."""
+    rng = np.random.default_rng(7 + n_az)
+    rings = []
+    for k in range(16):
+        # the azimuth advances in bursts: `spread` of a radian per point inside a burst, a jump between bursts
+        steps = np.where(rng.random(n_az) < 0.01 * (k + 1), 0.05 + 0.2 * rng.random(n_az), spread * rng.random(n_az) / 50)
+        az = -np.cumsum(steps)
+        az *= (2 * np.pi - 1e-3) / abs(az[-1])                     # one sweep
+        r = 6.0 + 0.004 * rng.standard_normal(n_az)
+        if k == 5:                                                 # revisit: the second half retraces the first
+            az = np.concatenate([az[: n_az // 2], az[: n_az - n_az // 2] - 1e-4])
+        e = np.deg2rad(-15 + 2 * k)
+        rings.append(np.stack([r * np.cos(az), r * np.sin(az), r * np.tan(e)], axis=1))
+    scan = _ring_scan(rings)
+    ref = _assert_extract_equal(api, orc, scan, 16, f"voxel runs ({n_az})", minimum_range=0.5)
+    n_lf_in = int((ref["label"] <= 0).sum())
+    assert len(ref["less_flat"]) * 8 < n_lf_in, "the construction must put many points into each voxel"
+
+
 def test_vote_disabled_keeps_all(case, odo):
     """now_frame <= 5 branch (laserOdometry.cpp:781-787): every plane correspondence, weight 1."""
     ctx = case["ctx"]
