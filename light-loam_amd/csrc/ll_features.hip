@@ -36,7 +36,12 @@ __device__ __forceinline__ bool ll_xcd_map2(int id, int per_scan, int count, int
     return scan < count;
 }
 
+#ifndef LL_FTILE
 #define LL_FTILE 512      /* points per curvature tile */
+#endif
+#ifndef LL_FWAVES
+#define LL_FWAVES 6
+#endif
 #ifdef LL_PHASE_STOP
 #define LL_LOOKBACK_SPINS 1            /* instruction-count builds return early and never publish: do not wait for them */
 #else
@@ -234,7 +239,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char ll_smem[];
 
 /* 2nd launch bound = waves per SIMD: six 256-thread workgroups per CU for the common 2304-point capacity (<= 80 VGPRs) */
 template <int ROWS>
-__global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? 6 : 1)) void k_ring_features(LLView V, int first, int count)
+__global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : 1)) void k_ring_features(LLView V, int first, int count)
 {
     int sl, r;
     if (!ll_xcd_map2(blockIdx.x, V.R, count, sl, r)) return;
