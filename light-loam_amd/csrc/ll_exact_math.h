@@ -258,3 +258,7 @@ LL_HD float ll_f32_floor(double c)
  * verified over all 2^31 inputs by tests/test_exact_math.py against the host libm). */
 #define LL_VOTE_GAP2_BITS 0x3d273506u
 LL_HD bool ll_vote_incompatible(float gap2) { return ll_f2u(gap2) >= LL_VOTE_GAP2_BITS && !(gap2 != gap2); }
+/* the same predicate on gap = fabsf(s1 - s2) itself: RN(gap * gap) is monotone in gap, and 0x3e4ee4cd is the smallest float
+ * whose square rounds to at least the threshold above (tests/test_exact_math.py: every non-negative float) */
+#define LL_VOTE_GAP_BITS 0x3e4ee4cdu
+LL_HD bool ll_vote_incompatible_gap(float gap) { return ll_f2u(gap) >= LL_VOTE_GAP_BITS && !(gap != gap); }

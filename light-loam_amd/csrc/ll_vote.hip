@@ -59,11 +59,22 @@ __device__ __forceinline__ int ll_vote_core(const float *S3, const float *T3, in
                 /* Distance() (:153-162): f32 sqrt of dx*dx + dy*dy + dz*dz; the squares make the operand order irrelevant
                  * bit-for-bit, so (i, j) and (j, i) are the same test */
                 float dx = ax - S3[3 * j], dy = ay - S3[3 * j + 1], dz = az - S3[3 * j + 2];
-                const float s1 = sqrtf(dx * dx + dy * dy + dz * dz);
+                const float a2 = dx * dx + dy * dy + dz * dz;
                 dx = bx - T3[3 * j]; dy = by - T3[3 * j + 1]; dz = bz - T3[3 * j + 2];
-                const float s2 = sqrtf(dx * dx + dy * dy + dz * dz);
-                const float gap = fabsf(s1 - s2);
-                if (ll_vote_incompatible(gap * gap)) { ++cnt; atomicAdd(&cntL[j], 1); }
+                const float b2 = dx * dx + dy * dy + dz * dz;
+                /* The reference's test is gap >= g_T on correctly rounded square roots (ll_vote_incompatible_gap).  The
+                 * hardware square root (v_sqrt_f32, ~1 ulp) decides it unless the approximate gap lies within
+                 * (s1 + s2) * 2^-20 of g_T -- more than three times what two approximate roots (a few ulp each) and the
+                 * roundings of the two subtractions can move it -- and only those pairs take the exact roots. */
+                const float s1a = __builtin_amdgcn_sqrtf(a2), s2a = __builtin_amdgcn_sqrtf(b2);
+                const float ga = fabsf(s1a - s2a), e2 = (s1a + s2a) * 9.5367431640625e-07f;
+                const float gT = ll_u2f(LL_VOTE_GAP_BITS);
+                bool inc = ga >= gT + e2;
+                if (!inc && !(ga <= gT - e2)) {                                    /* too close to call (or not finite) */
+                    const float s1 = sqrtf(a2), s2 = sqrtf(b2);
+                    inc = ll_vote_incompatible_gap(fabsf(s1 - s2));
+                }
+                if (inc) { ++cnt; atomicAdd(&cntL[j], 1); }
             }
             if (cnt) atomicAdd(&cntL[i], cnt);
         }

@@ -191,4 +191,17 @@ long long em_check_vote(unsigned long long first, unsigned long long stride)
     return bad;
 }
 
+/* ll_vote_incompatible_gap(g) == ll_vote_incompatible(g * g) for the non-negative float patterns first, first + stride, ... */
+long long em_check_vote_gap(unsigned long long first, unsigned long long stride)
+{
+    long long bad = 0;
+#pragma omp parallel for reduction(+ : bad) schedule(static)
+    for (long long u = (long long)first; u <= 0x7f800000LL; u += (long long)stride) {
+        const float g = ll_u2f((uint32_t)u);
+        volatile float g2 = g * g;
+        if (ll_vote_incompatible(g2) != ll_vote_incompatible_gap(g)) bad++;
+    }
+    return bad;
+}
+
 }  // extern "C"

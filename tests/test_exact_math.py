@@ -33,6 +33,8 @@ def em():
     lib.em_ring_lut_models.restype = C.c_longlong
     lib.em_check_f32_bounds.restype = C.c_longlong
     lib.em_check_f32_bounds.argtypes = [C.c_longlong, C.c_ulonglong]
+    lib.em_check_vote_gap.restype = C.c_longlong
+    lib.em_check_vote_gap.argtypes = [C.c_ulonglong, C.c_ulonglong]
     lib.em_check_vote.restype = C.c_longlong
     lib.em_check_vote.argtypes = [C.c_ulonglong, C.c_ulonglong]
     return lib
@@ -100,3 +102,9 @@ def test_atan2f_random_pairs(em):
 def test_vote_predicate_threshold_all_non_negative_floats(em):
     """std::exp(-gap2) < 0.96f  <=>  gap2 >= 0x3d273506, for EVERY non-negative f32 (2^31 inputs, ~7 s on 8 cores)."""
     assert em.em_check_vote(0, 1) == 0
+
+
+def test_vote_predicate_on_the_gap_itself_all_non_negative_floats(em):
+    """k_vote compares gap = |s1 - s2| with one constant instead of squaring it: gap >= 0x3e4ee4cd  <=>  RN(gap * gap) >= 0x3d273506
+    for EVERY non-negative f32 (2^31 inputs)."""
+    assert em.em_check_vote_gap(0, 1) == 0
