@@ -32,7 +32,8 @@ __device__ __forceinline__ int ll_block_compact(int n, int *sc, F emit, const in
     return total;
 }
 
-/* the vote proper on LDS-staged src (S3) / tgt (T3) xyz triples; returns this thread's number of selected entries.
+/* the vote proper on LDS-staged records S3[6 * i .. 6 * i + 5] = (src xyz, tgt xyz) of correspondence i (T3 = the end of the
+ * records); returns this thread's number of selected entries.
  * Every unordered pair of a region is evaluated ONCE, like the reference's i < j loop (:228-252): entry i of a region of m
  * takes the partners at circular offsets 1 .. (m - 1) / 2 (and, for even m, the lower half takes offset m / 2), which
  * gives every lane the same trip count; an incompatible pair bumps the entry's own register count and the partner's
@@ -48,8 +49,8 @@ __device__ __forceinline__ int ll_vote_core(const float *S3, const float *T3, in
             const int rg = (chunk > 0) ? min(i / chunk, number_of_region - 1) : number_of_region - 1;
             const int b0 = chunk * rg, b1 = (rg == number_of_region - 1) ? n_p : chunk * (rg + 1);
             const int m = b1 - b0;
-            const float ax = S3[3 * i], ay = S3[3 * i + 1], az = S3[3 * i + 2];
-            const float bx = T3[3 * i], by = T3[3 * i + 1], bz = T3[3 * i + 2];
+            const float ax = S3[6 * i], ay = S3[6 * i + 1], az = S3[6 * i + 2];
+            const float bx = S3[6 * i + 3], by = S3[6 * i + 4], bz = S3[6 * i + 5];
             const int half = (m - 1) / 2;
             const int nd = half + (((m & 1) == 0 && (i - b0) < m / 2) ? 1 : 0);        /* even m: offset m / 2 once per pair */
             int cnt = 0;
@@ -58,9 +59,11 @@ __device__ __forceinline__ int ll_vote_core(const float *S3, const float *T3, in
                 ++j; if (j >= b1) j -= m;
                 /* Distance() (:153-162): f32 sqrt of dx*dx + dy*dy + dz*dz; the squares make the operand order irrelevant
                  * bit-for-bit, so (i, j) and (j, i) are the same test */
-                float dx = ax - S3[3 * j], dy = ay - S3[3 * j + 1], dz = az - S3[3 * j + 2];
+                const float2 *pj = (const float2 *)(S3 + 6 * j);                  /* one record: three 8-byte reads */
+                const float2 p0 = pj[0], p1 = pj[1], p2 = pj[2];
+                float dx = ax - p0.x, dy = ay - p0.y, dz = az - p1.x;
                 const float a2 = dx * dx + dy * dy + dz * dz;
-                dx = bx - T3[3 * j]; dy = by - T3[3 * j + 1]; dz = bz - T3[3 * j + 2];
+                dx = bx - p1.y; dy = by - p2.x; dz = bz - p2.y;
                 const float b2 = dx * dx + dy * dy + dz * dz;
                 /* The reference's test is gap >= g_T on correctly rounded square roots (ll_vote_incompatible_gap).  The
                  * hardware square root (v_sqrt_f32, ~1 ulp) decides it unless the approximate gap lies within
@@ -120,15 +123,15 @@ __global__ __launch_bounds__(LL_BLOCK) void k_vote(LLView V, int first, int coun
     const int n_p = ll_block_compact(nf, sc, [&](int i, int pos) { ps[pos] = i; pa[pos] = pqa[i]; pb[pos] = pqb[i]; pc[pos] = pqc[i]; }, pqa);
 
     /* stage Corre_Match.src (raw current point, :753) and .tgt (closest target point, :754) */
-    float *S3 = (float *)ll_vsm;                 /* [n_p][3] */
-    float *T3 = S3 + 3 * (size_t)V.cap_flat;     /* [n_p][3] */
+    float *S3 = (float *)ll_vsm;                 /* [n_p][6]: src xyz, tgt xyz */
+    float *T3 = S3 + 3 * (size_t)V.cap_flat;     /* S3 + 6 * cap_flat = T3 + 3 * cap_flat: the counts */
     const float4 *flat = V.flat + (size_t)s * V.cap_flat;
     if (tid == 0) nsel_sh = 0;
     __syncthreads();
     for (int i = tid; i < n_p; i += LL_BLOCK) {
         const float4 a = flat[ps[i]], b = surf[pa[i]];
-        S3[3 * i] = a.x; S3[3 * i + 1] = a.y; S3[3 * i + 2] = a.z;
-        T3[3 * i] = b.x; T3[3 * i + 1] = b.y; T3[3 * i + 2] = b.z;
+        S3[6 * i] = a.x; S3[6 * i + 1] = a.y; S3[6 * i + 2] = a.z;
+        S3[6 * i + 3] = b.x; S3[6 * i + 4] = b.y; S3[6 * i + 5] = b.z;
     }
     __syncthreads();
     const int my_sel = ll_vote_core(S3, T3, n_p, 10 /* plane case (:186-187) */, enable,
@@ -149,8 +152,8 @@ __global__ __launch_bounds__(LL_BLOCK) void k_vote_points(const float4 *src, con
     float *S3 = (float *)ll_vsm, *T3 = S3 + 3 * (size_t)n;
     for (int i = threadIdx.x; i < n; i += LL_BLOCK) {
         const float4 a = src[i], b = tgt[i];
-        S3[3 * i] = a.x; S3[3 * i + 1] = a.y; S3[3 * i + 2] = a.z;
-        T3[3 * i] = b.x; T3[3 * i + 1] = b.y; T3[3 * i + 2] = b.z;
+        S3[6 * i] = a.x; S3[6 * i + 1] = a.y; S3[6 * i + 2] = a.z;
+        S3[6 * i + 3] = b.x; S3[6 * i + 4] = b.y; S3[6 * i + 5] = b.z;
     }
     __syncthreads();
     (void)ll_vote_core(S3, T3, n, regions, 1, vc, vs, vw, (int *)(T3 + 3 * (size_t)n));
