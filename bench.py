@@ -244,7 +244,9 @@ def main():
         # dominant kernel by summed HIP-event time (events on the library's own stream)
         dom = max(prof, key=lambda k: prof[k][0])
         dom_ms, dom_launches = prof[dom]
-        launches_per_step = max(1, dom_launches // max(1, args.steps))
+        # launches of every kernel per step: one per chunk (the library's event pool holds ~800 steps; beyond that the
+        # recorded launches are a prefix of the run, so per-step figures come from the per-launch average, not the sum)
+        launches_per_step = 1 if args.chunk <= 0 else -(-args.batch // args.chunk)
         bytes_per_launch = kernel_bytes[dom] / launches_per_step
         avg_ms = dom_ms / max(1, dom_launches)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -275,8 +277,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "whole_path_algorithmic_GBps": (ab["ext"] + ab["assoc"] + ab["vote"] + ab["rj"]) * args.steps / elapsed / 1e9,
-                         "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1]},
-                         "kernel_algorithmic_GBps": {k: kernel_bytes[k] / (v[0] / args.steps * 1e-3) / 1e9
+                         "kernel_ms_per_step": {k: v[0] / v[1] * launches_per_step for k, v in prof.items() if v[1]},
+                         "kernel_algorithmic_GBps": {k: kernel_bytes[k] / (v[0] / v[1] * launches_per_step * 1e-3) / 1e9
                                                      for k, v in prof.items() if v[1] and kernel_bytes.get(k)}},
         }
         if cpu is not None:
