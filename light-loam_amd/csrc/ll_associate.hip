@@ -36,20 +36,6 @@ __device__ __forceinline__ int ll_cell_coord(float v)
     return min(max(c, 0), LL_GRID_G - 1);
 }
 
-/* squared distance from (qx, qy) to the rectangle of cell (cx, cy), shrunk by a 1 mm margin so that float rounding
- * in ll_cell_coord can never make it an over-estimate; border cells are unbounded outwards */
-__device__ __forceinline__ float ll_cell_lb2(float qx, float qy, int cx, int cy)
-{
-    const float lox = (float)cx * LL_GRID_CELL - LL_GRID_ORG, loy = (float)cy * LL_GRID_CELL - LL_GRID_ORG;
-    float dx = 0.0f, dy = 0.0f;
-    if (qx < lox && cx > 0) dx = lox - qx;
-    else if (qx > lox + LL_GRID_CELL && cx < LL_GRID_G - 1) dx = qx - (lox + LL_GRID_CELL);
-    if (qy < loy && cy > 0) dy = loy - qy;
-    else if (qy > loy + LL_GRID_CELL && cy < LL_GRID_G - 1) dy = qy - (loy + LL_GRID_CELL);
-    dx = fmaxf(dx - 1e-3f, 0.0f); dy = fmaxf(dy - 1e-3f, 0.0f);
-    return dx * dx + dy * dy;
-}
-
 /* walk bounds of a start ring rc: the up-walk stops at the first ring > rc + NEARBY_SCAN, the down-walk at the
  * first ring < rc - NEARBY_SCAN (compared in double like the reference); for integer rings that is > hi / < lo */
 __device__ __forceinline__ int ll_ring_hi(int rc, double nearby) { return (int)floor((double)rc + nearby); }
@@ -278,28 +264,61 @@ __device__ __forceinline__ void ll_ring_entry(int ring, int e, int cx, int cy, i
 #define LL_SCAN_UN 2              /* point loads a lane keeps in flight while scanning a cell */
 #define LL_RING_CELLS 24          /* entries (rows / side cells) whose bounds are fetched per round; wider rings take several rounds */
 
-/* visit the cells around (qx, qy) in Chebyshev rings; scan(cell_start, cell_end) scans one cell, bound() is the current
- * pruning radius^2 (shrinks as candidates are found), sync() shares the best inside the 8-lane group.
- * The bounds of ALL cells of a ring are fetched at once -- lane `sub` of the group takes cells sub, sub+8, sub+16 -- and
- * exchanged through a per-group LDS table: one parallel round of loads per ring instead of one dependent load per cell. */
+/* squared distance from (qx, qy) to the rectangle of cells [xa, xb] of row yy, shrunk by a 1 mm margin so that float rounding
+ * in ll_cell_coord can never make it an over-estimate; border cells are unbounded outwards */
+__device__ __forceinline__ float ll_range_lb2(float qx, float qy, int xa, int xb, int yy)
+{
+    const float lox = (float)xa * LL_GRID_CELL - LL_GRID_ORG, hix = (float)(xb + 1) * LL_GRID_CELL - LL_GRID_ORG;
+    const float loy = (float)yy * LL_GRID_CELL - LL_GRID_ORG;
+    float dx = 0.0f, dy = 0.0f;
+    if (qx < lox && xa > 0) dx = lox - qx;
+    else if (qx > hix && xb < LL_GRID_G - 1) dx = qx - hix;
+    if (qy < loy && yy > 0) dy = loy - qy;
+    else if (qy > loy + LL_GRID_CELL && yy < LL_GRID_G - 1) dy = qy - (loy + LL_GRID_CELL);
+    dx = fmaxf(dx - 1e-3f, 0.0f); dy = fmaxf(dy - 1e-3f, 0.0f);
+    return dx * dx + dy * dy;
+}
+
+/* Entry e of what lies between Chebyshev ring LL_NEAR_RINGS and ring rmax, as row ranges ordered from near to far: the rows
+ * that cross the inner block contribute a left and a right part (e < 2 * (2 * LL_NEAR_RINGS + 1)), every other row is one
+ * range of 2 * rmax + 1 cells.  2 * rmax + 2 * LL_NEAR_RINGS + 2 entries instead of the 4 * ring entries of every ring: a
+ * query whose partner is far away (or missing: ground points far out have no neighbour on the next ring within the
+ * 5 m limit) walks 18 ranges, not 72 entries. */
+#define LL_NEAR_RINGS 2
+__device__ __forceinline__ void ll_annulus_entry(int rmax, int e, int cx, int cy, int &x0, int &x1, int &yy)
+{
+    constexpr int NP = 2 * (2 * LL_NEAR_RINGS + 1);
+    if (e < NP) {
+        const int r = e >> 1, k = (r + 1) >> 1;                       /* rows 0, -1, +1, -2, +2 */
+        yy = cy + ((r & 1) ? -k : k);
+        if (e & 1) { x0 = cx + LL_NEAR_RINGS + 1; x1 = cx + rmax; } else { x0 = cx - rmax; x1 = cx - LL_NEAR_RINGS - 1; }
+        return;
+    }
+    const int t = e - NP, k = LL_NEAR_RINGS + 1 + (t >> 1);
+    yy = cy + ((t & 1) ? k : -k);
+    x0 = cx - rmax; x1 = cx + rmax;
+}
+
+/* visit the cells around (qx, qy) from near to far; scan(start, end) scans one contiguous range of the cell-ordered points,
+ * bound() is the current pruning radius^2 (shrinks as candidates are found), sync() shares the best inside the 8-lane group.
+ * Chebyshev rings 0 .. LL_NEAR_RINGS one by one (most searches end there), then the rest as row ranges in one sweep.
+ * The bounds of ALL entries of a round are fetched at once -- lane `sub` of the group takes entries sub, sub+8, sub+16 -- and
+ * exchanged through a per-group LDS table: one parallel round of loads instead of one dependent load per entry. */
 template <typename Scan, typename Bound, typename Sync>
 __device__ __forceinline__ void ll_grid_search(const int *gstart, float qx, float qy, int rmax, int *cellb, int sub,
                                                Scan scan, Bound bound, Sync sync)
 {
     const int cx = ll_cell_coord(qx), cy = ll_cell_coord(qy);
-    for (int ring = 0; ring <= rmax; ++ring) {
-        if (ring >= 2) { const float lbr = (float)(ring - 1) * LL_GRID_CELL - 1e-3f; if (lbr * lbr > bound()) break; }
-        const int ncell = ring == 0 ? 1 : 4 * ring;                   /* entries: two rows + the side cells */
-        for (int e0 = 0; e0 < ncell; e0 += LL_RING_CELLS) {           /* wide rings go through the table in chunks */
-            const int ne = min(LL_RING_CELLS, ncell - e0);
+    auto sweep = [&](int nent, auto entry) __attribute__((always_inline)) {
+        for (int e0 = 0; e0 < nent; e0 += LL_RING_CELLS) {            /* more entries than the table holds: several rounds */
+            const int ne = min(LL_RING_CELLS, nent - e0);
             const float bnd = bound();
             for (int e = sub; e < ne; e += 8) {
-                int x0, x1, yy; ll_ring_entry(ring, e0 + e, cx, cy, x0, x1, yy);
+                int x0, x1, yy; entry(e0 + e, x0, x1, yy);
                 const int xa = max(x0, 0), xb = min(x1, LL_GRID_G - 1);
                 int st = 0, en = 0; float lb = 0.0f;
                 if (xa <= xb && yy >= 0 && yy < LL_GRID_G) {
-                    /* a row passes through the query's column: only its distance in y counts */
-                    lb = ll_cell_lb2(qx, qy, x0 == x1 ? xa : cx, yy);
+                    lb = ll_range_lb2(qx, qy, xa, xb, yy);
                     if (!(lb > bnd)) { st = gstart[yy * LL_GRID_G + xa]; en = gstart[yy * LL_GRID_G + xb + 1]; }
                 }
                 cellb[3 * e] = st; cellb[3 * e + 1] = en; cellb[3 * e + 2] = __float_as_int(lb);
@@ -314,6 +333,16 @@ __device__ __forceinline__ void ll_grid_search(const int *gstart, float qx, floa
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             sync();
         }
+    };
+    const int near = min(rmax, LL_NEAR_RINGS);
+    for (int ring = 0; ring <= near; ++ring) {
+        if (ring >= 2) { const float lbr = (float)(ring - 1) * LL_GRID_CELL - 1e-3f; if (lbr * lbr > bound()) return; }
+        sweep(ring == 0 ? 1 : 4 * ring, [&](int e, int &x0, int &x1, int &yy) { ll_ring_entry(ring, e, cx, cy, x0, x1, yy); });
+    }
+    if (rmax > LL_NEAR_RINGS) {
+        const float lbr = (float)LL_NEAR_RINGS * LL_GRID_CELL - 1e-3f;
+        if (lbr * lbr > bound()) return;
+        sweep(2 * rmax + 2 * LL_NEAR_RINGS + 2, [&](int e, int &x0, int &x1, int &yy) { ll_annulus_entry(rmax, e, cx, cy, x0, x1, yy); });
     }
 }
 
