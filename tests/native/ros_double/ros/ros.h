@@ -1,0 +1,63 @@
+/* Declared test double of the part of roscpp that ros/lightloam_*_node.cpp use -- NOT ROS.  This image has no ROS; the
+ * double lets the node sources be compiled as they are and their callbacks driven from a test: advertise() records the
+ * topic, publish() keeps the last message per topic, subscribe() keeps the callback, spin() returns at once. */
+#pragma once
+#include <cstdio>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace ros {
+
+struct Time { unsigned sec = 0, nsec = 0; bool operator==(const Time &o) const { return sec == o.sec && nsec == o.nsec; } };
+
+struct Double {                                   /* the state a test inspects */
+    std::map<std::string, int> advertised;        /* topic -> queue size */
+    std::map<std::string, int> subscribed;
+    std::map<std::string, std::shared_ptr<void>> last;        /* topic -> last published message */
+    std::map<std::string, int> published;                     /* topic -> count */
+    std::map<std::string, double> params_d; std::map<std::string, int> params_i;
+    std::function<void(const std::shared_ptr<const void> &)> callback;        /* of the one subscription */
+    int warnings = 0, errors = 0;
+    static Double &get() { static Double d; return d; }
+};
+
+inline void init(int &, char **, const std::string &) {}
+inline void spin() {}
+inline bool ok() { return true; }
+
+class Publisher {
+public:
+    std::string topic;
+    template <class M> void publish(const M &m) const {
+        Double::get().last[topic] = std::make_shared<M>(m);
+        Double::get().published[topic]++;
+    }
+};
+class Subscriber {};
+
+class NodeHandle {
+public:
+    template <class T> void param(const std::string &name, T &out, const T &dflt) const {
+        auto &D = Double::get();
+        if (D.params_d.count(name)) out = (T)D.params_d[name];
+        else if (D.params_i.count(name)) out = (T)D.params_i[name];
+        else out = dflt;
+    }
+    template <class M> Publisher advertise(const std::string &topic, int queue) {
+        Double::get().advertised[topic] = queue;
+        Publisher p; p.topic = topic; return p;
+    }
+    template <class M> Subscriber subscribe(const std::string &topic, int queue, void (*cb)(const std::shared_ptr<const M> &)) {
+        Double::get().subscribed[topic] = queue;
+        Double::get().callback = [cb](const std::shared_ptr<const void> &m) { cb(std::static_pointer_cast<const M>(m)); };
+        return Subscriber();
+    }
+};
+
+}  // namespace ros
+
+#define ROS_WARN(...) do { ros::Double::get().warnings++; } while (0)
+#define ROS_ERROR(...) do { ros::Double::get().errors++; std::fprintf(stderr, __VA_ARGS__); std::fprintf(stderr, "\n"); } while (0)
