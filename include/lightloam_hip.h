@@ -123,6 +123,13 @@ int ll_download_features(ll_ctx *ctx, int slot,
  * ll_set_target uploaded).  pose_guess: count x 7 doubles (qx,qy,qz,qw,tx,ty,tz) = para_q/para_t at entry
  * (:61-62); NULL = identity.                                                                           */
 int ll_set_target(ll_ctx *ctx, const ll_point *host_corner_last, int m_c, const ll_point *host_surf_last, int m_s);
+/* The four feature clouds of a scan from host memory into a slot, in place of ll_extract_batch: what a separate
+ * laserOdometry process receives on /laser_cloud_sharp, _less_sharp, _flat, _less_flat (laserOdometry.cpp:116-150,
+ * :404-423) when the registration node runs elsewhere.  The slot then serves ll_associate_batch .. ll_odometry_frames and
+ * ll_set_target_from_slot like an extracted one (its laserCloud / labels are empty).  intensity must carry the ring id
+ * as the registration node stores it (int part = scanID).  LL_ERR_CAPACITY beyond the per-scan feature capacities.     */
+int ll_upload_features(ll_ctx *ctx, int slot, const ll_point *host_sharp, int n_sharp, const ll_point *host_less_sharp, int n_less_sharp,
+                       const ll_point *host_flat, int n_flat, const ll_point *host_less_flat, int n_less_flat);
 int ll_set_target_from_slot(ll_ctx *ctx, int slot);   /* device-to-device: slot's less-sharp/less-flat become the carry */
 int ll_associate_batch(ll_ctx *ctx, int first, int count, const double *host_pose_guess);
 /* Store the guess in HBM; ll_hot_path_batch(..., NULL, ...) then restarts every slot from it without touching the host. */

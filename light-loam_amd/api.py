@@ -18,7 +18,7 @@ STATUS = {0: "LL_OK", -1: "LL_ERR_DEVICE", -2: "LL_ERR_ARG", -3: "LL_ERR_BAD_RIN
 EXPORTS = [
     "ll_default_params", "ll_create", "ll_destroy", "ll_last_error", "ll_abi_version", "ll_stream", "ll_synchronize",
     "ll_upload_scan", "ll_extract_batch", "ll_get_scan_info", "ll_download_cloud", "ll_download_labels",
-    "ll_download_features", "ll_set_target", "ll_set_target_from_slot", "ll_associate_batch", "ll_get_pair_info",
+    "ll_download_features", "ll_set_target", "ll_upload_features", "ll_set_target_from_slot", "ll_associate_batch", "ll_get_pair_info",
     "ll_download_edge_corr", "ll_download_plane_corr", "ll_vote_batch", "ll_download_vote",
     "ll_normal_equations_batch", "ll_download_normal_equations", "ll_gn_step_batch", "ll_download_pose",
     "ll_residual_jacobian", "ll_hot_path_batch", "ll_algorithmic_bytes", "ll_profile_enable", "ll_profile_read", "ll_set_pose_guess", "ll_debug_counters", "ll_vote_host", "ll_debug_calibration_copy",
@@ -173,6 +173,12 @@ class Context:
         c = np.ascontiguousarray(corner_last, np.float32).reshape(-1, 4)
         s = np.ascontiguousarray(surf_last, np.float32).reshape(-1, 4)
         self._ck(self.lib.ll_set_target(self.h, _ptr(c), len(c), _ptr(s), len(s)))
+
+    def upload_features(self, slot, sharp, less_sharp, flat, less_flat):
+        """the four feature clouds of a scan from host arrays into a slot (what a separate odometry process gets by topic)"""
+        a = [np.ascontiguousarray(x, np.float32).reshape(-1, 4) for x in (sharp, less_sharp, flat, less_flat)]
+        self._ck(self.lib.ll_upload_features(self.h, slot, _ptr(a[0]), len(a[0]), _ptr(a[1]), len(a[1]), _ptr(a[2]), len(a[2]),
+                                             _ptr(a[3]), len(a[3])))
 
     def set_target_from_slot(self, slot):
         self._ck(self.lib.ll_set_target_from_slot(self.h, slot))

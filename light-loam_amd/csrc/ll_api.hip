@@ -255,6 +255,28 @@ extern "C" int ll_set_target(ll_ctx *ctx, const ll_point *corner, int m_c, const
     return LL_OK;
 }
 
+extern "C" int ll_upload_features(ll_ctx *ctx, int slot, const ll_point *sharp, int ns, const ll_point *lsharp, int nls,
+                                  const ll_point *flat, int nf, const ll_point *lflat, int nlf)
+{
+    int rc = check_range(ctx, slot, 1); if (rc) return rc;
+    LLView &V = ctx->V;
+    if (ns < 0 || nls < 0 || nf < 0 || nlf < 0 || (ns && !sharp) || (nls && !lsharp) || (nf && !flat) || (nlf && !lflat)) return LL_ERR_ARG;
+    if (ns > V.cap_sharp || nls > V.cap_lsharp || nf > V.cap_flat || nlf > V.NP) { ctx->err = "feature cloud larger than capacity"; return LL_ERR_CAPACITY; }
+    if (ns) LL_HIP(hipMemcpyAsync(V.sharp + (size_t)slot * V.cap_sharp, sharp, (size_t)ns * 16, hipMemcpyHostToDevice, ctx->stream));
+    if (nls) LL_HIP(hipMemcpyAsync(V.lsharp + (size_t)slot * V.cap_lsharp, lsharp, (size_t)nls * 16, hipMemcpyHostToDevice, ctx->stream));
+    if (nf) LL_HIP(hipMemcpyAsync(V.flat + (size_t)slot * V.cap_flat, flat, (size_t)nf * 16, hipMemcpyHostToDevice, ctx->stream));
+    if (nlf) LL_HIP(hipMemcpyAsync(V.lflat + (size_t)slot * V.NP, lflat, (size_t)nlf * 16, hipMemcpyHostToDevice, ctx->stream));
+    ScanHdr h;
+    std::memset(&h, 0, sizeof(h));
+    h.first_kept = 0; h.last_kept = -1; h.half_idx = 0;
+    h.n_sharp = ns; h.n_less_sharp = nls; h.n_flat = nf; h.n_less_flat = nlf;
+    h.status = 0;
+    LL_HIP(hipMemcpyAsync(V.hdr + slot, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+    LL_HIP(hipStreamSynchronize(ctx->stream));              /* the host arrays and h may go away */
+    if ((size_t)slot < ctx->n_in_host.size()) ctx->n_in_host[slot] = 0;
+    return LL_OK;
+}
+
 __global__ void k_copy_carry(LLView V, int slot)
 {
     const ScanHdr h = V.hdr[slot];

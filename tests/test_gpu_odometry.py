@@ -131,3 +131,32 @@ def test_forty_frame_s64_drive_ate(api, orc, synth):
     assert travelled > 30 and ate_o < 0.02 * travelled, (ate_o, travelled)
     assert abs(ate_d - ate_o) <= 0.01 * ate_o + 1e-9, (ate_d, ate_o)              # ATE within 1 % of the CPU path
     assert np.abs(rel_d - np.array(rel_o)).max() < 1e-5
+
+
+def test_features_uploaded_from_host_give_the_same_frames(api, synth):
+    """A separate laserOdometry process gets the four feature clouds by topic, not from an extracted slot:
+    ll_upload_features + ll_odometry_frames on one slot + ll_set_target_from_slot per frame must reproduce the relative
+    poses of the all-on-device sequence bit for bit (same kernels, same clouds)."""
+    rings, nframes = 16, 9
+    cfg = synth.default_cfg(rings)
+    scans = [synth.scan(cfg, k) for k in range(nframes)]
+    pose0 = np.array([0, 0, 0, 1.0, 0.9, 0.0, 0.0])
+    reg = api.Context(api.default_params(rings, batch=nframes, max_points=max(map(len, scans))))
+    for k, s in enumerate(scans):
+        reg.upload_scan(k, s)
+    reg.extract(0, nframes)
+    reg.set_target_from_slot(0)
+    rel_a = reg.odometry_frames(1, nframes - 1, pose0=pose0, n_outer=3, first_frame_index=1)
+    feats = [reg.features(k) for k in range(nframes)]
+    reg.close()
+    odo = api.Context(api.default_params(rings, batch=2, max_points=max(map(len, scans))))
+    odo.set_target(feats[0]["less_sharp"], feats[0]["less_flat"])          # the first frame only initialises (:426-430)
+    guess = pose0.copy(); rel_b = []
+    for k in range(1, nframes):
+        f = feats[k]
+        odo.upload_features(0, f["sharp"], f["less_sharp"], f["flat"], f["less_flat"])
+        guess = odo.odometry_frames(0, 1, pose0=guess, n_outer=3, first_frame_index=k)[0]      # warm start (:61-65)
+        rel_b.append(guess.copy())
+        odo.set_target_from_slot(0)                                         # the pointer swap + kd-tree rebuild (:882-896)
+    odo.close()
+    assert np.array_equal(np.array(rel_b), rel_a)
