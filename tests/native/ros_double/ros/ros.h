@@ -3,6 +3,7 @@
  * topic, publish() keeps the last message per topic, subscribe() keeps the callback, spin() returns at once. */
 #pragma once
 #include <cstdio>
+#include <cstdlib>
 #include <functional>
 #include <map>
 #include <memory>
@@ -11,7 +12,13 @@
 
 namespace ros {
 
-struct Time { unsigned sec = 0, nsec = 0; bool operator==(const Time &o) const { return sec == o.sec && nsec == o.nsec; } };
+struct Time {
+    unsigned sec = 0, nsec = 0;
+    bool operator==(const Time &o) const { return sec == o.sec && nsec == o.nsec; }
+    double toSec() const { return (double)sec + 1e-9 * (double)nsec; }
+    Time &fromSec(double t) { sec = (unsigned)t; nsec = (unsigned)((t - (double)sec) * 1e9 + 0.5); return *this; }
+};
+struct Rate { explicit Rate(double) {} void sleep() {} };
 
 struct Double {                                   /* the state a test inspects */
     std::map<std::string, int> advertised;        /* topic -> queue size */
@@ -19,14 +26,18 @@ struct Double {                                   /* the state a test inspects *
     std::map<std::string, std::shared_ptr<void>> last;        /* topic -> last published message */
     std::map<std::string, int> published;                     /* topic -> count */
     std::map<std::string, double> params_d; std::map<std::string, int> params_i;
-    std::function<void(const std::shared_ptr<const void> &)> callback;        /* of the one subscription */
+    std::function<void(const std::shared_ptr<const void> &)> callback;        /* of the last subscription */
+    std::map<std::string, std::function<void(const std::shared_ptr<const void> &)>> callbacks;   /* topic -> callback */
+    std::function<bool()> on_spin;                /* spinOnce(): the test delivers messages here; false ends ros::ok() */
+    bool running = true;
     int warnings = 0, errors = 0;
     static Double &get() { static Double d; return d; }
 };
 
 inline void init(int &, char **, const std::string &) {}
 inline void spin() {}
-inline bool ok() { return true; }
+inline void spinOnce() { auto &D = Double::get(); if (D.on_spin) D.running = D.on_spin(); else D.running = false; }
+inline bool ok() { return Double::get().running; }
 
 class Publisher {
 public:
@@ -53,6 +64,7 @@ public:
     template <class M> Subscriber subscribe(const std::string &topic, int queue, void (*cb)(const std::shared_ptr<const M> &)) {
         Double::get().subscribed[topic] = queue;
         Double::get().callback = [cb](const std::shared_ptr<const void> &m) { cb(std::static_pointer_cast<const M>(m)); };
+        Double::get().callbacks[topic] = Double::get().callback;
         return Subscriber();
     }
 };
@@ -60,4 +72,5 @@ public:
 }  // namespace ros
 
 #define ROS_WARN(...) do { ros::Double::get().warnings++; } while (0)
+#define ROS_BREAK() do { std::fprintf(stderr, "ROS_BREAK\n"); std::abort(); } while (0)
 #define ROS_ERROR(...) do { ros::Double::get().errors++; std::fprintf(stderr, __VA_ARGS__); std::fprintf(stderr, "\n"); } while (0)

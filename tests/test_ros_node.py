@@ -31,6 +31,16 @@ def test_cloud2_layout_and_topic_surface_without_a_device(tmp_path, api):
     assert lines[2:] == ["roundtrip 1", "odd_layout 1", "missing_field_rejected 1", "bad_scan_line_exit 0 advertised 0"]
 
 
+def test_odometry_node_compiles_against_the_doubles(tmp_path, api):
+    """no GPU: ros/lightloam_laser_odometry_node.cpp as it is, against the declared doubles, linked with the C-ABI library"""
+    from lightloam_amd import build
+    lib_dir = os.path.dirname(build.lib_path())
+    subprocess.check_call(["g++", "-O0", "-std=c++14", "-I", os.path.join(ROOT, "tests", "native", "ros_double"),
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "ros_odometry_double.cpp"),
+                           "-o", str(tmp_path / "ros_odometry_double"), "-L", lib_dir, "-llightloam_hip", "-Wl,-rpath," + lib_dir,
+                           "-Wl,-rpath,/opt/rocm/lib"])
+
+
 @pytest.mark.gpu
 def test_node_publishes_the_five_clouds_of_the_reference(tmp_path, orc, synth, api):
     """One 64-ring scan through main() + laserCloudHandler: the reference's subscription and six advertisements with
@@ -58,3 +68,54 @@ def test_node_publishes_the_five_clouds_of_the_reference(tmp_path, orc, synth, a
     for topic, key in topics.items():
         got = np.fromfile(str(path) + "." + topic.replace("/", "_") + ".f4", dtype=np.float32)
         assert got.tobytes() == ref[key].tobytes(), topic
+
+
+@pytest.mark.gpu
+def test_odometry_node_frame_loop_and_topics(tmp_path, synth, api):
+    """ros/lightloam_laser_odometry_node.cpp on an 8-frame 16-ring drive: five subscriptions and five advertisements with
+    the reference's names and queue sizes (laserOdometry.cpp:354-372), one odometry + path message per frame (the first
+    frame only initialises: identity), the clouds every mapping_skip_frame-th frame in "/camera", and the published
+    world poses = the device frame loop's relative poses composed as :830-831 does."""
+    from lightloam_amd import build
+    from test_gpu_odometry import integrate, qmul
+    rings, nframes = 16, 8
+    cfg = synth.default_cfg(rings)
+    scans = [synth.scan(cfg, k) for k in range(nframes)]
+    reg = api.Context(api.default_params(rings, batch=nframes, max_points=max(map(len, scans))))
+    for k, s in enumerate(scans):
+        reg.upload_scan(k, s)
+    reg.extract(0, nframes)
+    reg.set_target_from_slot(0)
+    rel = reg.odometry_frames(1, nframes - 1, pose0=None, n_outer=3, first_frame_index=1)
+    for k in range(nframes):
+        f = reg.features(k)
+        for name in ("sharp", "less_sharp", "flat", "less_flat"):
+            np.ascontiguousarray(f[name], "<f4").tofile(tmp_path / f"{k}.{name}.f4")
+        np.ascontiguousarray(reg.cloud(k)[0], "<f4").tofile(tmp_path / f"{k}.cloud.f4")
+    reg.close()
+    lib_dir = os.path.dirname(build.lib_path())
+    exe = str(tmp_path / "ros_odometry_double")
+    subprocess.check_call(["g++", "-O1", "-std=c++14", "-I", os.path.join(ROOT, "tests", "native", "ros_double"),
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "ros_odometry_double.cpp"),
+                           "-o", exe, "-L", lib_dir, "-llightloam_hip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe, str(tmp_path), str(nframes), str(rings)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert lines[0] == "rc 0"
+    assert lines[1] == ("subscribed /laser_cloud_flat:100 /laser_cloud_less_flat:100 /laser_cloud_less_sharp:100 "
+                        "/laser_cloud_sharp:100 /velodyne_cloud_2:100")
+    assert lines[2] == ("advertised /laser_cloud_corner_last:100 /laser_cloud_surf_last:100 /laser_odom_path:100 "
+                        "/laser_odom_to_init:100 /velodyne_cloud_3:100")
+    assert lines[3] == (f"published /laser_cloud_corner_last:{nframes // 2} /laser_cloud_surf_last:{nframes // 2} "
+                        f"/laser_odom_path:{nframes} /laser_odom_to_init:{nframes} /velodyne_cloud_3:{nframes // 2}")
+    assert lines[4] == f"path_poses {nframes} path_frame rslidar cloud_frame /camera cloud_stamp {100 + nframes - 2}"
+    rows = [ln.split() for ln in open(tmp_path / "odom.txt").read().strip().splitlines()]
+    assert len(rows) == nframes and all(r[8] == "rslidar" and r[9] == "/laser_odom" for r in rows)
+    assert [int(r[7]) for r in rows] == [100 + k for k in range(nframes)]
+    got = np.array([[float(v) for v in r[:7]] for r in rows])
+    assert np.array_equal(got[0], [0, 0, 0, 1, 0, 0, 0])                 # the initialisation frame
+    tw = integrate(rel)                                                   # t_w after every frame (:830)
+    qw = np.array([0, 0, 0, 1.0]); qs = [qw]
+    for p in rel:
+        qw = qmul(qw, p[:4]); qs.append(qw)                               # q_w (:831)
+    assert np.allclose(got[:, 4:], tw, rtol=0, atol=1e-12) and np.allclose(got[:, :4], np.array(qs), rtol=0, atol=1e-12)
