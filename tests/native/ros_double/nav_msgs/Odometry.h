@@ -13,6 +13,9 @@ struct PoseStamped { std_msgs::Header header; Pose pose; };
 }  // namespace geometry_msgs
 
 namespace nav_msgs {
-struct Odometry { std_msgs::Header header; std::string child_frame_id; geometry_msgs::PoseWithCovariance pose; };
+struct Odometry {
+    std_msgs::Header header; std::string child_frame_id; geometry_msgs::PoseWithCovariance pose;
+    typedef std::shared_ptr<const Odometry> ConstPtr;
+};
 struct Path { std_msgs::Header header; std::vector<geometry_msgs::PoseStamped> poses; };
 }  // namespace nav_msgs

@@ -7,6 +7,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -25,17 +26,25 @@ struct Double {                                   /* the state a test inspects *
     std::map<std::string, int> subscribed;
     std::map<std::string, std::shared_ptr<void>> last;        /* topic -> last published message */
     std::map<std::string, int> published;                     /* topic -> count */
-    std::map<std::string, double> params_d; std::map<std::string, int> params_i;
+    std::map<std::string, double> params_d; std::map<std::string, int> params_i; std::map<std::string, std::string> params_s;
     std::function<void(const std::shared_ptr<const void> &)> callback;        /* of the last subscription */
     std::map<std::string, std::function<void(const std::shared_ptr<const void> &)>> callbacks;   /* topic -> callback */
     std::function<bool()> on_spin;                /* spinOnce(): the test delivers messages here; false ends ros::ok() */
     bool running = true;
+    std::mutex mu;                                 /* publish() may come from a node's worker thread */
+    int count(const std::string &topic) { std::lock_guard<std::mutex> l(mu); return published.count(topic) ? published[topic] : 0; }
+    std::shared_ptr<void> latest(const std::string &topic) { std::lock_guard<std::mutex> l(mu); return last.count(topic) ? last[topic] : nullptr; }
     int warnings = 0, errors = 0;
     static Double &get() { static Double d; return d; }
 };
 
 inline void init(int &, char **, const std::string &) {}
-inline void spin() {}
+inline void spin()                                 /* the test's on_spin delivers messages until it returns false */
+{
+    auto &D = Double::get();
+    while (D.on_spin && D.on_spin()) {}
+    D.running = false;
+}
 inline void spinOnce() { auto &D = Double::get(); if (D.on_spin) D.running = D.on_spin(); else D.running = false; }
 inline bool ok() { return Double::get().running; }
 
@@ -43,14 +52,20 @@ class Publisher {
 public:
     std::string topic;
     template <class M> void publish(const M &m) const {
-        Double::get().last[topic] = std::make_shared<M>(m);
-        Double::get().published[topic]++;
+        auto &D = Double::get();
+        std::lock_guard<std::mutex> l(D.mu);
+        D.last[topic] = std::make_shared<M>(m);
+        D.published[topic]++;
     }
 };
 class Subscriber {};
 
 class NodeHandle {
 public:
+    void param(const std::string &name, std::string &out, const std::string &dflt) const {
+        auto &D = Double::get();
+        out = D.params_s.count(name) ? D.params_s[name] : dflt;
+    }
     template <class T> void param(const std::string &name, T &out, const T &dflt) const {
         auto &D = Double::get();
         if (D.params_d.count(name)) out = (T)D.params_d[name];

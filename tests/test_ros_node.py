@@ -1,5 +1,5 @@
-"""The ROS1 node wrapper (ros/lightloam_scan_registration_node.cpp) compiled as it is against DECLARED TEST DOUBLES of the
-roscpp / sensor_msgs classes it uses (tests/native/ros_double -- this image has no ROS) and driven like roscpp would:
+"""The ROS1 node wrappers (ros/lightloam_*_node.cpp) compiled as they are against DECLARED TEST DOUBLES of the
+roscpp / sensor_msgs / nav_msgs / tf classes they use (tests/native/ros_double -- this image has no ROS) and driven like roscpp would:
 parameters -> main() -> the subscription's callback with a PointCloud2 -> what was published on which topic."""
 import os
 import subprocess
@@ -31,13 +31,15 @@ def test_cloud2_layout_and_topic_surface_without_a_device(tmp_path, api):
     assert lines[2:] == ["roundtrip 1", "odd_layout 1", "missing_field_rejected 1", "bad_scan_line_exit 0 advertised 0"]
 
 
-def test_odometry_node_compiles_against_the_doubles(tmp_path, api):
-    """no GPU: ros/lightloam_laser_odometry_node.cpp as it is, against the declared doubles, linked with the C-ABI library"""
+@pytest.mark.parametrize("driver", ["ros_odometry_double", "ros_mapping_double"])
+def test_odometry_and_mapping_nodes_compile_against_the_doubles(tmp_path, api, driver):
+    """no GPU: ros/lightloam_laser_odometry_node.cpp and ros/lightloam_laser_mapping_node.cpp as they are, against the
+    declared doubles, linked with the C-ABI library"""
     from lightloam_amd import build
     lib_dir = os.path.dirname(build.lib_path())
-    subprocess.check_call(["g++", "-O0", "-std=c++14", "-I", os.path.join(ROOT, "tests", "native", "ros_double"),
-                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "ros_odometry_double.cpp"),
-                           "-o", str(tmp_path / "ros_odometry_double"), "-L", lib_dir, "-llightloam_hip", "-Wl,-rpath," + lib_dir,
+    subprocess.check_call(["g++", "-O0", "-std=c++14", "-pthread", "-I", os.path.join(ROOT, "tests", "native", "ros_double"),
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", driver + ".cpp"),
+                           "-o", str(tmp_path / driver), "-L", lib_dir, "-llightloam_hip", "-Wl,-rpath," + lib_dir,
                            "-Wl,-rpath,/opt/rocm/lib"])
 
 
@@ -119,3 +121,96 @@ def test_odometry_node_frame_loop_and_topics(tmp_path, synth, api):
     for p in rel:
         qw = qmul(qw, p[:4]); qs.append(qw)                               # q_w (:831)
     assert np.allclose(got[:, 4:], tw, rtol=0, atol=1e-12) and np.allclose(got[:, :4], np.array(qs), rtol=0, atol=1e-12)
+
+
+def _qmul(a, b):
+    ax, ay, az, aw = a; bx, by, bz, bw = b
+    return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                     aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz])
+
+
+def _qrot(q, v):
+    u, w = np.asarray(q[:3]), q[3]
+    uv = 2 * np.cross(u, v)
+    return v + w * uv + np.cross(u, uv)
+
+
+@pytest.mark.gpu
+def test_mapping_node_frame_loop_and_topics(tmp_path, synth, api):
+    """ros/lightloam_laser_mapping_node.cpp on a 7-frame 16-ring drive: four subscriptions and six advertisements
+    (laserMapping.cpp:2369-2387), per frame one /aft_mapped_to_init + path + registered cloud + tf + RESULT_PATH line, the
+    surround cloud on frame 0 and 5, the map cloud on frame 0, the high-frequency republish with the reference's field
+    permutation; mapped poses = transformAssociateToMap -> ll_cubemap_process -> transformUpdate driven from Python."""
+    from lightloam_amd import build
+    from test_gpu_odometry import integrate
+    rings, nframes = 16, 7
+    cfg = synth.default_cfg(rings)
+    scans = [synth.scan(cfg, k) for k in range(nframes)]
+    reg = api.Context(api.default_params(rings, batch=nframes, max_points=max(map(len, scans))))
+    for k, s in enumerate(scans):
+        reg.upload_scan(k, s)
+    reg.extract(0, nframes)
+    reg.set_target_from_slot(0)
+    rel = reg.odometry_frames(1, nframes - 1, pose0=np.array([0, 0, 0, 1.0, 0.9, 0, 0]), n_outer=3, first_frame_index=1)
+    tw = integrate(rel)
+    qw = [np.array([0, 0, 0, 1.0])]
+    for p in rel:
+        qw.append(_qmul(qw[-1], p[:4]))
+    feats = []
+    for k in range(nframes):
+        f = reg.features(k); cloud = reg.cloud(k)[0]
+        feats.append((f["less_sharp"].copy(), f["less_flat"].copy(), cloud.copy()))
+        for name, arr in (("less_sharp", f["less_sharp"]), ("less_flat", f["less_flat"]), ("cloud", cloud)):
+            np.ascontiguousarray(arr, "<f4").tofile(tmp_path / f"{k}.{name}.f4")
+        with open(tmp_path / f"{k}.odom.txt", "w") as fo:
+            fo.write(" ".join(repr(float(v)) for v in list(qw[k]) + list(tw[k])))
+    # ---- the same frames through the Python binding
+    cm = api.CubeMap(reg, 20000, 200000, pool_points=1 << 22)
+    q_wmap, t_wmap = np.array([0, 0, 0, 1.0]), np.zeros(3)
+    expect, expect_high = [], []
+    for k in range(nframes):
+        qh = _qmul(q_wmap, qw[k]); th = _qrot(q_wmap, tw[k]) + t_wmap                      # laserOdometryHandler (:168-247)
+        expect_high.append(th)
+        guess = np.concatenate([qh, th])                                                    # transformAssociateToMap (:113-117)
+        pose, _ = cm.process(guess, feats[k][0], feats[k][1])
+        expect.append(pose)
+        qinv = np.array([-qw[k][0], -qw[k][1], -qw[k][2], qw[k][3]]) / np.dot(qw[k], qw[k])
+        q_wmap = _qmul(pose[:4], qinv); t_wmap = pose[4:] - _qrot(q_wmap, tw[k])            # transformUpdate (:119-123)
+    cen, _ = cm.info()
+    cm.close(); reg.close()
+    lib_dir = os.path.dirname(build.lib_path())
+    exe = str(tmp_path / "ros_mapping_double")
+    subprocess.check_call(["g++", "-O1", "-std=c++14", "-pthread", "-I", os.path.join(ROOT, "tests", "native", "ros_double"),
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "ros_mapping_double.cpp"),
+                           "-o", exe, "-L", lib_dir, "-llightloam_hip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe, str(tmp_path), str(nframes)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert lines[0] == f"rc 0 frames {nframes}"
+    assert lines[1] == "subscribed /laser_cloud_corner_last:100 /laser_cloud_surf_last:100 /laser_odom_to_init:100 /velodyne_cloud_3:100"
+    assert lines[2] == ("advertised /aft_mapped_path:100 /aft_mapped_to_init:100 /aft_mapped_to_init_high_frec:100 "
+                        "/laser_cloud_map:100 /laser_cloud_surround:100 /velodyne_cloud_registered:100")
+    assert lines[3] == (f"published /aft_mapped_path:{nframes} /aft_mapped_to_init:{nframes} /aft_mapped_to_init_high_frec:{nframes} "
+                        f"/laser_cloud_map:1 /laser_cloud_surround:2 /velodyne_cloud_registered:{nframes}")
+    words = lines[4].split()
+    assert words[1] == str(nframes) and int(words[3]) > 1000 and int(words[5]) > 0 and int(words[7]) == len(feats[-1][2]) and words[9] == "rslidar"
+    assert lines[5] == f"tf {nframes} rslidar /aft_mapped"
+    rows = [ln.split() for ln in open(tmp_path / "mapped.txt").read().strip().splitlines()]
+    got = np.array([[float(v) for v in r[:7]] for r in rows])
+    assert len(rows) == nframes and all(r[8] == "rslidar" and r[9] == "/aft_mapped" for r in rows)
+    assert np.allclose(got, np.array(expect), rtol=0, atol=1e-9)
+    tfrow = np.array([float(v) for v in open(tmp_path / "tf.txt").read().split()])
+    assert np.array_equal(tfrow, got[-1])
+    # RESULT_PATH: one KITTI line per frame, the first one the identity (H_init^-1 H)
+    res = [[float(v) for v in ln.split()] for ln in open(tmp_path / "result.txt").read().strip().splitlines()]
+    assert len(res) == nframes and np.allclose(res[0], [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], atol=1e-6)
+    # the full-resolution scan in map coordinates: q_w_curr * p + t_w_curr in f64, stored f32 (:125-133)
+    regd = np.fromfile(tmp_path / "registered.f4", dtype=np.float32).reshape(-1, 4)
+    src = feats[-1][2].astype(np.float64)
+    want = np.array([_qrot(expect[-1][:4], p[:3]) + expect[-1][4:] for p in src[:500]])
+    assert np.allclose(regd[:500, :3], want.astype(np.float32), atol=1e-5) and np.array_equal(regd[:, 3], feats[-1][2][:, 3])
+    # high-frequency republish: position = the odometry moved by the last correction; orientation permuted as :237-240
+    hrows = [[float(v) for v in ln.split()[:7]] for ln in open(tmp_path / "high.txt").read().strip().splitlines()]
+    assert np.allclose(np.array(hrows)[:, 4:], np.array(expect_high), atol=1e-9)
+    x, y, z, w = hrows[0][:4]                                        # identity pose: roll = yaw = pi/2 -> q_after = (.5, .5, .5, .5)
+    assert np.allclose([x, y, z, w], [0.5, -0.5, 0.5, -0.5], atol=1e-12)
