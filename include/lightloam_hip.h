@@ -55,7 +55,7 @@ typedef struct {
     float lower_bound;        /* "lowerBound" default -24.9 */
     float up_bound;           /* "upBound" default 2 */
     int   max_points;         /* per-scan point capacity (<= 400000 like the reference arrays) */
-    int   max_ring_points;    /* per-ring capacity of the feature kernel's LDS staging */
+    int   max_ring_points;    /* per-ring capacity of the feature kernel's LDS staging: 32 .. 8192 (default 2304) */
     int   batch;              /* scan slots resident in HBM */
     /* thresholds; ll_default_params() fills the reference constants */
     float curv_threshold;     /* 0.1  (:266, :321) compared as double like the reference */

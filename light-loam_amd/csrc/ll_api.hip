@@ -77,7 +77,7 @@ extern "C" int ll_create(int device, const ll_params *p, ll_ctx **out)
     if (!p || !out) return LL_ERR_ARG;
     *out = nullptr;
     if (p->n_scans < 1 || p->n_scans > LL_MAX_RINGS || p->batch < 1 || p->max_points < 32 || p->max_points > 400000 ||
-        p->max_ring_points < 32 || p->max_ring_points > 9216) { g_create_err = "bad parameter"; return LL_ERR_ARG; }
+        p->max_ring_points < 32 || p->max_ring_points > 8192) { g_create_err = "bad parameter"; return LL_ERR_ARG; }
     if (!(p->nn_dist_sq_max > 0.0f) || p->nn_dist_sq_max > 36.0f) {
         /* the cell search is exact for any radius; the bound keeps the worst case (no neighbour: every ring of 1 m cells
          * inside the radius is looked up) at 13 x 13 cells */

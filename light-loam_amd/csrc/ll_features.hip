@@ -72,7 +72,7 @@ static size_t ll_feat_tile_bytes(size_t rows)
 size_t ll_features_lds_bytes(int max_ring)
 {
     const size_t mr = (size_t)((max_ring + 255) / 256 * 256);
-    const size_t rows = (mr / 256 <= 9) ? 9 : (mr / 256 <= 18) ? 18 : 36;     /* the ROWS instantiation that will run */
+    const size_t rows = (mr / 256 <= 9) ? 9 : (mr / 256 <= 18) ? 18 : 32;     /* the ROWS instantiation that will run */
     size_t b = 4 * mr + 2 * mr;              /* k32 + k16 */
     b += ll_feat_tile_bytes(rows);           /* tile / pick scratch */
     b += 2 * 4 * (mr / 32 + 2);              /* bitmaps */
@@ -85,7 +85,7 @@ size_t ll_features_lds_bytes(int max_ring)
 __device__ __forceinline__ FeatLds ll_carve(unsigned char *base, int max_ring)
 {
     const size_t mr = (size_t)((max_ring + 255) / 256 * 256);
-    const size_t rows = (mr / 256 <= 9) ? 9 : (mr / 256 <= 18) ? 18 : 36;     /* the ROWS instantiation that will run */
+    const size_t rows = (mr / 256 <= 9) ? 9 : (mr / 256 <= 18) ? 18 : 32;     /* the ROWS instantiation that will run */
     const size_t tile = 3 * 4 * (size_t)(LL_FTILE + 16), wscr = 4 * 64 * ((rows * 256 + 383) / 384) * 2, cbytes = 4 * (32 * rows * 4 + 4);
     const size_t tile_bytes = (tile > wscr ? tile : wscr) > cbytes ? (tile > wscr ? tile : wscr) : cbytes;
     FeatLds L;
@@ -241,6 +241,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char ll_smem[];
 template <int ROWS>
 __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : 1)) void k_ring_features(LLView V, int first, int count)
 {
+    static_assert(ROWS <= 32, "lfm / headm / endm hold one bit per row of a thread");
     int sl, r;
     if (!ll_xcd_map2(blockIdx.x, V.R, count, sl, r)) return;
     const int s = first + sl;
@@ -755,6 +756,6 @@ void ll_launch_features(const LLView &V, int first, int count, size_t lds_bytes,
     const int rows = (V.max_ring + 255) / 256;                 /* sort records per thread */
     if (rows <= 9) ll_launch_ring_features<9>(Ve, first, count, grid, lds_bytes, st);
     else if (rows <= 18) ll_launch_ring_features<18>(Ve, first, count, grid, lds_bytes, st);
-    else ll_launch_ring_features<36>(Ve, first, count, grid, lds_bytes, st);
+    else ll_launch_ring_features<32>(Ve, first, count, grid, lds_bytes, st);   /* <= 8192 points: the per-thread row masks are 32 bits wide */
     ll_prof_mark(prof, LL_K_END, st);
 }

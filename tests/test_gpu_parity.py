@@ -191,13 +191,14 @@ def test_hot_path_matches_staged(case, odo):
         assert (ctx.pose(k) == staged[i]).all()
 
 
-def test_long_ring_capacity_path(api, orc, synth):
-    """max_ring_points above 2304 switches the feature kernel to its 18-row instantiation (more records per thread in
-    the pick and the voxel sort); the published clouds must not change."""
+@pytest.mark.parametrize("max_ring_points", [4608, 8192])
+def test_long_ring_capacity_path(api, orc, synth, max_ring_points):
+    """max_ring_points above 2304 switches the feature kernel to its 18-row / 32-row instantiation (more records per
+    thread in the pick and the voxel sort); the published clouds must not change."""
     cfg = synth.default_cfg(64)
     scan = synth.scan(cfg, 3)
     ref = orc.extract(scan, orc.params(64))
-    ctx = api.Context(api.default_params(64, batch=1, max_points=len(scan), max_ring_points=4608))
+    ctx = api.Context(api.default_params(64, batch=1, max_points=len(scan), max_ring_points=max_ring_points))
     ctx.upload_scan(0, scan)
     ctx.extract(0, 1)
     f = ctx.features(0)
