@@ -46,6 +46,24 @@ int main(int argc, char **argv)
         std::cout << "odd_layout " << (ok2 && xyz.size() == 8 && xyz[0] == 1 && xyz[2] == 3 && xyz[3] == 0 && xyz[4] == 4 && xyz[6] == 6) << "\n";
         sensor_msgs::PointCloud2 bad = make_input(in, false); bad.fields[1].name = "why";
         std::cout << "missing_field_rejected " << !lightloam::ros_io::xyz_from_cloud2(bad, xyz) << "\n";
+        {   // organised cloud: 2 rows x 2 points, rows padded to 40 bytes, fields in the order z y x
+            sensor_msgs::PointCloud2 o;
+            const char *nm[3] = {"z", "y", "x"};
+            for (int k = 0; k < 3; ++k) { sensor_msgs::PointField f; f.name = nm[k]; f.offset = 4 * k; f.datatype = 7; f.count = 1; o.fields.push_back(f); }
+            o.height = 2; o.width = 2; o.point_step = 12; o.row_step = 40; o.data.assign(80, 0);
+            const float v[4][3] = {{3, 2, 1}, {6, 5, 4}, {9, 8, 7}, {12, 11, 10}};     // stored z y x
+            for (int r = 0; r < 2; ++r) for (int c = 0; c < 2; ++c) std::memcpy(&o.data[r * 40 + c * 12], v[r * 2 + c], 12);
+            std::vector<float> q;
+            const bool ok3 = lightloam::ros_io::xyz_from_cloud2(o, q);
+            std::cout << "organised " << (ok3 && q.size() == 16 && q[0] == 1 && q[1] == 2 && q[2] == 3 && q[12] == 10 && q[13] == 11 && q[14] == 12) << "\n";
+            o.data.resize(60);                                                           // second row cut short
+            std::cout << "short_data_rejected " << !lightloam::ros_io::xyz_from_cloud2(o, q) << "\n";
+            o.data.resize(80); o.is_bigendian = 1;
+            std::cout << "bigendian_rejected " << !lightloam::ros_io::xyz_from_cloud2(o, q) << "\n";
+            sensor_msgs::PointCloud2 e; lightloam::ros_io::cloud2_from_points({}, e);     // an empty cloud is a valid message
+            std::vector<lightloam::PointXYZI> ep;
+            std::cout << "empty " << (lightloam::ros_io::points_from_cloud2(e, ep) && ep.empty() && e.width == 0 && e.data.empty()) << "\n";
+        }
         D.params_i["scan_line"] = 48;                       // not 16 / 32 / 64: main() returns 0 before it needs a device (:447-451)
         int ac = 1; char *av[] = {argv[0], nullptr};
         (void)ac; (void)av;

@@ -28,7 +28,8 @@ def test_cloud2_layout_and_topic_surface_without_a_device(tmp_path, api):
     lines = out.stdout.strip().splitlines()
     assert lines[0] == "fields x@0:7x1 y@4:7x1 z@8:7x1 intensity@16:7x1"
     assert lines[1] == "step 32 row 96 h 1 w 3 dense 1 be 0 bytes 96"
-    assert lines[2:] == ["roundtrip 1", "odd_layout 1", "missing_field_rejected 1", "bad_scan_line_exit 0 advertised 0"]
+    assert lines[2:] == ["roundtrip 1", "odd_layout 1", "missing_field_rejected 1", "organised 1", "short_data_rejected 1",
+                         "bigendian_rejected 1", "empty 1", "bad_scan_line_exit 0 advertised 0"]
 
 
 @pytest.mark.parametrize("driver", ["ros_odometry_double", "ros_mapping_double"])
