@@ -290,17 +290,37 @@ __global__ __launch_bounds__(LL_VB) void k_vx_centroid(const float4 *pts, const 
                                                       const int *rank, int n, float4 *out, int *seg_count)
 {
     const int i = blockIdx.x * LL_VB + threadIdx.x;
-    if (i >= n || !flag[i]) return;
-    const unsigned long long key = keys[i];
-    /* CentroidPoint<PointXYZI>: f32 sums from zero in input order, divided by float(n) */
-    float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f; int cn = 0;
-    for (int j = i; j < n && keys[j] == key; ++j) {
-        const float4 p = pts[vals[j]];
-        sx += p.x; sy += p.y; sz += p.z; si += p.w; ++cn;
+    const bool head = i < n && flag[i];
+    int seg = -1;
+    if (head) {
+        const unsigned long long key = keys[i];
+        seg = (int)(key >> 32);
+        /* the run ends at the next head: one dependent load per step (flag) instead of three (key, index, point) */
+        int e = i + 1;
+        while (e < n && !flag[e]) ++e;
+        /* CentroidPoint<PointXYZI>: f32 sums from zero in input order, divided by float(n); four independent gathers in flight */
+        float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f;
+        for (int j = i; j < e; j += 4) {
+            int v[4]; float4 p[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (j + k < e) v[k] = vals[j + k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (j + k < e) p[k] = pts[v[k]];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (j + k < e) { sx += p[k].x; sy += p[k].y; sz += p[k].z; si += p[k].w; }
+        }
+        const float fn = (float)(e - i);
+        out[rank[i]] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
     }
-    const float fn = (float)cn;
-    out[rank[i]] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
-    atomicAdd(&seg_count[(int)(key >> 32)], 1);
+    /* voxels per segment: the keys are sorted by segment, so a wave holds one or two of them -- one atomic per wave and
+     * segment instead of one per voxel (tens of thousands of adds on a few dozen addresses serialise in the L2) */
+    unsigned long long todo = __ballot(head);
+    while (todo) {
+        const int s0 = __shfl(seg, __ffsll((long long)todo) - 1);
+        const unsigned long long same = __ballot(head && seg == s0);
+        if ((threadIdx.x & 63) == __ffsll((long long)same) - 1) atomicAdd(&seg_count[s0], __popcll(same));
+        todo &= ~same;
+    }
 }
 
 /* workspace for up to cap points / max_seg segments: one device allocation carved into LLVoxWork (ll_common.h) */
