@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256) void k_cm_assign(const float4 *stack, int n, c
                                                    float4 *tp, unsigned long long *keys, int *vals, int *addcnt)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    int cube = -1;                                            /* -1: no point / not counted */
+    if (i < n) {
     const float4 po = stack[i];
     const double ux = pose[0], uy = pose[1], uz = pose[2], w = pose[3];
     const double v[3] = {(double)po.x, (double)po.y, (double)po.z};
@@ -96,13 +97,20 @@ __global__ __launch_bounds__(256) void k_cm_assign(const float4 *stack, int n, c
     if ((double)sx + 25.0 < 0) ci--;
     if ((double)sy + 25.0 < 0) cj--;
     if ((double)sz + 25.0 < 0) ck--;
-    int cube = CM_N;
     if (ci >= 0 && ci < CM_W && cj >= 0 && cj < CM_H && ck >= 0 && ck < CM_D &&
-        (world == 1 || cm_owner(ci - cenx, cj - ceny, ck - cenz, world) == rank)) {          /* another rank's cube: not kept here */
-        cube = ci + CM_W * cj + CM_W * CM_H * ck; atomicAdd(&addcnt[cube], 1);
-    }
-    keys[i] = (unsigned long long)cube;
+        (world == 1 || cm_owner(ci - cenx, cj - ceny, ck - cenz, world) == rank))            /* another rank's cube: not kept here */
+        cube = ci + CM_W * cj + CM_W * CM_H * ck;
+    keys[i] = (unsigned long long)(cube >= 0 ? cube : CM_N);
     vals[i] = i;
+    }
+    /* the points of a scan fall into a handful of cubes: one add per wave and cube, not one per point on the same address */
+    unsigned long long todo = __ballot(cube >= 0);
+    while (todo) {
+        const int c0 = __shfl(cube, __ffsll((long long)todo) - 1);
+        const unsigned long long same = __ballot(cube == c0);
+        if ((threadIdx.x & 63) == __ffsll((long long)same) - 1) atomicAdd(&addcnt[c0], __popcll(same));
+        todo &= ~same;
+    }
 }
 
 void ll_sort_pairs(unsigned long long *keys, int *vals, unsigned long long *tmp_keys, int *tmp_vals, int n, int *hist, int *tile_sum,
