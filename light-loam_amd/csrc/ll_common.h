@@ -191,7 +191,9 @@ struct LLMapView {
     const int *gid[2];                           /* tile shard: global id per map point (nullptr: position in the cloud) */
     float4 *nn_pt[2]; int *nn_id[2];             /* tile shard: per stack point 5 x (x, y, z, distance) and 5 global ids */
     int row_rank, row_world;                     /* k_map_normal_eq sums the blocks i with i % row_world == row_rank (0, 1: all) */
+    double *neq_part; unsigned *neq_ticket;      /* k_map_normal_eq: per-workgroup partial sums [LL_NEQ_NB][28], arrival counter */
 };
+#define LL_NEQ_NB 16                             /* workgroups of k_map_normal_eq */
 void ll_map_launch_bbox(const float4 *pts, int n, int *bbox_dev, hipStream_t st);
 void ll_map_bbox_to_grid(const int bbox_host[6], int n, int max_cells, LLGrid3 *G);
 void ll_map_launch_build(const LLGrid3 &G, const float4 *pts, int n, int *tile_sum, hipStream_t st);

@@ -394,9 +394,12 @@ __global__ __launch_bounds__(1024) void k_map_compact(LLMapView M)
     }
 }
 
-__global__ __launch_bounds__(1024) void k_map_normal_eq(LLMapView M)
+/* Normal equations of the residual blocks at M.pose: LL_NEQ_NB workgroups accumulate their rows, the last one to arrive adds
+ * the partial sums in workgroup order (a fixed order: the result does not depend on which workgroup came last). */
+__global__ __launch_bounds__(256) void k_map_normal_eq(LLMapView M)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gtid = blockIdx.x * 256 + tid, gsz = LL_NEQ_NB * 256;
     Pose P;
     for (int k = 0; k < 4; ++k) P.q[k] = M.pose[k];
     for (int k = 0; k < 3; ++k) P.t[k] = M.pose[4 + k];
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(1024) void k_map_normal_eq(LLMapView M)
 #pragma unroll
     for (int k = 0; k < LL_NACC; ++k) acc[k] = 0.0;
     const int rw = M.row_world > 1 ? M.row_world : 1, rr = M.row_world > 1 ? M.row_rank : 0;   /* this rank's share of the blocks */
-    for (int i = rr + rw * tid; i < n_e; i += 1024 * rw) {
+    for (int i = rr + rw * gtid; i < n_e; i += gsz * rw) {
         double r[3], Jq[3][4], Jt[3][3];
         ll_edge_d(P, M.stk[0][M.src[0][i]], &M.fa[(size_t)i * 3], &M.fb[(size_t)i * 3], r, Jq, Jt);
         const double sc = ll_huber_scale(r[0] * r[0] + r[1] * r[1] + r[2] * r[2], M.huber, acc[27]);
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(1024) void k_map_normal_eq(LLMapView M)
             ll_acc_row(acc, J, r[row] * sc);
         }
     }
-    for (int i = rr + rw * tid; i < n_p; i += 1024 * rw) {
+    for (int i = rr + rw * gtid; i < n_p; i += gsz * rw) {
         double r, Jq[4], Jt[3], J[6];
         ll_plane_norm(P, M.stk[1][M.src[1][i]], &M.fn[(size_t)i * 3], M.fd[i], r, Jq, Jt);
         const double sc = ll_huber_scale(r * r, M.huber, acc[27]);
@@ -426,7 +429,9 @@ __global__ __launch_bounds__(1024) void k_map_normal_eq(LLMapView M)
         for (int k = 0; k < 6; ++k) J[k] *= sc;
         ll_acc_row(acc, J, r * sc);
     }
-    __shared__ double red[16][LL_NACC];
+    __shared__ double red[4][LL_NACC];
+    __shared__ double tot[LL_NACC];
+    __shared__ int s_last;
 #pragma unroll
     for (int k = 0; k < LL_NACC; ++k) {
         double v = acc[k];
@@ -434,15 +439,29 @@ __global__ __launch_bounds__(1024) void k_map_normal_eq(LLMapView M)
         if (lane == 0) red[wave][k] = v;
     }
     __syncthreads();
+    if (tid < LL_NACC) {
+        const double v = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+        __hip_atomic_store(&M.neq_part[blockIdx.x * LL_NACC + tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = (__hip_atomic_fetch_add(M.neq_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == LL_NEQ_NB - 1);
+    __syncthreads();
+    if (!s_last) return;
+    if (tid < LL_NACC) {
+        double v = 0.0;
+        for (int b = 0; b < LL_NEQ_NB; ++b) v += __hip_atomic_load(&M.neq_part[b * LL_NACC + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tot[tid] = v;
+    }
+    __syncthreads();
     if (tid == 0) {
-        double tot[LL_NACC];
-        for (int k = 0; k < LL_NACC; ++k) { double v = 0.0; for (int w = 0; w < 16; ++w) v += red[w][k]; tot[k] = v; }
         double *out = M.neq;
         int k = 0;
         for (int a = 0; a < 6; ++a) for (int b = a; b < 6; ++b) { out[a * 6 + b] = tot[k]; out[b * 6 + a] = tot[k]; ++k; }
         for (int a = 0; a < 6; ++a) out[36 + a] = tot[21 + a];
         out[42] = tot[27];
         out[43] = (double)(3 * ((n_e - rr + rw - 1) / rw) + (n_p - rr + rw - 1) / rw);   /* rows summed here */
+        __hip_atomic_store(M.neq_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   /* for the next launch */
     }
 }
 
@@ -541,7 +560,7 @@ void ll_map_launch_associate_merged(const LLMapView &M, int n_parts, const float
 
 void ll_map_launch_normal_eq(const LLMapView &M, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_map_normal_eq, dim3(1), dim3(1024), 0, st, M);
+    hipLaunchKernelGGL(k_map_normal_eq, dim3(LL_NEQ_NB), dim3(256), 0, st, M);
 }
 
 void ll_map_launch_rows(const LLMapView &M, double *r, double *Jq, double *Jt, hipStream_t st)
