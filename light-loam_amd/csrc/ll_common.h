@@ -194,6 +194,10 @@ struct LLMapView {
     double *neq_part; unsigned *neq_ticket;      /* k_map_normal_eq: per-workgroup partial sums [LL_NEQ_NB][28], arrival counter */
 };
 #define LL_NEQ_NB 16                             /* workgroups of k_map_normal_eq */
+/* device-to-device copy / small constant fill as kernel launches: on this stack an asynchronous copy costs the host ~26 us,
+ * a launch ~8 us, and the mapping stage issues dozens of them per frame */
+void ll_copy_d2d(void *dst, const void *src, size_t bytes, hipStream_t st);
+void ll_fill_words(int *dst, int n, int a, int b, int split, hipStream_t st);        /* dst[i] = i < split ? a : b */
 void ll_map_launch_bbox(const float4 *pts, int n, int *bbox_dev, hipStream_t st);
 void ll_map_bbox_to_grid(const int bbox_host[6], int n, int max_cells, LLGrid3 *G);
 void ll_map_launch_build(const LLGrid3 &G, const float4 *pts, int n, int *tile_sum, hipStream_t st);

@@ -382,7 +382,7 @@ extern "C" int ll_cubemap_update(ll_cubemap *cm, const double *pose_w7)
         for (int v = 0; v < cm->n_valid; ++v) cm->cnt[w][cm->valid[v]] = 0;
         rc = cm_reserve(cm, w, need); if (rc) return rc;
         float4 *pool = cm->pool[w][cm->cur[w]];
-        if (n_out > 0) CM_HIP(hipMemcpyAsync(pool + cm->top[w], cm->d_out, (size_t)n_out * sizeof(float4), hipMemcpyDeviceToDevice, st));
+        if (n_out > 0) ll_copy_d2d(pool + cm->top[w], cm->d_out, (size_t)n_out * sizeof(float4), st);
         size_t at = cm->top[w];
         for (int v = 0; v < cm->n_valid; ++v) { const int c = cm->valid[v]; cm->off[w][c] = (int)at; cm->cnt[w][c] = seg_count[v]; at += (size_t)seg_count[v]; }
         std::vector<CmOp> grow;

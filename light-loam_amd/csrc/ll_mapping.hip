@@ -507,8 +507,7 @@ void ll_device_exscan(int *data, int n, int *tile_sum, hipStream_t st)
 
 void ll_map_launch_bbox(const float4 *pts, int n, int *bbox_dev, hipStream_t st)
 {
-    const int init[6] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN};
-    (void)hipMemcpyAsync(bbox_dev, init, sizeof(init), hipMemcpyHostToDevice, st);
+    ll_fill_words(bbox_dev, 6, INT_MAX, INT_MIN, 3, st);
     if (n > 0) hipLaunchKernelGGL(k_map_bbox, dim3(min(1024, (n + LL_MAPB - 1) / LL_MAPB)), dim3(LL_MAPB), 0, st, pts, n, bbox_dev);
 }
 
@@ -534,7 +533,7 @@ void ll_map_launch_build(const LLGrid3 &G, const float4 *pts, int n, int *tile_s
     (void)hipMemsetAsync(G.start, 0, (size_t)ns * sizeof(int), st);
     if (n > 0) hipLaunchKernelGGL(k_map_count, dim3((n + LL_MAPB - 1) / LL_MAPB), dim3(LL_MAPB), 0, st, G, pts, n);
     ll_device_exscan(G.start, ns, tile_sum, st);
-    (void)hipMemcpyAsync(G.cursor, G.start, (size_t)G.ncell * sizeof(int), hipMemcpyDeviceToDevice, st);
+    ll_copy_d2d(G.cursor, G.start, (size_t)G.ncell * sizeof(int), st);
     if (n > 0) hipLaunchKernelGGL(k_map_scatter, dim3((n + LL_MAPB - 1) / LL_MAPB), dim3(LL_MAPB), 0, st, G, pts, n);
 }
 

@@ -17,8 +17,41 @@
  */
 #include "ll_common.h"
 #include <limits.h>
+#include <algorithm>
+#include <stdint.h>
 
 #define LL_VB 256
+
+__global__ __launch_bounds__(256) void k_copy_words(unsigned *dst, const unsigned *src, size_t nwords)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void k_copy_quads(uint4 *dst, const uint4 *src, size_t nquads)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nquads; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+__global__ void k_fill_words(int *dst, int n, int a, int b, int split)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = i < split ? a : b;
+}
+
+void ll_copy_d2d(void *dst, const void *src, size_t bytes, hipStream_t st)
+{
+    if (bytes == 0) return;
+    if ((((uintptr_t)dst | (uintptr_t)src | bytes) & 15) == 0) {
+        const size_t nq = bytes / 16;
+        hipLaunchKernelGGL(k_copy_quads, dim3((unsigned)std::min<size_t>(2048, (nq + 255) / 256)), dim3(256), 0, st, (uint4 *)dst, (const uint4 *)src, nq);
+    } else if ((((uintptr_t)dst | (uintptr_t)src | bytes) & 3) == 0) {
+        const size_t nw = bytes / 4;
+        hipLaunchKernelGGL(k_copy_words, dim3((unsigned)std::min<size_t>(2048, (nw + 255) / 256)), dim3(256), 0, st, (unsigned *)dst, (const unsigned *)src, nw);
+    } else (void)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
+}
+
+void ll_fill_words(int *dst, int n, int a, int b, int split, hipStream_t st)
+{
+    if (n > 0) hipLaunchKernelGGL(k_fill_words, dim3((n + 63) / 64), dim3(64), 0, st, dst, n, a, b, split);
+}
 
 __device__ __forceinline__ int ll_vx_f2ord(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
 __device__ __forceinline__ float ll_vx_ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
@@ -254,9 +287,8 @@ void ll_sort_pairs(unsigned long long *keys, int *vals, unsigned long long *tmp_
         hipLaunchKernelGGL(k_rs_small, dim3(1), dim3(1024), lds, st, keys, vals, n);
         return;
     }
-    const unsigned long long init[2] = {0ull, ~0ull};
     unsigned long long oa[2];
-    (void)hipMemcpyAsync(or_and_dev, init, sizeof(init), hipMemcpyHostToDevice, st);
+    ll_fill_words((int *)or_and_dev, 4, 0, -1, 2, st);              /* {0, ~0}: the OR and the AND of all keys start here */
     hipLaunchKernelGGL(k_rs_or_and, dim3(min(1024, (n + LL_VB - 1) / LL_VB)), dim3(LL_VB), 0, st, keys, n, or_and_dev);
     (void)hipMemcpyAsync(oa, or_and_dev, sizeof(oa), hipMemcpyDeviceToHost, st);
     (void)hipStreamSynchronize(st);
@@ -272,8 +304,8 @@ void ll_sort_pairs(unsigned long long *keys, int *vals, unsigned long long *tmp_
         int *tv = vi; vi = vo; vo = tv;
     }
     if (ki != keys) {
-        (void)hipMemcpyAsync(keys, ki, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToDevice, st);
-        (void)hipMemcpyAsync(vals, vi, (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, st);
+        ll_copy_d2d(keys, ki, (size_t)n * sizeof(unsigned long long), st);
+        ll_copy_d2d(vals, vi, (size_t)n * sizeof(int), st);
     }
 }
 
@@ -368,9 +400,9 @@ void ll_voxel_grid_segments(const float4 *pts, int n, int nseg, float leaf, cons
     hipLaunchKernelGGL(k_vx_keys, dim3((n + LL_VB - 1) / LL_VB), dim3(LL_VB), 0, st, pts, W.segid, W.seg_off, W.sp, n, inv, W.keys, W.vals);
     ll_sort_pairs(W.keys, W.vals, W.tmp_keys, W.tmp_vals, n, W.hist, W.tile_sum, W.or_and, st);
     hipLaunchKernelGGL(k_vx_heads, dim3((max(n, nseg) + LL_VB - 1) / LL_VB), dim3(LL_VB), 0, st, W.keys, n, nseg, W.flag, W.seg_count);
-    (void)hipMemcpyAsync(W.rank, W.flag, (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, st);
-    (void)hipMemsetAsync(W.rank + n, 0, sizeof(int), st);
+    ll_copy_d2d(W.rank, W.flag, (size_t)n * sizeof(int), st);
+    ll_fill_words(W.rank + n, 1, 0, 0, 1, st);
     ll_device_exscan(W.rank, n + 1, W.tile_sum, st);                 /* rank[n] = number of voxels */
-    (void)hipMemcpyAsync(n_out_dev, W.rank + n, sizeof(int), hipMemcpyDeviceToDevice, st);
+    ll_copy_d2d(n_out_dev, W.rank + n, sizeof(int), st);
     hipLaunchKernelGGL(k_vx_centroid, dim3((n + LL_VB - 1) / LL_VB), dim3(LL_VB), 0, st, pts, W.keys, W.vals, W.flag, W.rank, n, out, W.seg_count);
 }
