@@ -577,8 +577,7 @@ int ll_map_rebuild(ll_map *m, int n_corner, int n_surf)
         m->M.n_map[w] = n[w];
         ll_map_launch_bbox(m->d_map[w], n[w], m->d_bbox + 6 * w, st);
     }
-    LLM_HIP(hipMemcpyAsync(bbox, m->d_bbox, sizeof(bbox), hipMemcpyDeviceToHost, st));
-    LLM_HIP(hipStreamSynchronize(st));                          /* the grid dimensions are launch parameters */
+    if (ll_read_back(bbox, m->d_bbox, sizeof(bbox), st)) { m->err = "read-back failed"; return LL_ERR_HIP; }   /* the grid dimensions are launch parameters */
     for (int w = 0; w < 2; ++w) {
         ll_map_bbox_to_grid(bbox + 6 * w, n[w], m->max_cells, &m->M.grid[w]);
         ll_map_launch_build(m->M.grid[w], m->d_map[w], n[w], m->d_tile, st);
@@ -636,8 +635,7 @@ extern "C" int ll_map_get_counts(ll_map *m, int *n_edge, int *n_plane)
 {
     if (!m) return LL_ERR_ARG;
     int c[2];
-    LLM_HIP(hipMemcpyAsync(c, m->M.counts, sizeof(c), hipMemcpyDeviceToHost, m->ctx->stream));
-    LLM_HIP(hipStreamSynchronize(m->ctx->stream));
+    if (ll_read_back(c, m->M.counts, sizeof(c), m->ctx->stream)) { m->err = "read-back failed"; return LL_ERR_HIP; }
     if (n_edge) *n_edge = c[0];
     if (n_plane) *n_plane = c[1];
     return LL_OK;
@@ -795,8 +793,7 @@ extern "C" int ll_map_solve(ll_map *m, double *pose_w7, const ll_lm_options *opt
     int rc = map_set_pose(m, pose_w7); if (rc) return rc;
     map_lm_solve(m, o);
     LLM_HIP(hipGetLastError());
-    LLM_HIP(hipMemcpyAsync(pose_w7, m->M.pose, 7 * sizeof(double), hipMemcpyDeviceToHost, m->ctx->stream));
-    LLM_HIP(hipStreamSynchronize(m->ctx->stream));
+    if (ll_read_back(pose_w7, m->M.pose, 7 * sizeof(double), m->ctx->stream)) { m->err = "read-back failed"; return LL_ERR_HIP; }
     return LL_OK;
 }
 
@@ -818,8 +815,7 @@ extern "C" int ll_map_optimize(ll_map *m, double *pose_w7, int n_outer, const ll
         map_lm_solve(m, o);
     }
     LLM_HIP(hipGetLastError());
-    LLM_HIP(hipMemcpyAsync(pose_w7, m->M.pose, 7 * sizeof(double), hipMemcpyDeviceToHost, st));
-    LLM_HIP(hipStreamSynchronize(st));
+    if (ll_read_back(pose_w7, m->M.pose, 7 * sizeof(double), st)) { m->err = "read-back failed"; return LL_ERR_HIP; }
     if (ran) *ran = 1;
     return LL_OK;
 }
@@ -858,8 +854,7 @@ extern "C" int ll_map_set_pose(ll_map *m, const double *pose_w7)
 extern "C" int ll_map_get_pose(ll_map *m, double *pose_w7)
 {
     if (!m || !pose_w7) return LL_ERR_ARG;
-    LLM_HIP(hipMemcpyAsync(pose_w7, m->M.pose, 7 * sizeof(double), hipMemcpyDeviceToHost, m->ctx->stream));
-    LLM_HIP(hipStreamSynchronize(m->ctx->stream));
+    if (ll_read_back(pose_w7, m->M.pose, 7 * sizeof(double), m->ctx->stream)) { m->err = "read-back failed"; return LL_ERR_HIP; }
     return LL_OK;
 }
 

@@ -196,6 +196,8 @@ struct LLMapView {
 #define LL_NEQ_NB 16                             /* workgroups of k_map_normal_eq */
 /* device-to-device copy / small constant fill as kernel launches: on this stack an asynchronous copy costs the host ~26 us,
  * a launch ~8 us, and the mapping stage issues dozens of them per frame */
+void *ll_pinned_scratch(size_t bytes);                                               /* per host thread, page-locked, >= bytes (NULL on failure) */
+int ll_read_back(void *host_dst, const void *dev_src, size_t bytes, hipStream_t st);  /* small device -> host copy + stream sync through it */
 void ll_copy_d2d(void *dst, const void *src, size_t bytes, hipStream_t st);
 void ll_fill_words(int *dst, int n, int a, int b, int split, hipStream_t st);        /* dst[i] = i < split ? a : b */
 void ll_map_launch_bbox(const float4 *pts, int n, int *bbox_dev, hipStream_t st);

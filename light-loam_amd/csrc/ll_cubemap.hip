@@ -277,8 +277,7 @@ static int cm_prepare(ll_cubemap *cm, const double *t_w3, const ll_point *corner
             CM_HIP(hipMemcpyAsync(cm->d_last, src[w], (size_t)n_in[w] * sizeof(ll_point), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
             CM_HIP(hipMemcpyAsync(cm->W.seg_off, seg_off, sizeof(seg_off), hipMemcpyHostToDevice, st));
             ll_voxel_grid_segments(cm->d_last, n_in[w], 1, cm->leaf[w], cm->W, cm->map->d_stk[w], cm->d_nout, st);
-            CM_HIP(hipMemcpyAsync(&n_out, cm->d_nout, sizeof(int), hipMemcpyDeviceToHost, st));
-            CM_HIP(hipStreamSynchronize(st));
+            if (ll_read_back(&n_out, cm->d_nout, sizeof(int), st)) { cm->err = "read-back failed"; return LL_ERR_HIP; }
         }
         cm->map->M.n_stk[w] = n_out;
     }
@@ -350,8 +349,7 @@ extern "C" int ll_cubemap_update(ll_cubemap *cm, const double *pose_w7)
                                cm->d_tp, cm->d_keys, cm->d_vals, cm->d_addcnt);
             ll_sort_pairs(cm->d_keys, cm->d_vals, cm->WS.keys, cm->WS.vals, ns, cm->WS.hist, cm->WS.tile_sum, cm->WS.or_and, st);   /* by cube, stack order kept */
         }
-        CM_HIP(hipMemcpyAsync(addcnt.data(), cm->d_addcnt, (CM_N + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
-        CM_HIP(hipStreamSynchronize(st));
+        if (ll_read_back(addcnt.data(), cm->d_addcnt, (CM_N + 1) * sizeof(int), st)) { cm->err = "read-back failed"; return LL_ERR_HIP; }
         goff[0] = 0;
         for (int c = 0; c < CM_N; ++c) goff[c + 1] = goff[c] + addcnt[c];              /* the new points of cube c in the sorted order */
         /* one voxel-grid segment per valid cube: its cloud, then its new points (:2119-2125 push_back, :2151-2165 filter) */
@@ -371,9 +369,16 @@ extern "C" int ll_cubemap_update(ll_cubemap *cm, const double *pose_w7)
         if (tot > 0) {
             CM_HIP(hipMemcpyAsync(cm->W.seg_off, seg_off.data(), seg_off.size() * sizeof(int), hipMemcpyHostToDevice, st));
             ll_voxel_grid_segments(cm->d_work, (int)tot, cm->n_valid, cm->leaf[w], cm->W, cm->d_out, cm->d_nout, st);
-            CM_HIP(hipMemcpyAsync(seg_count.data(), cm->W.seg_count, (size_t)cm->n_valid * sizeof(int), hipMemcpyDeviceToHost, st));
-            CM_HIP(hipMemcpyAsync(&n_out, cm->d_nout, sizeof(int), hipMemcpyDeviceToHost, st));
-            CM_HIP(hipStreamSynchronize(st));
+            /* seg_count and n_out in one page-locked read-back: n_out first, then the counts */
+            {
+                int *pin = (int *)ll_pinned_scratch((size_t)(cm->n_valid + 1) * sizeof(int));
+                if (!pin) { cm->err = "no page-locked scratch"; return LL_ERR_HIP; }
+                CM_HIP(hipMemcpyAsync(pin, cm->d_nout, sizeof(int), hipMemcpyDeviceToHost, st));
+                CM_HIP(hipMemcpyAsync(pin + 1, cm->W.seg_count, (size_t)cm->n_valid * sizeof(int), hipMemcpyDeviceToHost, st));
+                CM_HIP(hipStreamSynchronize(st));
+                n_out = pin[0];
+                for (int k = 0; k < cm->n_valid; ++k) seg_count[(size_t)k] = pin[1 + k];
+            }
         }
         /* pool space: the filtered valid cubes + the grown clouds of the other cubes that received points */
         size_t need = (size_t)n_out;
