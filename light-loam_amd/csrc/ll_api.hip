@@ -428,8 +428,7 @@ extern "C" int ll_odometry_frames(ll_ctx *ctx, int first, int count, const doubl
     }
     LL_HIP(hipGetLastError());
     if (host_poses_out) {
-        LL_HIP(hipMemcpyAsync(host_poses_out, ctx->V.pose + (size_t)first * 7, (size_t)count * 7 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        LL_HIP(hipStreamSynchronize(ctx->stream));
+        if (ll_read_back(host_poses_out, ctx->V.pose + (size_t)first * 7, (size_t)count * 7 * sizeof(double), ctx->stream)) { ctx->err = "read-back failed"; return LL_ERR_HIP; }
     }
     return LL_OK;
 }
@@ -932,8 +931,7 @@ static int dl(ll_ctx *ctx, void *dst, const void *src, size_t bytes)
 
 static int fetch_hdr(ll_ctx *ctx, int slot, ScanHdr *h)
 {
-    LL_HIP(hipMemcpyAsync(h, ctx->V.hdr + slot, sizeof(ScanHdr), hipMemcpyDeviceToHost, ctx->stream));
-    LL_HIP(hipStreamSynchronize(ctx->stream));
+    if (ll_read_back(h, ctx->V.hdr + slot, sizeof(ScanHdr), ctx->stream)) { ctx->err = "read-back failed"; return LL_ERR_HIP; }
     return LL_OK;
 }
 
@@ -998,8 +996,7 @@ extern "C" int ll_download_features(ll_ctx *ctx, int slot, ll_point *sharp, int 
 
 static int fetch_pair(ll_ctx *ctx, int slot, PairHdr *p)
 {
-    LL_HIP(hipMemcpyAsync(p, ctx->V.pair + slot, sizeof(PairHdr), hipMemcpyDeviceToHost, ctx->stream));
-    LL_HIP(hipStreamSynchronize(ctx->stream));
+    if (ll_read_back(p, ctx->V.pair + slot, sizeof(PairHdr), ctx->stream)) { ctx->err = "read-back failed"; return LL_ERR_HIP; }
     return LL_OK;
 }
 
