@@ -41,8 +41,16 @@ __global__ __launch_bounds__(LL_MAPB) void k_map_bbox(const float4 *pts, int n, 
     }
     for (int o = 32; o > 0; o >>= 1)
         for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], o)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o)); }
-    if ((threadIdx.x & 63) == 0)
-        for (int k = 0; k < 3; ++k) { atomicMin(&bbox[k], ll_f2ord(mn[k])); atomicMax(&bbox[3 + k], ll_f2ord(mx[k])); }
+    /* one set of global atomics per workgroup (they all hit the same six words) */
+    __shared__ float red[LL_MAPB / 64][6];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) for (int k = 0; k < 3; ++k) { red[wave][k] = mn[k]; red[wave][3 + k] = mx[k]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = red[0][threadIdx.x];
+        for (int w = 1; w < LL_MAPB / 64; ++w) v = threadIdx.x < 3 ? fminf(v, red[w][threadIdx.x]) : fmaxf(v, red[w][threadIdx.x]);
+        if (threadIdx.x < 3) atomicMin(&bbox[threadIdx.x], ll_f2ord(v)); else atomicMax(&bbox[threadIdx.x], ll_f2ord(v));
+    }
 }
 
 __device__ __forceinline__ int ll_cell3(const LLGrid3 &G, float x, float y, float z)
