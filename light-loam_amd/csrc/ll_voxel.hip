@@ -9,7 +9,7 @@
  * intensity: f32 sums divided by the count) per distinct index, in index order.  Here:
  *   k_vx_segid / k_vx_bbox / k_vx_params / k_vx_keys   segment of every point, bounding boxes by ordered-int atomics,
  *                       PCL's box arithmetic per segment, 64-bit keys (segment << 32 | voxel index)
- *   ll_sort_pairs       device-wide stable LSD radix sort (4-bit digits; tile histograms -> scan -> stable scatter with
+ *   ll_sort_pairs       device-wide stable LSD radix sort (8-bit digits; tile histograms -> scan -> stable scatter with
  *                       wave match-any ranking); digits that are equal for all keys are skipped
  *   k_vx_heads / scan / k_vx_centroid   run heads -> output rank -> sums in INPUT order (the sort is stable; PCL's
  *                       std::sort leaves the order inside a voxel unspecified, the oracle defines input order too)
@@ -170,59 +170,66 @@ __global__ __launch_bounds__(LL_VB) void k_rs_or_and(const unsigned long long *k
     if ((threadIdx.x & 63) == 0) { atomicOr(&or_and[0], o); atomicAnd(&or_and[1], a); }
 }
 
-__global__ __launch_bounds__(1024) void k_rs_hist(const unsigned long long *keys, int n, int shift, int nblk, int *hist /* [16][nblk] */)
+/* 8-bit digits (a pass is five launches: histogram, three for the scan, scatter).  A tile is 16 waves x 256
+ * consecutive keys; a wave ranks its four rows one after the other into its own 256 counters (its LDS operations execute in
+ * order), the rank inside a row is a wave match-any, and one scan of the digit-major (digit, wave) table turns the counters
+ * into offsets inside the tile's share of every digit -- the scheme of k_ring_features' voxel sort. */
+__global__ __launch_bounds__(1024) void k_rs_hist8(const unsigned long long *keys, int n, int shift, int nblk, int *hist /* [256][nblk] */)
 {
-    __shared__ int h[16];
+    __shared__ int h[256];
     const int tid = threadIdx.x;
-    if (tid < 16) h[tid] = 0;
+    if (tid < 256) h[tid] = 0;
     __syncthreads();
     const int base = blockIdx.x * LL_RS_TILE;
 #pragma unroll
     for (int r = 0; r < LL_RS_ROWS; ++r) {
         const int i = base + r * 1024 + tid;
-        const bool in = i < n;
-        const int d = in ? (int)((keys[i] >> shift) & 15ull) : 0;
-        unsigned mlo, mhi;
-        ll_match_any(d, 4, __ballot(in), mlo, mhi);
-        if (in && ll_match_rank(mlo, mhi) == 0) atomicAdd(&h[d], ll_match_count(mlo, mhi));
+        if (i < n) atomicAdd(&h[(int)((keys[i] >> shift) & 255ull)], 1);
     }
     __syncthreads();
-    if (tid < 16) hist[tid * nblk + blockIdx.x] = h[tid];
+    if (tid < 256) hist[tid * nblk + blockIdx.x] = h[tid];
 }
 
-__global__ __launch_bounds__(1024) void k_rs_scatter(const unsigned long long *keys, const int *vals, int n, int shift, int nblk,
-                                                     const int *hist_scanned, unsigned long long *keys_out, int *vals_out)
+__global__ __launch_bounds__(1024) void k_rs_scatter8(const unsigned long long *keys, const int *vals, int n, int shift, int nblk,
+                                                      const int *hist_scanned, unsigned long long *keys_out, int *vals_out)
 {
-    __shared__ int cnt[16 * LL_RS_ROWS * 16];        /* [digit][row * 16 + wave] */
+    __shared__ int cnt[16][256];                     /* [wave][digit] */
     __shared__ int sc[16];
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    cnt[tid] = 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 16 * 256; i += 1024) (&cnt[0][0])[i] = 0;
     __syncthreads();
-    const int base = blockIdx.x * LL_RS_TILE;
+    const int base = blockIdx.x * LL_RS_TILE + wave * (LL_RS_ROWS * 64);       /* the wave's 256 consecutive keys */
     unsigned long long k[LL_RS_ROWS]; int v[LL_RS_ROWS], rnk[LL_RS_ROWS];
+    int *wc = cnt[wave];
 #pragma unroll
     for (int r = 0; r < LL_RS_ROWS; ++r) {
-        const int i = base + r * 1024 + tid;
+        const int i = base + r * 64 + lane;
         const bool in = i < n;
         k[r] = in ? keys[i] : ~0ull; v[r] = in ? vals[i] : 0;
-        const int d = (int)((k[r] >> shift) & 15ull);
+        const int d = (int)((k[r] >> shift) & 255ull);
         unsigned mlo, mhi;
-        ll_match_any(d, 4, __ballot(in), mlo, mhi);
-        rnk[r] = ll_match_rank(mlo, mhi);
-        if (in && rnk[r] == 0) cnt[d * (LL_RS_ROWS * 16) + r * 16 + wave] = ll_match_count(mlo, mhi);
+        ll_match_any(d, 8, __ballot(in), mlo, mhi);
+        const int rk = ll_match_rank(mlo, mhi);
+        const int pre = in ? wc[d] : 0;                                          /* earlier rows of this wave with digit d */
+        rnk[r] = pre + rk;
+        if (in && rk == 0) wc[d] = pre + ll_match_count(mlo, mhi);
     }
     __syncthreads();
-    const int mine = cnt[tid];
+    /* exclusive scan of the table in digit-major order: thread t owns entries 4t .. 4t+3 of [digit][wave] */
+    int e[4]; int sum = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int idx = 4 * tid + u; e[u] = cnt[idx & 15][idx >> 4]; sum += e[u]; }
     int total;
-    const int ex = ll_block_exscan_n<16>(mine, sc, total);       /* digit-major: earlier digits, then earlier (row, wave) */
-    cnt[tid] = ex;
+    int run = ll_block_exscan_n<16>(sum, sc, total);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int idx = 4 * tid + u; cnt[idx & 15][idx >> 4] = run; run += e[u]; }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < LL_RS_ROWS; ++r) {
-        const int i = base + r * 1024 + tid;
+        const int i = base + r * 64 + lane;
         if (i >= n) continue;
-        const int d = (int)((k[r] >> shift) & 15ull);
-        const int within = cnt[d * (LL_RS_ROWS * 16) + r * 16 + wave] - cnt[d * (LL_RS_ROWS * 16)] + rnk[r];
+        const int d = (int)((k[r] >> shift) & 255ull);
+        const int within = cnt[wave][d] - cnt[0][d] + rnk[r];                   /* earlier waves' keys of this digit, then this wave's */
         const int pos = hist_scanned[d * nblk + blockIdx.x] + within;
         keys_out[pos] = k[r]; vals_out[pos] = v[r];
     }
@@ -320,11 +327,11 @@ void ll_sort_pairs(unsigned long long *keys, int *vals, unsigned long long *tmp_
     const unsigned long long vary = oa[0] ^ oa[1];                /* bits that differ between some two keys */
     const int nblk = (n + LL_RS_TILE - 1) / LL_RS_TILE;
     unsigned long long *ki = keys, *ko = tmp_keys; int *vi = vals, *vo = tmp_vals;
-    for (int shift = 0; shift < 64; shift += 4) {
-        if (((vary >> shift) & 15ull) == 0ull) continue;
-        hipLaunchKernelGGL(k_rs_hist, dim3(nblk), dim3(1024), 0, st, ki, n, shift, nblk, hist);
-        ll_device_exscan(hist, 16 * nblk, tile_sum, st);
-        hipLaunchKernelGGL(k_rs_scatter, dim3(nblk), dim3(1024), 0, st, ki, vi, n, shift, nblk, hist, ko, vo);
+    for (int shift = 0; shift < 64; shift += 8) {
+        if (((vary >> shift) & 255ull) == 0ull) continue;
+        hipLaunchKernelGGL(k_rs_hist8, dim3(nblk), dim3(1024), 0, st, ki, n, shift, nblk, hist);
+        ll_device_exscan(hist, 256 * nblk, tile_sum, st);
+        hipLaunchKernelGGL(k_rs_scatter8, dim3(nblk), dim3(1024), 0, st, ki, vi, n, shift, nblk, hist, ko, vo);
         unsigned long long *tk = ki; ki = ko; ko = tk;
         int *tv = vi; vi = vo; vo = tv;
     }
@@ -389,7 +396,7 @@ size_t ll_vox_work_bytes(int cap, int max_seg)
     b += (size_t)cap * sizeof(unsigned long long) * 2;              /* keys, tmp_keys */
     b += (size_t)max_seg * (6 + 1 + 1) * sizeof(int) + sizeof(int); /* bbox, seg_off (+1), seg_count */
     b += (size_t)max_seg * sizeof(LLVoxSeg);
-    b += 16 * nblk * sizeof(int) + (16 * nblk / 4096 + 2) * sizeof(int) + ((size_t)cap / 4096 + 2) * sizeof(int);
+    b += 256 * nblk * sizeof(int) + (256 * nblk / 4096 + 2) * sizeof(int) + ((size_t)cap / 4096 + 2) * sizeof(int);
     b += 2 * sizeof(unsigned long long);
     return b + 4096;
 }
@@ -406,8 +413,8 @@ void ll_vox_work_carve(void *base, int cap, int max_seg, LLVoxWork *W)
     W->vals = (int *)take((size_t)cap * 4); W->tmp_vals = (int *)take((size_t)cap * 4);
     W->bbox = (int *)take((size_t)max_seg * 24); W->seg_off = (int *)take((size_t)(max_seg + 1) * 4); W->seg_count = (int *)take((size_t)max_seg * 4);
     W->sp = (LLVoxSeg *)take((size_t)max_seg * sizeof(LLVoxSeg));
-    W->hist = (int *)take(16 * nblk * 4);
-    W->tile_sum = (int *)take((16 * nblk / 4096 + 2 + (size_t)cap / 4096 + 2) * 4);
+    W->hist = (int *)take(256 * nblk * 4);
+    W->tile_sum = (int *)take((256 * nblk / 4096 + 2 + (size_t)cap / 4096 + 2) * 4);
 }
 
 /* pts[0..n): nseg clouds back to back, seg_off (device, nseg + 1 ascending offsets, seg_off[nseg] = n).
