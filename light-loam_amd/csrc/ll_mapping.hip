@@ -382,7 +382,8 @@ __global__ __launch_bounds__(1024) void k_map_compact(LLMapView M)
 {
     __shared__ int sc[16];
     const int tid = threadIdx.x;
-    for (int which = 0; which < 2; ++which) {
+    {
+        const int which = blockIdx.x;                                /* one workgroup per cloud type: they are independent */
         const int n = M.n_stk[which];
         const int per = (n + 1023) / 1024;
         const int a0 = min(n, tid * per), a1 = min(n, a0 + per);
@@ -398,7 +399,6 @@ __global__ __launch_bounds__(1024) void k_map_compact(LLMapView M)
             ++pos;
         }
         if (tid == 0) M.counts[which] = total;
-        __syncthreads();
     }
 }
 
@@ -549,7 +549,7 @@ void ll_map_launch_associate(const LLMapView &M, hipStream_t st)
 {
     if (M.n_stk[0] > 0) hipLaunchKernelGGL(k_map_knn<true>, dim3((M.n_stk[0] + LL_MAPB - 1) / LL_MAPB), dim3(LL_MAPB), 0, st, M);
     if (M.n_stk[1] > 0) hipLaunchKernelGGL(k_map_knn<false>, dim3((M.n_stk[1] + LL_MAPB - 1) / LL_MAPB), dim3(LL_MAPB), 0, st, M);
-    hipLaunchKernelGGL(k_map_compact, dim3(1), dim3(1024), 0, st, M);
+    hipLaunchKernelGGL(k_map_compact, dim3(2), dim3(1024), 0, st, M);
 }
 
 void ll_map_launch_knn_partial(const LLMapView &M, hipStream_t st)
@@ -562,7 +562,7 @@ void ll_map_launch_associate_merged(const LLMapView &M, int n_parts, const float
 {
     if (M.n_stk[0] > 0) hipLaunchKernelGGL(k_map_fit_merged<true>, dim3((M.n_stk[0] + LL_MAPB - 1) / LL_MAPB), dim3(LL_MAPB), 0, st, M, n_parts, pt_all[0], id_all[0]);
     if (M.n_stk[1] > 0) hipLaunchKernelGGL(k_map_fit_merged<false>, dim3((M.n_stk[1] + LL_MAPB - 1) / LL_MAPB), dim3(LL_MAPB), 0, st, M, n_parts, pt_all[1], id_all[1]);
-    hipLaunchKernelGGL(k_map_compact, dim3(1), dim3(1024), 0, st, M);
+    hipLaunchKernelGGL(k_map_compact, dim3(2), dim3(1024), 0, st, M);
 }
 
 void ll_map_launch_normal_eq(const LLMapView &M, hipStream_t st)
