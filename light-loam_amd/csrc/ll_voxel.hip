@@ -99,18 +99,38 @@ __global__ __launch_bounds__(LL_VB) void k_vx_bbox(const float4 *pts, const int 
     const bool in = i < n;
     const float4 p = in ? pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     const int s = in ? segid[i] : -1;
-    /* most waves hold one segment: reduce in the wave, one set of atomics */
+    /* most waves hold one segment: reduce in the wave; most workgroups do too: then one set of atomics per workgroup
+     * (a segment's box is six words that every one of its points would otherwise hit) */
+    const int wave = threadIdx.x >> 6;
     const int s0 = __builtin_amdgcn_readfirstlane(s);
-    if (__ballot(s != s0 && in) == 0ull && s0 >= 0) {
-        float mn[3] = {in ? p.x : INFINITY, in ? p.y : INFINITY, in ? p.z : INFINITY};
-        float mx[3] = {in ? p.x : -INFINITY, in ? p.y : -INFINITY, in ? p.z : -INFINITY};
+    const bool uniform = __ballot(s != s0 && in) == 0ull && s0 >= 0;
+    __shared__ float red[LL_VB / 64][6];
+    __shared__ int wseg[LL_VB / 64];
+    float mn[3] = {in ? p.x : INFINITY, in ? p.y : INFINITY, in ? p.z : INFINITY};
+    float mx[3] = {in ? p.x : -INFINITY, in ? p.y : -INFINITY, in ? p.z : -INFINITY};
+    if (uniform) {
         for (int o = 32; o > 0; o >>= 1)
             for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], o)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o)); }
-        if ((threadIdx.x & 63) == 0)
-            for (int k = 0; k < 3; ++k) { atomicMin(&bbox[s0 * 6 + k], ll_vx_f2ord(mn[k])); atomicMax(&bbox[s0 * 6 + 3 + k], ll_vx_f2ord(mx[k])); }
+        if ((threadIdx.x & 63) == 0) for (int k = 0; k < 3; ++k) { red[wave][k] = mn[k]; red[wave][3 + k] = mx[k]; }
     } else if (in) {
         atomicMin(&bbox[s * 6 + 0], ll_vx_f2ord(p.x)); atomicMin(&bbox[s * 6 + 1], ll_vx_f2ord(p.y)); atomicMin(&bbox[s * 6 + 2], ll_vx_f2ord(p.z));
         atomicMax(&bbox[s * 6 + 3], ll_vx_f2ord(p.x)); atomicMax(&bbox[s * 6 + 4], ll_vx_f2ord(p.y)); atomicMax(&bbox[s * 6 + 5], ll_vx_f2ord(p.z));
+    }
+    if ((threadIdx.x & 63) == 0) wseg[wave] = uniform ? s0 : -1;      /* -1: nothing left to merge for this wave */
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        /* merge the waves that hold the same segment as an earlier wave into that wave's slot, then one atomic per distinct segment */
+        for (int w = 0; w < LL_VB / 64; ++w) {
+            const int sw = wseg[w];
+            if (sw < 0) continue;
+            bool first = true;
+            for (int u = 0; u < w; ++u) if (wseg[u] == sw) first = false;
+            if (!first) continue;
+            float v = red[w][k];
+            for (int u = w + 1; u < LL_VB / 64; ++u) if (wseg[u] == sw) v = k < 3 ? fminf(v, red[u][k]) : fmaxf(v, red[u][k]);
+            if (k < 3) atomicMin(&bbox[sw * 6 + k], ll_vx_f2ord(v)); else atomicMax(&bbox[sw * 6 + k], ll_vx_f2ord(v));
+        }
     }
 }
 
