@@ -47,7 +47,7 @@ void *ll_pinned_scratch(size_t bytes)
         if (buf) (void)hipHostFree(buf);
         buf = nullptr; cap = 0;
         const size_t want = bytes < 32768 ? 32768 : bytes;
-        if (hipHostMalloc(&buf, want, hipHostMallocDefault) != hipSuccess) { buf = nullptr; return nullptr; }
+        if (hipHostMalloc(&buf, want, hipHostMallocPortable) != hipSuccess) { buf = nullptr; return nullptr; }
         cap = want;
     }
     return buf;
