@@ -43,13 +43,28 @@ def build_synth(force=False):
 
 
 def build_hip(force=False, extra_flags=()):
+    """One object per .hip file (compiled in parallel, rebuilt only when it or a header changed), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
     out = lib_path()
-    deps = _all_files(_CSRC, (".hip", ".h", ".hpp")) + [os.path.join(_ROOT, "include", "lightloam_hip.h")]
-    if force or _newer(out, deps):
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        cmd = [hipcc] + HIPCC_FLAGS + list(extra_flags) + ["-I", os.path.join(_ROOT, "include"), "-I", _CSRC,
-                                                          "-o", out] + [os.path.join(_CSRC, s) for s in HIP_SOURCES]
-        subprocess.check_call(cmd)
+    hdrs = _all_files(_CSRC, (".h", ".hpp")) + [os.path.join(_ROOT, "include", "lightloam_hip.h")]
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = os.path.join(_CSRC, "_obj" + ("_" + str(abs(hash(tuple(extra_flags))) % 10**8) if extra_flags else ""))
+    os.makedirs(objdir, exist_ok=True)
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags) + ["-I", os.path.join(_ROOT, "include"), "-I", _CSRC]
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        path = os.path.join(_CSRC, src)
+        if force or _newer(obj, [path] + hdrs):
+            subprocess.check_call([hipcc] + cflags + ["-c", "-o", obj, path])
+            return obj, True
+        return obj, False
+
+    with ThreadPoolExecutor(max_workers=min(6, len(HIP_SOURCES))) as ex:
+        res = list(ex.map(compile_one, HIP_SOURCES))
+    objs = [o for o, _ in res]
+    if force or any(ch for _, ch in res) or _newer(out, objs):
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
     return out
 
 

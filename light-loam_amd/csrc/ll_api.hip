@@ -183,13 +183,24 @@ extern "C" int ll_create(int device, const ll_params *p, ll_ctx **out)
 extern "C" int ll_synchronize(ll_ctx *ctx)
 {
     if (!ctx) return LL_ERR_ARG;
+    LL_HIP(hipSetDevice(ctx->device));
     LL_HIP(hipStreamSynchronize(ctx->stream));
+    return LL_OK;
+}
+
+/* Every entry point that launches, allocates or copies starts here: the calling thread's current device becomes the
+ * context's (kernel attributes such as the dynamic-LDS limit, hipMalloc and the launches themselves act on the CURRENT
+ * device, not on the stream's), so contexts on several GPUs can be driven from one thread. */
+static int ll_enter(ll_ctx *ctx)
+{
+    if (!ctx) return LL_ERR_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return LL_ERR_HIP; }
     return LL_OK;
 }
 
 static int check_range(ll_ctx *ctx, int first, int count)
 {
-    if (!ctx) return LL_ERR_ARG;
+    int rc = ll_enter(ctx); if (rc) return rc;
     if (first < 0 || count < 1 || first + count > ctx->p.batch) { ctx->err = "slot range out of bounds"; return LL_ERR_ARG; }
     return LL_OK;
 }
@@ -243,7 +254,7 @@ extern "C" int ll_set_pose_guess(ll_ctx *ctx, int first, int count, const double
 
 extern "C" int ll_set_target(ll_ctx *ctx, const ll_point *corner, int m_c, const ll_point *surf, int m_s)
 {
-    if (!ctx) return LL_ERR_ARG;
+    int rc0 = ll_enter(ctx); if (rc0) return rc0;
     LLView &V = ctx->V;
     if (m_c < 0 || m_s < 0 || m_c > V.cap_lsharp || m_s > V.NP) { ctx->err = "target larger than capacity"; return LL_ERR_CAPACITY; }
     if (m_c) LL_HIP(hipMemcpyAsync(V.carry_corner, corner, (size_t)m_c * 16, hipMemcpyHostToDevice, ctx->stream));
@@ -272,6 +283,10 @@ extern "C" int ll_upload_features(ll_ctx *ctx, int slot, const ll_point *sharp, 
     h.n_sharp = ns; h.n_less_sharp = nls; h.n_flat = nf; h.n_less_flat = nlf;
     h.status = 0;
     LL_HIP(hipMemcpyAsync(V.hdr + slot, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+    /* the slot may become the target of slot + 1 (ll_associate_batch / ll_odometry_frames over a range): its search grid and
+     * ring tables are part of "serving like an extracted slot" */
+    ll_launch_build_grid(V, slot, 1, 0, ctx->stream, nullptr);
+    LL_HIP(hipGetLastError());
     LL_HIP(hipStreamSynchronize(ctx->stream));              /* the host arrays and h may go away */
     if ((size_t)slot < ctx->n_in_host.size()) ctx->n_in_host[slot] = 0;
     return LL_OK;
@@ -321,6 +336,7 @@ extern "C" int ll_vote_host(ll_ctx *ctx, const ll_point *src, const ll_point *tg
 {
     if (!ctx || n < 0 || (n > 0 && (!src || !tgt))) return LL_ERR_ARG;
     if (n == 0) return LL_OK;
+    LL_HIP(hipSetDevice(ctx->device));
     if ((size_t)n * 28 + 16 > 160 * 1024) { ctx->err = "ll_vote_host: more than 5850 correspondences do not fit one workgroup's LDS"; return LL_ERR_CAPACITY; }
     /* scratch: src, tgt (float4), count (int), weight (float), selected (u8) */
     const size_t bytes = (size_t)n * (16 + 16 + 4 + 4 + 1) + 64;
@@ -633,6 +649,7 @@ extern "C" int ll_map_associate(ll_map *m, const double *pose_w7)
 extern "C" int ll_map_get_counts(ll_map *m, int *n_edge, int *n_plane)
 {
     if (!m) return LL_ERR_ARG;
+    LLM_HIP(hipSetDevice(m->ctx->device));
     int c[2];
     if (ll_read_back(c, m->M.counts, sizeof(c), m->ctx->stream)) { m->err = "read-back failed"; return LL_ERR_HIP; }
     if (n_edge) *n_edge = c[0];
@@ -853,6 +870,7 @@ extern "C" int ll_map_set_pose(ll_map *m, const double *pose_w7)
 extern "C" int ll_map_get_pose(ll_map *m, double *pose_w7)
 {
     if (!m || !pose_w7) return LL_ERR_ARG;
+    LLM_HIP(hipSetDevice(m->ctx->device));
     if (ll_read_back(pose_w7, m->M.pose, 7 * sizeof(double), m->ctx->stream)) { m->err = "read-back failed"; return LL_ERR_HIP; }
     return LL_OK;
 }
@@ -908,9 +926,10 @@ extern "C" int ll_voxel_grid(ll_ctx *ctx, const ll_point *host_in, int n, float 
             hipMemcpyAsync(W.seg_off, seg_off, sizeof(seg_off), hipMemcpyHostToDevice, st) != hipSuccess) fail("upload failed");
     }
     if (rc == LL_OK) {
-        ll_voxel_grid_segments(d_in, n, 1, leaf_size, W, d_out, d_n, st);
+        const int vrc = ll_voxel_grid_segments(d_in, n, 1, leaf_size, W, d_out, d_n, st);
         int m = 0;
-        if (hipMemcpyAsync(&m, d_n, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) fail("voxel grid failed");
+        if (vrc) fail("voxel grid: read-back failed");
+        else if (hipMemcpyAsync(&m, d_n, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) fail("voxel grid failed");
         else if (m > cap) { ctx->err = "voxel grid output capacity too small"; rc = LL_ERR_CAPACITY; *n_out = m; }
         else {
             *n_out = m;
@@ -1108,7 +1127,7 @@ __global__ void k_calib_copy(const float4 *__restrict__ src, float4 *__restrict_
 
 extern "C" int ll_debug_calibration_copy(ll_ctx *ctx, unsigned long long bytes)
 {
-    if (!ctx) return LL_ERR_ARG;
+    int rc0 = ll_enter(ctx); if (rc0) return rc0;
     const size_t n = (size_t)(bytes / 16);
     void *a = nullptr, *b = nullptr;
     LL_HIP(hipMalloc(&a, n * 16)); LL_HIP(hipMalloc(&b, n * 16));
@@ -1123,6 +1142,7 @@ extern "C" int ll_debug_calibration_copy(ll_ctx *ctx, unsigned long long bytes)
 extern "C" int ll_debug_counters(ll_ctx *ctx, unsigned long long *out16, int reset)
 {
     if (!ctx || !out16) return LL_ERR_ARG;
+    LL_HIP(hipSetDevice(ctx->device));
     LL_HIP(hipMemcpyAsync(out16, ctx->V.dbg, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     if (reset) LL_HIP(hipMemsetAsync(ctx->V.dbg, 0, 16 * sizeof(unsigned long long), ctx->stream));
     LL_HIP(hipStreamSynchronize(ctx->stream));
@@ -1131,7 +1151,7 @@ extern "C" int ll_debug_counters(ll_ctx *ctx, unsigned long long *out16, int res
 
 extern "C" int ll_profile_enable(ll_ctx *ctx, int on)
 {
-    if (!ctx) return LL_ERR_ARG;
+    int rc0 = ll_enter(ctx); if (rc0) return rc0;
     LLProfiler &P = ctx->prof;
     if (on && P.ev.empty()) {
         P.ev.resize(LL_PROF_EVENTS); P.id.assign(LL_PROF_EVENTS, LL_K_END);
@@ -1145,6 +1165,7 @@ extern "C" int ll_profile_read(ll_ctx *ctx, int *n, const char **names, double *
 {
     if (!ctx || !n) return LL_ERR_ARG;
     LLProfiler &P = ctx->prof;
+    LL_HIP(hipSetDevice(ctx->device));
     LL_HIP(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i + 1 < P.n; ++i) {
         const int k = P.id[i] & 0xff;

@@ -57,6 +57,7 @@ struct ll_cubemap {
     void *sort_mem = nullptr; LLVoxWork WS;       /* scratch of the by-cube sort (same layout, stack-sized) */
     std::vector<void *> allocs;
     std::string err;
+    bool broken = false;                          /* an update failed half-way: the pair tables no longer describe the pools */
 };
 
 #define CM_HIP(call)                                                                         \
@@ -113,8 +114,8 @@ __global__ __launch_bounds__(256) void k_cm_assign(const float4 *stack, int n, c
     }
 }
 
-void ll_sort_pairs(unsigned long long *keys, int *vals, unsigned long long *tmp_keys, int *tmp_vals, int n, int *hist, int *tile_sum,
-                   unsigned long long *or_and_dev, hipStream_t st);
+int ll_sort_pairs(unsigned long long *keys, int *vals, unsigned long long *tmp_keys, int *tmp_vals, int n, int *hist, int *tile_sum,
+                  unsigned long long *or_and_dev, hipStream_t st);
 
 /* ------------------------------------------------------------------ host side */
 template <typename T>
@@ -238,6 +239,7 @@ static int cm_prepare(ll_cubemap *cm, const double *t_w3, const ll_point *corner
     if (!cm || !t_w3) return LL_ERR_ARG;
     if (n_corner < 0 || n_surf < 0 || (!corner_last && n_corner > 0) || (!surf_last && n_surf > 0)) { cm->err = "bad scan clouds"; return LL_ERR_ARG; }
     if (n_corner > cm->cap_last[0] || n_surf > cm->cap_last[1]) { cm->err = "scan cloud larger than the capacity given to ll_cubemap_create"; return LL_ERR_CAPACITY; }
+    if (cm->broken) { cm->err = "the cube map is unusable: an earlier ll_cubemap_update failed half-way"; return LL_ERR_STATE; }
     CM_HIP(hipSetDevice(cm->ctx->device));
     hipStream_t st = cm->ctx->stream;
     const int dim[3] = {CM_W, CM_H, CM_D};
@@ -276,7 +278,7 @@ static int cm_prepare(ll_cubemap *cm, const double *t_w3, const ll_point *corner
             const int seg_off[2] = {0, n_in[w]};
             CM_HIP(hipMemcpyAsync(cm->d_last, src[w], (size_t)n_in[w] * sizeof(ll_point), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
             CM_HIP(hipMemcpyAsync(cm->W.seg_off, seg_off, sizeof(seg_off), hipMemcpyHostToDevice, st));
-            ll_voxel_grid_segments(cm->d_last, n_in[w], 1, cm->leaf[w], cm->W, cm->map->d_stk[w], cm->d_nout, st);
+            if (ll_voxel_grid_segments(cm->d_last, n_in[w], 1, cm->leaf[w], cm->W, cm->map->d_stk[w], cm->d_nout, st)) { cm->err = "voxel filter: read-back failed"; return LL_ERR_HIP; }
             if (ll_read_back(&n_out, cm->d_nout, sizeof(int), st)) { cm->err = "read-back failed"; return LL_ERR_HIP; }
         }
         cm->map->M.n_stk[w] = n_out;
@@ -313,6 +315,7 @@ extern "C" int ll_cubemap_process_slot(ll_cubemap *cm, double *pose_w7, int slot
     if (!cm || !pose_w7) return LL_ERR_ARG;
     ll_ctx *ctx = cm->ctx;
     if (slot < 0 || slot >= ctx->p.batch) { cm->err = "slot out of range"; return LL_ERR_ARG; }
+    CM_HIP(hipSetDevice(ctx->device));
     ScanHdr h;
     CM_HIP(hipMemcpyAsync(&h, ctx->V.hdr + slot, sizeof(ScanHdr), hipMemcpyDeviceToHost, ctx->stream));
     CM_HIP(hipStreamSynchronize(ctx->stream));
@@ -336,10 +339,15 @@ extern "C" int ll_cubemap_optimize(ll_cubemap *cm, double *pose_w7, int n_outer,
 extern "C" int ll_cubemap_update(ll_cubemap *cm, const double *pose_w7)
 {
     if (!cm || !pose_w7) return LL_ERR_ARG;
+    if (cm->broken) { cm->err = "the cube map is unusable: an earlier ll_cubemap_update failed half-way"; return LL_ERR_STATE; }
     CM_HIP(hipSetDevice(cm->ctx->device));
     hipStream_t st = cm->ctx->stream;
     ll_map *m = cm->map;
     CM_HIP(hipMemcpyAsync(m->M.pose, pose_w7, 7 * sizeof(double), hipMemcpyHostToDevice, st));
+    /* Nothing above the "commit" line below changes the pair tables; a capacity overflow is detected before it (the map
+     * stays as it was).  A HIP failure after it leaves the tables half-updated: the cube map is then marked unusable and
+     * every later call returns LL_ERR_STATE instead of mapping on with an emptied neighbourhood. */
+    struct Guard { ll_cubemap *cm; bool armed = false; ~Guard() { if (armed) cm->broken = true; } } guard{cm};
     std::vector<int> addcnt(CM_N + 1), goff(CM_N + 2);
     for (int w = 0; w < 2; ++w) {
         const int ns = m->M.n_stk[w];
@@ -347,7 +355,7 @@ extern "C" int ll_cubemap_update(ll_cubemap *cm, const double *pose_w7)
         if (ns > 0) {
             hipLaunchKernelGGL(k_cm_assign, dim3((ns + 255) / 256), dim3(256), 0, st, m->d_stk[w], ns, m->M.pose, cm->cen[0], cm->cen[1], cm->cen[2], cm->rank, cm->world,
                                cm->d_tp, cm->d_keys, cm->d_vals, cm->d_addcnt);
-            ll_sort_pairs(cm->d_keys, cm->d_vals, cm->WS.keys, cm->WS.vals, ns, cm->WS.hist, cm->WS.tile_sum, cm->WS.or_and, st);   /* by cube, stack order kept */
+            if (ll_sort_pairs(cm->d_keys, cm->d_vals, cm->WS.keys, cm->WS.vals, ns, cm->WS.hist, cm->WS.tile_sum, cm->WS.or_and, st)) { cm->err = "sort by cube: read-back failed"; return LL_ERR_HIP; }   /* by cube, stack order kept */
         }
         if (ll_read_back(addcnt.data(), cm->d_addcnt, (CM_N + 1) * sizeof(int), st)) { cm->err = "read-back failed"; return LL_ERR_HIP; }
         goff[0] = 0;
@@ -368,7 +376,7 @@ extern "C" int ll_cubemap_update(ll_cubemap *cm, const double *pose_w7)
         std::vector<int> seg_count(cm->n_valid, 0); int n_out = 0;
         if (tot > 0) {
             CM_HIP(hipMemcpyAsync(cm->W.seg_off, seg_off.data(), seg_off.size() * sizeof(int), hipMemcpyHostToDevice, st));
-            ll_voxel_grid_segments(cm->d_work, (int)tot, cm->n_valid, cm->leaf[w], cm->W, cm->d_out, cm->d_nout, st);
+            if (ll_voxel_grid_segments(cm->d_work, (int)tot, cm->n_valid, cm->leaf[w], cm->W, cm->d_out, cm->d_nout, st)) { cm->err = "voxel filter: read-back failed"; return LL_ERR_HIP; }
             /* seg_count and n_out in one page-locked read-back: n_out first, then the counts */
             {
                 int *pin = (int *)ll_pinned_scratch((size_t)(cm->n_valid + 1) * sizeof(int));
@@ -383,7 +391,14 @@ extern "C" int ll_cubemap_update(ll_cubemap *cm, const double *pose_w7)
         /* pool space: the filtered valid cubes + the grown clouds of the other cubes that received points */
         size_t need = (size_t)n_out;
         for (int c = 0; c < CM_N; ++c) if (!is_valid[c] && addcnt[c] > 0) need += (size_t)cm->cnt[w][c] + (size_t)addcnt[c];
-        /* the valid cubes' old clouds are dead from here on: do not carry them through a compaction */
+        /* will it fit?  Decided BEFORE any table changes: a compaction keeps the clouds of the cubes outside the valid set only */
+        if (cm->top[w] + need > cm->cap_pool * 3 / 4) {
+            size_t live = 0;
+            for (int c = 0; c < CM_N; ++c) if (!is_valid[c]) live += (size_t)cm->cnt[w][c];
+            if (live + need > cm->cap_pool) { cm->err = "cube map pool exhausted (pool_points too small)"; return LL_ERR_CAPACITY; }
+        }
+        /* ---- commit: the valid cubes' old clouds are dead from here on (not carried through a compaction) ---- */
+        guard.armed = true;
         for (int v = 0; v < cm->n_valid; ++v) cm->cnt[w][cm->valid[v]] = 0;
         rc = cm_reserve(cm, w, need); if (rc) return rc;
         float4 *pool = cm->pool[w][cm->cur[w]];
@@ -400,6 +415,7 @@ extern "C" int ll_cubemap_update(ll_cubemap *cm, const double *pose_w7)
         rc = cm_run_ops(cm, grow, pool, cm->d_tp, cm->d_vals, pool); if (rc) return rc;
         cm->top[w] = at;
         CM_HIP(hipStreamSynchronize(st));
+        guard.armed = false;                                         /* this cloud type is consistent again */
     }
     CM_HIP(hipGetLastError());
     return LL_OK;
@@ -429,6 +445,7 @@ extern "C" int ll_cubemap_download_cloud(ll_cubemap *cm, int which, ll_point *ou
     const float4 *src = which < 2 ? cm->map->d_map[which] : cm->map->d_stk[which - 2];
     *n = cnt;
     if (cnt > cap) { cm->err = "cloud capacity too small"; return LL_ERR_CAPACITY; }
+    CM_HIP(hipSetDevice(cm->ctx->device));
     if (cnt > 0 && out) { CM_HIP(hipMemcpyAsync(out, src, (size_t)cnt * sizeof(ll_point), hipMemcpyDeviceToHost, cm->ctx->stream)); CM_HIP(hipStreamSynchronize(cm->ctx->stream)); }
     return LL_OK;
 }
@@ -439,6 +456,7 @@ extern "C" int ll_cubemap_download_cube(ll_cubemap *cm, int surf, int cube, ll_p
     const int w = surf ? 1 : 0, cnt = cm->cnt[w][cube];
     *n = cnt;
     if (cnt > cap) { cm->err = "cube capacity too small"; return LL_ERR_CAPACITY; }
+    CM_HIP(hipSetDevice(cm->ctx->device));
     if (cnt > 0 && out) {
         CM_HIP(hipMemcpyAsync(out, cm->pool[w][cm->cur[w]] + cm->off[w][cube], (size_t)cnt * sizeof(ll_point), hipMemcpyDeviceToHost, cm->ctx->stream));
         CM_HIP(hipStreamSynchronize(cm->ctx->stream));

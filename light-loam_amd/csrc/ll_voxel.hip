@@ -329,21 +329,23 @@ __global__ __launch_bounds__(1024) void k_rs_small(unsigned long long *keys, int
 
 /* sorts (keys, vals) by keys, stable; the result is in (keys, vals) again.  tmp_* hold n elements, hist 16 * ceil(n/4096)
  * ints, tile_sum as for ll_device_exscan of that, or_and_host is pinned host memory for the varying-bit mask */
-void ll_sort_pairs(unsigned long long *keys, int *vals, unsigned long long *tmp_keys, int *tmp_vals, int n, int *hist, int *tile_sum,
-                   unsigned long long *or_and_dev, hipStream_t st)
+int ll_sort_pairs(unsigned long long *keys, int *vals, unsigned long long *tmp_keys, int *tmp_vals, int n, int *hist, int *tile_sum,
+                  unsigned long long *or_and_dev, hipStream_t st)
 {
-    if (n <= 1) return;
+    if (n <= 1) return 0;
     if (n <= LL_RSS_MAX) {
         const size_t lds = (size_t)LL_RSS_MAX * 12 + 16 * LL_RSS_ROWS * 16 * sizeof(int);
         static size_t attr_bytes[LL_MAX_DEVICES] = {0};
         ll_ensure_dynamic_lds(k_rs_small, lds, attr_bytes);
         hipLaunchKernelGGL(k_rs_small, dim3(1), dim3(1024), lds, st, keys, vals, n);
-        return;
+        return 0;
     }
     unsigned long long oa[2];
     ll_fill_words((int *)or_and_dev, 4, 0, -1, 2, st);              /* {0, ~0}: the OR and the AND of all keys start here */
     hipLaunchKernelGGL(k_rs_or_and, dim3(min(1024, (n + LL_VB - 1) / LL_VB)), dim3(LL_VB), 0, st, keys, n, or_and_dev);
-    (void)ll_read_back(oa, or_and_dev, sizeof(oa), st);
+    /* a failed read-back must not leave the pass mask to chance: report it (the callers fail loudly) and sort on every digit */
+    const int rb = ll_read_back(oa, or_and_dev, sizeof(oa), st);
+    if (rb) { oa[0] = ~0ull; oa[1] = 0ull; }
     const unsigned long long vary = oa[0] ^ oa[1];                /* bits that differ between some two keys */
     const int nblk = (n + LL_RS_TILE - 1) / LL_RS_TILE;
     unsigned long long *ki = keys, *ko = tmp_keys; int *vi = vals, *vo = tmp_vals;
@@ -359,6 +361,7 @@ void ll_sort_pairs(unsigned long long *keys, int *vals, unsigned long long *tmp_
         ll_copy_d2d(keys, ki, (size_t)n * sizeof(unsigned long long), st);
         ll_copy_d2d(vals, vi, (size_t)n * sizeof(int), st);
     }
+    return rb;
 }
 
 /* ------------------------------------------------------------------ runs -> centroids */
@@ -440,21 +443,22 @@ void ll_vox_work_carve(void *base, int cap, int max_seg, LLVoxWork *W)
 /* pts[0..n): nseg clouds back to back, seg_off (device, nseg + 1 ascending offsets, seg_off[nseg] = n).
  * out: the filtered clouds back to back in segment order; seg_count (W.seg_count, device): points per filtered cloud;
  * *n_out_dev (device int, may alias nothing else): total.  Everything is enqueued on st except the sort's one
- * host read-back of the varying key bits. */
-void ll_voxel_grid_segments(const float4 *pts, int n, int nseg, float leaf, const LLVoxWork &W, float4 *out, int *n_out_dev, hipStream_t st)
+ * host read-back of the varying key bits.  Returns non-zero when that read-back failed (a HIP error the caller reports). */
+int ll_voxel_grid_segments(const float4 *pts, int n, int nseg, float leaf, const LLVoxWork &W, float4 *out, int *n_out_dev, hipStream_t st)
 {
     const float inv = 1.0f / leaf;                                   /* inverse_leaf_size_ = Array4f::Ones() / leaf_size_ */
     const int nb = (max(n, nseg * 6) + LL_VB - 1) / LL_VB;
     hipLaunchKernelGGL(k_vx_segid, dim3(max(nb, 1)), dim3(LL_VB), 0, st, W.seg_off, nseg, n, W.segid, W.bbox);
-    if (n <= 0) { (void)hipMemsetAsync(W.seg_count, 0, (size_t)nseg * sizeof(int), st); (void)hipMemsetAsync(n_out_dev, 0, sizeof(int), st); return; }
+    if (n <= 0) { (void)hipMemsetAsync(W.seg_count, 0, (size_t)nseg * sizeof(int), st); (void)hipMemsetAsync(n_out_dev, 0, sizeof(int), st); return 0; }
     hipLaunchKernelGGL(k_vx_bbox, dim3((n + LL_VB - 1) / LL_VB), dim3(LL_VB), 0, st, pts, W.segid, n, W.bbox);
     hipLaunchKernelGGL(k_vx_params, dim3((nseg + 63) / 64), dim3(64), 0, st, W.bbox, W.seg_off, nseg, inv, W.sp);
     hipLaunchKernelGGL(k_vx_keys, dim3((n + LL_VB - 1) / LL_VB), dim3(LL_VB), 0, st, pts, W.segid, W.seg_off, W.sp, n, inv, W.keys, W.vals);
-    ll_sort_pairs(W.keys, W.vals, W.tmp_keys, W.tmp_vals, n, W.hist, W.tile_sum, W.or_and, st);
+    const int rc = ll_sort_pairs(W.keys, W.vals, W.tmp_keys, W.tmp_vals, n, W.hist, W.tile_sum, W.or_and, st);
     hipLaunchKernelGGL(k_vx_heads, dim3((max(n, nseg) + LL_VB - 1) / LL_VB), dim3(LL_VB), 0, st, W.keys, n, nseg, W.flag, W.seg_count);
     ll_copy_d2d(W.rank, W.flag, (size_t)n * sizeof(int), st);
     ll_fill_words(W.rank + n, 1, 0, 0, 1, st);
     ll_device_exscan(W.rank, n + 1, W.tile_sum, st);                 /* rank[n] = number of voxels */
     ll_copy_d2d(n_out_dev, W.rank + n, sizeof(int), st);
     hipLaunchKernelGGL(k_vx_centroid, dim3((n + LL_VB - 1) / LL_VB), dim3(LL_VB), 0, st, pts, W.keys, W.vals, W.flag, W.rank, n, out, W.seg_count);
+    return rc;                                                       /* non-zero: the sort's read-back failed (the output is still sorted) */
 }

@@ -49,6 +49,7 @@ const int laserCloudNum = laserCloudWidth * laserCloudHeight * laserCloudDepth; 
 std::queue<sensor_msgs::PointCloud2ConstPtr> cornerLastBuf, surfLastBuf, fullResBuf;                /* :94-96 */
 std::queue<nav_msgs::Odometry::ConstPtr> odometryBuf;                                               /* :97 */
 std::mutex mBuf;                                                                                    /* :98 */
+std::mutex mPose;                                                                                   /* q_wmap_wodom / t_wmap_wodom between transformUpdate and the odometry callback */
 std::unique_ptr<lightloam::Context> g_ll;
 std::unique_ptr<lightloam::LaserMapping> g_lm;
 std::string RESULT_PATH;
@@ -75,9 +76,9 @@ void laserCloudFullResHandler(const sensor_msgs::PointCloud2ConstPtr &m) { std::
 void laserOdometryHandler(const nav_msgs::Odometry::ConstPtr &laserOdometry)                        /* :168-247 */
 {
     double q_wmap_wodom[4], t_wmap_wodom[3];
+    { std::lock_guard<std::mutex> l(mBuf); odometryBuf.push(laserOdometry); }
     {
-        std::lock_guard<std::mutex> l(mBuf);
-        odometryBuf.push(laserOdometry);
+        std::lock_guard<std::mutex> l(mPose);                                                       /* never held across device work */
         for (int k = 0; k < 4; ++k) q_wmap_wodom[k] = g_lm->q_wmap_wodom[k];
         for (int k = 0; k < 3; ++k) t_wmap_wodom[k] = g_lm->t_wmap_wodom[k];
     }
@@ -173,11 +174,14 @@ void process()                                                                  
             double guess_t[3];
             int cen[3] = {0, 0, 0};
             try {
-                std::lock_guard<std::mutex> l(mBuf);                                                /* q_wmap_wodom is read by the odometry callback */
+                /* mBuf is held around the queue pops only, as in the reference (:1505-1578): the subscriber callbacks -- the
+                 * high-frequency republish of laserOdometryHandler among them -- keep running during the device work.
+                 * q_wmap_wodom / t_wmap_wodom are written by this thread alone (transformUpdate) and read by that callback:
+                 * their own small mutex covers the write */
                 g_lm->transformAssociateToMap(q_wodom_curr, t_wodom_curr);                          /* :1581 */
                 for (int k = 0; k < 3; ++k) guess_t[k] = g_lm->parameters[4 + k];
                 g_lm->process(cornerLast, surfLast);                                                /* :1584-2165 */
-                g_lm->transformUpdate(q_wodom_curr, t_wodom_curr);                                  /* :2101 */
+                { std::lock_guard<std::mutex> l(mPose); g_lm->transformUpdate(q_wodom_curr, t_wodom_curr); }   /* :2101 */
                 if (ll_cubemap_info(g_lm->get(), cen, nullptr) != LL_OK) throw lightloam::Error(LL_ERR_STATE, "cube map info");
             } catch (const lightloam::Error &e) {
                 ROS_ERROR("laser mapping: %s (code %d)", e.what(), e.code);

@@ -160,3 +160,34 @@ def test_features_uploaded_from_host_give_the_same_frames(api, synth):
         odo.set_target_from_slot(0)                                         # the pointer swap + kd-tree rebuild (:882-896)
     odo.close()
     assert np.array_equal(np.array(rel_b), rel_a)
+
+
+def test_uploaded_slots_serve_as_targets_of_the_next_slot(api, synth):
+    """ll_upload_features into slots 0..k and ONE ll_odometry_frames over the whole range: slot j-1 is the target of slot
+    j, so every uploaded slot needs its own search grid and ring tables (built by ll_upload_features itself, not only by
+    the extract / set_target paths).  Same relative poses as the all-on-device sequence, bit for bit."""
+    rings, nframes = 16, 7
+    cfg = synth.default_cfg(rings)
+    scans = [synth.scan(cfg, k) for k in range(nframes)]
+    pose0 = np.array([0, 0, 0, 1.0, 0.9, 0.0, 0.0])
+    reg = api.Context(api.default_params(rings, batch=nframes, max_points=max(map(len, scans))))
+    for k, s in enumerate(scans):
+        reg.upload_scan(k, s)
+    reg.extract(0, nframes)
+    reg.set_target_from_slot(0)
+    rel_a = reg.odometry_frames(1, nframes - 1, pose0=pose0, n_outer=3, first_frame_index=1)
+    feats = [reg.features(k) for k in range(nframes)]
+    reg.close()
+    odo = api.Context(api.default_params(rings, batch=nframes, max_points=max(map(len, scans))))
+    # stale grids on purpose: the slots first hold OTHER clouds (the scans in reverse order), then the real ones
+    for k in range(nframes):
+        f = feats[nframes - 1 - k]
+        odo.upload_features(k, f["sharp"], f["less_sharp"], f["flat"], f["less_flat"])
+    for k in range(nframes):
+        f = feats[k]
+        odo.upload_features(k, f["sharp"], f["less_sharp"], f["flat"], f["less_flat"])
+    odo.set_target_from_slot(0)
+    rel_b = odo.odometry_frames(1, nframes - 1, pose0=pose0, n_outer=3, first_frame_index=1)
+    # and the staged path: associate over a range of uploaded slots gives the same correspondences as on extracted slots
+    odo.close()
+    assert np.array_equal(rel_b, rel_a)

@@ -416,3 +416,43 @@ def test_two_contexts_on_two_host_threads(api, synth):
             assert (pa == pb).all()
     for c in ctxs:
         c.close()
+
+
+def test_contexts_on_two_devices_driven_from_one_thread(api, synth):
+    """Every C-ABI entry makes the context's device current (hipSetDevice): kernels that need more than 64 KB of dynamic
+    LDS (k_vote with 128 rings: 86 KB, k_build_grid: 68 KB) get their per-device attribute on the right GPU, and scratch
+    allocations land next to the stream that uses them.  Two contexts on two GPUs, interleaved calls from this one thread,
+    same results as each alone.  Needs two visible devices (the driver's multi-GPU box); skipped on a one-GPU box."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one visible device")
+    cfg = synth.default_cfg(128)
+    scans = [synth.scan(cfg, k) for k in range(3)]
+    extra = RING_MODEL[128]
+    mk = lambda dev: api.Context(api.default_params(128, batch=3, max_points=max(map(len, scans)), **extra), device=dev)
+    pose = np.array([0, 0, 0, 1.0, 0.45, 0.0, 0.0])
+    outs = []
+    ctxs = [mk(1), mk(0)]                                       # device 1 first: the thread's current device is 0 at that point
+    for c in ctxs:
+        for k, s in enumerate(scans):
+            c.upload_scan(k, s)
+    for c in ctxs:                                              # interleaved: the current device flips with every call
+        c.extract(0, 1)
+    for c in ctxs:
+        c.set_target_from_slot(0)
+    for c in ctxs:
+        c.hot_path(1, 2, pose, vote=True)
+    for c in ctxs:
+        c.synchronize()
+        outs.append(([c.features(k) for k in (1, 2)], [c.pose(k).copy() for k in (1, 2)], [c.pair_info(k).n_plane_selected for k in (1, 2)]))
+        r, Jq, Jt = c.residual_jacobian(1, pose)                 # allocates its row scratch on the context's device
+        assert np.isfinite(r).all() and len(r) > 100
+    for c in ctxs:
+        c.close()
+    (fa, pa, na), (fb, pb, nb) = outs
+    assert na == nb and min(na) > 100
+    for x, y in zip(fa, fb):
+        for key in ("sharp", "less_sharp", "flat", "less_flat"):
+            assert_bit_equal(x[key], y[key], key)
+    for x, y in zip(pa, pb):
+        assert (x == y).all()
