@@ -322,6 +322,14 @@ int ll_debug_counters(ll_ctx *ctx, unsigned long long *out16, int reset);
 /* one float4 streaming copy of `bytes` in + `bytes` out ("k_calib_copy"): the known-byte-count launch that calibrates
  * rocprofv3's FETCH_SIZE / WRITE_SIZE counters (tools/pmc_traffic.py) */
 int ll_debug_calibration_copy(ll_ctx *ctx, unsigned long long bytes);
+/* The DEVICE's evaluation of the arithmetic that must equal the host libm bit for bit (scanRegistration.cpp:139, :177 call
+ * atan / atan2 / sqrt of glibc), over host arrays a, b, c (n floats each; unused ones may be NULL), results in out (n x 4 B):
+ *   op 0  atanf(a)                    op 1  atan2f(a, b), general path     op 2  atan2f(a, b), k_classify's fast path
+ *   op 3  (float)((double)a / M_PI)   op 4  a / sqrtf(b*b + c*c)  (:139's argument, z = a, x = b, y = c)
+ *   op 5  ring id (int) of the point (x = b, y = c, z = a) by k_classify's threshold search with this context's parameters
+ *   op 6  ring id (int) by evaluating the reference's formula chain directly on the device (:139-168)
+ * Test surface (tests/test_gpu_a1_edges.py compares with glibc on the GPU box); not used by the pipeline. */
+int ll_debug_exact_math(ll_ctx *ctx, int op, const float *a, const float *b, const float *c, int n, void *out);
 
 /* Algorithmic HBM bytes of the last ll_hot_path_batch / stage calls, summed over the slots they covered,
  * by SURVEY.md section 8d's formula (B_ext, B_assoc, B_vote, B_rj).                                      */

@@ -21,7 +21,7 @@ EXPORTS = [
     "ll_download_features", "ll_set_target", "ll_upload_features", "ll_set_target_from_slot", "ll_associate_batch", "ll_get_pair_info",
     "ll_download_edge_corr", "ll_download_plane_corr", "ll_vote_batch", "ll_download_vote",
     "ll_normal_equations_batch", "ll_download_normal_equations", "ll_gn_step_batch", "ll_download_pose",
-    "ll_residual_jacobian", "ll_hot_path_batch", "ll_algorithmic_bytes", "ll_profile_enable", "ll_profile_read", "ll_set_pose_guess", "ll_debug_counters", "ll_vote_host", "ll_debug_calibration_copy",
+    "ll_residual_jacobian", "ll_hot_path_batch", "ll_algorithmic_bytes", "ll_profile_enable", "ll_profile_read", "ll_set_pose_guess", "ll_debug_counters", "ll_vote_host", "ll_debug_calibration_copy", "ll_debug_exact_math",
     "ll_lm_default_options", "ll_lm_solve_batch", "ll_odometry_frames",
     "ll_map_create", "ll_map_destroy", "ll_map_last_error", "ll_map_set_map", "ll_map_set_scan", "ll_map_associate",
     "ll_map_residual_jacobian", "ll_map_get_counts", "ll_map_download_edges", "ll_map_download_planes", "ll_map_normal_equations", "ll_map_optimize",
@@ -299,6 +299,15 @@ class Context:
         r = np.zeros(max(rows, 1)); Jq = np.zeros((max(rows, 1), 4)); Jt = np.zeros((max(rows, 1), 3))
         self._ck(self.lib.ll_factor_blocks_evaluate(self.h, _ptr(q), _ptr(t), _ptr(r), _ptr(Jq), _ptr(Jt), len(r)))
         return r[:rows], Jq[:rows], Jt[:rows]
+
+    def exact_math(self, op, a, b=None, c=None):
+        """the DEVICE's bit-exact libm restatements over float32 arrays (ll_debug_exact_math); ops 5 / 6 return int32 ring ids"""
+        a = np.ascontiguousarray(a, np.float32)
+        b = None if b is None else np.ascontiguousarray(b, np.float32)
+        c = None if c is None else np.ascontiguousarray(c, np.float32)
+        out = np.zeros(len(a), np.int32 if op >= 5 else np.float32)
+        self._ck(self.lib.ll_debug_exact_math(self.h, int(op), _ptr(a), _ptr(b), _ptr(c), len(a), _ptr(out)))
+        return out
 
     def algorithmic_bytes(self, first=0, count=1):
         b = [C.c_double(0) for _ in range(4)]

@@ -1139,6 +1139,29 @@ extern "C" int ll_debug_calibration_copy(ll_ctx *ctx, unsigned long long bytes)
     return LL_OK;
 }
 
+extern "C" int ll_debug_exact_math(ll_ctx *ctx, int op, const float *a, const float *b, const float *c, int n, void *out)
+{
+    int rc = ll_enter(ctx); if (rc) return rc;
+    if (op < 0 || op > 6 || n < 0 || (n > 0 && (!a || !out)) || (n > 0 && (op == 1 || op == 2 || op >= 4) && !b) || (n > 0 && op >= 4 && !c)) {
+        ctx->err = "bad ll_debug_exact_math arguments"; return LL_ERR_ARG;
+    }
+    if (n == 0) return LL_OK;
+    float *d = nullptr;
+    LL_HIP(hipMalloc((void **)&d, (size_t)n * 4 * sizeof(float)));
+    hipError_t e = hipMemcpyAsync(d, a, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && b) e = hipMemcpyAsync(d + n, b, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && c) e = hipMemcpyAsync(d + 2 * (size_t)n, c, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        ll_launch_debug_exact_math(ctx->V, op, d, b ? d + n : nullptr, c ? d + 2 * (size_t)n : nullptr, n, d + 3 * (size_t)n, ctx->stream);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d + 3 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) { ctx->err = std::string("ll_debug_exact_math: ") + hipGetErrorString(e); return LL_ERR_HIP; }
+    return LL_OK;
+}
+
 extern "C" int ll_debug_counters(ll_ctx *ctx, unsigned long long *out16, int reset)
 {
     if (!ctx || !out16) return LL_ERR_ARG;

@@ -296,6 +296,47 @@ __global__ __launch_bounds__(LL_BLOCK) void k_scatter(LLView V, int first, int c
     }
 }
 
+/* ll_debug_exact_math: the device arithmetic of a1 on caller-supplied operands (see include/lightloam_hip.h) */
+__global__ __launch_bounds__(LL_BLOCK) void k_debug_exact_math(LLView V, int op, const float *a, const float *b, const float *c, int n, float *out)
+{
+    __shared__ int thr[LL_MAX_RINGS + 2];
+    __shared__ int lut[LL_RING_LUT_MAX];
+    const int tid = threadIdx.x;
+    if (tid <= V.R) thr[tid] = V.ring_thr[tid];
+    if (tid == 0) thr[V.R + 1] = INT_MAX;
+    for (int i = tid; i < V.lut_nb; i += LL_BLOCK) lut[i] = V.ring_lut[i];
+    __syncthreads();
+    for (int i = blockIdx.x * LL_BLOCK + tid; i < n; i += gridDim.x * LL_BLOCK) {
+        const float x = a[i], y = b ? b[i] : 0.0f, z = c ? c[i] : 0.0f;
+        float r = 0.0f;
+        switch (op) {
+        case 0: r = ll_atanf(x); break;
+        case 1: r = ll_atan2f(x, y); break;
+        case 2: r = ll_atan2f_finite(x, y); break;
+        case 3: r = ll_div_pi_f32(x); break;
+        case 4: r = x / sqrtf(y * y + z * z); break;
+        case 5: {
+            const float4 p = make_float4(y, z, x, 0.0f);
+            const int id = V.lut_nb > 0 ? ll_scan_id<true>(thr, lut, V.lut_nb, V.lut_t0, V.lut_scale, V.R, p)
+                                        : ll_scan_id<false>(thr, lut, 0, 0.0f, 0.0f, V.R, p);
+            r = __int_as_float(id); break;
+        }
+        default: {
+            const float t = x / sqrtf(y * y + z * z);
+            int id = ll_ring_of_t(t, V.ring_model, V.R, V.lower_bound, V.factor);
+            if (id > V.R - 1 || id < 0) id = -1;
+            r = __int_as_float(id); break;
+        }
+        }
+        out[i] = r;
+    }
+}
+
+void ll_launch_debug_exact_math(const LLView &V, int op, const float *a, const float *b, const float *c, int n, float *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_debug_exact_math, dim3(min(2048, (n + LL_BLOCK - 1) / LL_BLOCK)), dim3(LL_BLOCK), 0, st, V, op, a, b, c, n, out);
+}
+
 void ll_launch_organize(const LLView &V, int first, int count, hipStream_t st, LLProfiler *prof)
 {
     const int groups = (count + 7) / 8;

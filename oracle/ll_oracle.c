@@ -26,6 +26,46 @@ static int trunc_to_int(double v)
     return (int)v;
 }
 
+/* scanRegistration.cpp:139-162: the ring number of one point before the range check of :145-149 / :164-168.
+ * float angle = atan(point.z / sqrt(point.x*point.x + point.y*point.y)) * 180 / M_PI;   (:139)
+ * float overloads of sqrt/atan (libstdc++ <math.h> wrapper is in the TU via ros/tf headers):
+ * atanf(...) * 180 is an f32 product, "/ M_PI" promotes to f64, the result is stored as f32. */
+static int scan_id_of(float x, float y, float z, const orc_params *P, float factor)
+{
+    const float angle = (float)((double)(atanf(z / sqrtf(x * x + y * y)) * 180.0f) / M_PI);
+    if (P->ring_model == 0 && P->n_scans == 16)
+        return trunc_to_int((double)((angle + 15.0f) / 2.0f) + 0.5);                        /* :144 */
+    if (P->ring_model == 0 && P->n_scans == 32)
+        return trunc_to_int(((double)angle + 92.0 / 3.0) * 3.0 / 4.0);                      /* :153 */
+    return trunc_to_int((double)((angle - P->lower_bound) * factor) + 0.5);                 /* :162 */
+}
+
+/* test helper: the ring of every input point as the loop of :130-168 computes it (-1 = rejected), no filtering */
+void orc_scan_ids(const float *xyz, int stride, int n, const orc_params *P, int *ids)
+{
+    const float factor = (float)(P->n_scans - 1) / (P->up_bound - P->lower_bound);           /* :441 */
+    for (int i = 0; i < n; ++i) {
+        const int id = scan_id_of(xyz[(size_t)i * stride], xyz[(size_t)i * stride + 1], xyz[(size_t)i * stride + 2], P, factor);
+        ids[i] = (id > P->n_scans - 1 || id < 0) ? -1 : id;
+    }
+}
+
+/* test helper: the HOST libm (what the reference links) over arrays, for the device-vs-glibc check of the restated
+ * atanf / atan2f (tests/test_gpu_a1_edges.py).  op 0: atanf(a); 1: atan2f(a, b); 2: (float)((double)a / M_PI);
+ * 3: a / sqrtf(b * b + c * c) (the argument of :139); 4: expf(a) */
+void orc_libm_batch(int op, const float *a, const float *b, const float *c, int n, float *out)
+{
+    for (int i = 0; i < n; ++i) {
+        switch (op) {
+        case 0: out[i] = atanf(a[i]); break;
+        case 1: out[i] = atan2f(a[i], b[i]); break;
+        case 2: out[i] = (float)((double)a[i] / M_PI); break;
+        case 3: out[i] = a[i] / sqrtf(b[i] * b[i] + c[i] * c[i]); break;
+        default: out[i] = expf(a[i]); break;
+        }
+    }
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* a1  scanRegistration.cpp:58-85 (removeClosedPointCloud), :105-221                           */
 /* ------------------------------------------------------------------------------------------ */
@@ -66,17 +106,7 @@ int orc_organize(const float *xyz, int stride, int n_in, const orc_params *P,
     int count = cloudSize;
     for (int i = 0; i < cloudSize; ++i) {
         const float x = kept[3 * i], y = kept[3 * i + 1], z = kept[3 * i + 2];
-        /* float angle = atan(point.z / sqrt(point.x*point.x + point.y*point.y)) * 180 / M_PI;   (:139)
-         * float overloads of sqrt/atan (libstdc++ <math.h> wrapper is in the TU via ros/tf headers):
-         * atanf(...) * 180 is an f32 product, "/ M_PI" promotes to f64, the result is stored as f32. */
-        const float angle = (float)((double)(atanf(z / sqrtf(x * x + y * y)) * 180.0f) / M_PI);
-        int scanID;
-        if (P->ring_model == 0 && N_SCANS == 16)
-            scanID = trunc_to_int((double)((angle + 15.0f) / 2.0f) + 0.5);                  /* :144 */
-        else if (P->ring_model == 0 && N_SCANS == 32)
-            scanID = trunc_to_int(((double)angle + 92.0 / 3.0) * 3.0 / 4.0);                /* :153 */
-        else
-            scanID = trunc_to_int((double)((angle - P->lower_bound) * factor) + 0.5);       /* :162 */
+        const int scanID = scan_id_of(x, y, z, P, factor);
         if (scanID > (N_SCANS - 1) || scanID < 0) { ring[i] = -1; count--; continue; }      /* :145-149, :164-168 */
 
         float ori = -atan2f(y, x);                                                            /* :177 */

@@ -45,6 +45,10 @@ enum { ORC_OK = 0, ORC_ERR_EMPTY = -1, ORC_ERR_BAD_RINGS = -2, ORC_ERR_CAPACITY 
 int orc_organize(const float *xyz, int stride_floats, int n_in, const orc_params *P,
                  orc_point *cloud, int *n_out, int *scan_start, int *scan_end);
 
+/* test helpers: per-point ring ids of :139-168 without the filtering; the host libm over arrays (see ll_oracle.c) */
+void orc_scan_ids(const float *xyz, int stride_floats, int n, const orc_params *P, int *ids);
+void orc_libm_batch(int op, const float *a, const float *b, const float *c, int n, float *out);
+
 /* ---- a2: curvature, scanRegistration.cpp:225-235 (curv[i] valid for i in [5, n-5)) ---- */
 void orc_curvature(const orc_point *cloud, int n, float *curv);
 

@@ -69,6 +69,23 @@ def organize(xyz, P):
     return rc, cloud[:n.value].copy(), ss, se
 
 
+def scan_ids(xyz, P):
+    """ring id of every point by scanRegistration.cpp:139-168 (-1 = rejected), no filtering"""
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+    ids = np.zeros(len(xyz), np.int32)
+    lib().orc_scan_ids(_p(xyz), xyz.shape[1], len(xyz), C.byref(P), _p(ids))
+    return ids
+
+
+def libm(op, a, b=None, c=None):
+    """the host libm over float32 arrays: op 0 atanf(a), 1 atan2f(a, b), 2 (float)((double)a / M_PI), 3 a / sqrtf(b*b + c*c), 4 expf(a)"""
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(a if b is None else b, np.float32); c = np.ascontiguousarray(a if c is None else c, np.float32)
+    out = np.zeros(len(a), np.float32)
+    lib().orc_libm_batch(int(op), _p(a), _p(b), _p(c), len(a), _p(out))
+    return out
+
+
 def curvature(cloud):
     cloud = _f4(cloud)
     curv = np.zeros(len(cloud), np.float32)

@@ -30,6 +30,11 @@ SHAPES = {
     # BASELINE config 5: 128 rings over [-25, +15] deg -- the reference aborts on scan_line 128 (scanRegistration.cpp:170-174);
     # ring_model 1 applies the 64-ring linear formula (:162) with these bounds
     "S128_linear_model": dict(rings=128),
+    # BASELINE config 3 stand-in (KITTI itself is not in the image): the HDL-64E's TRUE laser table (two blocks, 1/3 and 1/2
+    # deg apart), per-laser mounting heights and rotational offsets, ~120 k returns per scan -- elevations fall anywhere
+    # inside the bins of scanRegistration.cpp:162 -- in a KITTI .bin's laser-by-laser order and in raw firing order
+    "HDL64E_table_kitti_order": dict(rings=64, gen="hdl64", order="kitti"),
+    "HDL64E_table_firing_order": dict(rings=64, gen="hdl64", order="firing"),
 }
 
 RING_MODEL = {128: dict(ring_model=1, lower_bound=-25.0, up_bound=15.0, minimum_range=0.3)}
@@ -38,8 +43,12 @@ RING_MODEL = {128: dict(ring_model=1, lower_bound=-25.0, up_bound=15.0, minimum_
 @pytest.fixture(scope="module", params=list(SHAPES))
 def case(request, api, orc, synth):
     kw = dict(SHAPES[request.param]); rings = kw.pop("rings")
-    cfg = synth.default_cfg(rings, **kw)
-    scans = [synth.scan(cfg, k) for k in range(3)]
+    if kw.pop("gen", None) == "hdl64":
+        import scangen
+        scans = [scangen.hdl64_scan(k, **kw) for k in range(3)]
+    else:
+        cfg = synth.default_cfg(rings, **kw)
+        scans = [synth.scan(cfg, k) for k in range(3)]
     extra = RING_MODEL.get(rings, {})
     P = orc.params(rings, **extra)
     prm = api.default_params(rings, batch=3, write_curvature=1, max_points=max(len(s) for s in scans) + 7, **extra)
