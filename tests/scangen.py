@@ -129,3 +129,41 @@ def ring_thresholds(orc, P):
         ge = ring_unclamped_ge(key_float(mid), ks)
         hi = np.where(ge, mid, hi); lo = np.where(ge, lo, mid + 1)
     return lo                                          # keys
+
+
+def spread_scan(rng, n, lo_deg, hi_deg, sweep, nan_frac=0.002):
+    """n points with elevations uniform over [lo_deg, hi_deg], ranges log-uniform 1.5 .. 110 m (some inside minimum_range),
+    azimuths as one clockwise sweep with jitter (sweep=True) or in random order, a few NaN / inf returns"""
+    el = np.deg2rad(rng.uniform(lo_deg, hi_deg, n))
+    az = -2 * np.pi * (np.arange(n) + rng.uniform(-0.4, 0.4, n)) / n if sweep else rng.uniform(-np.pi, np.pi, n)
+    r = 10 ** rng.uniform(np.log10(1.5), np.log10(110.0), n)
+    p = np.stack([r * np.cos(el) * np.cos(az), r * np.cos(el) * np.sin(az), r * np.sin(el), rng.random(n)], axis=1).astype(np.float32)
+    bad = rng.random(n) < nan_frac
+    p[bad, rng.integers(0, 3, int(bad.sum()))] = rng.choice(np.array([np.nan, np.inf, -np.inf], np.float32), int(bad.sum()))
+    return p
+
+
+def wrap_scan(rng, s0, last_gap, per_boundary=1900, window=2.5e-6):
+    """A 16-ring scan whose first point has ori = s0 and whose azimuths crowd around every constant the wrap / halfPassed
+    logic compares against (scanRegistration.cpp:177-205), before AND after the half-way flip."""
+    two_pi = 2 * np.pi
+    e0 = s0 + two_pi - last_gap                                   # ori of the last point + 2 pi, before the 3 pi / pi fix (:115-126)
+    consts = [s0 - np.pi / 2, s0 + 3 * np.pi / 2, s0 + np.pi, s0 - np.pi, e0 - 3 * np.pi / 2, e0 + np.pi / 2, e0 - two_pi, s0]
+    fold = lambda a: (a + np.pi) % two_pi - np.pi                 # raw ori lives in (-pi, pi]
+    groups = []
+    for c in consts:
+        for img in (c, c - two_pi, c + two_pi):
+            groups.append(fold(img) + rng.uniform(-window, window, per_boundary))
+    near = np.concatenate(groups)
+    fill = rng.uniform(-np.pi, np.pi, 3000)
+
+    def block():
+        a = np.concatenate([near, fill]); return a[rng.permutation(len(a))]
+
+    flip = fold(s0 + np.pi + 0.5)                                 # clearly past the half: sets halfPassed for what follows
+    ori = np.concatenate([[fold(s0)], block(), [flip], block(), [fold(e0)]])
+    ring = rng.integers(0, 16, len(ori))
+    el = np.deg2rad(-15.0 + 2.0 * ring)
+    r = rng.uniform(6.0, 30.0, len(ori))
+    az = -ori                                                     # ori = -atan2(y, x)
+    return np.stack([r * np.cos(el) * np.cos(az), r * np.cos(el) * np.sin(az), r * np.sin(el), np.zeros(len(ori))], axis=1).astype(np.float32)

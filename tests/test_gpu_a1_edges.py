@@ -134,21 +134,9 @@ def test_ring_ids_at_every_threshold(api, orc, model):
     ctx.close()
 
 
-def _spread_scan(rng, n, lo_deg, hi_deg, sweep, nan_frac=0.002):
-    """n points with elevations uniform over [lo_deg, hi_deg], ranges log-uniform 1.5 .. 110 m (some inside minimum_range),
-    azimuths as one clockwise sweep with jitter (sweep=True) or in random order, a few NaN / inf returns"""
-    el = np.deg2rad(rng.uniform(lo_deg, hi_deg, n))
-    az = -2 * np.pi * (np.arange(n) + rng.uniform(-0.4, 0.4, n)) / n if sweep else rng.uniform(-np.pi, np.pi, n)
-    r = 10 ** rng.uniform(np.log10(1.5), np.log10(110.0), n)
-    p = np.stack([r * np.cos(el) * np.cos(az), r * np.cos(el) * np.sin(az), r * np.sin(el), rng.random(n)], axis=1).astype(np.float32)
-    bad = rng.random(n) < nan_frac
-    p[bad, rng.integers(0, 3, int(bad.sum()))] = rng.choice(np.array([np.nan, np.inf, -np.inf], np.float32), int(bad.sum()))
-    return p
-
-
-@pytest.mark.parametrize("model,n", [("HDL64", 300_000), ("linear128", 390_000), ("HDL32", 200_000), ("VLP16", 110_000)])
+@pytest.mark.parametrize("model,n", [("HDL64", 300_000), ("linear128", 390_000), ("HDL32", 140_000), ("VLP16", 70_000)])
 def test_elevations_spread_over_the_whole_range(api, orc, model, n):
-    """4 scans per model, 4.4 million points in total: elevations anywhere (3 deg beyond both ends: rejected rings), in
+    """4 scans per model, 3.6 million points in total (ring 0 is two bins wide -- int() truncates towards zero -- and must fit 8192): elevations anywhere (3 deg beyond both ends: rejected rings), in
     sweep order and in random order (the halfPassed flag flips at an arbitrary point), NaN / inf returns, points inside
     minimum_range.  laserCloud bit-exact; for the 64-ring model also the four feature clouds (4.7 k points per ring: the
     32-row instantiation of the feature kernel)."""
@@ -157,7 +145,7 @@ def test_elevations_spread_over_the_whole_range(api, orc, model, n):
     lo = P.lower_bound if (rings == 64 or P.ring_model == 1) else (-15.0 if rings == 16 else -92.0 / 3.0)
     hi = P.up_bound if (rings == 64 or P.ring_model == 1) else (15.0 if rings == 16 else 92.0 / 3.0 - 20.0)
     rng = np.random.default_rng(1000 + rings)
-    scans = [_spread_scan(rng, n, lo - 3.0, hi + 3.0, sweep=(k % 2 == 0)) for k in range(4)]
+    scans = [scangen.spread_scan(rng, n, lo - 3.0, hi + 3.0, sweep=(k % 2 == 0)) for k in range(4)]
     ctx = api.Context(api.default_params(rings, batch=4, max_points=n, max_ring_points=8192, **prm))
     for k, s in enumerate(scans):
         ctx.upload_scan(k, s)
@@ -180,32 +168,6 @@ def test_elevations_spread_over_the_whole_range(api, orc, model, n):
     ctx.close()
 
 
-def _wrap_scan(rng, s0, last_gap, per_boundary=1900, window=2.5e-6):
-    """A 16-ring scan whose first point has ori = s0 and whose azimuths crowd around every constant the wrap / halfPassed
-    logic compares against (scanRegistration.cpp:177-205), before AND after the half-way flip."""
-    two_pi = 2 * np.pi
-    e0 = s0 + two_pi - last_gap                                   # ori of the last point + 2 pi, before the 3 pi / pi fix (:115-126)
-    consts = [s0 - np.pi / 2, s0 + 3 * np.pi / 2, s0 + np.pi, s0 - np.pi, e0 - 3 * np.pi / 2, e0 + np.pi / 2, e0 - two_pi, s0]
-    fold = lambda a: (a + np.pi) % two_pi - np.pi                 # raw ori lives in (-pi, pi]
-    groups = []
-    for c in consts:
-        for img in (c, c - two_pi, c + two_pi):
-            groups.append(fold(img) + rng.uniform(-window, window, per_boundary))
-    near = np.concatenate(groups)
-    fill = rng.uniform(-np.pi, np.pi, 3000)
-
-    def block():
-        a = np.concatenate([near, fill]); return a[rng.permutation(len(a))]
-
-    flip = fold(s0 + np.pi + 0.5)                                 # clearly past the half: sets halfPassed for what follows
-    ori = np.concatenate([[fold(s0)], block(), [flip], block(), [fold(e0)]])
-    ring = rng.integers(0, 16, len(ori))
-    el = np.deg2rad(-15.0 + 2.0 * ring)
-    r = rng.uniform(6.0, 30.0, len(ori))
-    az = -ori                                                     # ori = -atan2(y, x)
-    return np.stack([r * np.cos(el) * np.cos(az), r * np.cos(el) * np.sin(az), r * np.sin(el), np.zeros(len(ori))], axis=1).astype(np.float32)
-
-
 @pytest.mark.parametrize("s0,last_gap", [(0.3, 0.01), (np.pi / 2, 0.2), (3.1, 0.05), (-3.1, 1.0), (-1.2, 3.3), (0.0, 2 * np.pi - 0.3)])
 def test_azimuths_at_the_wrap_and_half_sweep_boundaries(api, orc, s0, last_gap):
     """~100 000 points per scan within +-2.5e-6 rad (~20 float steps) of startOri - pi/2, startOri + 3 pi/2, the halfPassed
@@ -213,7 +175,7 @@ def test_azimuths_at_the_wrap_and_half_sweep_boundaries(api, orc, s0, last_gap):
     well short of / beyond a revolution (the 3 pi / pi fix of endOri, :120-126).  The intensity bits carry relTime, so
     laserCloud bit-exact means every compare of :181-203 went the reference's way."""
     rng = np.random.default_rng(int(abs(s0) * 1000) + 7)
-    scan = _wrap_scan(rng, s0, last_gap)
+    scan = scangen.wrap_scan(rng, s0, last_gap)
     P = orc.params(16)
     # the crowding is real: raw ori values on both sides of (double)startOri - pi/2 within two float steps, or the image of it
     ori = -orc.libm(1, scan[:, 1], scan[:, 0]).astype(np.float64)

@@ -43,15 +43,17 @@ RING_MODEL = {128: dict(ring_model=1, lower_bound=-25.0, up_bound=15.0, minimum_
 @pytest.fixture(scope="module", params=list(SHAPES))
 def case(request, api, orc, synth):
     kw = dict(SHAPES[request.param]); rings = kw.pop("rings")
+    extra_prm = {}
     if kw.pop("gen", None) == "hdl64":
         import scangen
         scans = [scangen.hdl64_scan(k, **kw) for k in range(3)]
+        extra_prm = dict(max_ring_points=4608)       # the upper block's lasers are 1/3 deg apart, the bins 0.427 deg: some rings hold two lasers
     else:
         cfg = synth.default_cfg(rings, **kw)
         scans = [synth.scan(cfg, k) for k in range(3)]
     extra = RING_MODEL.get(rings, {})
     P = orc.params(rings, **extra)
-    prm = api.default_params(rings, batch=3, write_curvature=1, max_points=max(len(s) for s in scans) + 7, **extra)
+    prm = api.default_params(rings, batch=3, write_curvature=1, max_points=max(len(s) for s in scans) + 7, **extra, **extra_prm)
     ctx = api.Context(prm)
     for k, s in enumerate(scans):
         ctx.upload_scan(k, s)

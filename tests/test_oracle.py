@@ -556,3 +556,229 @@ def test_map_grid_search_equals_brute_force(orc):
     assert len(a[0]) > 5 and len(a[3]) > 50
     for x, y in zip(a, b):
         assert x.shape == y.shape and (x == y).all()
+
+
+# ----------------------------------------------------------------------------- second, independent restatements
+# Written from the reference source alone (line numbers in the comments), in plain Python with explicit float32 / float64
+# steps and the host libm through ctypes -- NOT from oracle/ll_oracle.c.  Two readings of the same lines by two pieces of
+# code must agree on every bit / index; this is what stands in for reference-held golden vectors (there are none).
+import ctypes as _C
+import ctypes.util as _Cu
+import math as _m
+
+_libm = _C.CDLL(_Cu.find_library("m") or "libm.so.6")
+for _n, _k in (("atanf", 1), ("atan2f", 2), ("expf", 1), ("sqrtf", 1)):
+    getattr(_libm, _n).restype = _C.c_float
+    getattr(_libm, _n).argtypes = [_C.c_float] * _k
+_f = np.float32
+
+
+def py_organize(xyz, n_scans, min_range, lower=-24.9, upper=2.0):
+    """scanRegistration.cpp:105-221 (a1).  Returns (laserCloud [n, 4] float32, scanStartInd, scanEndInd)."""
+    pts = [(_f(p[0]), _f(p[1]), _f(p[2])) for p in xyz if np.isfinite(p[0]) and np.isfinite(p[1]) and np.isfinite(p[2])]   # :109
+    thres = _f(min_range)
+    pts = [p for p in pts if not (p[0] * p[0] + p[1] * p[1] + p[2] * p[2] < thres * thres)]                                   # :72 (float)
+    start = _f(-_libm.atan2f(pts[0][1], pts[0][0]))                                                                            # :114
+    end = _f(float(_f(-_libm.atan2f(pts[-1][1], pts[-1][0]))) + 2 * _m.pi)                                                     # :115-117
+    if float(end - start) > 3 * _m.pi:                                                                                         # :119-126
+        end = _f(float(end) - 2 * _m.pi)
+    elif float(end - start) < _m.pi:
+        end = _f(float(end) + 2 * _m.pi)
+    lower_b, upper_b = _f(lower), _f(upper)
+    factor = _f(n_scans - 1) / (upper_b - lower_b)                                                                             # :441 (float)
+    half_passed = False
+    rings = [[] for _ in range(n_scans)]
+    for (x, y, z) in pts:
+        ang = _f(float(_f(_libm.atanf(z / _f(_libm.sqrtf(x * x + y * y)))) * _f(180.0)) / _m.pi)                               # :139
+        if n_scans == 16:
+            sid = int(float((ang + _f(15)) / _f(2)) + 0.5)                                                                     # :144
+        elif n_scans == 32:
+            sid = int((float(ang) + 92.0 / 3.0) * 3.0 / 4.0)                                                                   # :153
+        else:
+            sid = int(float((ang - lower_b) * factor) + 0.5)                                                                   # :162
+        if sid > n_scans - 1 or sid < 0:
+            continue
+        ori = _f(-_libm.atan2f(y, x))                                                                                          # :177
+        if not half_passed:                                                                                                    # :178-193
+            if float(ori) < float(start) - _m.pi / 2:
+                ori = _f(float(ori) + 2 * _m.pi)
+            elif float(ori) > float(start) + _m.pi * 3 / 2:
+                ori = _f(float(ori) - 2 * _m.pi)
+            if float(ori - start) > _m.pi:
+                half_passed = True
+        else:                                                                                                                  # :194-205
+            ori = _f(float(ori) + 2 * _m.pi)
+            if float(ori) < float(end) - _m.pi * 3 / 2:
+                ori = _f(float(ori) + 2 * _m.pi)
+            elif float(ori) > float(end) + _m.pi / 2:
+                ori = _f(float(ori) - 2 * _m.pi)
+        rel = (ori - start) / (end - start)                                                                                    # :207 (float)
+        rings[sid].append((x, y, z, _f(sid + 0.1 * float(rel))))                                                               # :208: int + double * float
+    cloud, ss, se = [], [], []
+    for r in range(n_scans):                                                                                                   # :215-221
+        ss.append(len(cloud) + 5)
+        cloud += rings[r]
+        se.append(len(cloud) - 6)
+    return np.array(cloud, np.float32).reshape(-1, 4), np.array(ss), np.array(se)
+
+
+@pytest.mark.parametrize("shape", ["vlp16_ringmajor", "hdl64_azmajor_jitter_nan", "wrap_0.3", "wrap_3.1", "wrap_-3.1", "spread32"])
+def test_organize_against_independent_python_restatement(orc, synth, shape):
+    import scangen
+    n_scans, mr = 16, 0.3
+    if shape == "vlp16_ringmajor":
+        scan = synth.scan(synth.default_cfg(16), 2)
+    elif shape == "hdl64_azmajor_jitter_nan":
+        n_scans, mr = 64, 5.0
+        scan = synth.scan(synth.default_cfg(64, order=1, az_jitter_deg=0.4, drop_prob=0.03, emit_nan=1, azimuths=512), 1)
+    elif shape.startswith("wrap_"):
+        s0 = float(shape[5:])
+        scan = scangen.wrap_scan(np.random.default_rng(5), s0, 0.05, per_boundary=250)
+    else:
+        n_scans = 32
+        scan = scangen.spread_scan(np.random.default_rng(6), 30000, -34.0, 14.0, sweep=False)
+    rc, cloud, ss, se = orc.organize(scan, orc.params(n_scans, minimum_range=mr))
+    want, wss, wse = py_organize(scan, n_scans, mr)
+    assert rc == 0 and len(cloud) == len(want) > 1000
+    assert (cloud.view(np.uint32) == want.view(np.uint32)).all()
+    assert (ss == wss).all() and (se == wse).all()
+
+
+def _py_transform_to_start(q, t, p):
+    """laserOdometry.cpp:77-95 with DISTORTION 0: s = 1, Identity.slerp(1, q) = q; Eigen's q * v = v + w (2 u x v) + u x (2 u x v)
+    in double, the result stored into a float point (:91-94)."""
+    ux, uy, uz, w = (float(c) for c in q)
+    v = (float(p[0]), float(p[1]), float(p[2]))
+    uv = [uy * v[2] - uz * v[1], uz * v[0] - ux * v[2], ux * v[1] - uy * v[0]]
+    uv = [c + c for c in uv]
+    r = [v[0] + w * uv[0] + (uy * uv[2] - uz * uv[1]), v[1] + w * uv[1] + (uz * uv[0] - ux * uv[2]), v[2] + w * uv[2] + (ux * uv[1] - uy * uv[0])]
+    return _f(r[0] + float(t[0])), _f(r[1] + float(t[1])), _f(r[2] + float(t[2]))
+
+
+def _py_sqdist_all(tgt, sel):
+    """f32 (dx*dx + dy*dy) + dz*dz of every target point to sel: FLANN's L2_Simple accumulation and the walks' expression
+    (:509-514) are the same f32 arithmetic"""
+    dx = tgt[:, 0] - sel[0]; dy = tgt[:, 1] - sel[1]; dz = tgt[:, 2] - sel[2]
+    return (dx * dx + dy * dy) + dz * dz
+
+
+def py_associate(q, t, queries, target, plane):
+    """laserOdometry.cpp:491-620 (plane=False) / :653-793 (plane=True): exact brute-force K = 1 (ties: lowest index), then the
+    two sequential walks with their continue / break rules and strict '<' on a running minimum."""
+    tgt = np.ascontiguousarray(target[:, :3], np.float32)
+    ring = target[:, 3].astype(np.int64)                       # int(intensity): non-negative, so truncation = floor
+    out = []
+    for i, p in enumerate(queries):
+        sel = _py_transform_to_start(q, t, p)
+        d = _py_sqdist_all(tgt, sel)
+        c = int(np.argmin(d))
+        if not (d[c] < _f(25.0)):                              # :497 / :659
+            continue
+        rc = int(ring[c])
+        m2, i2, m3, i3 = 25.0, -1, 25.0, -1
+        for j in range(c + 1, len(tgt)):                       # increasing scan line
+            if plane:
+                if ring[j] > rc + 2.5:
+                    break
+                dj = float(d[j])
+                if ring[j] <= rc and dj < m2:
+                    m2, i2 = dj, j
+                elif ring[j] > rc and dj < m3:
+                    m3, i3 = dj, j
+            else:
+                if ring[j] <= rc:
+                    continue
+                if ring[j] > rc + 2.5:
+                    break
+                dj = float(d[j])
+                if dj < m2:
+                    m2, i2 = dj, j
+        for j in range(c - 1, -1, -1):                         # decreasing scan line
+            if plane:
+                if ring[j] < rc - 2.5:
+                    break
+                dj = float(d[j])
+                if ring[j] >= rc and dj < m2:
+                    m2, i2 = dj, j
+                elif ring[j] < rc and dj < m3:
+                    m3, i3 = dj, j
+            else:
+                if ring[j] >= rc:
+                    continue
+                if ring[j] < rc - 2.5:
+                    break
+                dj = float(d[j])
+                if dj < m2:
+                    m2, i2 = dj, j
+        if plane and i2 >= 0 and i3 >= 0:
+            out.append((i, c, i2, i3))
+        elif not plane and i2 >= 0:
+            out.append((i, c, i2))
+    return np.array(out, np.int64).reshape(-1, 4 if plane else 3)
+
+
+@pytest.mark.parametrize("pose", [[0, 0, 0, 1, 0.9, 0, 0], [0.004, -0.003, 0.02, 1, 0.7, -0.2, 0.05], [0, 0, 0.3, 1, 6.0, 1.0, 0.0]])
+def test_association_against_independent_python_restatement(orc, synth, pose):
+    """a5-a7 on a VLP-16 pair, near the true motion, at a perturbed pose and at a poor one (few neighbours inside 5 m)"""
+    cfg = synth.default_cfg(16)
+    e0 = orc.extract(synth.scan(cfg, 0), orc.params(16)); e1 = orc.extract(synth.scan(cfg, 1), orc.params(16))
+    q = np.array(pose[:4], float); q /= np.linalg.norm(q); t = np.array(pose[4:], float)
+    es, ea, eb = orc.associate_corner(q, t, e1["sharp"], e0["less_sharp"])
+    ps, pa, pb, pc = orc.associate_plane(q, t, e1["flat"], e0["less_flat"])
+    we = py_associate(q, t, e1["sharp"], e0["less_sharp"], plane=False)
+    wp = py_associate(q, t, e1["flat"], e0["less_flat"], plane=True)
+    assert len(we) == len(es) and (np.stack([es, ea, eb], 1) == we).all()
+    assert len(wp) == len(ps) and (np.stack([ps, pa, pb, pc], 1) == wp).all()
+    if pose[4] < 1.0:
+        assert len(es) > 100 and len(ps) > 200
+
+
+def py_vote(src, tgt, corner_case=False):
+    """laserOdometry.cpp:153-342: per region the all-pairs count of score < 0.96f, then the walk from the low-count end of the
+    descending sort (:255, :304-329).  Returns (counts, {index: weight})."""
+    n = len(src)
+    regions = 5 if corner_case else 10                                                           # :179-188
+    thr = _f(0.96)
+    counts = np.zeros(n, np.int64); sel = {}
+
+    def dist(a, b):                                                                              # :153-162, float throughout
+        dx, dy, dz = _f(a[0]) - _f(b[0]), _f(a[1]) - _f(b[1]), _f(a[2]) - _f(b[2])
+        return _f(_libm.sqrtf(dx * dx + dy * dy + dz * dz))
+
+    for r in range(regions):
+        i0 = n // regions * r                                                                    # :202
+        i1 = n if r == regions - 1 else n // regions * (r + 1)                                   # :204-211
+        m = i1 - i0
+        score = [0.0] * m
+        for i in range(m):                                                                       # :228-252
+            for j in range(i + 1, m):
+                s1 = dist(src[i0 + i], src[i0 + j]); s2 = dist(tgt[i0 + i], tgt[i0 + j])
+                gap = _f(abs(s1 - s2))
+                sc = _f(_libm.expf(-(gap * gap) / (_f(1) * _f(1))))
+                if sc < thr:
+                    score[i] += 1; score[j] += 1
+        counts[i0:i1] = score
+        order = sorted(range(m), key=lambda k: -score[k])                                        # descending by score (:255)
+        num_selected = _f(0.90) * _f(m)                                                          # :299-300, float
+        for k in range(m - 1, -1, -1):                                                           # :304: from the low-count end
+            if _f(score[order[k]]) > num_selected:                                               # :312-316
+                break
+            sel[i0 + order[k]] = 5.0 if score[order[k]] <= 50 else 1.0                           # :317-322
+    return counts, sel
+
+
+@pytest.mark.parametrize("n,outliers", [(7, 1), (95, 20), (333, 150), (64, 60)])
+def test_vote_against_independent_python_restatement(orc, n, outliers):
+    """consistent correspondences + outliers whose target is displaced by 0.1 .. 3 m: gaps on both sides of the exp threshold,
+    counts on both sides of 50 and of 0.9 m; n not divisible by 10 (the last region takes the remainder)"""
+    rng = np.random.default_rng(n)
+    src = rng.uniform(-15, 15, (n, 4)).astype(np.float32)
+    tgt = src.copy(); tgt[:, :3] += rng.normal(0, 0.03, (n, 3)).astype(np.float32)
+    bad = rng.choice(n, outliers, replace=False)
+    tgt[bad, :3] += (rng.uniform(0.1, 3.0, (outliers, 1)) * rng.standard_normal((outliers, 3))).astype(np.float32)
+    cnt, idx, w = orc.vote(src, tgt)
+    wcnt, wsel = py_vote(src, tgt)
+    assert (cnt == wcnt).all()
+    assert dict(zip(idx.tolist(), w.tolist())) == wsel
+    if n >= 95:
+        assert 0 < len(idx) < n or outliers < 30
