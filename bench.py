@@ -82,19 +82,39 @@ def cpu_baseline(orc, rings, base, order, guesses, budget_s=15.0):
     return units / el, units, el
 
 
+def _host_topology():
+    """(logical cpus this process may use, ordered so that the first P entries are one hardware thread of each of the P
+    physical cores; P)"""
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    first, rest, seen = [], [], set()
+    for c in allowed:
+        try:
+            sib = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
+        except OSError:
+            sib = str(c)
+        if sib in seen:
+            rest.append(c)
+        else:
+            seen.add(sib); first.append(c)
+    return first + rest, len(first)
+
+
 def cpu_baseline_host(args, rank_seed):
     """The CPU baseline on the box's host cores, run BEFORE this process touches the GPU, in child processes
-    (`bench.py --cpu-worker`, each rebuilding the same synthetic stream from its seed): about a third of the budget on
-    ONE core (what a reference node gets: the ROS nodes are single-threaded, scanRegistration.cpp:475), the rest with one
-    scan stream per core on ALL cores -- the generous CPU figure."""
+    (`bench.py --cpu-worker`, each rebuilding the same synthetic stream from its seed and PINNED to its own logical cpu, one
+    hardware thread per physical core first): a sweep over 1 / 8 / 64 / all cpus, one scan stream per process.  The one-core
+    figure is what a reference node gets (the ROS nodes are single-threaded, scanRegistration.cpp:475); `value` is the
+    all-cpu figure, the most the host can give."""
     import subprocess
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cpus, physical = _host_topology()
 
     def run(n_proc, budget):
-        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", "--rings", str(args.rings), "--batch", str(args.batch),
-               "--distinct", str(args.distinct), "--cpu-budget", str(budget), "--seed", str(rank_seed)]
-        env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", NUMEXPR_NUM_THREADS="1")   # one thread per process:
-        procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for _ in range(n_proc)]     # no BLAS pools
+        env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", NUMEXPR_NUM_THREADS="1")   # one thread per process
+        procs = []
+        for i in range(n_proc):
+            cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", "--rings", str(args.rings), "--batch", str(args.batch),
+                   "--distinct", str(args.distinct), "--cpu-budget", str(budget), "--seed", str(rank_seed), "--pin", str(cpus[i % len(cpus)])]
+            procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
         res = []
         for p in procs:
             try:
@@ -106,16 +126,28 @@ def cpu_baseline_host(args, rank_seed):
             res.append(json.loads(so.strip().splitlines()[-1]))
         return res
 
-    one = run(1, args.cpu_budget / 3.0)[0]
-    try:
-        many = run(cores, args.cpu_budget * 2.0 / 3.0) if cores > 1 else [one]
-    except Exception as e:                       # a reported baseline, not the product: fall back to the one-core figure, say why
-        return {"value": one["value"], "unit": "scans/s", "cores": 1, "kind": "port", "single_thread": one["value"],
-                "sample": f"{one['units']} scan pairs in {one['elapsed']:.1f} s on one core; the all-core run ({cores} processes) failed: {e}"}
-    v_all = sum(r["value"] for r in many); u_all = sum(r["units"] for r in many); e_all = max(r["elapsed"] for r in many)
-    return {"value": v_all, "unit": "scans/s", "cores": cores, "kind": "port", "single_thread": one["value"],
-            "sample": f"{u_all} scan pairs of the same synthetic stream in {e_all:.1f} s on {cores} cores (one stream and one process "
-                      f"per core), after {one['units']} pairs in {one['elapsed']:.1f} s on one core = {one['value']:.1f} scans/s; "
+    points = sorted({n for n in (1, 8, 64, len(cpus)) if n <= len(cpus)})
+    share = args.cpu_budget / (len(points) + 1.0)                  # the one-core point gets a double share
+    sweep, detail = {}, {}
+    one = None
+    for n in points:
+        try:
+            r = run(n, share * (2.0 if n == 1 else 1.0))
+        except Exception as e:                                     # a reported baseline, not the product: keep what was measured, say why
+            detail[str(n)] = f"failed: {e}"
+            continue
+        sweep[str(n)] = sum(x["value"] for x in r)
+        detail[str(n)] = f"{sum(x['units'] for x in r)} scan pairs in {max(x['elapsed'] for x in r):.1f} s"
+        if n == 1:
+            one = r[0]
+    if one is None:
+        raise RuntimeError("CPU baseline: the one-core run failed: " + str(detail))
+    top = max((int(k) for k in sweep), default=1)
+    return {"value": sweep[str(top)], "unit": "scans/s", "cores": top, "kind": "port", "single_thread": one["value"],
+            "physical_cores": physical, "logical_cpus": len(cpus), "pinned": True, "sweep_scans_per_s": sweep,
+            "sample": f"one scan stream per process, every process pinned to its own logical cpu (one hardware thread per physical "
+                      f"core first; {physical} physical cores, {len(cpus)} logical cpus): " + "; ".join(f"{k} cpu(s): {v}" for k, v in detail.items()) +
+                      f"; one core = {one['value']:.1f} scans/s is what a single-threaded reference node gets; "
                       "oracle/ll_oracle.c (extract + grid-NN associate + vote + autodiff normal equations + solve)"}
 
 
@@ -129,14 +161,22 @@ def main():
     ap.add_argument("--rings", type=int, default=64)
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic poses the batch cycles through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=21.0, help="seconds of CPU baseline: a third on one core, the rest on all cores")
+    ap.add_argument("--cpu-budget", type=float, default=24.0, help="seconds of CPU baseline, split over the 1 / 8 / 64 / all-cpu points of the sweep")
     ap.add_argument("--calibrate", action="store_true",
                     help="also launch k_calib_copy (1 GiB in + 1 GiB out) once: the known-byte launch tools/pmc_traffic.py "
                          "uses to calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)       # child of cpu_baseline_host: no GPU, no torch
     ap.add_argument("--seed", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--pin", type=int, default=-1, help=argparse.SUPPRESS)                # cpu-worker: the logical cpu to run on
+    ap.add_argument("--max-ring-points", type=int, default=0,
+                    help="ring capacity of the context (0: 2304, enough for the synthetic 2048-column scans; real HDL-64E data needs 4608)")
     args = ap.parse_args()
     if args.cpu_worker:
+        if args.pin >= 0 and hasattr(os, "sched_setaffinity"):
+            try:
+                os.sched_setaffinity(0, {args.pin})
+            except OSError:
+                pass
         import lightloam_amd  # noqa: F401
         from lightloam_amd import synth
         from oracle import orc
@@ -174,6 +214,8 @@ def main():
     from lightloam_amd import api
     max_pts = max(len(s) for s in base)
     extra = dict(ring_model=1, lower_bound=-25.0, up_bound=15.0, minimum_range=0.3) if args.rings not in (16, 32, 64) else {}
+    if args.max_ring_points > 0:
+        extra["max_ring_points"] = args.max_ring_points
     prm = api.default_params(args.rings, batch=args.batch + 1, max_points=max_pts, chunk=args.chunk, **extra)
     ctx = api.Context(prm, device=local_rank)
     # slot B holds the carry scan: extract it once, make it the carry target, then load the batch
@@ -214,19 +256,29 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
 
-    # sanity on the result of the timed work (not timed): every slot converged to a finite pose, counts are sane
-    info = ctx.scan_info(0); pair = ctx.pair_info(0); pose = ctx.pose(0)
-    assert info.status == 0 and pair.n_edge > 0 and pair.n_plane_selected > 0 and np.isfinite(pose).all()
+    # sanity on the result of the timed work (not timed): EVERY slot extracted (status 0; a look-back time-out would be -7),
+    # found correspondences and solved to a finite pose; slots that hold the same (previous, current) pair of scans and the
+    # same guess must give bit-identical poses (the batch cycles through `distinct`+1 scans)
+    info = ctx.scan_info(0)
     ab = ctx.algorithmic_bytes(0, args.batch)
     # per-kernel share of SURVEY.md section 8d's algorithmic bytes (every array counted once, at the kernel that must touch
     # it), summed over the batch from the run's actual counts
     tot = dict(n_in=0, n=0, feat=0, lsharp=0, lflat=0, q=0, ne=0, np_=0, nsel=0)
+    pose_of_pair = {}
+    bad = []
     for i in range(args.batch):
-        si = ctx.scan_info(i); pi = ctx.pair_info(i)
+        si = ctx.scan_info(i); pi = ctx.pair_info(i); pose = ctx.pose(i)
+        if si.status != 0 or pi.n_edge <= 0 or pi.n_plane_selected <= 0 or not np.isfinite(pose).all():
+            bad.append((i, si.status, pi.n_edge, pi.n_plane_selected))
+        key = (order[i], order[i + 1])
+        if pose_of_pair.setdefault(key, pose).tobytes() != pose.tobytes():
+            bad.append((i, "pose differs from the slot with the same scan pair", key))
         tot["n_in"] += si.n_in; tot["n"] += si.n
         tot["feat"] += si.n_sharp + si.n_less_sharp + si.n_flat + si.n_less_flat
         tot["lsharp"] += si.n_less_sharp; tot["lflat"] += si.n_less_flat; tot["q"] += si.n_sharp + si.n_flat
         tot["ne"] += pi.n_edge; tot["np_"] += pi.n_plane; tot["nsel"] += pi.n_plane_selected
+    if bad:
+        raise SystemExit(f"bench self-check failed on rank {rank}: {len(bad)} slot(s), first {bad[:5]}")
     kernel_bytes = {
         "k_first_kept": 0.0, "k_offsets": 0.0, "k_compact": 0.0, "k_gn_step": 0.0,
         "k_classify": 16.0 * tot["n_in"],                            # read the raw scan
@@ -271,6 +323,8 @@ def main():
                                     "%d-ring synthetic scan" % args.rings) + ", feature extraction "
                                    "+ graph-match + one GN iteration per scan pair, inputs resident in HBM",
                        "scans_per_gpu_per_step": args.batch, "chunk": args.chunk or args.batch,
+                       "distinct_scans": args.distinct + 1, "distinct_scan_pairs": len(pose_of_pair),
+                       "self_check": "every slot: status 0, correspondences > 0, finite pose; equal scan pairs -> bit-identical poses",
                        "points_per_scan_in": int(info.n_in), "points_per_scan_kept": int(info.n),
                        "parallelism": f"scan-parallel x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
