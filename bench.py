@@ -151,6 +151,117 @@ def cpu_baseline_host(args, rank_seed):
                       "oracle/ll_oracle.c (extract + grid-NN associate + vote + autodiff normal equations + solve)"}
 
 
+def rccl_check(torch, dist, world, rank, local_rank, iters=200):
+    """{"rccl_world": N, "rccl_allreduce_28xf64_us": t} -- one RCCL all-reduce of 28 doubles per iteration on a device buffer;
+    a failure to bring RCCL up is reported, not fatal (the headline number does not depend on it)."""
+    try:
+        import torch.distributed as tdist
+        if not tdist.is_initialized():
+            import socket
+            if "MASTER_PORT" not in os.environ:
+                s = socket.socket(); s.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(s.getsockname()[1]); s.close()
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            tdist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dev = torch.device("cuda", local_rank)
+        v = torch.arange(28, dtype=torch.float64, device=dev) * (rank + 1)
+        tdist.all_reduce(v)
+        want = torch.arange(28, dtype=torch.float64, device=dev) * (world * (world + 1) / 2)
+        ok = bool((v == want).all().item())
+        buf = torch.zeros(28, dtype=torch.float64, device=dev)
+        for _ in range(10):
+            tdist.all_reduce(buf)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            tdist.all_reduce(buf)
+        e1.record(); torch.cuda.synchronize()
+        return {"rccl_world": world if ok else None, "rccl_allreduce_28xf64_us": 1e3 * e0.elapsed_time(e1) / iters, "rccl_sum_correct": ok}
+    except Exception as e:                                   # pragma: no cover
+        return {"rccl_world": None, "rccl_error": repr(e)[:300]}
+
+
+def bench_map(args, rank, local_rank, world):
+    """BASELINE config 4: laserMapping scan-to-submap (laserMapping.cpp:1584-2165) with the 21 x 21 x 11 cube map sharded over
+    the ranks (tile-parallel K-NN + all-gather of the candidates) and, with --row-parallel, the Levenberg-Marquardt evaluations
+    split as well (RCCL all-reduce of the 44-double normal-equation record per evaluation).  Every rank gets the whole scan of
+    every frame; a STEP is one frame.  All collectives run on device buffers on the library's stream (parallel.DeviceCollectives)."""
+    import torch
+    import torch.distributed as dist
+    from lightloam_amd import api, parallel, synth
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in os.environ:
+        import socket
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(s.getsockname()[1]); s.close()
+    dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    cfg = synth.default_cfg(args.rings, seed=0x5EED0000)
+    n_frames = args.warmup + args.steps
+    distinct = min(n_frames, 40)
+    scans = [synth.scan(cfg, k) for k in range(distinct)]
+    poses = [synth.pose(cfg, k) for k in range(distinct)]
+    extra = dict(ring_model=1, lower_bound=-25.0, up_bound=15.0, minimum_range=0.3) if args.rings not in (16, 32, 64) else {}
+    ctx = api.Context(api.default_params(args.rings, batch=distinct, max_points=max(map(len, scans)), **extra), device=local_rank)
+    for k, sc in enumerate(scans):
+        ctx.upload_scan(k, sc)
+    ctx.extract(0, distinct)
+    feats = [ctx.features(k) for k in range(distinct)]            # what laserOdometry publishes to laserMapping (host side of the seam)
+    coll = parallel.DeviceCollectives(ctx, local_rank)
+    cm = api.CubeMap(ctx, 16384, 65536, pool_points=1 << 22)
+    cm.set_shard(rank, world)
+
+    def frame(i):
+        k = i % distinct if (i // distinct) % 2 == 0 else distinct - 1 - (i % distinct)     # drive to and fro over the same road
+        x, y, yaw = poses[k]
+        guess = np.array([0.0, 0.0, np.sin(yaw / 2), np.cos(yaw / 2), x + 0.05, y - 0.04, 0.02])
+        return parallel.cubemap_process_tile_parallel_dev(cm, coll, guess, feats[k]["less_sharp"], feats[k]["less_flat"],
+                                                          row_parallel=args.row_parallel)
+
+    for i in range(args.warmup):
+        frame(i)
+    dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ran = 0
+    for i in range(args.warmup, n_frames):
+        pose, r = frame(i); ran += int(r)
+    dist.barrier(); torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda"); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    assert np.isfinite(pose).all() and ran == args.steps
+    # every rank must hold the same pose: the LM state is replicated (tile-parallel) or all-reduced (row-parallel)
+    pt = torch.from_numpy(pose).to("cuda"); got = [torch.zeros_like(pt) for _ in range(world)]
+    dist.all_gather(got, pt)
+    assert all(bool((got[0] == g).all()) for g in got), "ranks disagree on the pose"
+    _, cnt = cm.info()
+    rccl = rccl_check(torch, dist, world, rank, local_rank)
+    # the collectives by themselves, on the buffers of the last frame
+    own, al = coll.candidates((cnt[2], cnt[3]))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(50):
+        for o, a in zip(own, al):
+            dist.all_gather_into_tensor(a, o)
+    e1.record(); torch.cuda.synchronize()
+    gather_us = 1e3 * e0.elapsed_time(e1) / 50
+    if rank == 0:
+        out = {"metric": "laserMapping frames/sec (scan-to-submap, voxel-tiled map sharded over the GPUs)", "value": args.steps / elapsed, "unit": "frames/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "f32 (K-NN, voxel filter) + f64 (line / plane fits, normal equations, LM)", "data": "synthetic",
+               "config": {"workload": f"{args.rings}-ring synthetic drive, one laserMapping frame per step (prepare + 2 x (K=5 search, line/plane fit, LM <= 4 "
+                                      "iterations) + map update), map = 21 x 21 x 11 cubes of 50 m sharded by cube over the ranks",
+                          "parallelism": f"tile-parallel x{world}" + (" + row-parallel LM" if args.row_parallel else " (LM replicated)"),
+                          "stack_points": [int(cnt[2]), int(cnt[3])], "map_points_this_rank": [int(cnt[0]), int(cnt[1])],
+                          "collectives_per_frame": {"all_gather": coll.n_allgather / n_frames, "all_reduce_44xf64": coll.n_allreduce / n_frames},
+                          "candidate_all_gather_us": gather_us, "candidate_bytes_per_rank": int(sum(o.numel() * o.element_size() for o in own))}}
+        out.update(rccl)
+        print(json.dumps(out), flush=True)
+    cm.close(); ctx.close()
+    dist.barrier(); dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,6 +271,10 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="scans per launch sequence inside a step (0 = whole batch)")
     ap.add_argument("--rings", type=int, default=64)
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic poses the batch cycles through")
+    ap.add_argument("--mode", choices=["hot", "map"], default="hot",
+                    help="hot: the headline metric (scans/s of the per-scan hot path, scan-parallel).  map: BASELINE config 4, laserMapping "
+                         "frames/s with the voxel-tiled map sharded over the GPUs and the RCCL all-reduce of JtJ / Jtr (strong scaling)")
+    ap.add_argument("--row-parallel", action="store_true", help="--mode map: split the LM evaluations over the ranks too (all-reduce per evaluation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=24.0, help="seconds of CPU baseline, split over the 1 / 8 / 64 / all-cpu points of the sweep")
     ap.add_argument("--calibrate", action="store_true",
@@ -195,6 +310,8 @@ def main():
 
     import lightloam_amd  # noqa: F401
     from lightloam_amd import synth
+    if args.mode == "map":
+        return bench_map(args, rank, local_rank, world)
     # every rank owns its own scans (different seed => different noise), same shape
     base, order, guesses = build_workload(synth, args.rings, args.batch, args.distinct, 0x5EED0000 + rank)
     cpu = None
@@ -337,11 +454,17 @@ def main():
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
+    # RCCL sanity on every run (also N = 1): the 28-double all-reduce of the row-parallel mode (21 + 6 + 1 unique values of
+    # JtJ, Jtr, cost) on a device buffer, checked against the closed form and timed.  Not part of `value`.
+    rccl = rccl_check(torch, dist, world, rank, local_rank)
+    if rank == 0:
+        out.update(rccl)
         print(json.dumps(out), flush=True)
     ctx.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    import torch.distributed as tdist
+    if tdist.is_initialized():
+        tdist.barrier()
+        tdist.destroy_process_group()
 
 
 if __name__ == "__main__":

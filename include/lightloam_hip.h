@@ -248,6 +248,19 @@ int ll_map_knn_partial(ll_map *m, const double *pose_w7, float *corner_nn, int *
 int ll_map_associate_merged(ll_map *m, const double *pose_w7, int n_parts, const float *corner_nn, const int *corner_id,
                             const float *surf_nn, const int *surf_id);
 int ll_map_solve(ll_map *m, double *pose_w7, const ll_lm_options *opt);
+/* Device-resident variants of the same steps for the collectives: every pointer is a DEVICE pointer on the context's GPU, the
+ * calls only enqueue on ll_stream(ctx) (no host hop, no synchronisation) and work at the pose already on the device
+ * (ll_map_set_pose before, ll_map_get_pose after).  The caller's RCCL all-reduce (44 doubles, of which 28 matter) /
+ * all-gather (100 B per stack point and rank) runs on the same buffers, stream-ordered with ll_stream(ctx); this is what
+ * lightloam_amd/parallel.py does on the GPU box (laserMapping.cpp:1832-2095 spread over the GPUs of a node).              */
+int ll_map_evaluate_dev(ll_map *m, double *neq44_dev);
+int ll_map_lm_begin_dev(ll_map *m, const double *neq44_sum_dev, const ll_lm_options *opt);
+int ll_map_lm_propose_dev(ll_map *m, const ll_lm_options *opt);
+int ll_map_lm_accept_dev(ll_map *m, const double *neq44_sum_dev, const ll_lm_options *opt);
+int ll_map_knn_partial_dev(ll_map *m, float *corner_nn_dev, int *corner_id_dev, float *surf_nn_dev, int *surf_id_dev);
+int ll_map_associate_merged_dev(ll_map *m, int n_parts, const float *corner_nn_dev, const int *corner_id_dev,
+                                const float *surf_nn_dev, const int *surf_id_dev);   /* buffers must stay valid until the stream has run it */
+int ll_map_solve_dev(ll_map *m, const ll_lm_options *opt);
 /* BASELINE config 4 in full -- tiles for the search AND rows for the solve: after ll_map_associate_merged every rank holds
  * all residual blocks; with a row shard set, ll_map_evaluate / ll_map_normal_equations sum only the blocks i with
  * i % world == rank, and the LM runs through evaluate -> all-reduce(JtJ, Jtr, cost) -> ll_map_lm_begin / _accept as in the

@@ -29,6 +29,8 @@ EXPORTS = [
     "ll_cubemap_process", "ll_cubemap_process_slot", "ll_cubemap_info", "ll_cubemap_download_cloud", "ll_cubemap_download_cube",
     "ll_map_set_map_ids", "ll_map_knn_partial", "ll_map_associate_merged", "ll_map_solve", "ll_map_set_row_shard", "ll_cubemap_set_shard", "ll_cubemap_map",
     "ll_factor_blocks_set", "ll_factor_blocks_evaluate",
+    "ll_map_evaluate_dev", "ll_map_lm_begin_dev", "ll_map_lm_propose_dev", "ll_map_lm_accept_dev", "ll_map_knn_partial_dev",
+    "ll_map_associate_merged_dev", "ll_map_solve_dev",
     "ll_voxel_grid", "ll_map_set_pose", "ll_map_get_pose", "ll_map_evaluate", "ll_map_lm_begin", "ll_map_lm_propose", "ll_map_lm_accept",
 ]
 
@@ -461,6 +463,28 @@ class Map:
     def lm_accept(self, neq44, opt=None):
         v = np.ascontiguousarray(neq44, np.float64)
         self._ck(self.lib.ll_map_lm_accept(self.h, _ptr(v), None if opt is None else C.byref(opt)))
+
+    # ---- device-resident variants: raw DEVICE pointers (ints), enqueue only -- for RCCL collectives on ll_stream(ctx)
+    def evaluate_dev(self, neq44_ptr):
+        self._ck(self.lib.ll_map_evaluate_dev(self.h, C.c_void_p(neq44_ptr)))
+
+    def lm_begin_dev(self, neq44_ptr, opt=None):
+        self._ck(self.lib.ll_map_lm_begin_dev(self.h, C.c_void_p(neq44_ptr), None if opt is None else C.byref(opt)))
+
+    def lm_propose_dev(self, opt=None):
+        self._ck(self.lib.ll_map_lm_propose_dev(self.h, None if opt is None else C.byref(opt)))
+
+    def lm_accept_dev(self, neq44_ptr, opt=None):
+        self._ck(self.lib.ll_map_lm_accept_dev(self.h, C.c_void_p(neq44_ptr), None if opt is None else C.byref(opt)))
+
+    def knn_partial_dev(self, cn_ptr, ci_ptr, sn_ptr, si_ptr):
+        self._ck(self.lib.ll_map_knn_partial_dev(self.h, C.c_void_p(cn_ptr), C.c_void_p(ci_ptr), C.c_void_p(sn_ptr), C.c_void_p(si_ptr)))
+
+    def associate_merged_dev(self, n_parts, cn_ptr, ci_ptr, sn_ptr, si_ptr):
+        self._ck(self.lib.ll_map_associate_merged_dev(self.h, int(n_parts), C.c_void_p(cn_ptr), C.c_void_p(ci_ptr), C.c_void_p(sn_ptr), C.c_void_p(si_ptr)))
+
+    def solve_dev(self, opt=None):
+        self._ck(self.lib.ll_map_solve_dev(self.h, None if opt is None else C.byref(opt)))
 
 
 class CubeMap:

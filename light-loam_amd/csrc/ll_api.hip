@@ -906,6 +906,82 @@ extern "C" int ll_map_lm_begin(ll_map *m, const double *neq44_sum, const ll_lm_o
 extern "C" int ll_map_lm_propose(ll_map *m, const ll_lm_options *opt) { return map_lm_stage(m, 1, nullptr, opt); }
 extern "C" int ll_map_lm_accept(ll_map *m, const double *neq44_sum, const ll_lm_options *opt) { return map_lm_stage(m, 2, neq44_sum, opt); }
 
+/* ---- device-resident variants for the collectives of SURVEY 8e: every pointer is a DEVICE pointer on the context's GPU, every
+ * call only enqueues on ll_stream(ctx) and returns (no host hop, no stream synchronisation).  The caller runs its collective
+ * (RCCL all-reduce / all-gather on the same buffers) stream-ordered with ll_stream(ctx): the 224 B all-reduce of the normal
+ * equations and the K-NN candidates never touch the host. ---- */
+extern "C" int ll_map_evaluate_dev(ll_map *m, double *neq44_dev)
+{
+    if (!m || !neq44_dev) return LL_ERR_ARG;
+    LLM_HIP(hipSetDevice(m->ctx->device));
+    ll_map_launch_normal_eq(m->M, m->ctx->stream);
+    ll_copy_d2d(neq44_dev, m->M.neq, LL_NEQ_STRIDE * sizeof(double), m->ctx->stream);
+    LLM_HIP(hipGetLastError());
+    return LL_OK;
+}
+
+static int map_lm_stage_dev(ll_map *m, int stage, const double *neq44_sum_dev, const ll_lm_options *opt)
+{
+    if (!m || (stage != 1 && !neq44_sum_dev)) return LL_ERR_ARG;
+    const LLLmOpt o = ll_to_dev_opt(opt);
+    LLM_HIP(hipSetDevice(m->ctx->device));
+    hipStream_t st = m->ctx->stream;
+    if (neq44_sum_dev) ll_copy_d2d(m->M.neq, neq44_sum_dev, LL_NEQ_STRIDE * sizeof(double), st);
+    LLView Vm = m->ctx->V;
+    Vm.pose = m->M.pose; Vm.neq = m->M.neq; Vm.lm = m->M.lm;
+    if (stage == 0) ll_launch_lm_begin(Vm, 0, 1, o, st);
+    else if (stage == 1) ll_launch_lm_propose(Vm, 0, 1, o, st);
+    else ll_launch_lm_accept(Vm, 0, 1, o, st);
+    LLM_HIP(hipGetLastError());
+    return LL_OK;
+}
+extern "C" int ll_map_lm_begin_dev(ll_map *m, const double *neq44_sum_dev, const ll_lm_options *opt) { return map_lm_stage_dev(m, 0, neq44_sum_dev, opt); }
+extern "C" int ll_map_lm_propose_dev(ll_map *m, const ll_lm_options *opt) { return map_lm_stage_dev(m, 1, nullptr, opt); }
+extern "C" int ll_map_lm_accept_dev(ll_map *m, const double *neq44_sum_dev, const ll_lm_options *opt) { return map_lm_stage_dev(m, 2, neq44_sum_dev, opt); }
+
+extern "C" int ll_map_knn_partial_dev(ll_map *m, float *corner_nn_dev, int *corner_id_dev, float *surf_nn_dev, int *surf_id_dev)
+{
+    if (!m) return LL_ERR_ARG;
+    if ((m->M.n_stk[0] > 0 && (!corner_nn_dev || !corner_id_dev)) || (m->M.n_stk[1] > 0 && (!surf_nn_dev || !surf_id_dev))) { m->err = "null candidate buffers"; return LL_ERR_ARG; }
+    LLM_HIP(hipSetDevice(m->ctx->device));
+    hipStream_t st = m->ctx->stream;
+    ll_map_launch_knn_partial(m->M, st);                        /* at the pose already on the device */
+    float *nn[2] = {corner_nn_dev, surf_nn_dev}; int *id[2] = {corner_id_dev, surf_id_dev};
+    for (int w = 0; w < 2; ++w) {
+        const size_t n = (size_t)m->M.n_stk[w] * 5;
+        if (n == 0) continue;
+        ll_copy_d2d(nn[w], m->M.nn_pt[w], n * sizeof(float4), st);
+        ll_copy_d2d(id[w], m->M.nn_id[w], n * sizeof(int), st);
+    }
+    LLM_HIP(hipGetLastError());
+    return LL_OK;
+}
+
+extern "C" int ll_map_associate_merged_dev(ll_map *m, int n_parts, const float *corner_nn_dev, const int *corner_id_dev, const float *surf_nn_dev, const int *surf_id_dev)
+{
+    if (!m) return LL_ERR_ARG;
+    if (n_parts < 1 || n_parts > 64) { m->err = "n_parts out of range"; return LL_ERR_ARG; }
+    if ((m->M.n_stk[0] > 0 && (!corner_nn_dev || !corner_id_dev)) || (m->M.n_stk[1] > 0 && (!surf_nn_dev || !surf_id_dev))) { m->err = "null candidate buffers"; return LL_ERR_ARG; }
+    LLM_HIP(hipSetDevice(m->ctx->device));
+    /* the gathered candidates are read in place: no copy into the map's own buffers */
+    const float4 *pt_all[2] = {(const float4 *)corner_nn_dev, (const float4 *)surf_nn_dev}; const int *id_all[2] = {corner_id_dev, surf_id_dev};
+    ll_map_launch_associate_merged(m->M, n_parts, pt_all, id_all, m->ctx->stream);
+    LLM_HIP(hipGetLastError());
+    return LL_OK;
+}
+
+extern "C" int ll_map_solve_dev(ll_map *m, const ll_lm_options *opt)
+{
+    if (!m) return LL_ERR_ARG;
+    const LLLmOpt o = ll_to_dev_opt(opt);
+    if (o.max_num_iterations < 0 || o.max_num_iterations > 64) { m->err = "max_num_iterations out of range"; return LL_ERR_ARG; }
+    if (m->M.row_world > 1) { m->err = "the map sums a row shard: step with ll_map_evaluate_dev + all-reduce + ll_map_lm_*_dev"; return LL_ERR_STATE; }
+    LLM_HIP(hipSetDevice(m->ctx->device));
+    map_lm_solve(m, o);                                          /* from the pose on the device, result left there (ll_map_get_pose) */
+    LLM_HIP(hipGetLastError());
+    return LL_OK;
+}
+
 extern "C" int ll_voxel_grid(ll_ctx *ctx, const ll_point *host_in, int n, float leaf_size, ll_point *host_out, int cap, int *n_out)
 {
     if (!ctx || !n_out || n < 0 || (n > 0 && !host_in) || !(leaf_size > 0.0f)) { if (ctx) ctx->err = "bad voxel grid arguments"; return LL_ERR_ARG; }

@@ -159,3 +159,114 @@ def cubemap_process_tile_parallel(cm, pose_w, corner_last, surf_last, opt=None, 
     pose, ran = map_optimize_tile_parallel(cm.map(), pose_w, (cnt[2], cnt[3]), (int(tot[0]), int(tot[1])), 2, opt, group, device, gather, row_parallel)
     cm.update(pose)
     return pose, ran
+
+
+# ------------------------------------------------------------------ device-resident collectives (RCCL on the GPU box)
+class DeviceCollectives:
+    """The collectives of the two mapping modes on DEVICE buffers, stream-ordered with the library's own HIP stream: the
+    normal equations and the K-NN candidates never visit the host, and nothing synchronises until the caller reads the pose.
+    torch owns the buffers; the library copies into / reads from them through raw pointers on ll_stream(ctx); the collective
+    is issued with that stream current (ProcessGroupNCCL orders its internal stream against the current stream with events).
+    Backend "nccl" is RCCL on ROCm; world size 1 is legal and still goes through RCCL."""
+
+    def __init__(self, ctx, device_index, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.dev = torch.device("cuda", device_index)
+        self.stream = torch.cuda.ExternalStream(ctx.stream, device=self.dev)
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.neq = torch.zeros(44, dtype=torch.float64, device=self.dev)
+        self._cand = {}
+        self.n_allreduce = 0
+        self.n_allgather = 0
+
+    def reduced_neq(self, m):
+        """this rank's normal equations (at the map's current device pose) summed over the ranks -> device pointer"""
+        m.evaluate_dev(self.neq.data_ptr())
+        with self.torch.cuda.stream(self.stream):
+            self.dist.all_reduce(self.neq, op=self.dist.ReduceOp.SUM, group=self.group)
+        self.n_allreduce += 1
+        return self.neq.data_ptr()
+
+    def candidates(self, n_stack):
+        """(own, all) buffers of the four candidate arrays for (corner, surf) stack sizes n_stack; cached by size"""
+        key = tuple(int(x) for x in n_stack)
+        if key not in self._cand:
+            t = self.torch
+            nc, ns = key
+            own = [t.empty(max(nc, 1) * 20, dtype=t.float32, device=self.dev), t.empty(max(nc, 1) * 5, dtype=t.int32, device=self.dev),
+                   t.empty(max(ns, 1) * 20, dtype=t.float32, device=self.dev), t.empty(max(ns, 1) * 5, dtype=t.int32, device=self.dev)]
+            al = [t.empty(self.world * o.numel(), dtype=o.dtype, device=self.dev) for o in own]
+            self._cand = {key: (own, al)}                      # one size class alive at a time
+        return self._cand[key]
+
+    def gathered_candidates(self, m, n_stack):
+        own, al = self.candidates(n_stack)
+        m.knn_partial_dev(*[o.data_ptr() for o in own])
+        with self.torch.cuda.stream(self.stream):
+            for o, a in zip(own, al):
+                self.dist.all_gather_into_tensor(a, o, group=self.group)
+        self.n_allgather += 4
+        return [a.data_ptr() for a in al]
+
+
+def map_optimize_row_parallel_dev(m, coll, pose_w, n_outer=2, max_num_iterations=4, opt=None):
+    """map_optimize_row_parallel with the 44-double all-reduce on device buffers: one host upload (the guess), one read-back
+    (the result); everything between is enqueued."""
+    if opt is not None:
+        max_num_iterations = opt.max_num_iterations
+    m.set_pose(pose_w)
+    for _ in range(n_outer):
+        m.associate()                                           # at the device pose, asynchronous
+        m.lm_begin_dev(coll.reduced_neq(m), opt)
+        for _ in range(max_num_iterations):
+            m.lm_propose_dev(opt)
+            m.lm_accept_dev(coll.reduced_neq(m), opt)
+    return m.pose()
+
+
+def map_optimize_tile_parallel_dev(m, coll, pose_w, n_stack, n_map_total, n_outer=2, opt=None, row_parallel=False):
+    """map_optimize_tile_parallel with the candidate all-gather (and, with row_parallel, the all-reduce of the normal
+    equations) on device buffers.  Same results as the host-hopped version: the kernels are the same, only the transport differs."""
+    pose = np.ascontiguousarray(pose_w, np.float64).copy()
+    if not (n_map_total[0] > 10 and n_map_total[1] > 50):
+        return pose, False
+    max_it = 4 if opt is None else opt.max_num_iterations
+    if row_parallel:
+        m.set_row_shard(coll.rank, coll.world)
+    try:
+        m.set_pose(pose)
+        nc, ns = int(n_stack[0]), int(n_stack[1])
+        _, al = coll.candidates((nc, ns))
+        for _ in range(n_outer):
+            ptrs = coll.gathered_candidates(m, (nc, ns))
+            # the all-gathered arrays are [world][max(n, 1)][5][..]: world consecutive parts of n rows when n > 0
+            m.associate_merged_dev(coll.world, *ptrs)
+            if row_parallel:
+                m.lm_begin_dev(coll.reduced_neq(m), opt)
+                for _ in range(max_it):
+                    m.lm_propose_dev(opt)
+                    m.lm_accept_dev(coll.reduced_neq(m), opt)
+            else:
+                m.solve_dev(opt)
+        pose = m.pose()                                         # the frame's one synchronising read-back
+    finally:
+        if row_parallel:
+            m.set_row_shard(0, 1)
+    return pose, True
+
+
+def cubemap_process_tile_parallel_dev(cm, coll, pose_w, corner_last, surf_last, opt=None, row_parallel=False, from_slot=None):
+    """cubemap_process_tile_parallel with device-resident collectives (one small all-reduce of the two cloud sizes per frame
+    still goes through the host: it decides control flow)."""
+    torch, dist = coll.torch, coll.dist
+    cm.prepare(np.asarray(pose_w, np.float64)[4:7], corner_last, surf_last)
+    _, cnt = cm.info()
+    tot = torch.tensor([cnt[0], cnt[1]], dtype=torch.int64, device=coll.dev)
+    dist.all_reduce(tot, group=coll.group)
+    tot = tot.cpu().numpy()
+    pose, ran = map_optimize_tile_parallel_dev(cm.map(), coll, pose_w, (cnt[2], cnt[3]), (int(tot[0]), int(tot[1])), 2, opt, row_parallel)
+    cm.update(pose)
+    return pose, ran
