@@ -98,6 +98,25 @@ int         ll_synchronize(ll_ctx *ctx);
  * Replaces pcl::fromROSMsg of the /rslidar_points message (scanRegistration.cpp:105-106, :453).
  * xyz: n points of `stride_floats` floats each (>= 3; 4 = KITTI .bin / PointXYZ padding).              */
 int ll_upload_scan(ll_ctx *ctx, int slot, const float *host_xyz, int stride_floats, int n);
+/* Streaming input (BASELINE config 5): the same upload, asynchronous on the context's COPY stream.  xyz4: n x (x, y, z, .)
+ * floats, 16-byte stride, ideally page-locked (ll_host_alloc); it must not be modified until the copy has run.  The copy
+ * stream (1) and the compute stream (0: every stage call) are ordered by caller-named events 0 .. 7, never by blocking the
+ * host: ll_stream_record marks "everything enqueued on that stream so far", ll_stream_wait makes what is enqueued on a stream
+ * from now on wait for a mark (a never-recorded event: no wait).  Slots in two halves + two events per half = a double
+ * buffer: the upload of one half overlaps the processing of the other (bench.py --stream-input).                         */
+#define LL_STREAM_COMPUTE 0
+#define LL_STREAM_COPY 1
+int   ll_upload_scan_async(ll_ctx *ctx, int slot, const float *xyz4, int n);
+int   ll_upload_scans_async(ll_ctx *ctx, int first, int count, const float *const *xyz4, const int *n);   /* slots first .. first+count-1 */
+/* the same for a run of slots out of ONE page-locked staging area, scan i at base + i * stride_bytes (stride a multiple of 16):
+ * two enqueues for the whole run (a per-scan feed is bounded by the host cost of the copy calls, not by PCIe) */
+int   ll_upload_scans_async_strided(ll_ctx *ctx, int first, int count, const float *base, size_t stride_bytes, const int *n);
+int   ll_stream_record(ll_ctx *ctx, int stream, int event_id);
+int   ll_stream_wait(ll_ctx *ctx, int stream, int event_id);
+int   ll_synchronize_copy(ll_ctx *ctx);
+void *ll_host_alloc(size_t bytes);            /* page-locked host memory (NULL on failure) */
+void  ll_host_free(void *p);
+
 
 /* ---------------------------------------------------------------- a1-a4: laserCloudHandler
  * scanRegistration.cpp:87-428 for slots [first, first+count): removeNaN + removeClosedPointCloud (:58-85,
@@ -323,6 +342,9 @@ int ll_cubemap_download_cube(ll_cubemap *cm, int surf, int cube_index, ll_point 
  * One pass: extract + associate + vote + normal equations + one GN step for slots [first, first+count),
  * everything device-resident, no host synchronisation inside.  `vote_enable` as above.                   */
 int ll_hot_path_batch(ll_ctx *ctx, int first, int count, const double *host_pose_guess, int vote_enable);
+/* The same pass continuing a batch that an earlier call opened: the target of slot `first` is slot first - 1, not the carry
+ * (a batch processed in pieces -- e.g. the halves of a double-buffered stream -- gives the results of one call over the whole). */
+int ll_hot_path_chain(ll_ctx *ctx, int first, int count, int vote_enable);
 
 /* ---------------------------------------------------------------- measurement
  * With profiling on, every kernel launched by the stage calls is bracketed by HIP events on the ctx stream.

@@ -21,7 +21,7 @@ EXPORTS = [
     "ll_download_features", "ll_set_target", "ll_upload_features", "ll_set_target_from_slot", "ll_associate_batch", "ll_get_pair_info",
     "ll_download_edge_corr", "ll_download_plane_corr", "ll_vote_batch", "ll_download_vote",
     "ll_normal_equations_batch", "ll_download_normal_equations", "ll_gn_step_batch", "ll_download_pose",
-    "ll_residual_jacobian", "ll_hot_path_batch", "ll_algorithmic_bytes", "ll_profile_enable", "ll_profile_read", "ll_set_pose_guess", "ll_debug_counters", "ll_vote_host", "ll_debug_calibration_copy", "ll_debug_exact_math",
+    "ll_residual_jacobian", "ll_hot_path_batch", "ll_algorithmic_bytes", "ll_profile_enable", "ll_profile_read", "ll_set_pose_guess", "ll_debug_counters", "ll_vote_host", "ll_debug_calibration_copy", "ll_debug_exact_math", "ll_upload_scan_async", "ll_upload_scans_async", "ll_upload_scans_async_strided", "ll_stream_record", "ll_stream_wait", "ll_hot_path_chain", "ll_synchronize_copy", "ll_host_alloc", "ll_host_free",
     "ll_lm_default_options", "ll_lm_solve_batch", "ll_odometry_frames",
     "ll_map_create", "ll_map_destroy", "ll_map_last_error", "ll_map_set_map", "ll_map_set_scan", "ll_map_associate",
     "ll_map_residual_jacobian", "ll_map_get_counts", "ll_map_download_edges", "ll_map_download_planes", "ll_map_normal_equations", "ll_map_optimize",
@@ -83,7 +83,63 @@ def load_library():
         _lib.ll_stream.argtypes = [C.c_void_p]
         _lib.ll_create.argtypes = [C.c_int, C.POINTER(Params), C.POINTER(C.c_void_p)]
         _lib.ll_destroy.argtypes = [C.c_void_p]
+        _lib.ll_host_alloc.restype = C.c_void_p
+        _lib.ll_host_alloc.argtypes = [C.c_size_t]
+        _lib.ll_host_free.argtypes = [C.c_void_p]
     return _lib
+
+
+class PinnedStaging:
+    """`count` scan slots of `stride_points` points each in ONE page-locked area: what an ingest thread fills and
+    ll_upload_scans_async_strided copies with two enqueues"""
+
+    def __init__(self, count, stride_points):
+        self.lib = load_library()
+        self.count, self.stride = int(count), int(stride_points) * 16
+        self.ptr = self.lib.ll_host_alloc(self.count * self.stride)
+        if not self.ptr:
+            raise MemoryError("ll_host_alloc failed")
+        self.n = (C.c_int * self.count)()
+
+    def put(self, i, xyz4):
+        a = np.ascontiguousarray(xyz4, np.float32)
+        assert a.ndim == 2 and a.shape[1] == 4 and a.nbytes <= self.stride
+        C.memmove(self.ptr + i * self.stride, a.ctypes.data, a.nbytes)
+        self.n[i] = len(a)
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.lib.ll_host_free(C.c_void_p(self.ptr)); self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PinnedScan:
+    """an (n, 4) float32 scan in page-locked host memory (ll_host_alloc): the source of ll_upload_scan_async"""
+
+    def __init__(self, xyz4):
+        a = np.ascontiguousarray(xyz4, np.float32)
+        assert a.ndim == 2 and a.shape[1] == 4
+        self.n = len(a)
+        self.lib = load_library()
+        self.ptr = self.lib.ll_host_alloc(max(a.nbytes, 16))
+        if not self.ptr:
+            raise MemoryError("ll_host_alloc failed")
+        C.memmove(self.ptr, a.ctypes.data, a.nbytes)
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.lib.ll_host_free(C.c_void_p(self.ptr)); self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def default_params(n_scans=64, **kw):
@@ -138,6 +194,37 @@ class Context:
         xyz = np.ascontiguousarray(xyz, dtype=np.float32)
         n, stride = (0, 4) if xyz.size == 0 else xyz.shape
         self._ck(self.lib.ll_upload_scan(self.h, slot, _ptr(xyz), stride, n))
+
+    def upload_scan_async(self, slot, pinned):
+        """enqueue the host -> device copy of a PinnedScan on the copy stream (ll_upload_scan_async)"""
+        self._ck(self.lib.ll_upload_scan_async(self.h, slot, C.c_void_p(pinned.ptr), pinned.n))
+
+    def upload_scans_async(self, first, pinned_list):
+        """one call for a run of slots (the loop is in C: a Python call per scan would cost more than the copy's enqueue)"""
+        k = len(pinned_list)
+        ptrs = (C.c_void_p * k)(*[p.ptr for p in pinned_list]); ns = (C.c_int * k)(*[p.n for p in pinned_list])
+        self._ck(self.lib.ll_upload_scans_async(self.h, first, k, ptrs, ns))
+
+    def upload_staging_async(self, first, staging, i0=0, count=None):
+        """slots first .. from entries i0 .. of a PinnedStaging (ll_upload_scans_async_strided)"""
+        count = staging.count - i0 if count is None else count
+        n = (C.c_int * count).from_buffer(staging.n, i0 * 4)
+        self._ck(self.lib.ll_upload_scans_async_strided(self.h, first, count, C.c_void_p(staging.ptr + i0 * staging.stride), C.c_size_t(staging.stride), n))
+
+    def stream_record(self, stream, ev):
+        """mark "everything enqueued so far" on the compute (0) / copy (1) stream as event ev (0 .. 7)"""
+        self._ck(self.lib.ll_stream_record(self.h, int(stream), int(ev)))
+
+    def stream_wait(self, stream, ev):
+        """what is enqueued on `stream` from now on waits for event ev"""
+        self._ck(self.lib.ll_stream_wait(self.h, int(stream), int(ev)))
+
+    def hot_path_chain(self, first, count, vote=True):
+        """hot_path continuing a batch: slot `first` is matched against slot first - 1"""
+        self._ck(self.lib.ll_hot_path_chain(self.h, first, count, int(bool(vote))))
+
+    def synchronize_copy(self):
+        self._ck(self.lib.ll_synchronize_copy(self.h))
 
     # ---- stages
     def extract(self, first=0, count=1):

@@ -67,6 +67,9 @@ extern "C" void ll_destroy(ll_ctx *ctx)
     for (void *p : ctx->allocs) (void)hipFree(p);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->ev_ok) for (auto &e : ctx->ev) (void)hipEventDestroy(e);
+    if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
+    for (auto &e : ctx->ev_x) if (e) (void)hipEventDestroy(e);
+    if (ctx->h_n_in_pinned) (void)hipHostFree(ctx->h_n_in_pinned);
     for (auto &e : ctx->prof.ev) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -220,6 +223,105 @@ extern "C" int ll_upload_scan(ll_ctx *ctx, int slot, const float *xyz, int strid
     ctx->n_in_host[slot] = n;
     LL_HIP(hipMemcpyAsync(const_cast<int *>(V.n_in) + slot, &ctx->n_in_host[slot], sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     LL_HIP(hipStreamSynchronize(ctx->stream));
+    return LL_OK;
+}
+
+/* ---- streaming input (BASELINE config 5: scans arrive while earlier ones are processed) ----
+ * ll_upload_scan_async enqueues the host -> device copy of one scan (x, y, z, . float4 stride, page-locked memory from
+ * ll_host_alloc for a truly asynchronous transfer) on the context's COPY stream and returns; the buffer must stay untouched
+ * until the copy has run.  The copy stream and the compute stream (every stage call) are ordered by events the caller
+ * names (0 .. 7), never by blocking the host: ll_stream_record(ctx, stream, e) marks "everything enqueued on `stream` so far",
+ * ll_stream_wait(ctx, stream, e) makes what is enqueued on `stream` from now on wait for that mark (a wait on an event that
+ * was never recorded returns at once).  stream: LL_STREAM_COMPUTE 0, LL_STREAM_COPY 1.  With the slots in two halves and
+ * two events per half this is a double buffer: the upload of one half overlaps the processing of the other
+ * (bench.py --stream-input; ll_hot_path_chain continues a batch across the halves). */
+static int ensure_copy_stream(ll_ctx *ctx)
+{
+    if (ctx->copy_stream) return LL_OK;
+    LL_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    LL_HIP(hipHostMalloc((void **)&ctx->h_n_in_pinned, (size_t)ctx->p.batch * sizeof(int), hipHostMallocDefault));
+    return LL_OK;
+}
+
+extern "C" void *ll_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+extern "C" void ll_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+extern "C" int ll_upload_scan_async(ll_ctx *ctx, int slot, const float *xyz4, int n)
+{
+    int rc = check_range(ctx, slot, 1); if (rc) return rc;
+    if (n < 0 || (!xyz4 && n > 0)) { ctx->err = "bad upload arguments"; return LL_ERR_ARG; }
+    if (n > ctx->p.max_points) { ctx->err = "scan larger than max_points"; return LL_ERR_CAPACITY; }
+    rc = ensure_copy_stream(ctx); if (rc) return rc;
+    LLView &V = ctx->V;
+    if (n > 0) LL_HIP(hipMemcpyAsync(const_cast<float4 *>(V.raw) + (size_t)slot * V.NP, xyz4, (size_t)n * 16, hipMemcpyHostToDevice, ctx->copy_stream));
+    ctx->n_in_host[slot] = n; ctx->h_n_in_pinned[slot] = n;
+    LL_HIP(hipMemcpyAsync(const_cast<int *>(V.n_in) + slot, ctx->h_n_in_pinned + slot, sizeof(int), hipMemcpyHostToDevice, ctx->copy_stream));
+    return LL_OK;
+}
+
+extern "C" int ll_upload_scans_async(ll_ctx *ctx, int first, int count, const float *const *xyz4, const int *n)
+{
+    int rc = check_range(ctx, first, count); if (rc) return rc;
+    if (!xyz4 || !n) return LL_ERR_ARG;
+    for (int i = 0; i < count; ++i) { rc = ll_upload_scan_async(ctx, first + i, xyz4[i], n[i]); if (rc) return rc; }
+    return LL_OK;
+}
+
+/* a run of slots from ONE page-locked staging area (scan i at base + i * stride_bytes): two enqueues for the whole run -- a 2-D
+ * copy (rows = scans, row width = the longest scan of the run) and the point counts -- instead of two per scan; on this stack
+ * an asynchronous copy costs the host tens of microseconds, which bounds a per-scan feed below the PCIe rate */
+extern "C" int ll_upload_scans_async_strided(ll_ctx *ctx, int first, int count, const float *base, size_t stride_bytes, const int *n)
+{
+    int rc = check_range(ctx, first, count); if (rc) return rc;
+    if (!base || !n || (stride_bytes & 15)) { ctx->err = "bad strided upload arguments"; return LL_ERR_ARG; }
+    rc = ensure_copy_stream(ctx); if (rc) return rc;
+    int nmax = 0;
+    for (int i = 0; i < count; ++i) {
+        if (n[i] < 0 || n[i] > ctx->p.max_points || (size_t)n[i] * 16 > stride_bytes) { ctx->err = "scan larger than max_points / the stride"; return LL_ERR_CAPACITY; }
+        nmax = n[i] > nmax ? n[i] : nmax;
+        ctx->n_in_host[first + i] = n[i]; ctx->h_n_in_pinned[first + i] = n[i];
+    }
+    LLView &V = ctx->V;
+    if (nmax > 0)
+        LL_HIP(hipMemcpy2DAsync(const_cast<float4 *>(V.raw) + (size_t)first * V.NP, (size_t)V.NP * 16, base, stride_bytes, (size_t)nmax * 16, (size_t)count,
+                                hipMemcpyHostToDevice, ctx->copy_stream));
+    LL_HIP(hipMemcpyAsync(const_cast<int *>(V.n_in) + first, ctx->h_n_in_pinned + first, (size_t)count * sizeof(int), hipMemcpyHostToDevice, ctx->copy_stream));
+    return LL_OK;
+}
+
+static int stream_event(ll_ctx *ctx, int stream, int ev, hipStream_t *st)
+{
+    int rc = ll_enter(ctx); if (rc) return rc;
+    if ((stream != 0 && stream != 1) || ev < 0 || ev >= 8) { ctx->err = "bad stream / event id"; return LL_ERR_ARG; }
+    rc = ensure_copy_stream(ctx); if (rc) return rc;
+    *st = stream ? ctx->copy_stream : ctx->stream;
+    return LL_OK;
+}
+
+extern "C" int ll_stream_record(ll_ctx *ctx, int stream, int ev)
+{
+    hipStream_t st; int rc = stream_event(ctx, stream, ev, &st); if (rc) return rc;
+    if (!ctx->ev_x[ev]) LL_HIP(hipEventCreateWithFlags(&ctx->ev_x[ev], hipEventDisableTiming));
+    LL_HIP(hipEventRecord(ctx->ev_x[ev], st));
+    return LL_OK;
+}
+
+extern "C" int ll_stream_wait(ll_ctx *ctx, int stream, int ev)
+{
+    hipStream_t st; int rc = stream_event(ctx, stream, ev, &st); if (rc) return rc;
+    if (ctx->ev_x[ev]) LL_HIP(hipStreamWaitEvent(st, ctx->ev_x[ev], 0));
+    return LL_OK;
+}
+
+extern "C" int ll_synchronize_copy(ll_ctx *ctx)
+{
+    int rc = ll_enter(ctx); if (rc) return rc;
+    if (ctx->copy_stream) LL_HIP(hipStreamSynchronize(ctx->copy_stream));
     return LL_OK;
 }
 
@@ -449,7 +551,18 @@ extern "C" int ll_odometry_frames(ll_ctx *ctx, int first, int count, const doubl
     return LL_OK;
 }
 
+static int hot_path(ll_ctx *ctx, int first, int count, const double *host_pose_guess, int vote_enable, int chain);
 extern "C" int ll_hot_path_batch(ll_ctx *ctx, int first, int count, const double *host_pose_guess, int vote_enable)
+{
+    return hot_path(ctx, first, count, host_pose_guess, vote_enable, 0);
+}
+/* the same pass, continuing a batch: the target of slot `first` is slot first - 1 (extracted by an earlier call), not the carry */
+extern "C" int ll_hot_path_chain(ll_ctx *ctx, int first, int count, int vote_enable)
+{
+    if (ctx && first < 1) { ctx->err = "ll_hot_path_chain needs a previous slot"; return LL_ERR_ARG; }
+    return hot_path(ctx, first, count, nullptr, vote_enable, 1);
+}
+static int hot_path(ll_ctx *ctx, int first, int count, const double *host_pose_guess, int vote_enable, int chain)
 {
     int rc = check_range(ctx, first, count); if (rc) return rc;
     rc = upload_poses(ctx, first, count, host_pose_guess); if (rc) return rc;
@@ -457,7 +570,7 @@ extern "C" int ll_hot_path_batch(ll_ctx *ctx, int first, int count, const double
     if (!host_pose_guess)
         LL_HIP(hipMemcpyAsync(ctx->V.pose + (size_t)first * 7, ctx->V.pose_guess + (size_t)first * 7, (size_t)count * 7 * sizeof(double),
                               hipMemcpyDeviceToDevice, ctx->stream));
-    ctx->V.carry_slot = first;
+    if (!chain) ctx->V.carry_slot = first;                      /* chain: the carry belongs to the slot that opened the batch */
     /* chunks keep a chunk's intermediates (ori/ring, laserCloud, feature slots) inside the Infinity Cache between
      * the producing and the consuming kernel; the target of a chunk's first slot is the previous chunk's last slot */
     const int chunk = (ctx->p.chunk > 0) ? ctx->p.chunk : count;

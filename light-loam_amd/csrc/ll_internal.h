@@ -38,6 +38,11 @@ struct ll_ctx {
     double *d_fb = nullptr, *d_fb_out = nullptr;
     size_t fb_cap = 0, fb_out_cap = 0;
     int fb_n[3] = {0, 0, 0};
+    /* streaming input (ll_upload_scan_async): a second stream for host -> device copies, ordered against the compute stream by
+     * ll_stream_fence; the per-slot point counts live in page-locked memory so that their copies are asynchronous too */
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_x[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   /* ll_stream_record / ll_stream_wait */
+    int *h_n_in_pinned = nullptr;
 };
 
 

@@ -467,3 +467,64 @@ def test_contexts_on_two_devices_driven_from_one_thread(api, synth):
             assert_bit_equal(x[key], y[key], key)
     for x, y in zip(pa, pb):
         assert (x == y).all()
+
+
+def test_streamed_halves_equal_the_resident_batch(api, synth):
+    """BASELINE config 5's plumbing: scans uploaded asynchronously from page-locked memory on the copy stream (per scan and as
+    a strided run), the slots in two halves ordered against the compute stream by events only, the second half continuing the
+    batch (ll_hot_path_chain) -- same poses, features and correspondence counts as one resident ll_hot_path_batch, bit for bit,
+    over several rounds of overwriting the halves while the other one is processed."""
+    cfg = synth.default_cfg(16)
+    B, H = 12, 6
+    scans = [synth.scan(cfg, k % 7) for k in range(B + 1)]
+    prm = lambda: api.default_params(16, batch=B + 1, max_points=max(map(len, scans)))
+    guess = np.array([0, 0, 0, 1.0, 0.9, 0.0, 0.0])
+    res = api.Context(prm())
+    for k, s in enumerate(scans):
+        res.upload_scan(k, s)
+    res.extract(B, 1); res.set_target_from_slot(B)
+    res.set_pose_guess(0, B, guess)
+    res.hot_path(0, B, None, vote=True); res.synchronize()
+    want = [(res.pose(k).copy(), res.features(k), res.pair_info(k).n_plane_selected) for k in range(B)]
+    res.close()
+
+    ctx = api.Context(prm())
+    ctx.upload_scan(B, scans[B]); ctx.extract(B, 1); ctx.set_target_from_slot(B)
+    ctx.set_pose_guess(0, B, guess)
+    pinned = [api.PinnedScan(s) for s in scans[:B]]
+    staging = api.PinnedStaging(H, max(map(len, scans)) + 5)
+    for i in range(H):
+        staging.put(i, scans[H + i])
+    junk = api.PinnedScan(np.full((100, 4), 7.0, np.float32))
+    COMPUTE, COPY = 0, 1
+    for rnd in range(4):
+        for h in (0, 1):
+            f = h * H
+            ctx.stream_wait(COPY, 2 + h)
+            if rnd % 2 == 1:                                    # first something else into the slots: the real scans must overwrite it in order
+                for i in range(H):
+                    ctx.upload_scan_async(f + i, junk)
+            if h == 0:
+                ctx.upload_scans_async(f, pinned[f:f + H])
+            else:
+                ctx.upload_staging_async(f, staging)
+            ctx.stream_record(COPY, h)
+            ctx.stream_wait(COMPUTE, h)
+            if h == 0:
+                ctx.hot_path(0, H, None, vote=True)
+            else:
+                ctx.hot_path_chain(H, H, vote=True)
+            ctx.stream_record(COMPUTE, 2 + h)
+    ctx.synchronize_copy(); ctx.synchronize()
+    for k in range(B):
+        pose, feats, nsel = want[k]
+        assert (ctx.pose(k) == pose).all(), k
+        assert ctx.pair_info(k).n_plane_selected == nsel > 10
+        f = ctx.features(k)
+        for name in ("sharp", "less_sharp", "flat", "less_flat"):
+            assert_bit_equal(f[name], feats[name], f"slot {k} {name}")
+    with pytest.raises(api.LightLoamError):
+        ctx.hot_path_chain(0, 2)                                # no previous slot
+    for p in pinned + [junk]:
+        p.close()
+    staging.close(); ctx.close()
