@@ -347,13 +347,13 @@ __device__ __forceinline__ void ll_grid_search(const int *gstart, float qx, floa
 }
 
 template <bool PLANE>
-__device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int qblock,
+__device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int qblock, int qpb,
                                                    const float4 *queries, int nq, const TargetRef T,
                                                    int *out_a, int *out_b, int *out_c, float4 *qs, int *nn, int *rb, int *rcl, int *cellb_all, int *tab, unsigned char *perm, int *hist)
 {
     const int tid = threadIdx.x, lane = tid & 63;
-    const int qi = qblock * LL_BLOCK + tid;
-    const bool have = qi < nq;
+    const int qi = qblock * qpb + tid;                        /* qpb queries per workgroup: 256 in a batch, 32 (one pass) when few scans must fill the chip */
+    const bool have = tid < qpb && qi < nq;
     /* a5: TransformToStart, s = 1 (DISTORTION 0): f64 rotate + translate, f32 store */
     float sx = 0.f, sy = 0.f, sz = 0.f;
     if (have) {
@@ -379,7 +379,8 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
             const int cnt = T.gstart[cell + 1] - T.gstart[cell];
             cls = min(30, cnt >> 3);
         }
-        const int rank = atomicAdd(&hist[cls], 1);
+        const bool dealt = tid < qpb;                                       /* one-pass workgroups order their 32 queries only */
+        const int rank = dealt ? atomicAdd(&hist[cls], 1) : 0;
         __syncthreads();
         if (tid < 64) {                                                     /* exclusive scan of the 32 class counts (one wave) */
             const int v = tid < 32 ? hist[tid] : 0;
@@ -389,7 +390,7 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
             if (tid < 32) hist[32 + tid] = inc - v;
         }
         __syncthreads();
-        perm[hist[32 + cls] + rank] = (unsigned char)tid;
+        if (dealt) perm[hist[32 + cls] + rank] = (unsigned char)tid;
         __syncthreads();
     }
 
@@ -400,7 +401,7 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
     const float4 *tgt = T.pts; const int M = T.m;
     const bool tab_ok = tab[2 * (LL_TAB + 1)] != 0 && tab[2 * (LL_TAB + 1) + 1] == M;
     const float dmax = V.nn_max;
-    for (int pass = 0; pass < LL_BLOCK / 32; ++pass) {
+    for (int pass = 0; pass < qpb / 32; ++pass) {
         const int ql = perm[((pass * (LL_BLOCK / 64) + (g >> 3)) << 3) + (g & 7)];
         const float4 q = qs[ql];
         int closest = -1, res_b = -1, res_c = -1;
@@ -535,7 +536,7 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
 
 /* 2nd launch bound = waves per SIMD.  Left alone the compiler spends 106 SGPRs and lands on 7; asked for 8 it fits in 78
  * with the same 60 VGPRs and no scratch -- the kernel is latency-bound, one more wave per SIMD is worth 17 % (A/B, one box). */
-__global__ __launch_bounds__(LL_BLOCK, 8) void k_associate(LLView V, int first, int count, int qb_corner, int qb_plane)
+__global__ __launch_bounds__(LL_BLOCK, 8) void k_associate(LLView V, int first, int count, int qb_corner, int qb_plane, int qpb)
 {
     const int per = qb_corner + qb_plane;
     const int sl = blockIdx.x / per, item = blockIdx.x % per;
@@ -551,14 +552,14 @@ __global__ __launch_bounds__(LL_BLOCK, 8) void k_associate(LLView V, int first, 
     const bool ok = h.status == 0;
     if (item < qb_corner) {
         const int nq = ok ? h.n_sharp : 0;
-        if (item * LL_BLOCK >= nq) return;
-        ll_associate_block<false>(V, s, item, V.sharp + (size_t)s * V.cap_sharp, nq, ll_target(V, s, 0),
+        if (item * qpb >= nq) return;
+        ll_associate_block<false>(V, s, item, qpb, V.sharp + (size_t)s * V.cap_sharp, nq, ll_target(V, s, 0),
                                   V.eq_a + (size_t)s * V.cap_sharp, V.eq_b + (size_t)s * V.cap_sharp, nullptr, qs, nn, rb, rcl, cellb, tab, perm, hist);
     } else {
         const int qb = item - qb_corner;
         const int nq = ok ? h.n_flat : 0;
-        if (qb * LL_BLOCK >= nq) return;
-        ll_associate_block<true>(V, s, qb, V.flat + (size_t)s * V.cap_flat, nq, ll_target(V, s, 1),
+        if (qb * qpb >= nq) return;
+        ll_associate_block<true>(V, s, qb, qpb, V.flat + (size_t)s * V.cap_flat, nq, ll_target(V, s, 1),
                                  V.pq_a + (size_t)s * V.cap_flat, V.pq_b + (size_t)s * V.cap_flat,
                                  V.pq_c + (size_t)s * V.cap_flat, qs, nn, rb, rcl, cellb, tab, perm, hist);
     }
@@ -575,8 +576,11 @@ void ll_launch_build_grid(const LLView &V, int first, int count, int carry, hipS
 
 void ll_launch_associate(const LLView &V, int first, int count, hipStream_t st, LLProfiler *prof)
 {
-    const int qbc = (V.cap_sharp + LL_BLOCK - 1) / LL_BLOCK, qbp = (V.cap_flat + LL_BLOCK - 1) / LL_BLOCK;
+    /* a node-style call (one scan pair) would put 9 workgroups of 8 sequential passes on a 256-CU chip: 217 us of dependent
+     * loads; 32 queries per workgroup (one pass) spread the same work over 72 workgroups */
+    const int qpb = (count <= 16) ? 32 : LL_BLOCK;
+    const int qbc = (V.cap_sharp + qpb - 1) / qpb, qbp = (V.cap_flat + qpb - 1) / qpb;
     ll_prof_mark(prof, LL_K_ASSOCIATE, st);
-    hipLaunchKernelGGL(k_associate, dim3(count * (qbc + qbp)), dim3(LL_BLOCK), 0, st, V, first, count, qbc, qbp);
+    hipLaunchKernelGGL(k_associate, dim3(count * (qbc + qbp)), dim3(LL_BLOCK), 0, st, V, first, count, qbc, qbp, qpb);
     ll_prof_mark(prof, LL_K_END, st);
 }
