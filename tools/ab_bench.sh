@@ -8,6 +8,6 @@ print("%.0f scans/s  %.2f ms/step | " % (d["value"], d["ms_per_step"]) + " ".joi
 for rep in 1 2; do
   for v in $GRAFT_REPO_ROOT/_ab/*.so tree; do
     if [ $v = tree ]; then unset LIGHTLOAM_HIP_LIB; else export LIGHTLOAM_HIP_LIB=$v; fi
-    printf "%-10s " "$(basename $v .so):"; timeout 600 python bench.py --steps 8 --warmup 2 --no-cpu-baseline "$@" 2>&1 | tail -1 | python -c "$fmt"
+    printf "%-10s " "$(basename $v .so):"; timeout 600 python bench.py --steps 8 --warmup 2 --no-cpu-baseline "$@" 2>&1 | grep "^{\"metric" | tail -1 | python -c "$fmt"
   done
 done
