@@ -261,7 +261,9 @@ __device__ __forceinline__ void ll_ring_entry(int ring, int e, int cx, int cy, i
     x0 = x1 = (t & 1) ? cx + ring : cx - ring;
 }
 
+#ifndef LL_SCAN_UN
 #define LL_SCAN_UN 2              /* point loads a lane keeps in flight while scanning a cell */
+#endif
 #define LL_RING_CELLS 24          /* entries (rows / side cells) whose bounds are fetched per round; wider rings take several rounds */
 
 /* squared distance from (qx, qy) to the rectangle of cells [xa, xb] of row yy, shrunk by a 1 mm margin so that float rounding
@@ -305,7 +307,7 @@ __device__ __forceinline__ void ll_annulus_entry(int rmax, int e, int cx, int cy
  * The bounds of ALL entries of a round are fetched at once -- lane `sub` of the group takes entries sub, sub+8, sub+16 -- and
  * exchanged through a per-group LDS table: one parallel round of loads instead of one dependent load per entry. */
 template <typename Scan, typename Bound, typename Sync>
-__device__ __forceinline__ void ll_grid_search(const int *gstart, float qx, float qy, int rmax, int *cellb, int sub,
+__device__ __forceinline__ void ll_grid_search(const int *gstart, float qx, float qy, int rmax, int *cellb, int sub, int ring_from,
                                                Scan scan, Bound bound, Sync sync)
 {
     const int cx = ll_cell_coord(qx), cy = ll_cell_coord(qy);
@@ -335,7 +337,7 @@ __device__ __forceinline__ void ll_grid_search(const int *gstart, float qx, floa
         }
     };
     const int near = min(rmax, LL_NEAR_RINGS);
-    for (int ring = 0; ring <= near; ++ring) {
+    for (int ring = ring_from; ring <= near; ++ring) {
         if (ring >= 2) { const float lbr = (float)(ring - 1) * LL_GRID_CELL - 1e-3f; if (lbr * lbr > bound()) return; }
         sweep(ring == 0 ? 1 : 4 * ring, [&](int e, int &x0, int &x1, int &yy) { ll_ring_entry(ring, e, cx, cy, x0, x1, yy); });
     }
@@ -412,8 +414,30 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
              * ring (closestPointScanID, :500 / :664) comes with it. */
             const unsigned long long knone = ((unsigned long long)__float_as_uint(dmax) << 32) | 0xffffffffull;
             unsigned long long kb = knone;
-            ll_grid_search(gstart, q.x, q.y, rmax, cellb, sub,
-                [&](int st, int en) {
+            /* The query's own cell and the four entries of Chebyshev ring 1 (row below, row above, left and right cell) serve
+             * BOTH searches: lane e of the group fetches entry e's bounds once and keeps them in its registers, the scans get
+             * them by a lane broadcast.  Own cell, share the best, the ring-1 entries the bound still admits, share again;
+             * only a search that is still open after that (its bound reaches beyond the 3 x 3 cells) goes on ring by ring. */
+            int a_st = 0, a_en = 0; float a_lb = 0.0f;
+            if (sub < 5) {
+                const int cx = ll_cell_coord(q.x), cy = ll_cell_coord(q.y);
+                int x0, x1, yy; ll_ring_entry(sub ? 1 : 0, sub ? sub - 1 : 0, cx, cy, x0, x1, yy);
+                const int xa = max(x0, 0), xb = min(x1, LL_GRID_G - 1);
+                if (xa <= xb && yy >= 0 && yy < LL_GRID_G) {
+                    a_lb = ll_range_lb2(q.x, q.y, xa, xb, yy);
+                    if (!(a_lb > dmax)) { a_st = gstart[yy * LL_GRID_G + xa]; a_en = gstart[yy * LL_GRID_G + xb + 1]; }
+                }
+            }
+            auto scan_near = [&](auto scan, auto bound, auto sync) __attribute__((always_inline)) {
+                for (int e = 0; e < 5; ++e) {
+                    const int st = __shfl(a_st, e, 8), en = __shfl(a_en, e, 8);
+                    const float lb = __shfl(a_lb, e, 8);
+                    if (st < en && !(lb > bound())) scan(st, en);
+                    if (e == 0) sync();
+                }
+                sync();
+            };
+            auto nn_scan = [&](int st, int en) {
                     for (int k0 = st + sub; k0 < en; k0 += 8 * LL_SCAN_UN) {      /* LL_SCAN_UN loads in flight per lane */
                         float4 pp[LL_SCAN_UN];
 #pragma unroll
@@ -429,14 +453,16 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
                             kb = (k < kb) ? k : kb;                           /* d < dmax is implied: kb starts at (dmax, ~0) */
                         }
                     }
-                },
-                [&]() { return __uint_as_float((unsigned)(kb >> 32)); },
-                [&]() {
+                };
+            auto nn_bound = [&]() { return __uint_as_float((unsigned)(kb >> 32)); };
+            auto nn_sync = [&]() {
                     for (int o = 1; o < 8; o <<= 1) {
                         const unsigned long long k2 = __shfl_xor(kb, o);
                         kb = (k2 < kb) ? k2 : kb;
                     }
-                });
+                };
+            scan_near(nn_scan, nn_bound, nn_sync);
+            ll_grid_search(gstart, q.x, q.y, rmax, cellb, sub, 2, nn_scan, nn_bound, nn_sync);
             int rc = 0;
             if (kb != knone) { closest = (int)((unsigned)kb >> 8); rc = (int)((unsigned)kb & 0xFFu); }   /* :497 / :659: d < DISTANCE_SQ_THRESHOLD */
 
@@ -451,8 +477,7 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
                 const int c1 = c + 1, mc = M + c - 1;
                 const unsigned long long wnone = ((unsigned long long)__float_as_uint(dmax) << 32) | 0x7fffffffull;
                 unsigned long long k2 = wnone, k3 = wnone;
-                ll_grid_search(gstart, q.x, q.y, rmax, cellb, sub,
-                    [&](int st, int en) {
+                auto w_scan = [&](int st, int en) {
                         for (int k0 = st + sub; k0 < en; k0 += 8 * LL_SCAN_UN) {
                           float4 pp[LL_SCAN_UN];
 #pragma unroll
@@ -479,14 +504,16 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
                             }
                           }
                         }
-                    },
-                    [&]() { const unsigned h2 = (unsigned)(k2 >> 32), h3 = (unsigned)(k3 >> 32); return __uint_as_float(PLANE ? max(h2, h3) : h2); },
-                    [&]() {
+                    };
+                auto w_bound = [&]() { const unsigned h2 = (unsigned)(k2 >> 32), h3 = (unsigned)(k3 >> 32); return __uint_as_float(PLANE ? max(h2, h3) : h2); };
+                auto w_sync = [&]() {
                         for (int o = 1; o < 8; o <<= 1) {
                             const unsigned long long t2 = __shfl_xor(k2, o); k2 = (t2 < k2) ? t2 : k2;
                             if (PLANE) { const unsigned long long t3 = __shfl_xor(k3, o); k3 = (t3 < k3) ? t3 : k3; }
                         }
-                    });
+                    };
+                scan_near(w_scan, w_bound, w_sync);
+                ll_grid_search(gstart, q.x, q.y, rmax, cellb, sub, 2, w_scan, w_bound, w_sync);
                 auto index_of = [&](unsigned long long k) { const int ord = (int)(unsigned)k; return (k == wnone) ? -1 : (ord < M ? c1 + ord : mc - ord); };   /* up: ord = j - c1 < M, down: ord = mc - j >= M */
                 res_b = index_of(k2); res_c = PLANE ? index_of(k3) : -1;
             }
