@@ -504,13 +504,7 @@ LLLmOpt ll_to_dev_opt(const ll_lm_options *opt)
 /* enqueue one LM solve for a slot range (carry_slot must already be set by the caller) */
 static void enqueue_lm(ll_ctx *ctx, int first, int count, const LLLmOpt &o)
 {
-    ll_launch_normal_equations(ctx->V, first, count, 0, ctx->stream, &ctx->prof);
-    ll_launch_lm_begin(ctx->V, first, count, o, ctx->stream);
-    for (int it = 0; it < o.max_num_iterations; ++it) {
-        ll_launch_lm_propose(ctx->V, first, count, o, ctx->stream);
-        ll_launch_normal_equations(ctx->V, first, count, 0, ctx->stream, &ctx->prof);
-        ll_launch_lm_accept(ctx->V, first, count, o, ctx->stream);
-    }
+    ll_launch_lm_solve(ctx->V, first, count, o, ctx->stream);      /* evaluate, begin, n x (propose, evaluate, accept) in one launch */
 }
 
 extern "C" int ll_lm_solve_batch(ll_ctx *ctx, int first, int count, const ll_lm_options *opt)
@@ -524,15 +518,18 @@ extern "C" int ll_lm_solve_batch(ll_ctx *ctx, int first, int count, const ll_lm_
     return LL_OK;
 }
 
+struct LLPose7 { double v[7]; };
+__global__ void k_set_pose7(double *dst, LLPose7 p) { if (threadIdx.x < 7) dst[threadIdx.x] = p.v[threadIdx.x]; }
+
 extern "C" int ll_odometry_frames(ll_ctx *ctx, int first, int count, const double *host_pose0, int n_outer, int first_frame_index,
                                   const ll_lm_options *opt, double *host_poses_out)
 {
     int rc = check_range(ctx, first, count); if (rc) return rc;
     if (n_outer < 1 || n_outer > 16) { ctx->err = "n_outer out of range"; return LL_ERR_ARG; }
     const LLLmOpt o = ll_to_dev_opt(opt);
-    double ident[7] = {0, 0, 0, 1, 0, 0, 0};
-    LL_HIP(hipMemcpyAsync(ctx->V.pose + (size_t)first * 7, host_pose0 ? host_pose0 : ident, 7 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    LL_HIP(hipStreamSynchronize(ctx->stream));
+    LLPose7 p0 = {{0, 0, 0, 1, 0, 0, 0}};
+    if (host_pose0) std::memcpy(p0.v, host_pose0, sizeof(p0.v));
+    hipLaunchKernelGGL(k_set_pose7, dim3(1), dim3(64), 0, ctx->stream, ctx->V.pose + (size_t)first * 7, p0);   /* by value: no copy to wait for */
     ctx->V.carry_slot = first;
     for (int k = first; k < first + count; ++k) {
         if (k > first)      /* para_q / para_t persist from the previous frame (:61-65) */

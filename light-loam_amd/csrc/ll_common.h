@@ -111,6 +111,7 @@ struct LLLmOpt {
     double function_tolerance, gradient_tolerance, parameter_tolerance;
     int jacobi_scaling;
 };
+void ll_launch_lm_solve(const LLView &V, int first, int count, const LLLmOpt &o, hipStream_t st);
 void ll_launch_lm_begin(const LLView &V, int first, int count, const LLLmOpt &o, hipStream_t st);
 void ll_launch_lm_propose(const LLView &V, int first, int count, const LLLmOpt &o, hipStream_t st);
 void ll_launch_lm_accept(const LLView &V, int first, int count, const LLLmOpt &o, hipStream_t st);

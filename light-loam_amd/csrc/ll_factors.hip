@@ -18,16 +18,17 @@
 
 #include "ll_factor_math.h"
 
-__global__ __launch_bounds__(LL_BLOCK) void k_normal_equations(LLView V, int first, int count, int do_step)
+/* the normal equations of slot s at the pose pose_in[7] (global or LDS), by the whole workgroup; thread 0 leaves the 44-double
+ * record in out[] (global or LDS).  Ends with every thread past the last barrier but WITHOUT a barrier after thread 0's
+ * stores: the caller synchronises before anybody else reads out[]. */
+template <int NT>
+__device__ __forceinline__ void ll_neq_eval(const LLView &V, int s, const double *pose_in, double *out, double (*red)[LL_NACC])
 {
-    if ((int)blockIdx.x >= count) return;
-    const int s = first + blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const PairHdr ph = V.pair[s];
     Pose P;
-    double *pose = V.pose + (size_t)s * 7;
-    for (int k = 0; k < 4; ++k) P.q[k] = pose[k];
-    for (int k = 0; k < 3; ++k) P.t[k] = pose[4 + k];
+    for (int k = 0; k < 4; ++k) P.q[k] = pose_in[k];
+    for (int k = 0; k < 3; ++k) P.t[k] = pose_in[4 + k];
     const float4 *corner, *surf; int mc, ms;
     ll_targets(V, s, corner, mc, surf, ms);
     const float4 *sharp = V.sharp + (size_t)s * V.cap_sharp, *flat = V.flat + (size_t)s * V.cap_flat;
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(LL_BLOCK) void k_normal_equations(LLView V, int fir
     double acc[LL_NACC];
 #pragma unroll
     for (int k = 0; k < LL_NACC; ++k) acc[k] = 0.0;
-    for (int i = tid; i < ph.n_edge; i += LL_BLOCK) {
+    for (int i = tid; i < ph.n_edge; i += NT) {
         double r[3], Jq[3][4], Jt[3][3];
         ll_edge(P, sharp[es[i]], corner[ea[i]], corner[eb[i]], r, Jq, Jt);
         const double sc = ll_huber_scale(r[0] * r[0] + r[1] * r[1] + r[2] * r[2], V.huber, acc[27]);
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(LL_BLOCK) void k_normal_equations(LLView V, int fir
             ll_acc_row(acc, J, r[row] * sc);
         }
     }
-    for (int i = tid; i < ph.n_plane; i += LL_BLOCK) {
+    for (int i = tid; i < ph.n_plane; i += NT) {
         if (!vs[i]) continue;
         double r, Jq[4], Jt[3], J[6];
         ll_plane(P, flat[ps[i]], surf[pa[i]], surf[pb[i]], surf[pc[i]], (double)vw[i], r, Jq, Jt);
@@ -60,7 +61,6 @@ __global__ __launch_bounds__(LL_BLOCK) void k_normal_equations(LLView V, int fir
         for (int k = 0; k < 6; ++k) J[k] *= sc;
         ll_acc_row(acc, J, r * sc);
     }
-    __shared__ double red[LL_BLOCK / 64][LL_NACC];
 #pragma unroll
     for (int k = 0; k < LL_NACC; ++k) {
         double v = acc[k];
@@ -70,20 +70,27 @@ __global__ __launch_bounds__(LL_BLOCK) void k_normal_equations(LLView V, int fir
     __syncthreads();
     if (tid == 0) {
         double tot[LL_NACC];
-        for (int k = 0; k < LL_NACC; ++k) { double v = 0.0; for (int w = 0; w < LL_BLOCK / 64; ++w) v += red[w][k]; tot[k] = v; }
-        double H[36], g[6];
+        for (int k = 0; k < LL_NACC; ++k) { double v = 0.0; for (int w = 0; w < NT / 64; ++w) v += red[w][k]; tot[k] = v; }
         int k = 0;
-        for (int a = 0; a < 6; ++a) for (int b = a; b < 6; ++b) { H[a * 6 + b] = tot[k]; H[b * 6 + a] = tot[k]; ++k; }
-        for (int a = 0; a < 6; ++a) g[a] = tot[21 + a];
-        double *out = V.neq + (size_t)s * LL_NEQ_STRIDE;
-        for (int i = 0; i < 36; ++i) out[i] = H[i];
-        for (int i = 0; i < 6; ++i) out[36 + i] = g[i];
+        for (int a = 0; a < 6; ++a) for (int b = a; b < 6; ++b) { out[a * 6 + b] = tot[k]; out[b * 6 + a] = tot[k]; ++k; }
+        for (int a = 0; a < 6; ++a) out[36 + a] = tot[21 + a];
         out[42] = tot[27];
         out[43] = (double)(3 * ph.n_edge + ph.n_plane_sel);
-        if (do_step) {
-            double d[6];
-            if (ll_chol_solve(H, g, d) == 0) ll_pose_plus(pose, d);
-        }
+    }
+}
+
+__global__ __launch_bounds__(LL_BLOCK) void k_normal_equations(LLView V, int first, int count, int do_step)
+{
+    if ((int)blockIdx.x >= count) return;
+    const int s = first + blockIdx.x;
+    __shared__ double red[LL_BLOCK / 64][LL_NACC];
+    double *pose = V.pose + (size_t)s * 7, *out = V.neq + (size_t)s * LL_NEQ_STRIDE;
+    ll_neq_eval<LL_BLOCK>(V, s, pose, out, red);
+    if (threadIdx.x == 0 && do_step) {
+        double H[36], g[6], d[6];
+        for (int i = 0; i < 36; ++i) H[i] = out[i];
+        for (int i = 0; i < 6; ++i) g[i] = out[36 + i];
+        if (ll_chol_solve(H, g, d) == 0) ll_pose_plus(pose, d);
     }
 }
 
@@ -152,13 +159,10 @@ void ll_launch_normal_equations(const LLView &V, int first, int count, int do_st
  * 56 radius, 57 decrease_factor, 58 iteration, 59 done, 60-66 candidate, 67 model_cost_change, 68 pending, 69 successes,
  * 70 initial cost.
  * ------------------------------------------------------------------------------------------------------------------ */
-__global__ void k_lm_begin(LLView V, int first, int count, LLLmOpt o)
+/* the three steps on one solve: L = its state (LL_LM_STRIDE doubles), in = the normal equations at `pose`, pose = where the next
+ * evaluation happens (global or LDS) */
+__device__ __forceinline__ void ll_lm_begin_one(double *L, const double *in, const double *pose, const LLLmOpt &o)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const int s = first + i;
-    double *L = V.lm + (size_t)s * LL_LM_STRIDE;
-    const double *in = V.neq + (size_t)s * LL_NEQ_STRIDE, *pose = V.pose + (size_t)s * 7;
     for (int k = 0; k < 7; ++k) L[k] = pose[k];
     L[7] = in[42];
     for (int k = 0; k < 36; ++k) L[8 + k] = in[k];
@@ -167,12 +171,8 @@ __global__ void k_lm_begin(LLView V, int first, int count, LLLmOpt o)
     L[56] = o.initial_radius; L[57] = 2.0; L[58] = 0.0; L[59] = 0.0; L[68] = 0.0; L[69] = 0.0; L[70] = in[42];
 }
 
-__global__ void k_lm_propose(LLView V, int first, int count, LLLmOpt o)
+__device__ __forceinline__ void ll_lm_propose_one(double *L, double *pose, const LLLmOpt &o)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const int s = first + i;
-    double *L = V.lm + (size_t)s * LL_LM_STRIDE, *pose = V.pose + (size_t)s * 7;
     L[68] = 0.0;
     if (L[59] == 0.0) {
         /* FinalizeIterationAndCheckIfMinimizerCanContinue */
@@ -216,14 +216,9 @@ __global__ void k_lm_propose(LLView V, int first, int count, LLLmOpt o)
     L[67] = mcc; L[68] = 1.0;
 }
 
-__global__ void k_lm_accept(LLView V, int first, int count, LLLmOpt o)
+__device__ __forceinline__ void ll_lm_accept_one(double *L, const double *in, double *pose, const LLLmOpt &o)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const int s = first + i;
-    double *L = V.lm + (size_t)s * LL_LM_STRIDE, *pose = V.pose + (size_t)s * 7;
     if (L[59] == 0.0 && L[68] != 0.0) {
-        const double *in = V.neq + (size_t)s * LL_NEQ_STRIDE;
         const double cc = in[42], cost = L[7];
         double step_norm = 0.0, x_norm = 0.0;
         for (int k = 0; k < 7; ++k) { const double e = L[60 + k] - L[k]; step_norm += e * e; x_norm += L[k] * L[k]; }
@@ -250,6 +245,62 @@ __global__ void k_lm_accept(LLView V, int first, int count, LLLmOpt o)
     for (int k = 0; k < 7; ++k) pose[k] = L[k];
 }
 
+__global__ void k_lm_begin(LLView V, int first, int count, LLLmOpt o)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int s = first + i;
+    ll_lm_begin_one(V.lm + (size_t)s * LL_LM_STRIDE, V.neq + (size_t)s * LL_NEQ_STRIDE, V.pose + (size_t)s * 7, o);
+}
+__global__ void k_lm_propose(LLView V, int first, int count, LLLmOpt o)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int s = first + i;
+    ll_lm_propose_one(V.lm + (size_t)s * LL_LM_STRIDE, V.pose + (size_t)s * 7, o);
+}
+__global__ void k_lm_accept(LLView V, int first, int count, LLLmOpt o)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int s = first + i;
+    ll_lm_accept_one(V.lm + (size_t)s * LL_LM_STRIDE, V.neq + (size_t)s * LL_NEQ_STRIDE, V.pose + (size_t)s * 7, o);
+}
+
+/* The whole solve of a slot in ONE launch: evaluate, begin, max_num_iterations x (propose, evaluate, accept) -- one workgroup per
+ * slot, the steps of the single-thread trust-region logic on thread 0 between the workgroup-wide evaluations, the pose and the
+ * normal equations handed over in LDS.  The same arithmetic in the same order as the launch-per-step sequence above (kept for
+ * the row-parallel mode, where an all-reduce sits between evaluate and accept): the results are bit-identical, the node-style
+ * odometry frame drops from 48 dependent launches to 9.  The state and the last normal equations are left in V.lm / V.neq. */
+#define LL_LM_THREADS 512     /* the solve is a chain of 1 + max_num_iterations evaluations on ONE workgroup: twice the threads, half the chain */
+__global__ __launch_bounds__(LL_LM_THREADS) void k_lm_solve(LLView V, int first, int count, LLLmOpt o)
+{
+    if ((int)blockIdx.x >= count) return;
+    const int s = first + blockIdx.x;
+    __shared__ double red[LL_LM_THREADS / 64][LL_NACC];
+    __shared__ double sp[7], sneq[LL_NEQ_STRIDE], sL[LL_LM_STRIDE];
+    const int tid = threadIdx.x;
+    if (tid < 7) sp[tid] = V.pose[(size_t)s * 7 + tid];
+    for (int k = tid; k < LL_LM_STRIDE; k += LL_LM_THREADS) sL[k] = 0.0;
+    __syncthreads();
+    ll_neq_eval<LL_LM_THREADS>(V, s, sp, sneq, red);
+    if (tid == 0) ll_lm_begin_one(sL, sneq, sp, o);
+    for (int it = 0; it < o.max_num_iterations; ++it) {
+        if (tid == 0) ll_lm_propose_one(sL, sp, o);
+        __syncthreads();
+        ll_neq_eval<LL_LM_THREADS>(V, s, sp, sneq, red);
+        if (tid == 0) ll_lm_accept_one(sL, sneq, sp, o);
+    }
+    __syncthreads();
+    if (tid < 7) V.pose[(size_t)s * 7 + tid] = sp[tid];
+    for (int k = tid; k < LL_NEQ_STRIDE; k += LL_LM_THREADS) V.neq[(size_t)s * LL_NEQ_STRIDE + k] = sneq[k];
+    for (int k = tid; k < LL_LM_STRIDE; k += LL_LM_THREADS) V.lm[(size_t)s * LL_LM_STRIDE + k] = sL[k];
+}
+
+void ll_launch_lm_solve(const LLView &V, int first, int count, const LLLmOpt &o, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_lm_solve, dim3(count), dim3(LL_LM_THREADS), 0, st, V, first, count, o);
+}
 void ll_launch_lm_begin(const LLView &V, int first, int count, const LLLmOpt &o, hipStream_t st)
 {
     hipLaunchKernelGGL(k_lm_begin, dim3((count + 63) / 64), dim3(64), 0, st, V, first, count, o);
