@@ -676,7 +676,7 @@ extern "C" int ll_map_create(ll_ctx *ctx, int max_map_corner, int max_map_surf, 
     for (int w = 0; w < 2 && ok; ++w)
         ok = ok && map_alloc(m, M.nn_pt[w], (size_t)m->cap_stk[w] * 5) && map_alloc(m, M.nn_id[w], (size_t)m->cap_stk[w] * 5);
     ok = ok && map_alloc(m, M.counts, 2) && map_alloc(m, M.pose, 7) && map_alloc(m, M.neq, LL_NEQ_STRIDE) && map_alloc(m, M.lm, LL_LM_STRIDE);
-    ok = ok && map_alloc(m, M.neq_part, (size_t)LL_NEQ_NB * 28) && map_alloc(m, M.neq_ticket, 1);
+    ok = ok && map_alloc(m, M.neq_part, (size_t)LL_NEQ_NB * 28) && map_alloc(m, M.neq_ticket, 1) && map_alloc(m, M.lm_go, 1);
     ok = ok && map_alloc(m, m->d_bbox, 12) && map_alloc(m, m->d_tile, (size_t)(m->max_cells + 1 + 4095) / 4096 + 1);
     if (!ok) { ctx->err = m->err; ll_map_destroy(m); return LL_ERR_HIP; }
     M.huber = ctx->V.huber;
@@ -889,16 +889,7 @@ extern "C" int ll_map_associate_merged(ll_map *m, const double *pose_w7, int n_p
 /* one ceres::Solve (:2072-2082) on the residual blocks the last association left behind */
 static void map_lm_solve(ll_map *m, const LLLmOpt &o)
 {
-    hipStream_t st = m->ctx->stream;
-    LLView Vm = m->ctx->V;                                    /* the LM kernels on a one-slot view of the map's state */
-    Vm.pose = m->M.pose; Vm.neq = m->M.neq; Vm.lm = m->M.lm;
-    ll_map_launch_normal_eq(m->M, st);
-    ll_launch_lm_begin(Vm, 0, 1, o, st);
-    for (int k = 0; k < o.max_num_iterations; ++k) {
-        ll_launch_lm_propose(Vm, 0, 1, o, st);
-        ll_map_launch_normal_eq(m->M, st);
-        ll_launch_lm_accept(Vm, 0, 1, o, st);
-    }
+    ll_map_launch_lm_solve(m->M, o, m->ctx->stream);          /* evaluate, begin, n x (propose, evaluate, accept): one launch */
 }
 
 extern "C" int ll_map_set_row_shard(ll_map *m, int rank, int world)

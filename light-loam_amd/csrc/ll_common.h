@@ -193,6 +193,7 @@ struct LLMapView {
     float4 *nn_pt[2]; int *nn_id[2];             /* tile shard: per stack point 5 x (x, y, z, distance) and 5 global ids */
     int row_rank, row_world;                     /* k_map_normal_eq sums the blocks i with i % row_world == row_rank (0, 1: all) */
     double *neq_part; unsigned *neq_ticket;      /* k_map_normal_eq: per-workgroup partial sums [LL_NEQ_NB][28], arrival counter */
+    unsigned *lm_go;                             /* k_map_lm_solve: the round workgroup 0 has released */
 };
 #define LL_NEQ_NB 16                             /* workgroups of k_map_normal_eq */
 /* device-to-device copy / small constant fill as kernel launches: on this stack an asynchronous copy costs the host ~26 us,
@@ -208,6 +209,7 @@ void ll_map_launch_associate(const LLMapView &M, hipStream_t st);
 void ll_map_launch_knn_partial(const LLMapView &M, hipStream_t st);
 void ll_map_launch_associate_merged(const LLMapView &M, int n_parts, const float4 *const pt_all[2], const int *const id_all[2], hipStream_t st);
 void ll_map_launch_normal_eq(const LLMapView &M, hipStream_t st);
+void ll_map_launch_lm_solve(const LLMapView &M, const LLLmOpt &o, hipStream_t st);
 void ll_map_launch_rows(const LLMapView &M, double *r, double *Jq, double *Jt, hipStream_t st);
 
 void ll_launch_factor_blocks(const double *pose, int n_e, const double *edge, int n_p, const double *plane, int n_n, const double *pnorm,

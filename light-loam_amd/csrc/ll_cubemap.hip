@@ -67,11 +67,14 @@ struct ll_cubemap {
     } while (0)
 
 /* ------------------------------------------------------------------ kernels */
-__global__ __launch_bounds__(256) void k_cm_copy(const float4 *pool, const float4 *points, const int *index, const CmOp *ops, int nops, float4 *dst, int *gid)
+/* the descriptors travel as a kernel ARGUMENT (<= CM_PACK of them per launch): no copy of a host array to wait for */
+#define CM_PACK 160
+struct CmOpPack { CmOp op[CM_PACK]; };
+__global__ __launch_bounds__(256) void k_cm_copy(const float4 *pool, const float4 *points, const int *index, CmOpPack ops, int nops, float4 *dst, int *gid)
 {
     const int o = blockIdx.y;
     if (o >= nops) return;
-    const CmOp op = ops[o];
+    const CmOp op = ops.op[o];
     for (int i = blockIdx.x * 256 + threadIdx.x; i < op.cnt; i += gridDim.x * 256) {
         dst[op.dst + i] = op.kind == 0 ? pool[op.src + i] : points[index[op.src + i]];
         if (gid) gid[op.dst + i] = op.tag + i;
@@ -182,13 +185,12 @@ extern "C" int ll_cubemap_create(ll_ctx *ctx, float line_res, float plane_res, i
 static int cm_run_ops(ll_cubemap *cm, const std::vector<CmOp> &ops, const float4 *pool, const float4 *points, const int *index, float4 *dst, int *gid = nullptr)
 {
     hipStream_t st = cm->ctx->stream;
-    for (size_t o0 = 0; o0 < ops.size(); o0 += CM_MAX_OPS) {
-        const int n = (int)std::min<size_t>(CM_MAX_OPS, ops.size() - o0);
+    for (size_t o0 = 0; o0 < ops.size(); o0 += CM_PACK) {
+        const int n = (int)std::min<size_t>(CM_PACK, ops.size() - o0);
+        CmOpPack pk;
         int mx = 1;
-        for (int i = 0; i < n; ++i) mx = std::max(mx, ops[o0 + i].cnt);
-        CM_HIP(hipMemcpyAsync(cm->d_ops, ops.data() + o0, (size_t)n * sizeof(CmOp), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_cm_copy, dim3(std::min(64, (mx + 255) / 256), n), dim3(256), 0, st, pool, points, index, cm->d_ops, n, dst, gid);
-        CM_HIP(hipStreamSynchronize(st));                      /* ops is host memory that goes out of scope */
+        for (int i = 0; i < n; ++i) { pk.op[i] = ops[o0 + i]; mx = std::max(mx, ops[o0 + i].cnt); }
+        hipLaunchKernelGGL(k_cm_copy, dim3(std::min(64, (mx + 255) / 256), n), dim3(256), 0, st, pool, points, index, pk, n, dst, gid);
     }
     return LL_OK;
 }

@@ -22,6 +22,7 @@
  * Everything after the f32 distances is f64; parity with the oracle is to rounding (1e-9), the selected blocks exact.
  */
 #include "ll_factor_math.h"
+#include "ll_lm_step.h"
 #include <limits.h>
 #include <string.h>
 
@@ -456,9 +457,13 @@ __global__ __launch_bounds__(256) void k_map_normal_eq(LLMapView M)
     if (tid == 0) s_last = (__hip_atomic_fetch_add(M.neq_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == LL_NEQ_NB - 1);
     __syncthreads();
     if (!s_last) return;
+    __shared__ double spart[LL_NEQ_NB * LL_NACC];
+    for (int e = tid; e < LL_NEQ_NB * LL_NACC; e += 256)
+        spart[e] = __hip_atomic_load(&M.neq_part[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
     if (tid < LL_NACC) {
         double v = 0.0;
-        for (int b = 0; b < LL_NEQ_NB; ++b) v += __hip_atomic_load(&M.neq_part[b * LL_NACC + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int b = 0; b < LL_NEQ_NB; ++b) v += spart[b * LL_NACC + tid];
         tot[tid] = v;
     }
     __syncthreads();
@@ -470,6 +475,126 @@ __global__ __launch_bounds__(256) void k_map_normal_eq(LLMapView M)
         out[42] = tot[27];
         out[43] = (double)(3 * ((n_e - rr + rw - 1) / rw) + (n_p - rr + rw - 1) / rw);   /* rows summed here */
         __hip_atomic_store(M.neq_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   /* for the next launch */
+    }
+}
+
+/* One ceres::Solve (:2072-2082) in ONE launch: evaluate, begin, n x (propose, evaluate, accept) on the LL_NEQ_NB workgroups of
+ * k_map_normal_eq, which stay resident for the whole solve.  Every round all workgroups sum their rows at the current pose
+ * (the same partition and the same fixed order of the partial sums as k_map_normal_eq: bit-identical normal equations);
+ * workgroup 0 waits for the LL_NEQ_NB partial sums, takes the single-thread trust-region step (ll_lm_step.h, state in its LDS),
+ * publishes the next pose and releases the others.  Partial sums, pose, arrival counter and round counter cross the
+ * workgroups (and the XCDs) as agent-scope atomics; every wait is bounded and a time-out leaves a NaN pose (fails loudly).
+ * 16 workgroups are always co-resident on a 256-CU chip.  Replaces 2 + 3 n dependent launches (the launch-per-step kernels
+ * stay for the row-parallel mode, where an all-reduce sits between evaluate and accept). */
+__global__ __launch_bounds__(256) void k_map_lm_solve(LLMapView M, LLLmOpt o)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = blockIdx.x;
+    const int gtid = wg * 256 + tid, gsz = LL_NEQ_NB * 256;
+    const int n_e = M.counts[0], n_p = M.counts[1];
+    __shared__ double red[4][LL_NACC];
+    __shared__ double sp[7], sneq[LL_NEQ_STRIDE], sL[LL_LM_STRIDE], stot[LL_NACC], spart[LL_NEQ_NB * LL_NACC];
+    __shared__ int s_fail;
+    if (tid == 0) s_fail = 0;
+    for (int k = tid; k < LL_LM_STRIDE; k += 256) sL[k] = 0.0;
+    constexpr int SPINS = 1 << 22;
+    for (int round = 0; round <= o.max_num_iterations; ++round) {
+        if (round == 0) { if (tid < 7) sp[tid] = M.pose[tid]; }
+        else if (wg != 0) {
+            if (tid == 0) {
+                int spins = 0;
+                while (__hip_atomic_load(M.lm_go, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)round && ++spins < SPINS) __builtin_amdgcn_s_sleep(4);
+                if (spins >= SPINS) s_fail = 1;
+            }
+            __syncthreads();
+            if (s_fail) return;                                   /* workgroup 0 timed out or died: give up, it reports */
+            if (tid < 7) sp[tid] = __hip_atomic_load(&M.pose[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        Pose P;
+        for (int k = 0; k < 4; ++k) P.q[k] = sp[k];
+        for (int k = 0; k < 3; ++k) P.t[k] = sp[4 + k];
+        double acc[LL_NACC];
+#pragma unroll
+        for (int k = 0; k < LL_NACC; ++k) acc[k] = 0.0;
+        for (int i = gtid; i < n_e; i += gsz) {
+            double r[3], Jq[3][4], Jt[3][3];
+            ll_edge_d(P, M.stk[0][M.src[0][i]], &M.fa[(size_t)i * 3], &M.fb[(size_t)i * 3], r, Jq, Jt);
+            const double sc = ll_huber_scale(r[0] * r[0] + r[1] * r[1] + r[2] * r[2], M.huber, acc[27]);
+            for (int row = 0; row < 3; ++row) {
+                double J[6];
+                ll_to_local(P, Jq[row], J);
+                J[3] = Jt[row][0]; J[4] = Jt[row][1]; J[5] = Jt[row][2];
+                for (int k = 0; k < 6; ++k) J[k] *= sc;
+                ll_acc_row(acc, J, r[row] * sc);
+            }
+        }
+        for (int i = gtid; i < n_p; i += gsz) {
+            double r, Jq[4], Jt[3], J[6];
+            ll_plane_norm(P, M.stk[1][M.src[1][i]], &M.fn[(size_t)i * 3], M.fd[i], r, Jq, Jt);
+            const double sc = ll_huber_scale(r * r, M.huber, acc[27]);
+            ll_to_local(P, Jq, J);
+            J[3] = Jt[0]; J[4] = Jt[1]; J[5] = Jt[2];
+            for (int k = 0; k < 6; ++k) J[k] *= sc;
+            ll_acc_row(acc, J, r * sc);
+        }
+#pragma unroll
+        for (int k = 0; k < LL_NACC; ++k) {
+            double v = acc[k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == 0) red[wave][k] = v;
+        }
+        __syncthreads();
+        if (tid < LL_NACC) {
+            const double v = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+            __hip_atomic_store(&M.neq_part[wg * LL_NACC + tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(M.neq_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (wg != 0) { if (round == o.max_num_iterations) return; continue; }
+        /* ---- workgroup 0: all partial sums of this round, then the step ---- */
+        if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(M.neq_ticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)((round + 1) * LL_NEQ_NB) && ++spins < SPINS) __builtin_amdgcn_s_sleep(4);
+            if (spins >= SPINS) s_fail = 1;
+        }
+        __syncthreads();
+        if (s_fail) break;
+        for (int e = tid; e < LL_NEQ_NB * LL_NACC; e += 256)      /* all loads in flight at once, the sums in workgroup order */
+            spart[e] = __hip_atomic_load(&M.neq_part[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (tid < LL_NACC) {
+            double v = 0.0;
+            for (int b = 0; b < LL_NEQ_NB; ++b) v += spart[b * LL_NACC + tid];
+            stot[tid] = v;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int k = 0;
+            for (int a = 0; a < 6; ++a) for (int b = a; b < 6; ++b) { sneq[a * 6 + b] = stot[k]; sneq[b * 6 + a] = stot[k]; ++k; }
+            for (int a = 0; a < 6; ++a) sneq[36 + a] = stot[21 + a];
+            sneq[42] = stot[27];
+            sneq[43] = (double)(3 * n_e + n_p);
+            if (round == 0) ll_lm_begin_one(sL, sneq, sp, o); else ll_lm_accept_one(sL, sneq, sp, o);
+            if (round < o.max_num_iterations) {
+                ll_lm_propose_one(sL, sp, o);
+                for (int q = 0; q < 7; ++q) __hip_atomic_store(&M.pose[q], sp[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(M.lm_go, (unsigned)(round + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+    }
+    /* workgroup 0 only: the result, and the counters back to zero for the next launch (nobody waits on them any more, except
+     * after a time-out -- then the round counter is pushed past every round so that stragglers leave) */
+    if (s_fail) { if (tid < 7) sp[tid] = __builtin_nan(""); }
+    __syncthreads();
+    if (tid < 7) M.pose[tid] = sp[tid];
+    for (int k = tid; k < LL_NEQ_STRIDE; k += 256) M.neq[k] = sneq[k];
+    for (int k = tid; k < LL_LM_STRIDE; k += 256) M.lm[k] = sL[k];
+    if (tid == 0) {
+        __hip_atomic_store(M.neq_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(M.lm_go, s_fail ? 0x7fffffffu : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -568,6 +693,11 @@ void ll_map_launch_associate_merged(const LLMapView &M, int n_parts, const float
 void ll_map_launch_normal_eq(const LLMapView &M, hipStream_t st)
 {
     hipLaunchKernelGGL(k_map_normal_eq, dim3(LL_NEQ_NB), dim3(256), 0, st, M);
+}
+
+void ll_map_launch_lm_solve(const LLMapView &M, const LLLmOpt &o, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_map_lm_solve, dim3(LL_NEQ_NB), dim3(256), 0, st, M, o);
 }
 
 void ll_map_launch_rows(const LLMapView &M, double *r, double *Jq, double *Jt, hipStream_t st)
