@@ -84,7 +84,10 @@ __global__ __launch_bounds__(LL_GB) void k_build_grid(LLView V, int first, int c
     if (tid == 0) okflag = (V.nearby >= 0.0) ? 1 : 0;
     __syncthreads();
     LL_GPHASE_BEGIN();
-    constexpr int UN = 8;                            /* independent loads in flight per thread: the kernel is latency-bound */
+#ifndef LL_GRID_UN
+#define LL_GRID_UN 8
+#endif
+    constexpr int UN = LL_GRID_UN;                   /* independent loads in flight per thread: the kernel is latency-bound */
     const int lane = tid & 63;
     bool bad = false;
     for (int i0 = tid; i0 < m; i0 += LL_GB * UN) {

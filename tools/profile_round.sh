@@ -19,5 +19,7 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_
 python3 tools/sq_summary.py $O/pmc_sq > $O/${TAG}_sq_counters.txt
 cp $O/pmc_traffic.json profiles/pmc_traffic.json          # bench.py reads roofline.traffic from here
 python3 bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
-python3 tools/phase_timing.py 64 > $O/${TAG}_phase_timing.txt 2>&1
+python3 tools/phase_timing.py 2048 > $O/${TAG}_phase_timing.txt 2>&1
+# keep what is merged back small: the raw counter tables and traces stay on the box
+rm -rf $O/prof_$TAG $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/liblightloam_hip_phase.so
 tail -n 3 $O/${TAG}_kernel_stats.txt; tail -c 600 $O/${TAG}_bench.json
