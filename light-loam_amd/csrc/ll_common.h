@@ -123,8 +123,8 @@ __device__ __forceinline__ void ll_match_any(int v, int bits, unsigned long long
 {
     mlo = (unsigned)among; mhi = (unsigned)(among >> 32);
     for (int b = 0; b < bits; ++b) {
-        const int y = -((v >> b) & 1);
-        const unsigned long long s = __ballot(y != 0);
+        const int y = __builtin_amdgcn_sbfe(v, (unsigned)b, 1u);           /* v_bfe_i32: the bit as 0 / ~0 in one instruction */
+        const unsigned long long s = __ballot(y < 0);
         mlo = __builtin_amdgcn_bitop3_b32(mlo, (unsigned)s, (unsigned)y, 0x90);
         mhi = __builtin_amdgcn_bitop3_b32(mhi, (unsigned)(s >> 32), (unsigned)y, 0x90);
     }
