@@ -128,16 +128,15 @@ extern "C" int ll_create(int device, const ll_params *p, ll_ctx **out)
     V.cap_sharp = R * LL_SEGS * LL_SHARP_PER_SEG; V.cap_lsharp = R * LL_SEGS * LL_LSHARP_PER_SEG; V.cap_flat = R * LL_SEGS * LL_FLAT_PER_SEG;
     V.carry_slot = 0;
 
-    const size_t BN = (size_t)B * NP, BT = (size_t)B * V.T;
+    const size_t BN = (size_t)B * NP;
     bool ok = true;
     float4 *raw = nullptr; int *n_in = nullptr;
     ok = ok && dev_alloc(ctx, raw, BN, false) && dev_alloc(ctx, n_in, B);
     V.raw = raw; V.n_in = n_in;
-    ok = ok && dev_alloc(ctx, V.ori, BN, false) && dev_alloc(ctx, V.ring, BN, false);
-    ok = ok && dev_alloc(ctx, V.tile_hist, BT * R) && dev_alloc(ctx, V.tile_base, BT * R) && dev_alloc(ctx, V.tile_first_p, BT) &&
-         dev_alloc(ctx, V.tile_first_kept, BT) && dev_alloc(ctx, V.tile_last_kept, BT);
     ok = ok && dev_alloc(ctx, V.hdr, B) && dev_alloc(ctx, V.ring_off, (size_t)B * (R + 1));
-    ok = ok && dev_alloc(ctx, V.cloud, BN, false) && dev_alloc(ctx, V.label, BN) && dev_alloc(ctx, V.curv, p->write_curvature ? BN : 1);
+    V.ring_cap = p->max_ring_points < NP ? p->max_ring_points : NP; V.CS = R * V.ring_cap;
+    ok = ok && dev_alloc(ctx, V.cloud, (size_t)B * V.CS, false) && dev_alloc(ctx, ctx->cloud_flat, NP, false);
+    ok = ok && dev_alloc(ctx, V.label, BN) && dev_alloc(ctx, V.curv, p->write_curvature ? BN : 1);
     ok = ok && dev_alloc(ctx, V.ring_pub, (size_t)B * R);
     {   /* ring thresholds of this sensor model (ll_exact_math.h), computed once with the same exact arithmetic */
         int *thr_dev = nullptr;
@@ -1149,7 +1148,8 @@ extern "C" int ll_download_cloud(ll_ctx *ctx, int slot, ll_point *cloud, int cap
     LLView &V = ctx->V;
     if (cloud) {
         if (cap < h.n) { ctx->err = "cloud capacity too small"; return LL_ERR_CAPACITY; }
-        rc = dl(ctx, cloud, V.cloud + (size_t)slot * V.NP, (size_t)h.n * 16); if (rc) return rc;
+        ll_launch_cloud_flatten(V, slot, ctx->cloud_flat, ctx->stream);          /* the rings sit at a fixed stride on the device */
+        rc = dl(ctx, cloud, ctx->cloud_flat, (size_t)h.n * 16); if (rc) return rc;
     }
     std::vector<int> off(V.R + 1);
     rc = dl(ctx, off.data(), V.ring_off + (size_t)slot * (V.R + 1), (size_t)(V.R + 1) * sizeof(int)); if (rc) return rc;

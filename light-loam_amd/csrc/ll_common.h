@@ -3,12 +3,9 @@
  *
  * HBM layout (B = batch slots, NP = max_points rounded up to a whole tile, R = n_scans, T = NP / LL_TILE):
  *   raw        float4 [B][NP]      uploaded points (x, y, z, reflectance/pad) -- KITTI .bin / PointXYZ stride
- *   ori        float  [B][NP]      -atan2f(y,x) per input point (scanRegistration.cpp:177)
- *   ring       int8   [B][NP]      scanID per input point, -1 = filtered / rejected
- *   tile_hist  int    [B][T][R]    per-tile ring histogram      -> tile_base (exclusive, in laserCloud positions)
  *   hdr        ScanHdr[B]          startOri / endOri / halfPassed index / sizes / status
- *   ring_off   int    [B][R+1]     ring r occupies laserCloud[ring_off[r], ring_off[r+1])
- *   cloud      float4 [B][NP]      laserCloud: ring-major, (x, y, z, intensity)
+ *   ring_off   int    [B][R+1]     ring r is laserCloud[ring_off[r], ring_off[r+1]) (labels, curvature, C ABI)
+ *   cloud      float4 [B][R][ring_cap]  laserCloud (x, y, z, intensity), every ring at a fixed stride (ring_cap = max_ring_points)
  *   label      int8   [B][NP]      cloudLabel   curv float [B][NP] (optional)
  *   ring_pub   u64 [B][R]          look-back words: the ring kernel writes its features straight at their final offsets in
  *   sharp / less_sharp / flat / less_flat float4 [B][cap] in the reference's publication order.
@@ -73,10 +70,9 @@ struct LLView {
     int cap_sharp, cap_lsharp, cap_flat;      /* per-scan capacities R*12, R*120, R*24 */
     /* organise */
     const float4 *raw; const int *n_in;
-    float *ori; int8_t *ring;
-    int *tile_hist; int *tile_base; int *tile_first_p; int *tile_first_kept; int *tile_last_kept;
     ScanHdr *hdr; int *ring_off;
-    float4 *cloud; int8_t *label; float *curv;
+    float4 *cloud; int ring_cap, CS;   /* laserCloud, ring r of slot s at cloud[s * CS + r * ring_cap]; CS = R * ring_cap */
+    int8_t *label; float *curv;
     /* features */
     unsigned long long *ring_pub;  /* [B][R] look-back word of every ring: launch tag << 40 | its four feature counts */
     int epoch;                     /* the tag of the current k_ring_features launch (1 .. 2^24 - 2) */
@@ -244,6 +240,7 @@ void ll_prof_mark(LLProfiler *p, int kernel_id, hipStream_t st);
 
 /* launchers implemented in the per-stage .hip files */
 void ll_launch_organize(const LLView &V, int first, int count, hipStream_t st, LLProfiler *prof);
+void ll_launch_cloud_flatten(const LLView &V, int slot, float4 *dst, hipStream_t st);
 void ll_launch_features(const LLView &V, int first, int count, size_t lds_bytes, hipStream_t st, LLProfiler *prof);
 void ll_launch_associate(const LLView &V, int first, int count, hipStream_t st, LLProfiler *prof);
 void ll_launch_build_grid(const LLView &V, int first, int count, int carry, hipStream_t st, LLProfiler *prof);

@@ -283,7 +283,20 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : 1)) void k_ring_
     const int S = off + 5, E = off + nr - 6;                          /* scanStartInd / scanEndInd (:218-220) */
     const bool active = (E - S >= 6);                                 /* :248 */
     const int Lseg = active ? (E - S) : 0;                            /* indices S .. E-1 are in segments */
-    const float4 *cloud = V.cloud + (size_t)s * V.NP;
+    /* the ring's points by local index; laserCloud index g of the reference = off + local index.  Neighbours beyond the
+     * ring's ends (the curvature of a ring's first / last five points reaches into the adjacent rings, :225-235) are looked
+     * up through the offsets table: the rings sit at a fixed stride (ll_organize.hip) */
+    const float4 *slot_cloud = V.cloud + (size_t)s * V.CS;
+    const float4 *cloud = slot_cloud + (size_t)r * V.ring_cap - off;          /* cloud[off + li] = the ring's point li */
+    auto cloud_at = [&](int g) -> float4 {                                      /* any laserCloud index 0 <= g < N */
+        int l = g - off;
+        if (l >= 0 && l < nr) return cloud[g];
+        const int *ro = V.ring_off + (size_t)s * (V.R + 1);
+        int q = r;
+        if (l < 0) { do { --q; l += ro[q + 1] - ro[q]; } while (l < 0); }
+        else { int c = nr; do { l -= c; ++q; c = ro[q + 1] - ro[q]; } while (l >= c); }
+        return slot_cloud[(size_t)q * V.ring_cap + l];
+    };
     FeatLds L = ll_carve(ll_smem, V.max_ring);
     float *fs = (float *)(L.sc + 32);                                 /* 24 floats: per-wave bounds */
 
@@ -343,7 +356,7 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : 1)) void k_ring_
 #pragma unroll
     for (int u = 0; u < TLOADS; ++u) {
         const int t = u * LL_BLOCK + tid, g = off - 5 + t;
-        if (t < LL_FTILE + 10 && g >= 0 && g < N) pre[u] = cloud[g];
+        if (t < LL_FTILE + 10 && g >= 0 && g < N) pre[u] = cloud_at(g);
     }
     for (int c0 = 0; c0 < nr; c0 += LL_FTILE) {
         const int g0 = off + c0;                                      /* global index of tile slot 5 */
@@ -357,7 +370,7 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : 1)) void k_ring_
 #pragma unroll
             for (int u = 0; u < TLOADS; ++u) {
                 const int t = u * LL_BLOCK + tid, g = g0 + LL_FTILE - 5 + t;
-                if (t < LL_FTILE + 10 && g >= 0 && g < N) pre[u] = cloud[g];
+                if (t < LL_FTILE + 10 && g >= 0 && g < N) pre[u] = cloud_at(g);
             }
         }
 #pragma unroll

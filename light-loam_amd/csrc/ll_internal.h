@@ -28,6 +28,7 @@ struct ll_ctx {
     std::string err;
     size_t feat_lds = 0;
     float4 *h_stage = nullptr;      /* pinned staging for uploads */
+    float4 *cloud_flat = nullptr;   /* [NP] device staging of ll_download_cloud: one slot's laserCloud without the ring stride */
     size_t h_stage_pts = 0;
     double *d_tmp_pose = nullptr, *d_rows = nullptr;
     size_t rows_cap = 0;

@@ -2,17 +2,8 @@
  * ll_organize.hip -- a1: NaN / minimum-range filter, ring + azimuth assignment, stable ring bucketing.
  * Replaces scanRegistration.cpp:58-85 (removeClosedPointCloud), :105-221 of /root/reference.
  *
- * The reference loop is sequential (one push_back per point, one halfPassed flag).  Restated data-parallel:
- *   k_classify  per 1024-point tile: keep test, scanID, ori = -atan2f(y,x), the state-free predicate
- *               P(i) = "(ori_i adjusted against startOri) - startOri > pi" whose first hit is where
- *               halfPassed flips (:189-192), per-tile ring histogram / first-P / first & last kept index.
- *   k_offsets   per scan: exclusive scan of the tile histograms -> laserCloud position of every
- *               (tile, ring) bucket, scanStartInd / scanEndInd (:218-220), endOri (:115-126), cloudSize.
- *   k_scatter   per tile: relTime / intensity (:207-208) and a stable multi-split by ring using 64-lane
- *               ballot matching (rank inside the wave) + per-(wave, ring) counters in LDS.
- * HBM traffic per input point: classify 16 B read + 5 B write, scatter 21 B read + 16 B write per kept point.
- * Block b runs on XCD b % 8 (observed); ll_xcd_map keeps all tiles of one scan on one XCD so the ori/ring
- * arrays written by k_classify are read by k_scatter from the same L2.
+ * The reference loop is sequential (one push_back per point, one halfPassed flag).  k_organize keeps the order of the
+ * walk -- one workgroup per scan, tile after tile -- and makes every tile data-parallel; see the kernel's comment.
  */
 #include "ll_common.h"
 #include <limits.h>
@@ -55,245 +46,212 @@ __device__ __forceinline__ int ll_scan_id(const int *thr, const int *lut, int nb
     return (id > R - 1 || id < 0) ? -1 : id;
 }
 
-/* first kept point of each scan -> startOri (:114).  One workgroup per scan, 4 points per thread per round, stops at
- * the first round that keeps anything.  (With minimum_range 5 the first rings of a ring-major scan are dropped
- * entirely: the first kept point can be tens of thousands of points in.) */
-__global__ __launch_bounds__(LL_BLOCK) void k_first_kept(LLView V, int first, int count)
+/* One workgroup per scan walks its input in order, tile after tile (LL_TILE points: lanes hold consecutive indices, so the
+ * first / last set lane of a ballot is the smallest / largest index):
+ *   search   the first and the last point that survive the filters (:109, :72) -> startOri, endOri (:114-126); nothing
+ *            before the first or after the last one is kept, so the walk covers only the tiles between them
+ *   per tile keep test, scanID, ori = -atan2f(y, x) (:177), the state-free predicate P(i) = "(ori_i adjusted against
+ *            startOri) - startOri > pi" whose first hit over the scan is where halfPassed flips (:189-192), relTime /
+ *            intensity (:194-208), and a stable multi-split by ring: rank inside the wave from a match-any of the ring id,
+ *            (sub-tile, wave, ring) counters in LDS, the rings' running totals carried from tile to tile in LDS.
+ * The sequential walk is what makes one pass enough: a point's position in its ring needs the ring's count over all
+ * earlier tiles, which a tile-parallel launch only has after a histogram pass over the whole scan (the round-1 design:
+ * k_classify + k_offsets + k_scatter read the scan twice and kept ori / ring per point in HBM).  Ring r of slot s lands at
+ * cloud[s * CS + r * ring_cap ...]: rings at a fixed stride, so no offset has to be known before the scan is through;
+ * ring_off keeps the contiguous laserCloud offsets (:218-220) for the labels, the curvature and the C ABI.
+ * HBM traffic per input point: 16 B read, 16 B written per kept point. */
+template <bool LUT>
+__global__ __launch_bounds__(LL_BLOCK) void k_organize(LLView V, int first, int count)
 {
     if ((int)blockIdx.x >= count) return;
     const int s = first + blockIdx.x;
     const int n_in = V.n_in[s];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float4 *raw = V.raw + (size_t)s * V.NP;
-    __shared__ int sh_first;
-    if (tid == 0) sh_first = INT_MAX;
+    constexpr int NK = LL_TILE / LL_BLOCK, NW = LL_BLOCK / 64;
+
+    __shared__ int thr[LL_MAX_RINGS + 2];
+    __shared__ int lut[LUT ? LL_RING_LUT_MAX : 1];
+    __shared__ int cnt[2][NK * NW][LL_MAX_RINGS];           /* double-buffered: tile t counts into one while tile t - 1's bases are still read */
+    __shared__ int ringtot[LL_MAX_RINGS];
+    __shared__ int sh_fk, sh_lk, sh_half;
+    if (tid <= V.R) thr[tid] = V.ring_thr[tid];
+    if (tid == 0) { sh_fk = INT_MAX; sh_lk = -1; sh_half = INT_MAX; thr[V.R + 1] = INT_MAX; }
+    if (tid < LL_MAX_RINGS) ringtot[tid] = 0;
+    if (LUT) for (int i = tid; i < V.lut_nb; i += LL_BLOCK) lut[i] = V.ring_lut[i];
+    for (int i = tid; i < 2 * NK * NW * LL_MAX_RINGS; i += LL_BLOCK) (&cnt[0][0][0])[i] = 0;
     __syncthreads();
+
+    /* ---- the first and the last kept point ---- */
     for (int c = 0; c < n_in; c += LL_TILE) {
         int mine = INT_MAX;
 #pragma unroll
-        for (int k = LL_TILE / LL_BLOCK - 1; k >= 0; --k) {
+        for (int k = NK - 1; k >= 0; --k) {
             const int i = c + k * LL_BLOCK + tid;
             if (i < n_in && ll_keep(raw[i], V.thres)) mine = i;
         }
         if (__syncthreads_or(mine != INT_MAX ? 1 : 0)) {
-            if (mine != INT_MAX) atomicMin(&sh_first, mine);
+            if (mine != INT_MAX) atomicMin(&sh_fk, mine);
             break;
         }
     }
     __syncthreads();
-    if (tid == 0) {
-        const int fk = sh_first;
-        float start_ori = 0.0f;
-        if (fk != INT_MAX) { const float4 p0 = raw[fk]; start_ori = -ll_atan2f(p0.y, p0.x); }
-        V.hdr[s].start_ori = start_ori; V.hdr[s].first_kept = fk;
-        V.hdr[s].so_lo_up = ll_f32_ceil((double)start_ori - M_PI / 2);
-        V.hdr[s].so_hi_dn = ll_f32_floor((double)start_ori + M_PI * 3 / 2);
+    const int fk = sh_fk;
+    ScanHdr h;
+    h.start_ori = 0.0f; h.end_ori = 0.0f; h.first_kept = fk; h.last_kept = -1; h.half_idx = INT_MAX; h.n = 0; h.status = 0; h.max_ring = 0;
+    h.n_sharp = h.n_less_sharp = h.n_flat = h.n_less_flat = 0; h.so_lo_up = 0.0f; h.so_hi_dn = 0.0f;
+    int *ring_off = V.ring_off + (size_t)s * (V.R + 1);
+    if (fk == INT_MAX) {                                                              /* nothing survives: LL_ERR_EMPTY */
+        if (tid <= V.R) ring_off[tid] = 0;
+        if (tid == 0) { h.status = -5; V.hdr[s] = h; }
+        return;
     }
-}
-
-template <bool LUT>
-__global__ __launch_bounds__(LL_BLOCK) void k_classify(LLView V, int first, int count)
-{
-    int sl, tile;
-    if (!ll_xcd_map(blockIdx.x, V.T, count, sl, tile)) return;
-    const int s = first + sl;
-    const int n_in = V.n_in[s];
-    const int base = tile * LL_TILE;
-    if (base >= n_in) return;
-    const int tid = threadIdx.x;
-    const float4 *raw = V.raw + (size_t)s * V.NP;
-
-    __shared__ int sh_first_p, sh_fk, sh_lk;
-    __shared__ int hist[LL_MAX_RINGS];
-    __shared__ int thr[LL_MAX_RINGS + 2];
-    __shared__ int lut[LUT ? LL_RING_LUT_MAX : 1];
-    if (tid <= V.R) thr[tid] = V.ring_thr[tid];
-    if (tid == 0) { sh_first_p = INT_MAX; sh_fk = INT_MAX; sh_lk = -1; thr[V.R + 1] = INT_MAX; }
-    if (tid < LL_MAX_RINGS) hist[tid] = 0;
-    if (LUT) for (int i = tid; i < V.lut_nb; i += LL_BLOCK) lut[i] = V.ring_lut[i];
+    const int t0 = fk / LL_TILE;
+    for (int c = (n_in - 1) / LL_TILE * LL_TILE; c >= t0 * LL_TILE; c -= LL_TILE) {
+        int mine = -1;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int i = c + k * LL_BLOCK + tid;
+            if (i < n_in && ll_keep(raw[i], V.thres)) mine = i;
+        }
+        if (__syncthreads_or(mine >= 0 ? 1 : 0)) {
+            if (mine >= 0) atomicMax(&sh_lk, mine);
+            break;
+        }
+    }
     __syncthreads();
-    const ScanHdr h0 = V.hdr[s];                                      /* k_first_kept */
-    const float start_ori = h0.start_ori, so_lo_up = h0.so_lo_up, so_hi_dn = h0.so_hi_dn;
+    const int lk = sh_lk, t1 = lk / LL_TILE;
+    /* startOri, endOri (:114-126): uniform, every thread computes them from the two points */
+    float start_ori, end_ori, so_lo_up, so_hi_dn;
+    {
+        const float4 p0 = raw[fk], p1 = raw[lk];
+        start_ori = -ll_atan2f(p0.y, p0.x);
+        so_lo_up = ll_f32_ceil((double)start_ori - M_PI / 2);
+        so_hi_dn = ll_f32_floor((double)start_ori + M_PI * 3 / 2);
+        float eo = (float)((double)(-ll_atan2f_finite(p1.y, p1.x)) + 2 * M_PI);       /* -atan2f(last kept) + 2*pi in f64, stored f32 */
+        if ((double)(eo - start_ori) > 3 * M_PI)     eo = (float)((double)eo - 2 * M_PI);
+        else if ((double)(eo - start_ori) < M_PI)    eo = (float)((double)eo + 2 * M_PI);
+        end_ori = eo;
+    }
 
-    float *ori = V.ori + (size_t)s * V.NP;
-    int8_t *ring = V.ring + (size_t)s * V.NP;
-    const int lane = tid & 63;
+    /* ---- the walk ---- */
+    float4 *cloud = V.cloud + (size_t)s * V.CS;
+    const int cap = V.ring_cap;
     int bits = 0; while ((1 << bits) < V.R) ++bits;
+    float4 p[NK];
 #pragma unroll
-    for (int k = 0; k < LL_TILE / LL_BLOCK; ++k) {
-        const int i = base + k * LL_BLOCK + tid;
-        const bool in = i < n_in;
-        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (in) p = raw[i];
-        const bool kept = in && ll_keep(p, V.thres);
-        int id = -1; float o = 0.0f; bool firstp = false;
-        if (kept) {
-            o = -ll_atan2f_finite(p.y, p.x);                                          /* :177 (also start/endOri source) */
-            id = ll_scan_id<LUT>(thr, lut, V.lut_nb, V.lut_t0, V.lut_scale, V.R, p);
-            if (id >= 0) {
-                /* the !halfPassed branch (:180-192) evaluated as if the flag were still false; the float-against-double
-                 * comparisons in f32 against the rounded-outward bounds of k_first_kept (ll_f32_ceil / ll_f32_floor) */
-                float a = o;
-                const bool below = a < so_lo_up, above = a > so_hi_dn;
-                if (below || above) a = (float)((double)a + (below ? 2 * M_PI : -(2 * M_PI)));
-                firstp = (a - start_ori) >= 3.14159274101257324f;                     /* (double)(a - startOri) > M_PI */
+    for (int k = 0; k < NK; ++k) {
+        const int i = t0 * LL_TILE + k * LL_BLOCK + tid;
+        p[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n_in) p[k] = raw[i];
+    }
+    int half = INT_MAX;                                                                /* half_idx once it is known (uniform) */
+    for (int t = t0; t <= t1; ++t) {
+        const int base = t * LL_TILE, buf = (t - t0) & 1;
+        float4 pn[NK];                                                                 /* the next tile's points, in flight during this tile */
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int i = base + LL_TILE + k * LL_BLOCK + tid;
+            pn[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < t1 && i < n_in) pn[k] = raw[i];
+        }
+        int my_ring[NK], my_rank[NK]; float my_o[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int i = base + k * LL_BLOCK + tid;
+            const bool kept = i < n_in && ll_keep(p[k], V.thres);
+            int id = -1; float o = 0.0f; bool firstp = false;
+            if (kept) {
+                o = -ll_atan2f_finite(p[k].y, p[k].x);                                    /* :177 */
+                id = ll_scan_id<LUT>(thr, lut, V.lut_nb, V.lut_t0, V.lut_scale, V.R, p[k]);
+                if (id >= 0 && half == INT_MAX) {
+                    /* the !halfPassed branch (:180-192) evaluated as if the flag were still false; the float-against-double
+                     * comparisons in f32 against bounds rounded outward (ll_f32_ceil / ll_f32_floor) */
+                    float a = o;
+                    const bool below = a < so_lo_up, above = a > so_hi_dn;
+                    if (below || above) a = (float)((double)a + (below ? 2 * M_PI : -(2 * M_PI)));
+                    firstp = (a - start_ori) >= 3.14159274101257324f;                 /* (double)(a - startOri) > M_PI */
+                }
             }
+            my_o[k] = o; my_ring[k] = id;
+            const int i0 = base + k * LL_BLOCK + (tid & ~63);
+            if (half == INT_MAX) {
+                const unsigned long long pm = __ballot(firstp);
+                if (pm && lane == 0) atomicMin(&sh_half, i0 + __ffsll((long long)pm) - 1);
+            }
+            /* rank among the wave's points of the same ring, in index order */
+            const unsigned long long m = __ballot(id >= 0);
+            const int id0 = __builtin_amdgcn_readfirstlane(id);
+            int rank = 0;
+            if (__ballot(id != id0) == 0ull) {                                         /* ring-major input: one ring per wave */
+                rank = lane;
+                if (id0 >= 0 && lane == 0) cnt[buf][k * NW + wave][id0] = 64;
+            } else if (m) {
+                unsigned mlo, mhi;
+                ll_match_any(id, bits, m, mlo, mhi);
+                rank = ll_match_rank(mlo, mhi);
+                if (id >= 0 && rank == 0) cnt[buf][k * NW + wave][id] = ll_match_count(mlo, mhi);
+            }
+            my_rank[k] = rank;
         }
-        if (in) { ori[i] = o; ring[i] = (int8_t)id; }
-        /* wave-level reductions by ballot: lanes hold consecutive indices, so first/last set lane = min/max index.
-         * (per-lane LDS atomics on one address serialise 64-way; ring-major input puts a whole wave on one bin) */
-        const int i0 = base + k * LL_BLOCK + (tid & ~63);
-        const unsigned long long km = __ballot(kept);
-        if (km && lane == 0) { atomicMin(&sh_fk, i0 + __ffsll((long long)km) - 1); atomicMax(&sh_lk, i0 + 63 - __clzll((long long)km)); }
-        const unsigned long long pm = __ballot(firstp);
-        if (pm && lane == 0) atomicMin(&sh_first_p, i0 + __ffsll((long long)pm) - 1);
-        const unsigned long long m = __ballot(id >= 0);
-        const int id0 = __builtin_amdgcn_readfirstlane(id);
-        if (__ballot(id != id0) == 0ull) {                                             /* ring-major input: one ring per wave */
-            if (id0 >= 0 && lane == 0) atomicAdd(&hist[id0], __popcll(m));
-        } else if (m) {
-            unsigned mlo, mhi;
-            ll_match_any(id, bits, m, mlo, mhi);
-            if (id >= 0 && ll_match_rank(mlo, mhi) == 0) atomicAdd(&hist[id], ll_match_count(mlo, mhi));   /* one add per distinct ring */
-        }
-    }
-    __syncthreads();
-    const size_t tb = ((size_t)s * V.T + tile);
-    if (tid < V.R) V.tile_hist[tb * V.R + tid] = hist[tid];
-    if (tid == 0) {
-        V.tile_first_p[tb] = sh_first_p;
-        V.tile_first_kept[tb] = sh_fk;
-        V.tile_last_kept[tb] = sh_lk;
-    }
-}
-
-__global__ __launch_bounds__(LL_BLOCK) void k_offsets(LLView V, int first, int count)
-{
-    const int s = first + blockIdx.x;
-    if (blockIdx.x >= count) return;
-    const int tid = threadIdx.x;
-    const int n_in = V.n_in[s];
-    const int nt = (n_in + LL_TILE - 1) / LL_TILE;
-    __shared__ int ring_cnt[LL_MAX_RINGS + 1];
-    __shared__ int ring_off[LL_MAX_RINGS + 1];
-    __shared__ int sh_first_p, sh_lk;
-    if (tid == 0) { sh_first_p = INT_MAX; sh_lk = -1; }
-    __syncthreads();
-    const size_t tb = (size_t)s * V.T;
-    constexpr int TU = 8;                                   /* tile counters in flight per thread: the loops are latency chains */
-    if (tid < V.R) {
-        int run = 0;
-        for (int t = 0; t < nt; t += TU) {
-            int hh[TU];
+        __syncthreads();
+        /* bases of the (sub-tile, wave) groups of every ring = the ring's running total + the groups before */
+        if (tid < V.R) {
+            int run = ringtot[tid];
 #pragma unroll
-            for (int u = 0; u < TU; ++u) hh[u] = (t + u < nt) ? V.tile_hist[(tb + t + u) * V.R + tid] : 0;
-#pragma unroll
-            for (int u = 0; u < TU; ++u) run += hh[u];
+            for (int kw = 0; kw < NK * NW; ++kw) { const int c = cnt[buf][kw][tid]; cnt[buf][kw][tid] = run; run += c; }
+            ringtot[tid] = run;
         }
-        ring_cnt[tid] = run;
+        for (int i = tid; i < (NK * NW) << bits; i += LL_BLOCK) cnt[buf ^ 1][i >> bits][i & ((1 << bits) - 1)] = 0;    /* the next tile's counters */
+        if (half == INT_MAX) half = sh_half;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int r = my_ring[k];
+            if (r < 0) continue;
+            const int i = base + k * LL_BLOCK + tid;
+            float o = my_o[k];
+            if (i <= half) {                                                          /* !halfPassed (:178-193) */
+                if ((double)o < (double)start_ori - M_PI / 2)            o = (float)((double)o + 2 * M_PI);
+                else if ((double)o > (double)start_ori + M_PI * 3 / 2)   o = (float)((double)o - 2 * M_PI);
+            } else {                                                                  /* :194-205 */
+                o = (float)((double)o + 2 * M_PI);
+                if ((double)o < (double)end_ori - M_PI * 3 / 2)          o = (float)((double)o + 2 * M_PI);
+                else if ((double)o > (double)end_ori + M_PI / 2)         o = (float)((double)o - 2 * M_PI);
+            }
+            const float rel = (o - start_ori) / (end_ori - start_ori);               /* :207 */
+            const int pos = cnt[buf][k * NW + wave][r] + my_rank[k];
+            if (pos < cap) cloud[(size_t)r * cap + pos] = make_float4(p[k].x, p[k].y, p[k].z, (float)((double)r + 0.1 * (double)rel));   /* :208 */
+        }
+#pragma unroll
+        for (int k = 0; k < NK; ++k) p[k] = pn[k];
     }
-    int fp = INT_MAX, lk = -1;
-    for (int t = tid; t < nt; t += LL_BLOCK) {
-        fp = min(fp, V.tile_first_p[tb + t]);
-        lk = max(lk, V.tile_last_kept[tb + t]);
-    }
-    if (fp != INT_MAX) atomicMin(&sh_first_p, fp);
-    if (lk >= 0) atomicMax(&sh_lk, lk);
     __syncthreads();
+    /* contiguous laserCloud offsets, cloudSize (:212), status */
     if (tid == 0) {
         int run = 0, mx = 0;
-        for (int r = 0; r < V.R; ++r) { ring_off[r] = run; run += ring_cnt[r]; mx = max(mx, ring_cnt[r]); }
+        for (int r = 0; r < V.R; ++r) { const int c = ringtot[r]; ring_off[r] = run; run += c; mx = max(mx, c); }
         ring_off[V.R] = run;
-        ScanHdr h = V.hdr[s];
-        h.n = run; h.max_ring = mx; h.half_idx = sh_first_p; h.last_kept = sh_lk;
-        h.n_sharp = h.n_less_sharp = h.n_flat = h.n_less_flat = 0;
-        h.status = 0;
-        if (n_in <= 0 || sh_lk < 0) { h.status = -5; h.n = 0; }                    /* LL_ERR_EMPTY */
-        else {
-            /* endOri (:115-126): -atan2f(last kept) + 2*pi in f64, stored f32, then the 3*pi / pi adjustment */
-            const float so = h.start_ori;
-            float eo = (float)((double)V.ori[(size_t)s * V.NP + sh_lk] + 2 * M_PI);
-            if ((double)(eo - so) > 3 * M_PI)     eo = (float)((double)eo - 2 * M_PI);
-            else if ((double)(eo - so) < M_PI)    eo = (float)((double)eo + 2 * M_PI);
-            h.end_ori = eo;
-            if (mx > V.max_ring) h.status = -4;                                      /* LL_ERR_CAPACITY */
-        }
+        h.start_ori = start_ori; h.end_ori = end_ori; h.so_lo_up = so_lo_up; h.so_hi_dn = so_hi_dn;
+        h.last_kept = lk; h.half_idx = half; h.n = run; h.max_ring = mx;
+        if (mx > V.max_ring) h.status = -4;                                            /* LL_ERR_CAPACITY: the ring's tail was not stored */
         V.hdr[s] = h;
-    }
-    __syncthreads();
-    if (tid <= V.R) V.ring_off[(size_t)s * (V.R + 1) + tid] = ring_off[tid];
-    if (tid < V.R) {
-        int run = ring_off[tid];
-        for (int t = 0; t < nt; t += TU) {
-            int hh[TU];
-#pragma unroll
-            for (int u = 0; u < TU; ++u) hh[u] = (t + u < nt) ? V.tile_hist[(tb + t + u) * V.R + tid] : 0;
-#pragma unroll
-            for (int u = 0; u < TU; ++u)
-                if (t + u < nt) { V.tile_base[(tb + t + u) * V.R + tid] = run; run += hh[u]; }
-        }
     }
 }
 
-__global__ __launch_bounds__(LL_BLOCK) void k_scatter(LLView V, int first, int count)
+/* laserCloud as the reference holds it -- ring after ring without gaps -- for the C ABI (ll_download_cloud) */
+__global__ __launch_bounds__(LL_BLOCK) void k_cloud_flatten(LLView V, int slot, float4 *dst)
 {
-    int sl, tile;
-    if (!ll_xcd_map(blockIdx.x, V.T, count, sl, tile)) return;
-    const int s = first + sl;
-    const int n_in = V.n_in[s];
-    const int base = tile * LL_TILE;
-    if (base >= n_in) return;
-    const ScanHdr h = V.hdr[s];
-    if (h.status == -5) return;
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int NK = LL_TILE / LL_BLOCK, NW = LL_BLOCK / 64;
-    __shared__ int cnt[NK * NW][LL_MAX_RINGS];
-    for (int i = tid; i < NK * NW * LL_MAX_RINGS; i += LL_BLOCK) (&cnt[0][0])[i] = 0;
-    __syncthreads();
+    const int r = blockIdx.x;
+    const int *ring_off = V.ring_off + (size_t)slot * (V.R + 1);
+    const int off = ring_off[r], n = min(ring_off[r + 1] - off, V.ring_cap);
+    const float4 *src = V.cloud + (size_t)slot * V.CS + (size_t)r * V.ring_cap;
+    for (int i = threadIdx.x; i < n; i += LL_BLOCK) dst[off + i] = src[i];
+}
 
-    const float4 *raw = V.raw + (size_t)s * V.NP;
-    const float *ori = V.ori + (size_t)s * V.NP;
-    const int8_t *ring = V.ring + (size_t)s * V.NP;
-    int bits = 0; while ((1 << bits) < V.R) ++bits;
-
-    int my_ring[NK], my_rank[NK];
-#pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        const int i = base + k * LL_BLOCK + tid;
-        const int r = (i < n_in) ? (int)ring[i] : -1;
-        unsigned mlo, mhi;
-        ll_match_any(r, bits, __ballot(r >= 0), mlo, mhi);
-        my_ring[k] = r;
-        my_rank[k] = ll_match_rank(mlo, mhi);
-        if (r >= 0 && my_rank[k] == 0) cnt[k * NW + wave][r] = ll_match_count(mlo, mhi);
-    }
-    __syncthreads();
-    if (tid < V.R) {
-        int run = V.tile_base[((size_t)s * V.T + tile) * V.R + tid];
-        for (int kw = 0; kw < NK * NW; ++kw) { const int c = cnt[kw][tid]; cnt[kw][tid] = run; run += c; }
-    }
-    __syncthreads();
-    float4 *cloud = V.cloud + (size_t)s * V.NP;
-    const float so = h.start_ori, eo = h.end_ori;
-#pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        const int r = my_ring[k];
-        if (r < 0) continue;
-        const int i = base + k * LL_BLOCK + tid;
-        float o = ori[i];
-        if (i <= h.half_idx) {                                                          /* !halfPassed (:178-193) */
-            if ((double)o < (double)so - M_PI / 2)            o = (float)((double)o + 2 * M_PI);
-            else if ((double)o > (double)so + M_PI * 3 / 2)   o = (float)((double)o - 2 * M_PI);
-        } else {                                                                        /* :194-205 */
-            o = (float)((double)o + 2 * M_PI);
-            if ((double)o < (double)eo - M_PI * 3 / 2)        o = (float)((double)o + 2 * M_PI);
-            else if ((double)o > (double)eo + M_PI / 2)       o = (float)((double)o - 2 * M_PI);
-        }
-        const float rel = (o - so) / (eo - so);                                         /* :207 */
-        const float4 p = raw[i];
-        const int pos = cnt[k * NW + wave][r] + my_rank[k];
-        cloud[pos] = make_float4(p.x, p.y, p.z, (float)((double)r + 0.1 * (double)rel)); /* :208 */
-    }
+void ll_launch_cloud_flatten(const LLView &V, int slot, float4 *dst, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_cloud_flatten, dim3(V.R), dim3(LL_BLOCK), 0, st, V, slot, dst);
 }
 
 /* ll_debug_exact_math: the device arithmetic of a1 on caller-supplied operands (see include/lightloam_hip.h) */
@@ -339,16 +297,8 @@ void ll_launch_debug_exact_math(const LLView &V, int op, const float *a, const f
 
 void ll_launch_organize(const LLView &V, int first, int count, hipStream_t st, LLProfiler *prof)
 {
-    const int groups = (count + 7) / 8;
-    const int grid = 8 * V.T * groups;
-    ll_prof_mark(prof, LL_K_FIRST, st);
-    hipLaunchKernelGGL(k_first_kept, dim3(count), dim3(LL_BLOCK), 0, st, V, first, count);
     ll_prof_mark(prof, LL_K_CLASSIFY, st);
-    if (V.lut_nb > 0) hipLaunchKernelGGL(k_classify<true>, dim3(grid), dim3(LL_BLOCK), 0, st, V, first, count);
-    else hipLaunchKernelGGL(k_classify<false>, dim3(grid), dim3(LL_BLOCK), 0, st, V, first, count);
-    ll_prof_mark(prof, LL_K_OFFSETS, st);
-    hipLaunchKernelGGL(k_offsets, dim3(count), dim3(LL_BLOCK), 0, st, V, first, count);
-    ll_prof_mark(prof, LL_K_SCATTER, st);
-    hipLaunchKernelGGL(k_scatter, dim3(grid), dim3(LL_BLOCK), 0, st, V, first, count);
+    if (V.lut_nb > 0) hipLaunchKernelGGL(k_organize<true>, dim3(count), dim3(LL_BLOCK), 0, st, V, first, count);
+    else hipLaunchKernelGGL(k_organize<false>, dim3(count), dim3(LL_BLOCK), 0, st, V, first, count);
     ll_prof_mark(prof, LL_K_END, st);
 }
