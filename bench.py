@@ -494,9 +494,10 @@ def main():
     if bad and not os.environ.get("LL_BENCH_TIMING_BUILD"):     # set only by tools/ that time deliberately incomplete builds
         raise SystemExit(f"bench self-check failed on rank {rank}: {len(bad)} slot(s), first {bad[:5]}")
     kernel_bytes = {
-        "k_first_kept": 0.0, "k_offsets": 0.0, "k_compact": 0.0, "k_gn_step": 0.0,
-        "k_classify": 16.0 * tot["n_in"],                            # read the raw scan
-        "k_scatter": 16.0 * tot["n"],                                # write laserCloud
+        "k_first_kept": 0.0, "k_offsets": 0.0, "k_gn_step": 0.0,
+        "k_organize": 16.0 * tot["n_in"] + 16.0 * tot["n"],          # read the raw scan, write laserCloud (one pass)
+        "k_classify": 16.0 * tot["n_in"],                            # (tile-parallel path of small calls) read the raw scan
+        "k_scatter": 16.0 * tot["n"],                                # (tile-parallel path) write laserCloud
         "k_ring_features": 17.0 * tot["n"] + 16.0 * tot["feat"],     # read laserCloud, write labels + the four feature clouds
         "k_build_grid": 16.0 * (tot["lsharp"] + tot["lflat"]),       # read the target clouds once
         "k_associate": 16.0 * tot["q"] + 8.0 * tot["ne"] + 12.0 * tot["np_"],

@@ -4,10 +4,12 @@
  * code object is unusable, ll_create fails with LL_ERR_DEVICE.
  */
 #include "ll_internal.h"
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cmath>
 
-static const char *const kKernelNames[LL_K_COUNT] = {"k_classify", "k_offsets", "k_scatter", "k_ring_features", "k_compact",
+static const char *const kKernelNames[LL_K_COUNT] = {"k_classify", "k_offsets", "k_scatter", "k_ring_features", "k_organize",
                                                      "k_associate", "k_vote", "k_normal_equations", "k_gn_step", "k_build_grid", "k_first_kept"};
 
 void ll_prof_mark(LLProfiler *p, int kernel_id, hipStream_t st)
@@ -133,6 +135,17 @@ extern "C" int ll_create(int device, const ll_params *p, ll_ctx **out)
     float4 *raw = nullptr; int *n_in = nullptr;
     ok = ok && dev_alloc(ctx, raw, BN, false) && dev_alloc(ctx, n_in, B);
     V.raw = raw; V.n_in = n_in;
+    V.org_small = LL_ORG_SMALL;
+    if (const char *e = std::getenv("LIGHTLOAM_ORG_SMALL")) {                   /* tests: 0 sends every call through k_organize */
+        const int v = std::atoi(e);
+        if (v >= 0 && v <= LL_ORG_SMALL) V.org_small = v;
+    }
+    {   /* scratch of the tile-parallel organise path: org_small scans */
+        const size_t S = (size_t)std::max(1, std::min(B, V.org_small)), SN = S * NP, ST = S * V.T;
+        ok = ok && dev_alloc(ctx, V.ori, SN, false) && dev_alloc(ctx, V.ring, SN, false);
+        ok = ok && dev_alloc(ctx, V.tile_hist, ST * R) && dev_alloc(ctx, V.tile_base, ST * R) && dev_alloc(ctx, V.tile_first_p, ST) &&
+             dev_alloc(ctx, V.tile_first_kept, ST) && dev_alloc(ctx, V.tile_last_kept, ST);
+    }
     ok = ok && dev_alloc(ctx, V.hdr, B) && dev_alloc(ctx, V.ring_off, (size_t)B * (R + 1));
     V.ring_cap = p->max_ring_points < NP ? p->max_ring_points : NP; V.CS = R * V.ring_cap;
     ok = ok && dev_alloc(ctx, V.cloud, (size_t)B * V.CS, false) && dev_alloc(ctx, ctx->cloud_flat, NP, false);

@@ -18,6 +18,7 @@
 #include "ll_exact_math.h"
 
 #define LL_TILE 1024          /* points per organise tile: 256 threads x 4 */
+#define LL_ORG_SMALL 64       /* calls of at most this many scans take the tile-parallel organise kernels */
 #define LL_BLOCK 256
 #define LL_MAX_RINGS 128
 #define LL_SHARP_PER_SEG 2
@@ -57,6 +58,7 @@ struct PairHdr {
 struct LLView {
     /* configuration */
     int B, NP, T, R, ring_model, max_ring, write_curv;
+    int org_small;                 /* calls of at most this many scans take the tile-parallel organise kernels (LL_ORG_SMALL; test override) */
     float thres, lower_bound, factor;
     const int *ring_thr;           /* [R + 1] ll_ring_thresholds: keys of the smallest t = z / sqrt(x^2 + y^2) of every ring */
     const int *ring_lut; int lut_nb; float lut_t0, lut_scale;   /* ll_ring_lut_build: first guess per t bucket (lut_nb = 0: unused) */
@@ -70,6 +72,9 @@ struct LLView {
     int cap_sharp, cap_lsharp, cap_flat;      /* per-scan capacities R*12, R*120, R*24 */
     /* organise */
     const float4 *raw; const int *n_in;
+    /* scratch of the tile-parallel organise path (calls of at most LL_ORG_SMALL scans), indexed by the position in the launch */
+    float *ori; int8_t *ring;
+    int *tile_hist; int *tile_base; int *tile_first_p; int *tile_first_kept; int *tile_last_kept;
     ScanHdr *hdr; int *ring_off;
     float4 *cloud; int ring_cap, CS;   /* laserCloud, ring r of slot s at cloud[s * CS + r * ring_cap]; CS = R * ring_cap */
     int8_t *label; float *curv;
@@ -165,7 +170,7 @@ __device__ __forceinline__ void ll_targets(const LLView &V, int s, const float4 
 }
 
 /* per-kernel HIP-event profiler (ll_api.hip); mark(id) = "kernel id starts here, the previous one ended" */
-enum { LL_K_CLASSIFY = 0, LL_K_OFFSETS, LL_K_SCATTER, LL_K_RING_FEATURES, LL_K_COMPACT, LL_K_ASSOCIATE, LL_K_VOTE,
+enum { LL_K_CLASSIFY = 0, LL_K_OFFSETS, LL_K_SCATTER, LL_K_RING_FEATURES, LL_K_ORGANIZE, LL_K_ASSOCIATE, LL_K_VOTE,
        LL_K_NORMAL_EQ, LL_K_GN_STEP, LL_K_GRID, LL_K_FIRST, LL_K_COUNT, LL_K_END = -1 };
 /* ---- mapping stage (ll_mapping.hip): one scan against the clouds gathered from the cube map ---- */
 struct LLGrid3 {                       /* dense cell grid over a cloud's bounding box */

@@ -242,6 +242,257 @@ __global__ __launch_bounds__(LL_BLOCK, LL_OWAVES) void k_organize(LLView V, int 
     }
 }
 
+/* ---- the tile-parallel path for calls of at most LL_ORG_SMALL scans (one scan at a time, the way the ROS nodes drive the
+ * library): a lone workgroup walking a whole scan is latency-bound (~0.75 ms per 64-ring scan), so few scans are split
+ * over (tile, scan) workgroups instead, at the price of a second pass over the input:
+ *   k_first_kept  first kept point -> startOri
+ *   k_classify    per tile: keep test, scanID, ori, first-P, ring histogram; ori / ring per point to scratch
+ *   k_offsets     per scan: scan of the tile histograms -> position of every (tile, ring) bucket inside its ring, endOri
+ *   k_scatter     per tile: relTime / intensity, stable multi-split by ring
+ * Same arithmetic, same laserCloud layout (rings at a fixed stride) and the same ScanHdr as k_organize; the scratch arrays
+ * (ori, ring, tile tables) hold LL_ORG_SMALL scans and are indexed by the scan's position in the launch. ---- */
+/* first kept point of each scan -> startOri (:114).  One workgroup per scan, 4 points per thread per round, stops at
+ * the first round that keeps anything.  (With minimum_range 5 the first rings of a ring-major scan are dropped
+ * entirely: the first kept point can be tens of thousands of points in.) */
+__global__ __launch_bounds__(LL_BLOCK) void k_first_kept(LLView V, int first, int count)
+{
+    if ((int)blockIdx.x >= count) return;
+    const int s = first + blockIdx.x;
+    const int n_in = V.n_in[s];
+    const int tid = threadIdx.x;
+    const float4 *raw = V.raw + (size_t)s * V.NP;
+    __shared__ int sh_first;
+    if (tid == 0) sh_first = INT_MAX;
+    __syncthreads();
+    for (int c = 0; c < n_in; c += LL_TILE) {
+        int mine = INT_MAX;
+#pragma unroll
+        for (int k = LL_TILE / LL_BLOCK - 1; k >= 0; --k) {
+            const int i = c + k * LL_BLOCK + tid;
+            if (i < n_in && ll_keep(raw[i], V.thres)) mine = i;
+        }
+        if (__syncthreads_or(mine != INT_MAX ? 1 : 0)) {
+            if (mine != INT_MAX) atomicMin(&sh_first, mine);
+            break;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int fk = sh_first;
+        float start_ori = 0.0f;
+        if (fk != INT_MAX) { const float4 p0 = raw[fk]; start_ori = -ll_atan2f(p0.y, p0.x); }
+        V.hdr[s].start_ori = start_ori; V.hdr[s].first_kept = fk;
+        V.hdr[s].so_lo_up = ll_f32_ceil((double)start_ori - M_PI / 2);
+        V.hdr[s].so_hi_dn = ll_f32_floor((double)start_ori + M_PI * 3 / 2);
+    }
+}
+
+template <bool LUT>
+__global__ __launch_bounds__(LL_BLOCK) void k_classify(LLView V, int first, int count)
+{
+    int sl, tile;
+    if (!ll_xcd_map(blockIdx.x, V.T, count, sl, tile)) return;
+    const int s = first + sl;
+    const int n_in = V.n_in[s];
+    const int base = tile * LL_TILE;
+    if (base >= n_in) return;
+    const int tid = threadIdx.x;
+    const float4 *raw = V.raw + (size_t)s * V.NP;
+
+    __shared__ int sh_first_p, sh_fk, sh_lk;
+    __shared__ int hist[LL_MAX_RINGS];
+    __shared__ int thr[LL_MAX_RINGS + 2];
+    __shared__ int lut[LUT ? LL_RING_LUT_MAX : 1];
+    if (tid <= V.R) thr[tid] = V.ring_thr[tid];
+    if (tid == 0) { sh_first_p = INT_MAX; sh_fk = INT_MAX; sh_lk = -1; thr[V.R + 1] = INT_MAX; }
+    if (tid < LL_MAX_RINGS) hist[tid] = 0;
+    if (LUT) for (int i = tid; i < V.lut_nb; i += LL_BLOCK) lut[i] = V.ring_lut[i];
+    __syncthreads();
+    const ScanHdr h0 = V.hdr[s];                                      /* k_first_kept */
+    const float start_ori = h0.start_ori, so_lo_up = h0.so_lo_up, so_hi_dn = h0.so_hi_dn;
+
+    float *ori = V.ori + (size_t)sl * V.NP;                            /* scratch: by position in the launch */
+    int8_t *ring = V.ring + (size_t)sl * V.NP;
+    const int lane = tid & 63;
+    int bits = 0; while ((1 << bits) < V.R) ++bits;
+#pragma unroll
+    for (int k = 0; k < LL_TILE / LL_BLOCK; ++k) {
+        const int i = base + k * LL_BLOCK + tid;
+        const bool in = i < n_in;
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in) p = raw[i];
+        const bool kept = in && ll_keep(p, V.thres);
+        int id = -1; float o = 0.0f; bool firstp = false;
+        if (kept) {
+            o = -ll_atan2f_finite(p.y, p.x);                                          /* :177 (also start/endOri source) */
+            id = ll_scan_id<LUT>(thr, lut, V.lut_nb, V.lut_t0, V.lut_scale, V.R, p);
+            if (id >= 0) {
+                /* the !halfPassed branch (:180-192) evaluated as if the flag were still false; the float-against-double
+                 * comparisons in f32 against the rounded-outward bounds of k_first_kept (ll_f32_ceil / ll_f32_floor) */
+                float a = o;
+                const bool below = a < so_lo_up, above = a > so_hi_dn;
+                if (below || above) a = (float)((double)a + (below ? 2 * M_PI : -(2 * M_PI)));
+                firstp = (a - start_ori) >= 3.14159274101257324f;                     /* (double)(a - startOri) > M_PI */
+            }
+        }
+        if (in) { ori[i] = o; ring[i] = (int8_t)id; }
+        /* wave-level reductions by ballot: lanes hold consecutive indices, so first/last set lane = min/max index.
+         * (per-lane LDS atomics on one address serialise 64-way; ring-major input puts a whole wave on one bin) */
+        const int i0 = base + k * LL_BLOCK + (tid & ~63);
+        const unsigned long long km = __ballot(kept);
+        if (km && lane == 0) { atomicMin(&sh_fk, i0 + __ffsll((long long)km) - 1); atomicMax(&sh_lk, i0 + 63 - __clzll((long long)km)); }
+        const unsigned long long pm = __ballot(firstp);
+        if (pm && lane == 0) atomicMin(&sh_first_p, i0 + __ffsll((long long)pm) - 1);
+        const unsigned long long m = __ballot(id >= 0);
+        const int id0 = __builtin_amdgcn_readfirstlane(id);
+        if (__ballot(id != id0) == 0ull) {                                             /* ring-major input: one ring per wave */
+            if (id0 >= 0 && lane == 0) atomicAdd(&hist[id0], __popcll(m));
+        } else if (m) {
+            unsigned mlo, mhi;
+            ll_match_any(id, bits, m, mlo, mhi);
+            if (id >= 0 && ll_match_rank(mlo, mhi) == 0) atomicAdd(&hist[id], ll_match_count(mlo, mhi));   /* one add per distinct ring */
+        }
+    }
+    __syncthreads();
+    const size_t tb = ((size_t)sl * V.T + tile);
+    if (tid < V.R) V.tile_hist[tb * V.R + tid] = hist[tid];
+    if (tid == 0) {
+        V.tile_first_p[tb] = sh_first_p;
+        V.tile_first_kept[tb] = sh_fk;
+        V.tile_last_kept[tb] = sh_lk;
+    }
+}
+
+__global__ __launch_bounds__(LL_BLOCK) void k_offsets(LLView V, int first, int count)
+{
+    const int s = first + blockIdx.x;
+    if (blockIdx.x >= count) return;
+    const int tid = threadIdx.x;
+    const int n_in = V.n_in[s];
+    const int nt = (n_in + LL_TILE - 1) / LL_TILE;
+    __shared__ int ring_cnt[LL_MAX_RINGS + 1];
+    __shared__ int ring_off[LL_MAX_RINGS + 1];
+    __shared__ int sh_first_p, sh_lk;
+    if (tid == 0) { sh_first_p = INT_MAX; sh_lk = -1; }
+    __syncthreads();
+    const size_t tb = (size_t)blockIdx.x * V.T;
+    constexpr int TU = 8;                                   /* tile counters in flight per thread: the loops are latency chains */
+    if (tid < V.R) {
+        int run = 0;
+        for (int t = 0; t < nt; t += TU) {
+            int hh[TU];
+#pragma unroll
+            for (int u = 0; u < TU; ++u) hh[u] = (t + u < nt) ? V.tile_hist[(tb + t + u) * V.R + tid] : 0;
+#pragma unroll
+            for (int u = 0; u < TU; ++u) run += hh[u];
+        }
+        ring_cnt[tid] = run;
+    }
+    int fp = INT_MAX, lk = -1;
+    for (int t = tid; t < nt; t += LL_BLOCK) {
+        fp = min(fp, V.tile_first_p[tb + t]);
+        lk = max(lk, V.tile_last_kept[tb + t]);
+    }
+    if (fp != INT_MAX) atomicMin(&sh_first_p, fp);
+    if (lk >= 0) atomicMax(&sh_lk, lk);
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0, mx = 0;
+        for (int r = 0; r < V.R; ++r) { ring_off[r] = run; run += ring_cnt[r]; mx = max(mx, ring_cnt[r]); }
+        ring_off[V.R] = run;
+        ScanHdr h = V.hdr[s];
+        h.n = run; h.max_ring = mx; h.half_idx = sh_first_p; h.last_kept = sh_lk;
+        h.n_sharp = h.n_less_sharp = h.n_flat = h.n_less_flat = 0;
+        h.status = 0;
+        if (n_in <= 0 || sh_lk < 0) { h.status = -5; h.n = 0; }                    /* LL_ERR_EMPTY */
+        else {
+            /* endOri (:115-126): -atan2f(last kept) + 2*pi in f64, stored f32, then the 3*pi / pi adjustment */
+            const float so = h.start_ori;
+            float eo = (float)((double)V.ori[(size_t)blockIdx.x * V.NP + sh_lk] + 2 * M_PI);
+            if ((double)(eo - so) > 3 * M_PI)     eo = (float)((double)eo - 2 * M_PI);
+            else if ((double)(eo - so) < M_PI)    eo = (float)((double)eo + 2 * M_PI);
+            h.end_ori = eo;
+            if (mx > V.max_ring) h.status = -4;                                      /* LL_ERR_CAPACITY */
+        }
+        V.hdr[s] = h;
+    }
+    __syncthreads();
+    if (tid <= V.R) V.ring_off[(size_t)s * (V.R + 1) + tid] = ring_off[tid];
+    if (tid < V.R) {
+        int run = 0;                                            /* positions inside the ring: the rings sit at a fixed stride */
+        for (int t = 0; t < nt; t += TU) {
+            int hh[TU];
+#pragma unroll
+            for (int u = 0; u < TU; ++u) hh[u] = (t + u < nt) ? V.tile_hist[(tb + t + u) * V.R + tid] : 0;
+#pragma unroll
+            for (int u = 0; u < TU; ++u)
+                if (t + u < nt) { V.tile_base[(tb + t + u) * V.R + tid] = run; run += hh[u]; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(LL_BLOCK) void k_scatter(LLView V, int first, int count)
+{
+    int sl, tile;
+    if (!ll_xcd_map(blockIdx.x, V.T, count, sl, tile)) return;
+    const int s = first + sl;
+    const int n_in = V.n_in[s];
+    const int base = tile * LL_TILE;
+    if (base >= n_in) return;
+    const ScanHdr h = V.hdr[s];
+    if (h.status == -5) return;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NK = LL_TILE / LL_BLOCK, NW = LL_BLOCK / 64;
+    __shared__ int cnt[NK * NW][LL_MAX_RINGS];
+    for (int i = tid; i < NK * NW * LL_MAX_RINGS; i += LL_BLOCK) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+
+    const float4 *raw = V.raw + (size_t)s * V.NP;
+    const float *ori = V.ori + (size_t)sl * V.NP;
+    const int8_t *ring = V.ring + (size_t)sl * V.NP;
+    int bits = 0; while ((1 << bits) < V.R) ++bits;
+
+    int my_ring[NK], my_rank[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int i = base + k * LL_BLOCK + tid;
+        const int r = (i < n_in) ? (int)ring[i] : -1;
+        unsigned mlo, mhi;
+        ll_match_any(r, bits, __ballot(r >= 0), mlo, mhi);
+        my_ring[k] = r;
+        my_rank[k] = ll_match_rank(mlo, mhi);
+        if (r >= 0 && my_rank[k] == 0) cnt[k * NW + wave][r] = ll_match_count(mlo, mhi);
+    }
+    __syncthreads();
+    if (tid < V.R) {
+        int run = V.tile_base[((size_t)sl * V.T + tile) * V.R + tid];
+        for (int kw = 0; kw < NK * NW; ++kw) { const int c = cnt[kw][tid]; cnt[kw][tid] = run; run += c; }
+    }
+    __syncthreads();
+    float4 *cloud = V.cloud + (size_t)s * V.CS;
+    const int cap = V.ring_cap;
+    const float so = h.start_ori, eo = h.end_ori;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int r = my_ring[k];
+        if (r < 0) continue;
+        const int i = base + k * LL_BLOCK + tid;
+        float o = ori[i];
+        if (i <= h.half_idx) {                                                          /* !halfPassed (:178-193) */
+            if ((double)o < (double)so - M_PI / 2)            o = (float)((double)o + 2 * M_PI);
+            else if ((double)o > (double)so + M_PI * 3 / 2)   o = (float)((double)o - 2 * M_PI);
+        } else {                                                                        /* :194-205 */
+            o = (float)((double)o + 2 * M_PI);
+            if ((double)o < (double)eo - M_PI * 3 / 2)        o = (float)((double)o + 2 * M_PI);
+            else if ((double)o > (double)eo + M_PI / 2)       o = (float)((double)o - 2 * M_PI);
+        }
+        const float rel = (o - so) / (eo - so);                                         /* :207 */
+        const float4 p = raw[i];
+        const int pos = cnt[k * NW + wave][r] + my_rank[k];
+        if (pos < cap) cloud[(size_t)r * cap + pos] = make_float4(p.x, p.y, p.z, (float)((double)r + 0.1 * (double)rel)); /* :208 */
+    }
+}
+
 /* laserCloud as the reference holds it -- ring after ring without gaps -- for the C ABI (ll_download_cloud) */
 __global__ __launch_bounds__(LL_BLOCK) void k_cloud_flatten(LLView V, int slot, float4 *dst)
 {
@@ -300,8 +551,23 @@ void ll_launch_debug_exact_math(const LLView &V, int op, const float *a, const f
 
 void ll_launch_organize(const LLView &V, int first, int count, hipStream_t st, LLProfiler *prof)
 {
+    if (count > V.org_small) {
+        ll_prof_mark(prof, LL_K_ORGANIZE, st);
+        if (V.lut_nb > 0) hipLaunchKernelGGL(k_organize<true>, dim3(count), dim3(LL_BLOCK), 0, st, V, first, count);
+        else hipLaunchKernelGGL(k_organize<false>, dim3(count), dim3(LL_BLOCK), 0, st, V, first, count);
+        ll_prof_mark(prof, LL_K_END, st);
+        return;
+    }
+    const int groups = (count + 7) / 8;
+    const int grid = 8 * V.T * groups;
+    ll_prof_mark(prof, LL_K_FIRST, st);
+    hipLaunchKernelGGL(k_first_kept, dim3(count), dim3(LL_BLOCK), 0, st, V, first, count);
     ll_prof_mark(prof, LL_K_CLASSIFY, st);
-    if (V.lut_nb > 0) hipLaunchKernelGGL(k_organize<true>, dim3(count), dim3(LL_BLOCK), 0, st, V, first, count);
-    else hipLaunchKernelGGL(k_organize<false>, dim3(count), dim3(LL_BLOCK), 0, st, V, first, count);
+    if (V.lut_nb > 0) hipLaunchKernelGGL(k_classify<true>, dim3(grid), dim3(LL_BLOCK), 0, st, V, first, count);
+    else hipLaunchKernelGGL(k_classify<false>, dim3(grid), dim3(LL_BLOCK), 0, st, V, first, count);
+    ll_prof_mark(prof, LL_K_OFFSETS, st);
+    hipLaunchKernelGGL(k_offsets, dim3(count), dim3(LL_BLOCK), 0, st, V, first, count);
+    ll_prof_mark(prof, LL_K_SCATTER, st);
+    hipLaunchKernelGGL(k_scatter, dim3(grid), dim3(LL_BLOCK), 0, st, V, first, count);
     ll_prof_mark(prof, LL_K_END, st);
 }

@@ -66,3 +66,12 @@ def assert_bit_equal(a, b, what=""):
         idx = np.argwhere(neq)[:5]
         raise AssertionError(f"{what}: {int(neq.sum())} of {neq.size} f32 values differ bitwise; first at {idx.tolist()}: "
                              f"{a[tuple(idx[0])]!r} vs {b[tuple(idx[0])]!r}")
+
+
+ORG_PATHS = {"tiles": "64", "walk": "0"}
+
+
+def set_org_path(name):
+    """Which organise kernels the contexts created from now on use for small calls: "tiles" = the tile-parallel path of
+    calls of at most 64 scans (the library's default), "walk" = k_organize (one workgroup per scan) for every call."""
+    os.environ["LIGHTLOAM_ORG_SMALL"] = ORG_PATHS[name]

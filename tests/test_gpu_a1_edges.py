@@ -16,6 +16,16 @@ from conftest import assert_bit_equal
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["tiles", "walk"])
+def org_path(request):
+    """Every test of this file runs through both organise paths of ll_organize.hip (tile-parallel kernels of small calls,
+    and k_organize, the one-pass walk of a batch)."""
+    from conftest import set_org_path
+    set_org_path(request.param)
+    yield request.param
+    set_org_path("tiles")
+
 MODELS = {
     "VLP16": dict(rings=16, prm=dict(minimum_range=0.3)),
     "HDL32": dict(rings=32, prm=dict(minimum_range=0.3)),

@@ -40,9 +40,12 @@ SHAPES = {
 RING_MODEL = {128: dict(ring_model=1, lower_bound=-25.0, up_bound=15.0, minimum_range=0.3)}
 
 
-@pytest.fixture(scope="module", params=list(SHAPES))
+@pytest.fixture(scope="module", params=[(s, o) for s in SHAPES for o in ("tiles", "walk")], ids=lambda p: f"{p[0]}-{p[1]}")
 def case(request, api, orc, synth):
-    kw = dict(SHAPES[request.param]); rings = kw.pop("rings")
+    from conftest import set_org_path
+    shape, org = request.param
+    set_org_path(org)                # both organise paths (ll_organize.hip) see every shape
+    kw = dict(SHAPES[shape]); rings = kw.pop("rings")
     extra_prm = {}
     if kw.pop("gen", None) == "hdl64":
         import scangen
@@ -59,7 +62,8 @@ def case(request, api, orc, synth):
         ctx.upload_scan(k, s)
     ctx.extract(0, 3)
     ref = [orc.extract(s, P) for s in scans]
-    yield dict(name=request.param, ctx=ctx, ref=ref, scans=scans, rings=rings)
+    set_org_path("tiles")
+    yield dict(name=f"{shape}-{org}", ctx=ctx, ref=ref, scans=scans, rings=rings)
     ctx.close()
 
 
