@@ -55,7 +55,8 @@ typedef struct {
     float lower_bound;        /* "lowerBound" default -24.9 */
     float up_bound;           /* "upBound" default 2 */
     int   max_points;         /* per-scan point capacity (<= 400000 like the reference arrays) */
-    int   max_ring_points;    /* per-ring capacity of the feature kernel's LDS staging: 32 .. 8192 (default 2304) */
+    int   max_ring_points;    /* per-ring capacity, 32 .. 8192 (default 2304): the feature kernel's LDS staging, and the stride at which
+                                 the rings of laserCloud sit in HBM (n_scans x max_ring_points points per slot) */
     int   batch;              /* scan slots resident in HBM */
     /* thresholds; ll_default_params() fills the reference constants */
     float curv_threshold;     /* 0.1  (:266, :321) compared as double like the reference */
