@@ -352,27 +352,27 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : 1)) void k_ring_
     LL_PHASE_BEGIN();
     /* ---------------- phase 1: curvature + gap flags + sort records ---------------- */
     constexpr int TLOADS = (LL_FTILE + 10 + LL_BLOCK - 1) / LL_BLOCK;
-    float4 pre[TLOADS];                                               /* the next tile's points, in flight during the math */
+    /* TWO tiles' points in flight during the math (preA: even tiles, preB: odd tiles): one tile ahead leaves a workgroup
+     * with 8 KB outstanding -- 48 KB per CU -- which is what bounds this phase (a latency-bound stream), not its arithmetic */
+    float4 preA[TLOADS], preB[TLOADS];
+    auto tile_fetch = [&](float4 (&buf)[TLOADS], int c0) __attribute__((always_inline)) {
+        if (c0 < nr) {
 #pragma unroll
-    for (int u = 0; u < TLOADS; ++u) {
-        const int t = u * LL_BLOCK + tid, g = off - 5 + t;
-        if (t < LL_FTILE + 10 && g >= 0 && g < N) pre[u] = cloud_at(g);
-    }
-    for (int c0 = 0; c0 < nr; c0 += LL_FTILE) {
+            for (int u = 0; u < TLOADS; ++u) {
+                const int t = u * LL_BLOCK + tid, g = off + c0 - 5 + t;
+                if (t < LL_FTILE + 10 && g >= 0 && g < N) buf[u] = cloud_at(g);
+            }
+        }
+    };
+    auto tile_math = [&](float4 (&buf)[TLOADS], int c0) __attribute__((always_inline)) {
         const int g0 = off + c0;                                      /* global index of tile slot 5 */
 #pragma unroll
         for (int u = 0; u < TLOADS; ++u) {
             const int t = u * LL_BLOCK + tid, g = g0 - 5 + t;
-            if (t < LL_FTILE + 10 && g >= 0 && g < N) { L.tx[t] = pre[u].x; L.ty[t] = pre[u].y; L.tz[t] = pre[u].z; }
+            if (t < LL_FTILE + 10 && g >= 0 && g < N) { L.tx[t] = buf[u].x; L.ty[t] = buf[u].y; L.tz[t] = buf[u].z; }
         }
         __syncthreads();
-        if (c0 + LL_FTILE < nr) {
-#pragma unroll
-            for (int u = 0; u < TLOADS; ++u) {
-                const int t = u * LL_BLOCK + tid, g = g0 + LL_FTILE - 5 + t;
-                if (t < LL_FTILE + 10 && g >= 0 && g < N) pre[u] = cloud_at(g);
-            }
-        }
+        tile_fetch(buf, c0 + 2 * LL_FTILE);                           /* this buffer's next tile */
 #pragma unroll
         for (int k = 0; k < LL_FTILE / LL_BLOCK; ++k) {
             const int li = c0 + k * LL_BLOCK + tid;
@@ -393,6 +393,12 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : 1)) void k_ring_
             }
         }
         __syncthreads();
+    };
+    tile_fetch(preA, 0);
+    tile_fetch(preB, LL_FTILE);
+    for (int c0 = 0; c0 < nr; c0 += 2 * LL_FTILE) {
+        tile_math(preA, c0);
+        if (c0 + LL_FTILE < nr) tile_math(preB, c0 + LL_FTILE);
     }
 
     LL_PHASE(0);
