@@ -136,15 +136,48 @@ __device__ __forceinline__ int ll_match_rank(unsigned mlo, unsigned mhi)     /* 
 }
 __device__ __forceinline__ int ll_match_count(unsigned mlo, unsigned mhi) { return __popc(mlo) + __popc(mhi); }
 
-/* exclusive prefix sum of one int per thread over a workgroup of NW waves: 64-lane shuffle scan + the wave totals
+/* Cross-lane steps as DPP operands of the ALU instruction itself (row shifts inside the 16-lane rows, then the two row
+ * broadcasts): ~10 cycles per dependent step against ~100 for a ds_bpermute (__shfl), and the kernels that use them are
+ * bound by exactly such dependent chains.  A lane without a source keeps `old` (bound_ctrl off). */
+#define LL_DPP_I(old, v, ctrl, rmask) __builtin_amdgcn_update_dpp((int)(old), (int)(v), ctrl, rmask, 0xf, false)
+/* inclusive prefix sum over the 64 lanes */
+__device__ __forceinline__ int ll_wave_incl_scan(int v)
+{
+    v += LL_DPP_I(0, v, 0x111, 0xf);          /* row_shr:1 */
+    v += LL_DPP_I(0, v, 0x112, 0xf);          /* row_shr:2 */
+    v += LL_DPP_I(0, v, 0x114, 0xf);          /* row_shr:4 */
+    v += LL_DPP_I(0, v, 0x118, 0xf);          /* row_shr:8  -> prefix inside every row */
+    v += LL_DPP_I(0, v, 0x142, 0xa);          /* row_bcast:15 into rows 1, 3 */
+    v += LL_DPP_I(0, v, 0x143, 0xc);          /* row_bcast:31 into rows 2, 3 */
+    return v;
+}
+/* wave-wide reductions, result uniform (read from lane 63): the pattern of ll_wave_max_u32 (ll_features.hip) */
+#define LL_WAVE_REDUCE(name, T, OP, IDENT, TOI, FROMI)                                                        \
+    __device__ __forceinline__ T name(T v)                                                                    \
+    {                                                                                                         \
+        v = OP(v, FROMI(LL_DPP_I(TOI(v), TOI(v), 0xb1, 0xf)));      /* quad_perm [1,0,3,2] */                  \
+        v = OP(v, FROMI(LL_DPP_I(TOI(v), TOI(v), 0x4e, 0xf)));      /* quad_perm [2,3,0,1] */                  \
+        v = OP(v, FROMI(LL_DPP_I(TOI(IDENT), TOI(v), 0x114, 0xf))); /* row_shr:4 */                            \
+        v = OP(v, FROMI(LL_DPP_I(TOI(IDENT), TOI(v), 0x118, 0xf))); /* row_shr:8 -> lanes 12..15 hold the row's result */ \
+        v = OP(v, FROMI(LL_DPP_I(TOI(IDENT), TOI(v), 0x142, 0xa))); /* row_bcast:15 */                         \
+        v = OP(v, FROMI(LL_DPP_I(TOI(IDENT), TOI(v), 0x143, 0xc))); /* row_bcast:31 */                         \
+        return FROMI(__builtin_amdgcn_readlane(TOI(v), 63));                                                  \
+    }
+#define LL_OP_ADD(a, b) ((a) + (b))
+#define LL_OP_OR(a, b) ((a) | (b))
+#define LL_ID(x) (x)
+LL_WAVE_REDUCE(ll_wave_sum_i32, int, LL_OP_ADD, 0, LL_ID, LL_ID)
+LL_WAVE_REDUCE(ll_wave_or_u32, unsigned, LL_OP_OR, 0u, (int), (unsigned))
+LL_WAVE_REDUCE(ll_wave_min_f32, float, fminf, __builtin_inff(), __float_as_int, __int_as_float)
+LL_WAVE_REDUCE(ll_wave_max_f32, float, fmaxf, -__builtin_inff(), __float_as_int, __int_as_float)
+
+/* exclusive prefix sum of one int per thread over a workgroup of NW waves: 64-lane DPP scan + the wave totals
  * through LDS (sc: >= NW ints).  Returns the exclusive prefix; total = workgroup sum.  Ends with a barrier. */
 template <int NW>
 __device__ __forceinline__ int ll_block_exscan_n(int v, int *sc, int &total)
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    const int inc = ll_wave_incl_scan(v);
     if (lane == 63) sc[wave] = inc;
     __syncthreads();
     int base = 0, tot = 0;

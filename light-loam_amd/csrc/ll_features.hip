@@ -132,7 +132,7 @@ __device__ __forceinline__ void ll_radix_sort(unsigned *k32, unsigned short *k16
         e32[k] = 0xffffffffu; e16[k] = 0;
         if (k < myrows && g < n) { e32[k] = k32[g]; e16[k] = k16[g]; vary |= e32[k] ^ hi0; }
     }
-    for (int o = 32; o > 0; o >>= 1) vary |= __shfl_xor(vary, o);
+    vary = ll_wave_or_u32(vary);
     if (tid == 0) sc[16] = 0;
     __syncthreads();
     if (lane == 0 && vary) atomicOr((unsigned *)&sc[16], vary);
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : 1)) void k_ring_
         int v[4] = {0, 0, 0, 0};
         for (int q = tid; q < r; q += LL_BLOCK) ll_poll(q, v);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) for (int o = 32; o > 0; o >>= 1) v[c] += __shfl_xor(v[c], o);
+        for (int c = 0; c < 4; ++c) v[c] = ll_wave_sum_i32(v[c]);
         __syncthreads();
         if (lane == 0) for (int c = 0; c < 4; ++c) L.sc[32 + (tid >> 6) * 4 + c] = v[c];
         __syncthreads();
@@ -621,10 +621,8 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : 1)) void k_ring_
                 mxx = fmaxf(mxx, px[u]); mxy = fmaxf(mxy, py[u]); mxz = fmaxf(mxz, pz[u]);
             }
         /* wave reduce min/max, then across the 4 waves through LDS */
-        for (int o = 32; o > 0; o >>= 1) {
-            mnx = fminf(mnx, __shfl_xor(mnx, o)); mny = fminf(mny, __shfl_xor(mny, o)); mnz = fminf(mnz, __shfl_xor(mnz, o));
-            mxx = fmaxf(mxx, __shfl_xor(mxx, o)); mxy = fmaxf(mxy, __shfl_xor(mxy, o)); mxz = fmaxf(mxz, __shfl_xor(mxz, o));
-        }
+        mnx = ll_wave_min_f32(mnx); mny = ll_wave_min_f32(mny); mnz = ll_wave_min_f32(mnz);
+        mxx = ll_wave_max_f32(mxx); mxy = ll_wave_max_f32(mxy); mxz = ll_wave_max_f32(mxz);
         if (lane == 0) { float *w = fs + (tid >> 6) * 6; w[0] = mnx; w[1] = mny; w[2] = mnz; w[3] = mxx; w[4] = mxy; w[5] = mxz; }
         int m = 0;
         int pos = ll_block_exscan(__popc(lfm), L.sc, m);             /* barriers inside also publish fs[] */
