@@ -455,7 +455,7 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : 1)) void k_ring_
                     if (cv < V.curv_lt) candf |= 1u << k;                 /* :321 */
                 }
             }
-            bool imported = (j == 0);
+            int imp_below = (j == 0) ? 0 : 5;                             /* a choice below this slot needs the earlier segments' marks first (0: imported) */
             int nrec[2] = {0, 0};
             /* the corner candidates (usually a small part of the segment) compacted to the front rows, ascending index:
              * the corner pass then scans ceil(nc / 64) rows per pick instead of SR */
@@ -470,11 +470,11 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : 1)) void k_ring_
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             const int ncr = (nc + 63) >> 6;
-            unsigned ck[SR]; int cli[SR];                                  /* masked key (0 = not eligible), local index */
+            unsigned ck[SR]; int cli[SR];                                  /* masked key (0 = not eligible); local index | suppression extents << 16 */
 #pragma unroll
             for (int r = 0; r < SR; ++r) {
                 ck[r] = 0u; cli[r] = 0;
-                if (r < ncr && r * 64 + lane < nc) { const int q = (int)wbuf[r * 64 + lane]; ck[r] = L.k32[sp + q]; cli[r] = sp + 5 + q; }
+                if (r < ncr && r * 64 + lane < nc) { const int q = (int)wbuf[r * 64 + lane]; ck[r] = L.k32[sp + q]; cli[r] = (sp + 5 + q) | ((int)L.k16[sp + q] << 16); }
             }
             for (int pass = 0; pass < 2; ++pass) {
                 int npick = 0;
@@ -508,7 +508,11 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : 1)) void k_ring_
                         if (kmax == 0u) break;                            /* nothing eligible is left */
                         const unsigned long long bal = __ballot(best == kmax);
                         int selp;                                         /* row * 64 + lane of the choice */
-                        if (__popcll(bal) == 1) {
+                        if (CORNER && NR == 1) {
+                            /* one row of candidates in ascending index: among equal curvatures the highest lane is the largest
+                             * index, which the descending walk meets first -- no tie path */
+                            selp = 63 - __builtin_clzll(bal);
+                        } else if (__popcll(bal) == 1) {
                             const int f = __ffsll((long long)bal) - 1;
                             selp = (NR > 1 ? __builtin_amdgcn_readlane(row_l, f) * 64 : 0) + f;
                         } else {                                          /* equal curvatures in several lanes: index decides */
@@ -518,35 +522,45 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : 1)) void k_ring_
                             selp = CORNER ? (int)tm - 1 : 0x10000 - (int)tm;
                         }
                         int selq = selp;                                  /* slot inside the segment */
-                        if (CORNER) {                                     /* compacted layout -> the element's own slot */
+                        int e = 0;                                        /* the choice's suppression extents: bn | fn << 4 */
+                        if (CORNER) {                                     /* compacted layout -> the element's own slot, its extents with it */
                             int sl = __builtin_amdgcn_readlane(cli[0], selp & 63);
 #pragma unroll
                             for (int r = 1; r < NR; ++r) if ((selp >> 6) == r) sl = __builtin_amdgcn_readlane(cli[r], selp & 63);
-                            selq = sl - sp - 5;
+                            selq = (sl & 0xffff) - sp - 5;
+                            e = sl >> 16;
                         }
-                        if (!imported && selq < 5) {
+                        if (selq < imp_below) {                           /* one of the segment's first five points, marks not imported yet */
                             const int need = (1 << j) - 1;
                             while ((__hip_atomic_load(donemask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & need) != need)
                                 __builtin_amdgcn_s_sleep(2);
                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                             if (lane < 5 && lane < len && ll_bit(L.picked, li0)) { mk[0] = 0u; sup |= 1u; }
-                            if (cli[0] - sp - 5 < 5 && ck[0] != 0u && ll_bit(L.picked, cli[0])) ck[0] = 0u;   /* ascending order: row 0 */
-                            imported = true;
+                            if ((cli[0] & 0xffff) - sp - 5 < 5 && ck[0] != 0u && ll_bit(L.picked, cli[0] & 0xffff)) ck[0] = 0u;   /* ascending order: row 0 */
+                            imp_below = 0;
                             continue;                                     /* select again: the choice may be gone */
                         }
                         npick++;
                         if (CORNER && npick > LL_LSHARP_PER_SEG) break;   /* :281-284 */
                         const int sel = sp + selq + 5;
-                        unsigned ew = 0u;                                 /* the owner's extents: uniform row, lane */
+                        if (!CORNER) {                                    /* the owner's extents: uniform row, lane */
+                            unsigned ew = 0u;
 #pragma unroll
-                        for (int w = 0; w < EW; ++w) if ((selq >> 8) == w) ew = (unsigned)__builtin_amdgcn_readlane((int)exw[w], selq & 63);
-                        const int e = (int)((ew >> (((selq >> 6) & 3) * 8)) & 0xffu);
-                        if (lane == npick - 1) myrec = (unsigned)sel | ((unsigned)e << 16);
+                            for (int w = 0; w < EW; ++w) if ((selq >> 8) == w) ew = (unsigned)__builtin_amdgcn_readlane((int)exw[w], selq & 63);
+                            e = (int)((ew >> (((selq >> 6) & 3) * 8)) & 0xffu);
+                        }
+                        {   /* lane n: pick n + 1 (value and lane come out of scalar instructions: no read / write-lane hazard) */
+                            const unsigned rec = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)sel | ((unsigned)e << 16)));
+                            const int ln = __builtin_amdgcn_readfirstlane(npick - 1);
+                            unsigned m0_keep;                               /* v_writelane takes one scalar operand + m0; m0 is the compiler's: put it back */
+                            asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+                                         : "+v"(myrec), "=&s"(m0_keep) : "s"(rec), "s"(ln));
+                        }
                         if (!CORNER && npick >= LL_FLAT_PER_SEG) break;   /* :328-331: labelled, but no marking */
                         const int slo = sel - (e & 15), shi = sel + (e >> 4);
                         if (CORNER) {                                     /* the marks themselves go to the bitmap after the pass */
 #pragma unroll
-                            for (int r = 0; r < NR; ++r) key[r] = ((unsigned)(cli[r] - slo) <= (unsigned)(shi - slo)) ? 0u : key[r];
+                            for (int r = 0; r < NR; ++r) key[r] = ((unsigned)((cli[r] & 0xffff) - slo) <= (unsigned)(shi - slo)) ? 0u : key[r];
                         } else {
                             /* rows are 64 apart and a pick marks at most 11 consecutive indices: per lane at most one row is hit */
                             const int dd = shi - li0;
