@@ -246,11 +246,12 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : 1)) void k_ring_
     if (!ll_xcd_map2(blockIdx.x, V.R, count, sl, r)) return;
     const int s = first + sl;
     const int tid = threadIdx.x, lane = tid & 63;
+    /* header and offsets fetched together -- the early exit below would otherwise put a memory round trip between them */
     const ScanHdr h = V.hdr[s];
-    if (h.status != 0) return;                                        /* every ring of the scan takes this exit: nobody waits */
-    const int N = h.n;
     const int off = V.ring_off[(size_t)s * (V.R + 1) + r];
     const int nr = V.ring_off[(size_t)s * (V.R + 1) + r + 1] - off;
+    if (h.status != 0) return;                                        /* every ring of the scan takes this exit: nobody waits */
+    const int N = h.n;
     /* One 64-bit word per ring carries the four counts AND the launch tag, written and polled with relaxed atomics: no
      * release / acquire fence is needed (at agent scope those write back / invalidate the whole L2 on this chip). */
     unsigned long long *ring_pub = V.ring_pub + (size_t)s * V.R;
