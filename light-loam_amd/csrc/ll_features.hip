@@ -615,14 +615,14 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : 1)) void k_ring_
      * prefetches every thread's points before the left-to-right f32 centroid sums. */
     int n_lf_out = 0;
     if (active) {
-        const int per = (Lseg + LL_BLOCK - 1) / LL_BLOCK;                        /* <= ROWS */
+        const int per = (Lseg + LL_BLOCK - 1) / LL_BLOCK;                        /* <= ROWS; uniform: the row loops below skip the rows beyond it by scalar branches */
         const int a0 = min(Lseg, tid * per), a1 = min(Lseg, a0 + per);          /* slots -> local index slot + 5 */
         float px[ROWS], py[ROWS], pz[ROWS];
         unsigned lfm = 0;                                                        /* bit u: slot a0 + u is less-flat */
 #pragma unroll
         for (int u = 0; u < ROWS; ++u) {
             const int q = a0 + u;
-            if (q < a1) {
+            if (u < per && q < a1) {
                 const float4 p = cloud[off + q + 5];
                 px[u] = p.x; py[u] = p.y; pz[u] = p.z;
                 if (L.lab[q + 5] <= 0) lfm |= 1u << u;
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : 1)) void k_ring_
         float mnx = INFINITY, mny = INFINITY, mnz = INFINITY, mxx = -INFINITY, mxy = -INFINITY, mxz = -INFINITY;
 #pragma unroll
         for (int u = 0; u < ROWS; ++u)
-            if ((lfm >> u) & 1u) {
+            if (u < per && ((lfm >> u) & 1u)) {
                 mnx = fminf(mnx, px[u]); mny = fminf(mny, py[u]); mnz = fminf(mnz, pz[u]);
                 mxx = fmaxf(mxx, px[u]); mxy = fmaxf(mxy, py[u]); mxz = fmaxf(mxz, pz[u]);
             }
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : 1)) void k_ring_
             const float fb0 = (float)min_b[0], fb1 = (float)min_b[1], fb2 = (float)min_b[2];
 #pragma unroll
             for (int u = 0; u < ROWS; ++u)
-                if ((lfm >> u) & 1u) {
+                if (u < per && ((lfm >> u) & 1u)) {
                     unsigned idx;
                     if (too_small) idx = (unsigned)pos;
                     else {
@@ -682,14 +682,14 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : 1)) void k_ring_
             float4 pt[ROWS]; unsigned vk[ROWS];
 #pragma unroll
             for (int u = 0; u < ROWS; ++u)
-                if (b0 + u < b1) { vk[u] = L.k32[b0 + u]; pt[u] = cloud[off + L.k16[b0 + u]]; }
+                if (u < perm && b0 + u < b1) { vk[u] = L.k32[b0 + u]; pt[u] = cloud[off + L.k16[b0 + u]]; }
             unsigned headm = 0;
             {
                 unsigned prev = 0; bool has_prev = false;
                 if (b0 > 0 && b0 < b1) { prev = L.k32[b0 - 1]; has_prev = true; }
 #pragma unroll
                 for (int u = 0; u < ROWS; ++u)
-                    if (b0 + u < b1) {
+                    if (u < perm && b0 + u < b1) {
                         if (!has_prev || vk[u] != prev) headm |= 1u << u;
                         prev = vk[u]; has_prev = true;
                     }
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : 1)) void k_ring_
             unsigned endm = 0;
 #pragma unroll
             for (int u = 0; u < ROWS; ++u)
-                if (b0 + u < b1) {
+                if (u < perm && b0 + u < b1) {
                     if ((headm >> u) & 1u) {
                         if (u > 0 && cn) {
                             const float fn = (float)cn;
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : 1)) void k_ring_
                 LL_PHASE(7);
                 float4 *out = V.lflat + (size_t)s * V.NP + roff[3];
 #pragma unroll
-                for (int u = 0; u < ROWS; ++u) if ((endm >> u) & 1u) out[o++] = pt[u];
+                for (int u = 0; u < ROWS; ++u) if (u < perm && ((endm >> u) & 1u)) out[o++] = pt[u];
                 if (cn) out[o] = last;
             }
         }
