@@ -374,24 +374,24 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : 1)) void k_ring_
         }
         __syncthreads();
         tile_fetch(buf, c0 + 2 * LL_FTILE);                           /* this buffer's next tile */
+        /* The arithmetic runs for every lane (the tile arrays are valid for every slot a lane can address; what lies beyond
+         * the ring is stale but harmless) and only the stores are predicated: no divergent regions around the math. */
 #pragma unroll
         for (int k = 0; k < LL_FTILE / LL_BLOCK; ++k) {
             const int li = c0 + k * LL_BLOCK + tid;
-            if (li >= nr) continue;
             const int g = off + li, t = li - c0 + 5;
-            if (g >= 1) {                                             /* gap to the previous point (:290-293) */
-                const float dx = L.tx[t] - L.tx[t - 1], dy = L.ty[t] - L.ty[t - 1], dz = L.tz[t] - L.tz[t - 1];
-                if (dx * dx + dy * dy + dz * dz > V.gap_gt) atomicOr(&L.gapf[li >> 5], 1u << (li & 31));   /* (double)g > 0.05 */
+            const float *X = L.tx + t, *Y = L.ty + t, *Z = L.tz + t;
+            {                                                         /* gap to the previous point (:290-293) */
+                const float dx = X[0] - X[-1], dy = Y[0] - Y[-1], dz = Z[0] - Z[-1];
+                if (li < nr && g >= 1 && dx * dx + dy * dy + dz * dz > V.gap_gt) atomicOr(&L.gapf[li >> 5], 1u << (li & 31));   /* (double)g > 0.05 */
             }
-            if (g >= 5 && g < N - 5) {                                /* :225-235, strict left-to-right */
-                const float *X = L.tx + t, *Y = L.ty + t, *Z = L.tz + t;
-                const float dX = X[-5] + X[-4] + X[-3] + X[-2] + X[-1] - 10 * X[0] + X[1] + X[2] + X[3] + X[4] + X[5];
-                const float dY = Y[-5] + Y[-4] + Y[-3] + Y[-2] + Y[-1] - 10 * Y[0] + Y[1] + Y[2] + Y[3] + Y[4] + Y[5];
-                const float dZ = Z[-5] + Z[-4] + Z[-3] + Z[-2] + Z[-1] - 10 * Z[0] + Z[1] + Z[2] + Z[3] + Z[4] + Z[5];
-                const float cv = dX * dX + dY * dY + dZ * dZ;
-                if (V.write_curv) V.curv[(size_t)s * V.NP + g] = cv;
-                if (active && g >= S && g < E) L.k32[g - S] = ll_f2u(cv);
-            }
+            /* :225-235, strict left-to-right */
+            const float dX = X[-5] + X[-4] + X[-3] + X[-2] + X[-1] - 10 * X[0] + X[1] + X[2] + X[3] + X[4] + X[5];
+            const float dY = Y[-5] + Y[-4] + Y[-3] + Y[-2] + Y[-1] - 10 * Y[0] + Y[1] + Y[2] + Y[3] + Y[4] + Y[5];
+            const float dZ = Z[-5] + Z[-4] + Z[-3] + Z[-2] + Z[-1] - 10 * Z[0] + Z[1] + Z[2] + Z[3] + Z[4] + Z[5];
+            const float cv = dX * dX + dY * dY + dZ * dZ;
+            if (V.write_curv) { if (li < nr && g >= 5 && g < N - 5) V.curv[(size_t)s * V.NP + g] = cv; }
+            if (active && g >= S && g < E) L.k32[g - S] = ll_f2u(cv);  /* S >= 5, E <= N - 5, E - off < nr: implies the bounds above */
         }
         __syncthreads();
     };

@@ -5,6 +5,6 @@ R=$GRAFT_REPO_ROOT
 export LL_PHASE_DIR=_phase
 for st in 0 1 2 3 4 12 13 5 7 9; do
   rm -rf $R/gpurun_out/pv$st
-  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --kernel-trace -f csv -d $R/gpurun_out/pv$st -o pv -- python3 $R/tools/phase_valu.py $st > $R/gpurun_out/pv$st.log 2>&1
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES --kernel-trace -f csv -d $R/gpurun_out/pv$st -o pv -- python3 $R/tools/phase_valu.py $st > $R/gpurun_out/pv$st.log 2>&1
   echo "stop $st: $(python3 $R/tools/sq_summary.py $R/gpurun_out/pv$st | grep k_ring)"
 done
