@@ -13,7 +13,16 @@ def scans(synth):
     return [synth.scan(cfg, k) for k in range(3)]
 
 
-def test_empty_and_all_nan_slots_inside_a_batch(api, orc, scans):
+@pytest.fixture(params=["tiles", "walk"])
+def org_path(request):
+    """both organise paths of ll_organize.hip: the tile-parallel kernels of small calls, the one-pass walk of a batch"""
+    from conftest import set_org_path
+    set_org_path(request.param)
+    yield request.param
+    set_org_path("tiles")
+
+
+def test_empty_and_all_nan_slots_inside_a_batch(api, orc, scans, org_path):
     """slot 1: no points at all; slot 2: only NaNs and points inside minimum_range -> LL_ERR_EMPTY for both (the reference
     would read points[0] of an empty cloud); slots 0 and 3 must come out exactly as if they were alone."""
     P = orc.params(16)
@@ -39,7 +48,7 @@ def test_empty_and_all_nan_slots_inside_a_batch(api, orc, scans):
     ctx.close()
 
 
-def test_ring_longer_than_capacity_is_reported(api, scans):
+def test_ring_longer_than_capacity_is_reported(api, scans, org_path):
     ctx = api.Context(api.default_params(16, batch=1, max_points=len(scans[0]), max_ring_points=1024))
     ctx.upload_scan(0, scans[0])                               # 1800 azimuths per ring > 1024
     ctx.extract(0, 1)
