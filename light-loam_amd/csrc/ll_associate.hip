@@ -29,6 +29,7 @@
  */
 #include "ll_common.h"
 #include <limits.h>
+#include <type_traits>
 
 __device__ __forceinline__ int ll_cell_coord(float v)
 {
@@ -432,12 +433,15 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
                 }
             }
             auto scan_near = [&](auto scan, auto bound, auto sync) __attribute__((always_inline)) {
-                for (int e = 0; e < 5; ++e) {
-                    const int st = __shfl(a_st, e, 8), en = __shfl(a_en, e, 8);
-                    const float lb = __shfl(a_lb, e, 8);
+                auto entry = [&](auto e_tag) __attribute__((always_inline)) {
+                    constexpr int e = decltype(e_tag)::value;
+                    const int st = ll_bcast8<e>(a_st), en = ll_bcast8<e>(a_en);
+                    const float lb = __int_as_float(ll_bcast8<e>(__float_as_int(a_lb)));
                     if (st < en && !(lb > bound())) scan(st, en);
-                    if (e == 0) sync();
-                }
+                };
+                entry(std::integral_constant<int, 0>{}); sync();
+                entry(std::integral_constant<int, 1>{}); entry(std::integral_constant<int, 2>{});
+                entry(std::integral_constant<int, 3>{}); entry(std::integral_constant<int, 4>{});
                 sync();
             };
             auto nn_scan = [&](int st, int en) {
@@ -458,12 +462,7 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
                     }
                 };
             auto nn_bound = [&]() { return __uint_as_float((unsigned)(kb >> 32)); };
-            auto nn_sync = [&]() {
-                    for (int o = 1; o < 8; o <<= 1) {
-                        const unsigned long long k2 = __shfl_xor(kb, o);
-                        kb = (k2 < kb) ? k2 : kb;
-                    }
-                };
+            auto nn_sync = [&]() { kb = ll_min8_u64(kb); };
             scan_near(nn_scan, nn_bound, nn_sync);
             ll_grid_search(gstart, q.x, q.y, rmax, cellb, sub, 2, nn_scan, nn_bound, nn_sync);
             int rc = 0;
@@ -509,12 +508,7 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
                         }
                     };
                 auto w_bound = [&]() { const unsigned h2 = (unsigned)(k2 >> 32), h3 = (unsigned)(k3 >> 32); return __uint_as_float(PLANE ? max(h2, h3) : h2); };
-                auto w_sync = [&]() {
-                        for (int o = 1; o < 8; o <<= 1) {
-                            const unsigned long long t2 = __shfl_xor(k2, o); k2 = (t2 < k2) ? t2 : k2;
-                            if (PLANE) { const unsigned long long t3 = __shfl_xor(k3, o); k3 = (t3 < k3) ? t3 : k3; }
-                        }
-                    };
+                auto w_sync = [&]() { k2 = ll_min8_u64(k2); if (PLANE) k3 = ll_min8_u64(k3); };
                 scan_near(w_scan, w_bound, w_sync);
                 ll_grid_search(gstart, q.x, q.y, rmax, cellb, sub, 2, w_scan, w_bound, w_sync);
                 auto index_of = [&](unsigned long long k) { const int ord = (int)(unsigned)k; return (k == wnone) ? -1 : (ord < M ? c1 + ord : mc - ord); };   /* up: ord = j - c1 < M, down: ord = mc - j >= M */

@@ -171,6 +171,30 @@ LL_WAVE_REDUCE(ll_wave_or_u32, unsigned, LL_OP_OR, 0u, (int), (unsigned))
 LL_WAVE_REDUCE(ll_wave_min_f32, float, fminf, __builtin_inff(), __float_as_int, __int_as_float)
 LL_WAVE_REDUCE(ll_wave_max_f32, float, fmaxf, -__builtin_inff(), __float_as_int, __int_as_float)
 
+/* groups of eight lanes (k_associate: eight lanes per query): the minimum of a 64-bit key over the group in every lane --
+ * xor 1 and xor 2 inside the quads, then row_half_mirror (lane i <-> 7 - i: the other quad) -- and the broadcast of lane E's
+ * value to the group: quad_perm [E, E, E, E], then the other quad takes it over by a row shift of four with a bank mask. */
+__device__ __forceinline__ unsigned long long ll_min8_u64(unsigned long long k)
+{
+#define LL_MIN8_STEP(ctrl) do { \
+        const unsigned lo = (unsigned)LL_DPP_I((int)(unsigned)k, (int)(unsigned)k, ctrl, 0xf), hi = (unsigned)LL_DPP_I((int)(unsigned)(k >> 32), (int)(unsigned)(k >> 32), ctrl, 0xf); \
+        const unsigned long long k2 = ((unsigned long long)hi << 32) | lo; k = (k2 < k) ? k2 : k; } while (0)
+    LL_MIN8_STEP(0xb1);           /* quad_perm [1,0,3,2] */
+    LL_MIN8_STEP(0x4e);           /* quad_perm [2,3,0,1] */
+    LL_MIN8_STEP(0x141);          /* row_half_mirror */
+#undef LL_MIN8_STEP
+    return k;
+}
+template <int E>
+__device__ __forceinline__ int ll_bcast8(int v)
+{
+    static_assert(E >= 0 && E < 8, "lane of the group");
+    constexpr int Q = (E & 3) * 0x55;                                                        /* quad_perm [E, E, E, E] */
+    const int t = __builtin_amdgcn_update_dpp(v, v, Q, 0xf, 0xf, false);
+    if (E < 4) return __builtin_amdgcn_update_dpp(t, t, 0x114, 0xf, 0xa, false);             /* row_shr:4 into banks 1, 3: the group's upper quad */
+    return __builtin_amdgcn_update_dpp(t, t, 0x104, 0xf, 0x5, false);                        /* row_shl:4 into banks 0, 2: the group's lower quad */
+}
+
 /* exclusive prefix sum of one int per thread over a workgroup of NW waves: 64-lane DPP scan + the wave totals
  * through LDS (sc: >= NW ints).  Returns the exclusive prefix; total = workgroup sum.  Ends with a barrier. */
 template <int NW>
