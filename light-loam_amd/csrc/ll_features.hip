@@ -110,13 +110,13 @@ __device__ __forceinline__ FeatLds ll_carve(unsigned char *base, int max_ring)
  * every wave counts into its own 2^BITS counters, one row after the other (a wave's LDS operations execute in order, so
  * the counter a row reads already holds the rows before it), the rank inside the row comes from a wave match-any, and one
  * workgroup exclusive scan over the digit-major (digit, wave) table turns the counters into bases.  Wave-private counters
- * make the table small enough for digits of up to 8 bits: the keys differ only in bits [lo, hi), which takes
- * ceil((hi - lo) / 8) passes of 5..8-bit digits (three for the usual 17..24 varying bits of a ring's voxel indices).
+ * make the table small enough for digits of up to 8 bits: the keys are below 2^key_bits (the caller knows: the voxel grid's
+ * dimensions), which takes ceil(key_bits / 8) passes of 5..8-bit digits (three for the usual 17..24 bits of a ring's voxel indices).
  * The last row is padded with all-ones keys that take part like records (they stay at the end, no per-record guards);
  * rows beyond it are skipped.  Keys must be < 0xffffffff.  Stability makes the result ordered by (k32, original
  * position): exactly the (voxel, input order) order the oracle defines. */
 template <int ROWS>
-__device__ __forceinline__ void ll_radix_sort(unsigned *k32, unsigned short *k16, int n, int *cnt, int *sc, int tid)
+__device__ __forceinline__ void ll_radix_sort(unsigned *k32, unsigned short *k16, int n, int key_bits, int *cnt, int *sc, int tid)
 {
     constexpr int NW = LL_BLOCK / 64;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      /* uniform: scalar registers / branches */
@@ -124,22 +124,14 @@ __device__ __forceinline__ void ll_radix_sort(unsigned *k32, unsigned short *k16
     const int wbase = wave * nrows * 64;                        /* the wave's first record */
     const int myrows = max(0, min(nrows, (n - wbase + 63) >> 6));   /* rows of this wave that hold a record */
     unsigned e32[ROWS]; unsigned short e16[ROWS];
-    unsigned vary = 0;
-    const unsigned hi0 = (n > 0) ? k32[0] : 0u;
 #pragma unroll
     for (int k = 0; k < ROWS; ++k) {
         const int g = wbase + k * 64 + lane;
         e32[k] = 0xffffffffu; e16[k] = 0;
-        if (k < myrows && g < n) { e32[k] = k32[g]; e16[k] = k16[g]; vary |= e32[k] ^ hi0; }
+        if (k < myrows && g < n) { e32[k] = k32[g]; e16[k] = k16[g]; }
     }
-    vary = ll_wave_or_u32(vary);
-    if (tid == 0) sc[16] = 0;
-    __syncthreads();
-    if (lane == 0 && vary) atomicOr((unsigned *)&sc[16], vary);
-    __syncthreads();
-    vary = (unsigned)sc[16];
-    if (vary == 0u) return;                                     /* one voxel (or none): already in order */
-    const int lo = __ffs((int)vary) - 1, hi = 32 - __clz((int)vary);
+    if (key_bits <= 0) return;                                  /* one voxel (or none): already in order */
+    const int lo = 0, hi = key_bits;                            /* the caller's bound on the keys: no reduction over them to find the varying bits */
     auto pass = [&](auto bits_tag, int sh) __attribute__((always_inline)) {
         constexpr int BITS = decltype(bits_tag)::value;
         constexpr int ND = 1 << BITS;
@@ -303,7 +295,7 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : 1)) void k_ring_
 
     const int nwords = (nr + 31) / 32 + 1;
     for (int i = tid; i < nwords; i += LL_BLOCK) { L.picked[i] = 0; L.gapf[i] = 0; }
-    for (int i = tid; i < nr; i += LL_BLOCK) L.lab[i] = 0;
+    for (int i = tid; i < (nr + 3) / 4; i += LL_BLOCK) ((unsigned *)L.lab)[i] = 0u;   /* labels, four at a time (the array is 4-byte aligned and padded) */
     if (tid < 3 * LL_SEGS) L.lists[156 + tid] = 0;                    /* per segment: n_sharp, n_lsharp, n_flat */
     if (tid == 0) L.sc[60] = 0;                                       /* segments finished (bit j) */
     __syncthreads();
@@ -654,6 +646,9 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : 1)) void k_ring_
                 div_b[c] = (int)floorf(mx[c] * inv) - min_b[c] + 1;
             }
             const bool too_small = d[0] * d[1] * d[2] > (long long)INT_MAX;        /* "leaf size too small": output = input */
+            /* every key is below the number of voxels of the bounding box (below m when the filter degenerates): the sort's digit range */
+            const long long key_end = too_small ? (long long)m : (long long)div_b[0] * div_b[1] * div_b[2];
+            const int key_bits = key_end <= 1 ? 0 : min(32, 64 - __clzll(key_end - 1));
             const int mul1 = div_b[0], mul2 = div_b[0] * div_b[1];
             const float fb0 = (float)min_b[0], fb1 = (float)min_b[1], fb2 = (float)min_b[2];
 #pragma unroll
@@ -672,7 +667,7 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : 1)) void k_ring_
                 }
             __syncthreads();
             LL_PHASE(3);
-            ll_radix_sort<ROWS>(L.k32, L.k16, m, L.cnt, L.sc, tid);
+            ll_radix_sort<ROWS>(L.k32, L.k16, m, key_bits, L.cnt, L.sc, tid);
             LL_PHASE(4);
             __syncthreads();
             /* voxel runs -> centroids.  Thread t owns sorted positions [t*perm, (t+1)*perm): its points are fetched up
