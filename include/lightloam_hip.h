@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LL_ABI_VERSION 1
+#define LL_ABI_VERSION 2          /* 2: ll_params.distortion */
 
 typedef struct ll_ctx ll_ctx;
 
@@ -68,6 +68,9 @@ typedef struct {
     int   write_curvature;    /* also store cloudCurvature[] to HBM (debug / parity output; off on the hot path) */
     int   chunk;              /* ll_hot_path_batch processes the slot range in chunks of this many scans so that a chunk's
                                  intermediates stay in the 256 MiB Infinity Cache between kernels; 0 = whole range */
+    int   distortion;         /* DISTORTION of laserOdometry.cpp:23.  0 (default) = the reference's build: s = 1.  1 = its other compile-time
+                                 path: every point's interpolation ratio s = (intensity - int(intensity)) / SCAN_PERIOD in TransformToStart
+                                 (:81-88) and in LidarEdgeFactor / LidarPlaneFactor_modify (:570-571, :740-741, lidarFactor.hpp:25-27) */
 } ll_params;
 
 /* Per-scan sizes produced by the extract stage. */
@@ -300,10 +303,13 @@ int ll_voxel_grid(ll_ctx *ctx, const ll_point *host_in, int n, float leaf_size, 
  *     edge9   [n_edge][9]   curr_point, last_point_a, last_point_b                         (lidarFactor.hpp:9-52,  3 rows each)
  *     plane13 [n_plane][13] curr_point, last_point_j, last_point_l, last_point_m, weight   (:203-251, 1 row each)
  *     pnorm7  [n_pnorm][7]  curr_point, plane_unit_norm, negative_OA_dot_norm              (:253-285, 1 row each)
- * all with s = 1 (the reference never passes anything else: DISTORTION 0, laserOdometry.cpp:23, :81-84).
+ * all with s = 1 (what the reference's build passes: DISTORTION 0, laserOdometry.cpp:23, :81-84) unless ll_factor_blocks_set_s
+ * follows: the functors' s_ of every edge / plane block (lidarFactor.hpp:25-27, :219-221: Identity.slerp(s, q), s * t), f64
+ * [n_edge] and [n_plane]; NULL = all ones.  ll_factor_blocks_set resets them to one.
  * ll_factor_blocks_evaluate: residuals [rows], jacobians w.r.t. q (x, y, z, w) [rows][4] and t [rows][3], row-major,
  * rows = 3 n_edge + n_plane + n_pnorm in that order; loss functions are the caller's (Ceres applies them).         */
 int ll_factor_blocks_set(ll_ctx *ctx, int n_edge, const double *edge9, int n_plane, const double *plane13, int n_pnorm, const double *pnorm7);
+int ll_factor_blocks_set_s(ll_ctx *ctx, const double *edge_s, const double *plane_s);
 int ll_factor_blocks_evaluate(ll_ctx *ctx, const double q[4], const double t[3], double *r, double *Jq, double *Jt, int cap_rows);
 
 /* ---------------------------------------------------------------- laserMapping's cube map (second stage)

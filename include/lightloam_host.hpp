@@ -49,10 +49,12 @@ struct Error : std::runtime_error {
 /* RAII ll_ctx; one per node thread (the reference nodes are single-threaded spinners, scanRegistration.cpp:475) */
 class Context {
 public:
+    /* distortion: the DISTORTION macro of laserOdometry.cpp:23 (0 in the reference's build; 1 = its per-point interpolation path) */
     explicit Context(int scan_line, int batch = 2, int device = 0, double minimum_range = -1.0,
-                     float lowerBound = -24.9f, float upBound = 2.0f) {
+                     float lowerBound = -24.9f, float upBound = 2.0f, int distortion = 0) {
         ll_default_params(&p_, scan_line);
         p_.batch = batch;
+        p_.distortion = distortion;
         if (minimum_range >= 0) p_.minimum_range = (float)minimum_range;       /* nh.param("minimum_range") :438 */
         p_.lower_bound = lowerBound; p_.up_bound = upBound;                     /* nh.param("lowerBound" / "upBound") :439-440 */
         const int rc = ll_create(device, &p_, &ctx_);

@@ -19,9 +19,10 @@
  *     ... the correspondence loops, unchanged ...
  *     ceres::Solve(options, &problem, &summary);       // unchanged; `batch` must outlive the problem
  *
- * Restrictions, checked loudly: s must be 1.0 (the reference never passes anything else: DISTORTION 0,
- * laserOdometry.cpp:23, :81-84 -- a different s throws lightloam::Error); all cost functions of a batch must be evaluated
- * with the same parameter blocks (they are: para_q / para_t, or parameters / parameters + 4).
+ * s_ is honoured per block (1.0 in the reference's build -- DISTORTION 0, laserOdometry.cpp:23, :81-84 -- and then the blocks
+ * take the closed-form s = 1 path; any other value goes through Identity.slerp(s, q), s * t like lidarFactor.hpp:25-27).
+ * Restriction, checked loudly: all cost functions of a batch must be evaluated with the same parameter blocks (they are:
+ * para_q / para_t, or parameters / parameters + 4).
  * Vector arguments: anything with x(), y(), z() (Eigen::Vector3d).
  * Needs <ceres/ceres.h>; this image has no Ceres, so tests compile the header against a declared test double of
  * ceres::CostFunction (tests/native/lidar_factor_adapter.cpp, -DLIGHTLOAM_CERES_TEST_DOUBLE).
@@ -64,9 +65,10 @@ public:
 
     enum Kind { EDGE = 0, PLANE = 1, PNORM = 2 };
     /* file one block; returns its index inside its kind */
-    int add(Kind k, const double *data, int n) {
+    int add(Kind k, const double *data, int n, double s = 1.0) {
         std::vector<double> &v = blocks_[k];
         v.insert(v.end(), data, data + n);
+        if (k != PNORM) { s_[k].push_back(s); if (s != 1.0) any_s_ = true; }
         uploaded_ = false; have_ = false;
         return count_[k]++;
     }
@@ -88,6 +90,7 @@ private:
         if (!uploaded_) {
             c_.check(ll_factor_blocks_set(c_.get(), count_[EDGE], blocks_[EDGE].data(), count_[PLANE], blocks_[PLANE].data(),
                                           count_[PNORM], blocks_[PNORM].data()));
+            if (any_s_) c_.check(ll_factor_blocks_set_s(c_.get(), s_[EDGE].data(), s_[PLANE].data()));   /* the functors' s_ (DISTORTION 1) */
             const size_t rows = (size_t)3 * count_[EDGE] + count_[PLANE] + count_[PNORM];
             r_.resize(rows); jq_.resize(rows * 4); jt_.resize(rows * 3);
             uploaded_ = true;
@@ -98,6 +101,8 @@ private:
     }
     Context &c_;
     std::vector<double> blocks_[3];
+    std::vector<double> s_[2];                                     /* s_ of every edge / plane block */
+    bool any_s_ = false;
     int count_[3] = {0, 0, 0};
     std::vector<double> r_, jq_, jt_;
     double q_[4] = {0, 0, 0, 0}, t_[3] = {0, 0, 0};
@@ -123,10 +128,6 @@ private:
     int index_;
 };
 
-inline void require_s_is_one(double s) {
-    if (s != 1.0) throw Error(LL_ERR_ARG, "lightloam functors are evaluated at s = 1 (the reference's DISTORTION 0 path)");
-}
-
 }  // namespace lightloam
 
 /* ---- the reference's names, global namespace like src/lidarFactor.hpp ------------------------------------------- */
@@ -134,11 +135,10 @@ inline void require_s_is_one(double s) {
 struct LidarEdgeFactor {                                              /* lidarFactor.hpp:9-52 */
     template <class V3>
     static ceres::CostFunction *Create(const V3 &curr_point_, const V3 &last_point_a_, const V3 &last_point_b_, const double s_) {
-        lightloam::require_s_is_one(s_);
         lightloam::FactorBatch &b = lightloam::FactorBatch::require();
         const double d[9] = {curr_point_.x(), curr_point_.y(), curr_point_.z(), last_point_a_.x(), last_point_a_.y(), last_point_a_.z(),
                              last_point_b_.x(), last_point_b_.y(), last_point_b_.z()};
-        return new lightloam::BatchBlockCost(b, lightloam::FactorBatch::EDGE, b.add(lightloam::FactorBatch::EDGE, d, 9));
+        return new lightloam::BatchBlockCost(b, lightloam::FactorBatch::EDGE, b.add(lightloam::FactorBatch::EDGE, d, 9, s_));
     }
 };
 
@@ -146,11 +146,10 @@ struct LidarPlaneFactor_modify {                                      /* lidarFa
     template <class V3>
     static ceres::CostFunction *Create(const V3 &curr_point_, const V3 &last_point_j_, const V3 &last_point_l_, const V3 &last_point_m_,
                                        const double s_, const double weight_) {
-        lightloam::require_s_is_one(s_);
         lightloam::FactorBatch &b = lightloam::FactorBatch::require();
         const double d[13] = {curr_point_.x(), curr_point_.y(), curr_point_.z(), last_point_j_.x(), last_point_j_.y(), last_point_j_.z(),
                               last_point_l_.x(), last_point_l_.y(), last_point_l_.z(), last_point_m_.x(), last_point_m_.y(), last_point_m_.z(), weight_};
-        return new lightloam::BatchBlockCost(b, lightloam::FactorBatch::PLANE, b.add(lightloam::FactorBatch::PLANE, d, 13));
+        return new lightloam::BatchBlockCost(b, lightloam::FactorBatch::PLANE, b.add(lightloam::FactorBatch::PLANE, d, 13, s_));
     }
 };
 

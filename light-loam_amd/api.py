@@ -28,7 +28,7 @@ EXPORTS = [
     "ll_cubemap_create", "ll_cubemap_destroy", "ll_cubemap_last_error", "ll_cubemap_prepare", "ll_cubemap_optimize", "ll_cubemap_update",
     "ll_cubemap_process", "ll_cubemap_process_slot", "ll_cubemap_info", "ll_cubemap_download_cloud", "ll_cubemap_download_cube",
     "ll_map_set_map_ids", "ll_map_knn_partial", "ll_map_associate_merged", "ll_map_solve", "ll_map_set_row_shard", "ll_cubemap_set_shard", "ll_cubemap_map",
-    "ll_factor_blocks_set", "ll_factor_blocks_evaluate",
+    "ll_factor_blocks_set", "ll_factor_blocks_set_s", "ll_factor_blocks_evaluate",
     "ll_map_evaluate_dev", "ll_map_lm_begin_dev", "ll_map_lm_propose_dev", "ll_map_lm_accept_dev", "ll_map_knn_partial_dev",
     "ll_map_associate_merged_dev", "ll_map_solve_dev",
     "ll_voxel_grid", "ll_map_set_pose", "ll_map_get_pose", "ll_map_evaluate", "ll_map_lm_begin", "ll_map_lm_propose", "ll_map_lm_accept",
@@ -41,7 +41,7 @@ class Params(C.Structure):
                 ("max_ring_points", C.c_int), ("batch", C.c_int), ("curv_threshold", C.c_float),
                 ("gap_sq_threshold", C.c_float), ("leaf_size", C.c_float), ("nn_dist_sq_max", C.c_float),
                 ("nearby_scan", C.c_float), ("huber_delta", C.c_float), ("write_curvature", C.c_int),
-                ("chunk", C.c_int)]
+                ("chunk", C.c_int), ("distortion", C.c_int)]
 
 
 class ScanInfo(C.Structure):
@@ -381,6 +381,12 @@ class Context:
         n = np.ascontiguousarray(pnorm7 if pnorm7 is not None else np.zeros((0, 7)), np.float64).reshape(-1, 7)
         self._fb_rows = 3 * len(e) + len(p) + len(n)
         self._ck(self.lib.ll_factor_blocks_set(self.h, len(e), _ptr(e), len(p), _ptr(p), len(n), _ptr(n)))
+
+    def factor_blocks_set_s(self, edge_s=None, plane_s=None):
+        """the functors' s_ of every edge / plane block (DISTORTION 1); None = all ones"""
+        e = None if edge_s is None else np.ascontiguousarray(edge_s, np.float64)
+        p = None if plane_s is None else np.ascontiguousarray(plane_s, np.float64)
+        self._ck(self.lib.ll_factor_blocks_set_s(self.h, _ptr(e), _ptr(p)))
 
     def factor_blocks_evaluate(self, q, t):
         q = np.ascontiguousarray(q, np.float64); t = np.ascontiguousarray(t, np.float64)

@@ -116,7 +116,7 @@ extern "C" int ll_create(int device, const ll_params *p, ll_ctx **out)
     const int B = p->batch, R = p->n_scans;
     const int NP = (p->max_points + LL_TILE - 1) / LL_TILE * LL_TILE;
     V.B = B; V.NP = NP; V.T = NP / LL_TILE; V.R = R; V.ring_model = p->ring_model;
-    V.max_ring = p->max_ring_points; V.write_curv = p->write_curvature;
+    V.max_ring = p->max_ring_points; V.write_curv = p->write_curvature; V.distortion = p->distortion ? 1 : 0;
     V.thres = p->minimum_range; V.lower_bound = p->lower_bound;
     V.factor = (float)(R - 1) / (p->up_bound - p->lower_bound);                 /* scanRegistration.cpp:441 */
     /* the reference compares f32 values with the double literals 0.1 / 0.05; a float param widened to double is not
@@ -619,6 +619,30 @@ extern "C" int ll_factor_blocks_set(ll_ctx *ctx, int n_edge, const double *edge9
     if (n_pnorm) LL_HIP(hipMemcpyAsync(d, pnorm7, (size_t)n_pnorm * 7 * sizeof(double), hipMemcpyHostToDevice, st));
     LL_HIP(hipStreamSynchronize(st));
     ctx->fb_n[0] = n_edge; ctx->fb_n[1] = n_plane; ctx->fb_n[2] = n_pnorm;
+    ctx->fb_has_s = false;
+    return LL_OK;
+}
+
+extern "C" int ll_factor_blocks_set_s(ll_ctx *ctx, const double *edge_s, const double *plane_s)
+{
+    if (!ctx) return LL_ERR_ARG;
+    const int ne = ctx->fb_n[0], np = ctx->fb_n[1];
+    if (!edge_s && !plane_s) { ctx->fb_has_s = false; return LL_OK; }
+    LL_HIP(hipSetDevice(ctx->device));
+    const size_t need = (size_t)ne + np;
+    if (need > ctx->fb_s_cap) {
+        double *p = nullptr;
+        if (!dev_alloc(ctx, p, need + need / 2 + 64, false)) return LL_ERR_HIP;
+        ctx->d_fb_s = p; ctx->fb_s_cap = need + need / 2 + 64;
+    }
+    std::vector<double> h(need, 1.0);
+    if (edge_s) std::copy(edge_s, edge_s + ne, h.begin());
+    if (plane_s) std::copy(plane_s, plane_s + np, h.begin() + ne);
+    if (need) {
+        LL_HIP(hipMemcpyAsync(ctx->d_fb_s, h.data(), need * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        LL_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    ctx->fb_has_s = true;
     return LL_OK;
 }
 
@@ -640,7 +664,7 @@ extern "C" int ll_factor_blocks_evaluate(ll_ctx *ctx, const double *q4, const do
     LL_HIP(hipMemcpyAsync(ctx->d_tmp_pose, pose, sizeof(pose), hipMemcpyHostToDevice, st));
     double *dr = ctx->d_fb_out, *dJq = dr + rows, *dJt = dJq + rows * 4;
     const double *edge = ctx->d_fb, *plane = edge + (size_t)ne * 9, *pnorm = plane + (size_t)np * 13;
-    ll_launch_factor_blocks(ctx->d_tmp_pose, ne, edge, np, plane, nn, pnorm, dr, dJq, dJt, st);
+    ll_launch_factor_blocks(ctx->d_tmp_pose, ne, edge, np, plane, nn, pnorm, ctx->fb_has_s ? ctx->d_fb_s : nullptr, dr, dJq, dJt, st);
     LL_HIP(hipGetLastError());
     if (r) LL_HIP(hipMemcpyAsync(r, dr, rows * sizeof(double), hipMemcpyDeviceToHost, st));
     if (Jq) LL_HIP(hipMemcpyAsync(Jq, dJq, rows * 4 * sizeof(double), hipMemcpyDeviceToHost, st));

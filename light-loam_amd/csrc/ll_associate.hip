@@ -28,6 +28,7 @@
  *                (break = ballot of "first lane whose ring leaves the +-2.5 window").  Both are exact.
  */
 #include "ll_common.h"
+#include "ll_factor_math.h"
 #include <limits.h>
 #include <type_traits>
 
@@ -360,15 +361,23 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
     const int tid = threadIdx.x, lane = tid & 63;
     const int qi = qblock * qpb + tid;                        /* qpb queries per workgroup: 256 in a batch, 32 (one pass) when few scans must fill the chip */
     const bool have = tid < qpb && qi < nq;
-    /* a5: TransformToStart, s = 1 (DISTORTION 0): f64 rotate + translate, f32 store */
+    /* a5: TransformToStart (s = 1 with DISTORTION 0, the reference's build): f64 rotate + translate, f32 store */
     float sx = 0.f, sy = 0.f, sz = 0.f;
     if (have) {
         const double *pose = V.pose + (size_t)s * 7;
         const float4 p = queries[qi];
         const double v[3] = {(double)p.x, (double)p.y, (double)p.z};
         double rr[3];
-        ll_rotate(pose, v, rr);
-        sx = (float)(rr[0] + pose[4]); sy = (float)(rr[1] + pose[5]); sz = (float)(rr[2] + pose[6]);
+        if (!V.distortion) {
+            ll_rotate(pose, v, rr);
+            sx = (float)(rr[0] + pose[4]); sy = (float)(rr[1] + pose[5]); sz = (float)(rr[2] + pose[6]);
+        } else {                                              /* DISTORTION 1 (:81-88): q_point_last = Identity.slerp(s, q), t_point_last = s * t */
+            const double sr = ll_point_s(1, p);
+            double qs4[4];
+            ll_slerp_identity(sr, pose, qs4, nullptr);
+            ll_rotate(qs4, v, rr);
+            sx = (float)(rr[0] + sr * pose[4]); sy = (float)(rr[1] + sr * pose[5]); sz = (float)(rr[2] + sr * pose[6]);
+        }
     }
     qs[tid] = make_float4(sx, sy, sz, have ? 1.0f : 0.0f);
     for (int i = tid; i < 2 * (LL_TAB + 1) + 2; i += LL_BLOCK) tab[i] = T.tab[i];      /* the ring tables: read by every query */

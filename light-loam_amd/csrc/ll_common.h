@@ -58,6 +58,7 @@ struct PairHdr {
 struct LLView {
     /* configuration */
     int B, NP, T, R, ring_model, max_ring, write_curv;
+    int distortion;                /* 0: the reference's build (DISTORTION 0); 1: per-point interpolation ratio s in TransformToStart and the factors */
     int org_small;                 /* calls of at most this many scans take the tile-parallel organise kernels (LL_ORG_SMALL; test override) */
     float thres, lower_bound, factor;
     const int *ring_thr;           /* [R + 1] ll_ring_thresholds: keys of the smallest t = z / sqrt(x^2 + y^2) of every ring */
@@ -271,7 +272,7 @@ void ll_map_launch_lm_solve(const LLMapView &M, const LLLmOpt &o, hipStream_t st
 void ll_map_launch_rows(const LLMapView &M, double *r, double *Jq, double *Jt, hipStream_t st);
 
 void ll_launch_factor_blocks(const double *pose, int n_e, const double *edge, int n_p, const double *plane, int n_n, const double *pnorm,
-                             double *r, double *Jq, double *Jt, hipStream_t st);                        /* ll_functors.hip */
+                             const double *s_ep, double *r, double *Jq, double *Jt, hipStream_t st);   /* s_ep: [n_e + n_p] or null (all ones) */                        /* ll_functors.hip */
 
 /* ---- whole-cloud VoxelGrid (ll_voxel.hip) ---- */
 struct LLVoxSeg;

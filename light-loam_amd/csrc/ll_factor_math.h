@@ -27,6 +27,58 @@ __device__ __forceinline__ void ll_lp_and_jac(const Pose &P, const double v[3], 
     Jq[0][3] = uvx; Jq[1][3] = uvy; Jq[2][3] = uvz;              /* d lp / d w = 2 u x v */
 }
 
+/* DISTORTION 1 (laserOdometry.cpp:23 is 0 in the reference's build; its other compile-time path): every point carries an
+ * interpolation ratio s = (intensity - int(intensity)) / SCAN_PERIOD (:81-82, :570-571, :740-741; float subtraction, f64
+ * division by 0.1) and is transformed by  Identity.slerp(s, q) * p + s * t  (:86-88, lidarFactor.hpp:25-27). */
+__device__ __forceinline__ double ll_point_s(int distortion, const float4 c)
+{
+    if (!distortion) return 1.0;
+    return (double)(c.w - (float)(int)c.w) / 0.1;
+}
+
+/* Eigen 3.3 QuaternionBase::slerp(s, q) called on Identity (coefficients x, y, z, w), and -- when J is not null -- its
+ * Jacobian d qs / d q (4 x 4, q's four coefficients independent, like the Jets of ceres::AutoDiffCostFunction see them):
+ *   d = q.w, theta = acos|d|, scale0 = sin((1 - s) theta) / sin theta, scale1 = +-sin(s theta) / sin theta (sign of d),
+ *   qs = (scale1 q.xyz, scale0 + scale1 q.w); both scales depend on q.w only.  |d| >= 1 - eps: scale0 = 1 - s, scale1 = +-s. */
+__device__ __forceinline__ void ll_slerp_identity(double s, const double q[4], double qs[4], double (*J)[4])
+{
+    const double one = 1.0 - 2.220446049250313e-16;
+    const double d = (0.0 * q[0] + 0.0 * q[1]) + (0.0 * q[2] + 1.0 * q[3]);
+    const double absD = fabs(d), sgn = d < 0.0 ? -1.0 : 1.0;
+    double scale0, scale1, ds0 = 0.0, ds1 = 0.0;                  /* ds*: derivative with respect to q.w */
+    if (absD >= one) { scale0 = 1.0 - s; scale1 = s; }
+    else {
+        const double theta = acos(absD), sinT = sin(theta), cosT = cos(theta);
+        const double a0 = (1.0 - s) * theta, a1 = s * theta;
+        scale0 = sin(a0) / sinT; scale1 = sin(a1) / sinT;
+        const double dth = -sgn / sqrt(1.0 - absD * absD);      /* d theta / d q.w */
+        ds0 = ((1.0 - s) * cos(a0) * sinT - sin(a0) * cosT) / (sinT * sinT) * dth;
+        ds1 = (s * cos(a1) * sinT - sin(a1) * cosT) / (sinT * sinT) * dth;
+    }
+    if (d < 0.0) { scale1 = -scale1; ds1 = -ds1; }
+    qs[0] = scale0 * 0.0 + scale1 * q[0]; qs[1] = scale0 * 0.0 + scale1 * q[1];
+    qs[2] = scale0 * 0.0 + scale1 * q[2]; qs[3] = scale0 * 1.0 + scale1 * q[3];
+    if (J) {
+        for (int i = 0; i < 4; ++i) for (int k = 0; k < 4; ++k) J[i][k] = (i == k) ? scale1 : 0.0;
+        J[0][3] = ds1 * q[0]; J[1][3] = ds1 * q[1]; J[2][3] = ds1 * q[2];
+        J[3][3] = ds0 + scale1 + ds1 * q[3];
+    }
+}
+
+/* lp = slerp(s, q) * v + s * t and d lp / d q (3 x 4); d lp / d t = s * I.  s == 1 is the reference's own build: slerp(1, q) = +-q
+ * and the rotation is the same for q and -q, so that case takes ll_lp_and_jac itself (bit for bit what it always computed). */
+__device__ __forceinline__ void ll_lp_and_jac_s(const Pose &P, const double v[3], double s, double lp[3], double Jq[3][4])
+{
+    if (s == 1.0) { ll_lp_and_jac(P, v, lp, Jq); return; }
+    Pose Ps; double D[4][4];
+    ll_slerp_identity(s, P.q, Ps.q, D);
+    Ps.t[0] = s * P.t[0]; Ps.t[1] = s * P.t[1]; Ps.t[2] = s * P.t[2];
+    double A[3][4];
+    ll_lp_and_jac(Ps, v, lp, A);                                 /* d lp / d qs */
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 4; ++k) Jq[i][k] = (A[i][0] * D[0][k] + A[i][1] * D[1][k]) + (A[i][2] * D[2][k] + A[i][3] * D[3][k]);
+}
+
 /* rows x 4 ambient -> rows x 3 tangent: J * PlusJacobian(q), P rows x:[w,z,-y] y:[-z,w,x] z:[y,-x,w] w:[-x,-y,-z] */
 __device__ __forceinline__ void ll_to_local(const Pose &P, const double Ja[4], double Jl[3])
 {
@@ -38,10 +90,10 @@ __device__ __forceinline__ void ll_to_local(const Pose &P, const double Ja[4], d
 
 /* LidarEdgeFactor (lidarFactor.hpp:9-52): r[3], ambient Jq[3][4], Jt[3][3]; a, b = the two points of the line in f64 */
 __device__ __forceinline__ void ll_edge_dd(const Pose &P, const double cp[3], const double a[3], const double b[3],
-                                           double r[3], double Jq[3][4], double Jt[3][3])
+                                           double r[3], double Jq[3][4], double Jt[3][3], double s = 1.0)
 {
     double lp[3], A[3][4];
-    ll_lp_and_jac(P, cp, lp, A);
+    ll_lp_and_jac_s(P, cp, s, lp, A);
     const double pa[3] = {lp[0] - a[0], lp[1] - a[1], lp[2] - a[2]}, pb[3] = {lp[0] - b[0], lp[1] - b[1], lp[2] - b[2]};
     const double nu[3] = {pa[1] * pb[2] - pa[2] * pb[1], pa[2] * pb[0] - pa[0] * pb[2], pa[0] * pb[1] - pa[1] * pb[0]};   /* :32 */
     const double de[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]};                                                        /* :33 */
@@ -51,22 +103,22 @@ __device__ __forceinline__ void ll_edge_dd(const Pose &P, const double cp[3], co
     const double D[3][3] = {{0.0, de[2] / n, -de[1] / n}, {-de[2] / n, 0.0, de[0] / n}, {de[1] / n, -de[0] / n, 0.0}};
     for (int i = 0; i < 3; ++i) {
         for (int k = 0; k < 4; ++k) Jq[i][k] = D[i][0] * A[0][k] + D[i][1] * A[1][k] + D[i][2] * A[2][k];
-        for (int k = 0; k < 3; ++k) Jt[i][k] = D[i][k];
+        for (int k = 0; k < 3; ++k) Jt[i][k] = (s == 1.0) ? D[i][k] : D[i][k] * s;    /* t_last_curr = s * t (:27) */
     }
 }
 
 __device__ __forceinline__ void ll_edge_d(const Pose &P, const float4 c, const double a[3], const double b[3],
-                                          double r[3], double Jq[3][4], double Jt[3][3])
+                                          double r[3], double Jq[3][4], double Jt[3][3], double s = 1.0)
 {
     const double cp[3] = {c.x, c.y, c.z};
-    ll_edge_dd(P, cp, a, b, r, Jq, Jt);
+    ll_edge_dd(P, cp, a, b, r, Jq, Jt, s);
 }
 
 __device__ __forceinline__ void ll_edge(const Pose &P, const float4 c, const float4 a4, const float4 b4,
-                                        double r[3], double Jq[3][4], double Jt[3][3])
+                                        double r[3], double Jq[3][4], double Jt[3][3], double s = 1.0)
 {
     const double a[3] = {a4.x, a4.y, a4.z}, b[3] = {b4.x, b4.y, b4.z};
-    ll_edge_d(P, c, a, b, r, Jq, Jt);
+    ll_edge_d(P, c, a, b, r, Jq, Jt, s);
 }
 
 /* LidarPlaneNormFactor (lidarFactor.hpp:253-285): r = n . (q * cp + t) + d */
@@ -87,7 +139,7 @@ __device__ __forceinline__ void ll_plane_norm(const Pose &P, const float4 c, con
 
 /* LidarPlaneFactor_modify (lidarFactor.hpp:203-251) */
 __device__ __forceinline__ void ll_plane_dd(const Pose &P, const double cp[3], const double j[3], const double l[3], const double m[3],
-                                            double weight, double &r, double Jq[4], double Jt[3])
+                                            double weight, double &r, double Jq[4], double Jt[3], double s = 1.0)
 {
     const double a[3] = {j[0] - l[0], j[1] - l[1], j[2] - l[2]};
     const double b[3] = {j[0] - m[0], j[1] - m[1], j[2] - m[2]};
@@ -95,18 +147,18 @@ __device__ __forceinline__ void ll_plane_dd(const Pose &P, const double cp[3], c
     const double z = (n[0] * n[0] + n[1] * n[1]) + n[2] * n[2];
     if (z > 0.0) { const double nn = sqrt(z); n[0] /= nn; n[1] /= nn; n[2] /= nn; }                      /* :211 normalize() */
     double lp[3], A[3][4];
-    ll_lp_and_jac(P, cp, lp, A);
+    ll_lp_and_jac_s(P, cp, s, lp, A);
     const double d[3] = {lp[0] - j[0], lp[1] - j[1], lp[2] - j[2]};
     r = (d[0] * n[0] + (d[1] * n[1] + d[2] * n[2])) * weight;                                              /* :233 */
     for (int k = 0; k < 4; ++k) Jq[k] = (n[0] * A[0][k] + n[1] * A[1][k] + n[2] * A[2][k]) * weight;
-    for (int k = 0; k < 3; ++k) Jt[k] = n[k] * weight;
+    for (int k = 0; k < 3; ++k) Jt[k] = (s == 1.0) ? n[k] * weight : n[k] * s * weight;                   /* t_last_curr = s * t (:221) */
 }
 
 __device__ __forceinline__ void ll_plane(const Pose &P, const float4 c, const float4 j4, const float4 l4, const float4 m4,
-                                         double weight, double &r, double Jq[4], double Jt[3])
+                                         double weight, double &r, double Jq[4], double Jt[3], double s = 1.0)
 {
     const double cp[3] = {c.x, c.y, c.z}, j[3] = {j4.x, j4.y, j4.z}, l[3] = {l4.x, l4.y, l4.z}, m[3] = {m4.x, m4.y, m4.z};
-    ll_plane_dd(P, cp, j, l, m, weight, r, Jq, Jt);
+    ll_plane_dd(P, cp, j, l, m, weight, r, Jq, Jt, s);
 }
 
 /* ceres HuberLoss(a) + Corrector (rho'' <= 0 branch): scale = sqrt(rho'), cost += rho/2 */

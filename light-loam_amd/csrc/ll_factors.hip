@@ -42,7 +42,7 @@ __device__ __forceinline__ void ll_neq_eval(const LLView &V, int s, const double
     for (int k = 0; k < LL_NACC; ++k) acc[k] = 0.0;
     for (int i = tid; i < ph.n_edge; i += NT) {
         double r[3], Jq[3][4], Jt[3][3];
-        ll_edge(P, sharp[es[i]], corner[ea[i]], corner[eb[i]], r, Jq, Jt);
+        ll_edge(P, sharp[es[i]], corner[ea[i]], corner[eb[i]], r, Jq, Jt, ll_point_s(V.distortion, sharp[es[i]]));
         const double sc = ll_huber_scale(r[0] * r[0] + r[1] * r[1] + r[2] * r[2], V.huber, acc[27]);
         for (int row = 0; row < 3; ++row) {
             double J[6];
@@ -55,7 +55,7 @@ __device__ __forceinline__ void ll_neq_eval(const LLView &V, int s, const double
     for (int i = tid; i < ph.n_plane; i += NT) {
         if (!vs[i]) continue;
         double r, Jq[4], Jt[3], J[6];
-        ll_plane(P, flat[ps[i]], surf[pa[i]], surf[pb[i]], surf[pc[i]], (double)vw[i], r, Jq, Jt);
+        ll_plane(P, flat[ps[i]], surf[pa[i]], surf[pb[i]], surf[pc[i]], (double)vw[i], r, Jq, Jt, ll_point_s(V.distortion, flat[ps[i]]));
         const double sc = ll_huber_scale(r * r, V.huber, acc[27]);
         ll_to_local(P, Jq, J);
         J[3] = Jt[0]; J[4] = Jt[1]; J[5] = Jt[2];
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(LL_BLOCK) void k_rows(LLView V, int s, const double
     const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
     for (int i = gtid; i < ph.n_edge; i += gsz) {
         double r[3], Jq[3][4], Jt[3][3];
-        ll_edge(P, sharp[es[i]], corner[ea[i]], corner[eb[i]], r, Jq, Jt);
+        ll_edge(P, sharp[es[i]], corner[ea[i]], corner[eb[i]], r, Jq, Jt, ll_point_s(V.distortion, sharp[es[i]]));
         for (int row = 0; row < 3; ++row) {
             const size_t R0 = (size_t)3 * i + row;
             r_out[R0] = r[row];
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(LL_BLOCK) void k_rows(LLView V, int s, const double
         for (int i = 0; i < ph.n_plane; ++i) {
             if (!vs[i]) continue;
             double r, Jq[4], Jt[3];
-            ll_plane(P, flat[ps[i]], surf[pa[i]], surf[pb[i]], surf[pc[i]], (double)vw[i], r, Jq, Jt);
+            ll_plane(P, flat[ps[i]], surf[pa[i]], surf[pb[i]], surf[pc[i]], (double)vw[i], r, Jq, Jt, ll_point_s(V.distortion, flat[ps[i]]));
             r_out[R0] = r;
             for (int k = 0; k < 4; ++k) Jq_out[R0 * 4 + k] = Jq[k];
             for (int k = 0; k < 3; ++k) Jt_out[R0 * 3 + k] = Jt[k];

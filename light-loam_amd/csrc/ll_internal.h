@@ -39,6 +39,7 @@ struct ll_ctx {
     double *d_fb = nullptr, *d_fb_out = nullptr;
     size_t fb_cap = 0, fb_out_cap = 0;
     int fb_n[3] = {0, 0, 0};
+    double *d_fb_s = nullptr; size_t fb_s_cap = 0; bool fb_has_s = false;   /* per-block s of the edge / plane blocks (ll_factor_blocks_set_s) */
     /* streaming input (ll_upload_scan_async): a second stream for host -> device copies, ordered against the compute stream by
      * ll_stream_fence; the per-slot point counts live in page-locked memory so that their copies are asynchronous too */
     hipStream_t copy_stream = nullptr;

@@ -347,17 +347,57 @@ static void quat_rotate(const double q[4], const double v[3], double out[3])
     out[2] = (v[2] + w * uvz) + (ux * uvy - uy * uvx);
 }
 
+/* DISTORTION (laserOdometry.cpp:23): the reference is built with 0; 1 is its other compile-time path (:81-82, :570-571, :740-741) */
+static int g_distortion = 0;
+void orc_set_distortion(int on) { g_distortion = on ? 1 : 0; }
+int orc_get_distortion(void) { return g_distortion; }
+
+/* the interpolation ratio of a point (:81-84): float intensity - int(intensity) in f32, / SCAN_PERIOD (0.1) in f64 */
+double orc_point_s(const orc_point *p)
+{
+    if (!g_distortion) return 1.0;
+    return (double)(p->intensity - (float)(int)p->intensity) / 0.1;
+}
+
+/* Eigen 3.3 QuaternionBase::slerp(t, other) called on Identity, plain doubles (the Jet form is slerp_from_identity below) */
+static void slerp_from_identity_d(double t, const double o[4] /* x y z w */, double out[4])
+{
+    const double one = 1.0 - 2.220446049250313e-16;
+    const double d = (0.0 * o[0] + 0.0 * o[1]) + (0.0 * o[2] + 1.0 * o[3]);
+    const double absD = fabs(d);
+    double scale0, scale1;
+    if (absD >= one) { scale0 = 1.0 - t; scale1 = t; }
+    else {
+        const double theta = acos(absD), sinTheta = sin(theta);
+        scale0 = sin((1.0 - t) * theta) / sinTheta;
+        scale1 = sin(t * theta) / sinTheta;
+    }
+    if (d < 0.0) scale1 = -scale1;
+    out[0] = scale0 * 0.0 + scale1 * o[0]; out[1] = scale0 * 0.0 + scale1 * o[1];
+    out[2] = scale0 * 0.0 + scale1 * o[2]; out[3] = scale0 * 1.0 + scale1 * o[3];
+}
+
 void orc_transform_to_start(const double q[4], const double t[3], const orc_point *pi, orc_point *po)
 {
-    /* s = 1.0 (:84).  Identity.slerp(1, q) (Eigen 3.3): scale0 = 0 and scale1 = +-1 exactly in both
-     * branches (1-t = 0; sin(theta)/sin(theta) = 1), so q_point_last = +-q and the rotation formula,
-     * even in (u,w), gives bit-identical results for q and -q.  t_point_last = 1.0 * t = t. */
     const double v[3] = {(double)pi->x, (double)pi->y, (double)pi->z};
     double r[3];
-    quat_rotate(q, v, r);
-    po->x = (float)(r[0] + t[0]);
-    po->y = (float)(r[1] + t[1]);
-    po->z = (float)(r[2] + t[2]);
+    if (!g_distortion) {
+        /* s = 1.0 (:84).  Identity.slerp(1, q) (Eigen 3.3): scale0 = 0 and scale1 = +-1 exactly in both
+         * branches (1-t = 0; sin(theta)/sin(theta) = 1), so q_point_last = +-q and the rotation formula,
+         * even in (u,w), gives bit-identical results for q and -q.  t_point_last = 1.0 * t = t. */
+        quat_rotate(q, v, r);
+        po->x = (float)(r[0] + t[0]);
+        po->y = (float)(r[1] + t[1]);
+        po->z = (float)(r[2] + t[2]);
+    } else {
+        const double s = orc_point_s(pi);                          /* :82 */
+        double qs[4];
+        slerp_from_identity_d(s, q, qs);                            /* :86 */
+        quat_rotate(qs, v, r);
+        po->x = (float)(r[0] + s * t[0]);                           /* :87, :89 */
+        po->y = (float)(r[1] + s * t[1]);
+        po->z = (float)(r[2] + s * t[2]);
+    }
     po->intensity = pi->intensity;
 }
 
@@ -843,14 +883,14 @@ void orc_normal_equations(const double q[4], const double t[3],
         const orc_point *c = &sharp[e_src[i]], *a = &corner_last[e_a[i]], *b = &corner_last[e_b[i]];
         const double cp[3] = {c->x, c->y, c->z}, pa[3] = {a->x, a->y, a->z}, pb[3] = {b->x, b->y, b->z};
         double r[3], Jq[12], Jt[9];
-        orc_edge_factor(q, t, cp, pa, pb, 1.0, r, Jq, Jt);
+        orc_edge_factor(q, t, cp, pa, pb, orc_point_s(c), r, Jq, Jt);          /* s: :568-571 */
         accumulate_block(3, r, Jq, Jt, P, huber_delta, H, g, cost);
     }
     for (int i = 0; i < n_p; ++i) {
         const orc_point *c = &flat[p_src[i]], *a = &surf_last[p_a[i]], *b = &surf_last[p_b[i]], *d = &surf_last[p_c[i]];
         const double cp[3] = {c->x, c->y, c->z}, pa[3] = {a->x, a->y, a->z}, pb[3] = {b->x, b->y, b->z}, pc[3] = {d->x, d->y, d->z};
         double r[1], Jq[4], Jt[3];
-        orc_plane_factor_modify(q, t, cp, pa, pb, pc, 1.0, p_w ? (double)p_w[i] : 1.0, r, Jq, Jt);
+        orc_plane_factor_modify(q, t, cp, pa, pb, pc, orc_point_s(c), p_w ? (double)p_w[i] : 1.0, r, Jq, Jt);   /* s: :738-741 */
         accumulate_block(1, r, Jq, Jt, P, huber_delta, H, g, cost);
     }
 }

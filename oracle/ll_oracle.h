@@ -70,7 +70,13 @@ int orc_extract(const float *xyz, int stride_floats, int n_in, const orc_params 
                 orc_point *sharp, int *n_sharp, orc_point *less_sharp, int *n_less_sharp,
                 orc_point *flat, int *n_flat, orc_point *less_flat, int *n_less_flat);
 
-/* ---- a5: TransformToStart with DISTORTION 0, laserOdometry.cpp:77-95 ---- */
+/* DISTORTION (laserOdometry.cpp:23): 0 = the reference's build (default); 1 = its other compile-time path: the interpolation ratio
+ * s = (intensity - int(intensity)) / SCAN_PERIOD of every point in TransformToStart (:81-82) and in the two odometry factors (:570, :740) */
+void orc_set_distortion(int on);
+int orc_get_distortion(void);
+double orc_point_s(const orc_point *p);
+
+/* ---- a5: TransformToStart, laserOdometry.cpp:77-95 ---- */
 void orc_transform_to_start(const double q[4] /*x,y,z,w*/, const double t[3], const orc_point *pi, orc_point *po);
 
 /* K=1 search strategy of a6/a7: 0 = linear scan (default; the plainest statement of "exact NN"),

@@ -124,6 +124,18 @@ def extract(xyz, P):
                 flat=flat[:nf.value].copy(), less_flat=less_flat[:nlf.value].copy())
 
 
+def set_distortion(on):
+    """DISTORTION of laserOdometry.cpp:23 for TransformToStart and the odometry factors of normal_equations / lm_solve /
+    odometry_frame: 0 = the reference's build (default), 1 = per-point s = (intensity - int(intensity)) / SCAN_PERIOD."""
+    lib().orc_set_distortion(int(bool(on)))
+
+
+def point_s(point):
+    lib().orc_point_s.restype = C.c_double
+    p = np.ascontiguousarray(point, dtype=np.float32).reshape(4)
+    return float(lib().orc_point_s(_p(p)))
+
+
 def set_nn_mode(mode):
     lib().orc_set_nn_mode(int(mode))
 

@@ -16,6 +16,7 @@
 #include <fstream>
 #include <iostream>
 #include <memory>
+#include <string>
 #include <vector>
 
 namespace ceres {
@@ -45,9 +46,12 @@ struct Vec3 {                                                    // stands in fo
 };
 static Vec3 v3(const double *p) { return Vec3{{p[0], p[1], p[2]}}; }
 
+static double block_s(bool on, int i) { return on ? 0.25 + 0.5 * ((i % 7) / 7.0) : 1.0; }   // DISTORTION 1: the functors' s_
+
 int main(int argc, char **argv)
 {
     if (argc < 3) return 2;
+    const bool with_s = argc > 3 && std::string(argv[3]) == "s";
     std::ifstream f(argv[1], std::ios::binary);
     int32_t n[3];
     f.read((char *)n, sizeof(n));
@@ -66,13 +70,10 @@ int main(int argc, char **argv)
         std::vector<int> kind;
         {
             lightloam::FactorBatch::Current use(batch);
-            bool bad_s = false;
-            try { LidarEdgeFactor::Create(v3(&edge[0]), v3(&edge[3]), v3(&edge[6]), 0.5); } catch (const lightloam::Error &e) { bad_s = e.code == LL_ERR_ARG; }
-            if (!bad_s) { std::cerr << "s != 1 did not throw\n"; return 1; }
             const int most = std::max(n[0], std::max(n[1], n[2]));
             for (int i = 0; i < most; ++i) {                       // interleaved, like a node with several loops would not -- the harder case
-                if (i < n[0]) { const double *e = &edge[(size_t)i * 9]; costs.emplace_back(LidarEdgeFactor::Create(v3(e), v3(e + 3), v3(e + 6), 1.0)); kind.push_back(0); }
-                if (i < n[1]) { const double *p = &plane[(size_t)i * 13]; costs.emplace_back(LidarPlaneFactor_modify::Create(v3(p), v3(p + 3), v3(p + 6), v3(p + 9), 1.0, p[12])); kind.push_back(1); }
+                if (i < n[0]) { const double *e = &edge[(size_t)i * 9]; costs.emplace_back(LidarEdgeFactor::Create(v3(e), v3(e + 3), v3(e + 6), block_s(with_s, i))); kind.push_back(0); }
+                if (i < n[1]) { const double *p = &plane[(size_t)i * 13]; costs.emplace_back(LidarPlaneFactor_modify::Create(v3(p), v3(p + 3), v3(p + 6), v3(p + 9), block_s(with_s, i), p[12])); kind.push_back(1); }
                 if (i < n[2]) { const double *p = &pnorm[(size_t)i * 7]; costs.emplace_back(LidarPlaneNormFactor::Create(v3(p), v3(p + 3), p[6])); kind.push_back(2); }
             }
         }

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(api):
     lib = api.load_library()
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     assert not missing, missing
-    assert lib.ll_abi_version() == 1
+    assert lib.ll_abi_version() == 2          # 2: ll_params.distortion
     assert sorted(api.EXPORTS) == sorted(s for s in declared_symbols())
 
 

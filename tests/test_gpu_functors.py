@@ -94,7 +94,36 @@ def test_block_entry_points_validate_their_arguments(api):
     ctx.close()
 
 
-def test_lidar_factor_header_keeps_the_reference_call_sites(tmp_path, api, orc):
+def test_blocks_with_per_block_s_match_the_oracle_functors(api, orc):
+    """DISTORTION 1: the functors' s_ per block (ll_factor_blocks_set_s) through Identity.slerp(s, q), s * t (lidarFactor.hpp:25-27)"""
+    ctx = api.Context(api.default_params(16, batch=1, max_points=4096))
+    edge, plane, pnorm = _blocks(31, 40, 90, 11)
+    rng = np.random.default_rng(7)
+    es, ps = rng.uniform(0.0, 1.0, len(edge)), rng.uniform(0.0, 1.0, len(plane))
+    es[:3] = [0.0, 1.0, 0.5]; ps[:2] = [1.0, 0.0]                                   # the ends of the sweep too
+    ctx.factor_blocks_set(edge, plane, pnorm)
+    ctx.factor_blocks_set_s(es, ps)
+    for pose in _poses():
+        q, t = pose[:4], pose[4:]
+        r, Jq, Jt = ctx.factor_blocks_evaluate(q, t)
+        ro, Jqo, Jto = [], [], []
+        for e, s_ in zip(edge, es):
+            a = orc.edge_factor(q, t, e[0:3], e[3:6], e[6:9], s_); ro.append(a[0]); Jqo.append(a[1]); Jto.append(a[2])
+        for p, s_ in zip(plane, ps):
+            a = orc.plane_factor_modify(q, t, p[0:3], p[3:6], p[6:9], p[9:12], s_, p[12]); ro.append(a[0]); Jqo.append(a[1]); Jto.append(a[2])
+        for p in pnorm:
+            a = orc.plane_norm_factor(q, t, p[0:3], p[3:6], p[6]); ro.append(a[0]); Jqo.append(a[1]); Jto.append(a[2])
+        _close(r, np.concatenate(ro), "residuals"); _close(Jq, np.vstack(Jqo), "d r / d q"); _close(Jt, np.vstack(Jto), "d r / d t")
+    # a new set of blocks starts at s = 1 again
+    ctx.factor_blocks_set(edge, plane, pnorm)
+    r, Jq, Jt = ctx.factor_blocks_evaluate(*np.split(_poses()[0], [4]))
+    ro, Jqo, Jto = _oracle_rows(orc, edge, plane, pnorm, _poses()[0])
+    _close(r, ro, "s reset"); _close(Jq, Jqo, "s reset Jq")
+    ctx.close()
+
+
+@pytest.mark.parametrize("with_s", [False, True])
+def test_lidar_factor_header_keeps_the_reference_call_sites(tmp_path, api, orc, with_s):
     from lightloam_amd import build
     lib_dir = os.path.dirname(build.lib_path())
     exe = str(tmp_path / "lidar_factor_adapter")
@@ -107,7 +136,8 @@ def test_lidar_factor_header_keeps_the_reference_call_sites(tmp_path, api, orc):
     with open(tmp_path / "blocks.bin", "wb") as f:
         f.write(np.array(n, np.int32).tobytes()); f.write(edge.tobytes()); f.write(plane.tobytes()); f.write(pnorm.tobytes())
         f.write(np.concatenate(poses).tobytes())
-    out = subprocess.run([exe, str(tmp_path / "blocks.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([exe, str(tmp_path / "blocks.bin"), str(tmp_path / "out.bin")] + (["s"] if with_s else []), capture_output=True, text=True, timeout=300)
+    bs = (lambda i: 0.25 + 0.5 * ((i % 7) / 7.0)) if with_s else (lambda i: 1.0)      # the s_ the program passes to Create()
     assert out.returncode == 0, out.stdout + out.stderr
     assert "2 device evaluations" in out.stdout                                        # 94 cost functions x 3 passes, two launches
     got = np.fromfile(tmp_path / "out.bin", np.float64)
@@ -119,9 +149,9 @@ def test_lidar_factor_header_keeps_the_reference_call_sites(tmp_path, api, orc):
         q, t = pose[:4], pose[4:]
         for k, i in order:
             if k == 0:
-                ro, Jqo, Jto = orc.edge_factor(q, t, edge[i, 0:3], edge[i, 3:6], edge[i, 6:9])
+                ro, Jqo, Jto = orc.edge_factor(q, t, edge[i, 0:3], edge[i, 3:6], edge[i, 6:9], bs(i))
             elif k == 1:
-                p = plane[i]; ro, Jqo, Jto = orc.plane_factor_modify(q, t, p[0:3], p[3:6], p[6:9], p[9:12], 1.0, p[12])
+                p = plane[i]; ro, Jqo, Jto = orc.plane_factor_modify(q, t, p[0:3], p[3:6], p[6:9], p[9:12], bs(i), p[12])
             else:
                 p = pnorm[i]; ro, Jqo, Jto = orc.plane_norm_factor(q, t, p[0:3], p[3:6], p[6])
             rows = len(ro)
