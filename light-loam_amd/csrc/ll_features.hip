@@ -139,20 +139,22 @@ __device__ __forceinline__ void ll_radix_sort(unsigned *k32, unsigned short *k16
         for (int i = tid; i < NW * ND; i += LL_BLOCK) cnt[i] = 0;
         __syncthreads();                                        /* also: every thread holds its records in registers */
         int *wc = cnt + wave * ND;                              /* this wave's counters */
-        int rnk[ROWS];
+        int rnk[ROWS], pre[ROWS];
 #pragma unroll
         for (int k = 0; k < ROWS; ++k) {
-            rnk[k] = 0;
+            rnk[k] = 0; pre[k] = 0;
             if (k < myrows) {
                 const int d = (int)((e32[k] >> sh) & DM);
                 unsigned mlo, mhi;
                 ll_match_any(d, BITS, ~0ull, mlo, mhi);
-                const int r = ll_match_rank(mlo, mhi);
-                const int pre = wc[d];                          /* records of the earlier rows of this wave with digit d */
-                rnk[k] = pre + r;
-                if (r == 0) wc[d] = pre + ll_match_count(mlo, mhi);
+                rnk[k] = ll_match_rank(mlo, mhi);
+                pre[k] = wc[d];                                 /* records of the earlier rows of this wave with digit d ... */
+                if (rnk[k] == 0) atomicAdd(&wc[d], ll_match_count(mlo, mhi));   /* ... bumped by an LDS add that does not wait for the read:
+                                                                                 * the wave's LDS operations execute in order, so the next row's read sees it */
             }
         }
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) rnk[k] += pre[k];
         __syncthreads();
         {   /* exclusive scan of the (digit, wave) table in digit-major order: thread d owns digit d */
             int v[NW]; int s = 0;
@@ -404,9 +406,8 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : 1)) void k_ring_
         const unsigned bits = (unsigned)(w >> (b0 & 31)) & 0x3ffu;                   /* bit t = gapf[li - 4 + t] */
         const unsigned fwd = bits >> 5;                                              /* l = 1..5  -> gapf[li + l] */
         const int fn = fwd ? (__ffs(fwd) - 1) : 5;
-        int bn = 5;                                                                  /* l = -1..-5 -> gapf[li + l + 1] */
-#pragma unroll
-        for (int mm = 4; mm >= 0; --mm) if ((bits >> (4 - mm)) & 1u) bn = mm;
+        const unsigned bwd = bits & 0x1fu;                                           /* l = -1..-5 -> gapf[li + l + 1] = bits 4..0 */
+        const int bn = bwd ? 4 - (31 - __clz((int)bwd)) : 5;                         /* stops at the first set bit walking down from bit 4 */
         L.k16[q] = (unsigned short)(bn | (fn << 4));
     }
     __syncthreads();
