@@ -22,7 +22,9 @@
 /* the normal equations of slot s at the pose pose_in[7] (global or LDS), by the whole workgroup; thread 0 leaves the 44-double
  * record in out[] (global or LDS).  Ends with every thread past the last barrier but WITHOUT a barrier after thread 0's
  * stores: the caller synchronises before anybody else reads out[]. */
-template <int NT>
+/* DIST: DISTORTION 1 (ll_params.distortion): a second instantiation of the kernels, so that the reference's own build (s = 1 everywhere) pays
+ * neither a branch nor a register for it */
+template <int NT, bool DIST>
 __device__ __forceinline__ void ll_neq_eval(const LLView &V, int s, const double *pose_in, double *out, double (*red)[LL_NACC])
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -42,7 +44,7 @@ __device__ __forceinline__ void ll_neq_eval(const LLView &V, int s, const double
     for (int k = 0; k < LL_NACC; ++k) acc[k] = 0.0;
     for (int i = tid; i < ph.n_edge; i += NT) {
         double r[3], Jq[3][4], Jt[3][3];
-        ll_edge(P, sharp[es[i]], corner[ea[i]], corner[eb[i]], r, Jq, Jt, ll_point_s(V.distortion, sharp[es[i]]));
+        ll_edge(P, sharp[es[i]], corner[ea[i]], corner[eb[i]], r, Jq, Jt, DIST ? ll_point_s(1, sharp[es[i]]) : 1.0);
         const double sc = ll_huber_scale(r[0] * r[0] + r[1] * r[1] + r[2] * r[2], V.huber, acc[27]);
         for (int row = 0; row < 3; ++row) {
             double J[6];
@@ -55,7 +57,7 @@ __device__ __forceinline__ void ll_neq_eval(const LLView &V, int s, const double
     for (int i = tid; i < ph.n_plane; i += NT) {
         if (!vs[i]) continue;
         double r, Jq[4], Jt[3], J[6];
-        ll_plane(P, flat[ps[i]], surf[pa[i]], surf[pb[i]], surf[pc[i]], (double)vw[i], r, Jq, Jt, ll_point_s(V.distortion, flat[ps[i]]));
+        ll_plane(P, flat[ps[i]], surf[pa[i]], surf[pb[i]], surf[pc[i]], (double)vw[i], r, Jq, Jt, DIST ? ll_point_s(1, flat[ps[i]]) : 1.0);
         const double sc = ll_huber_scale(r * r, V.huber, acc[27]);
         ll_to_local(P, Jq, J);
         J[3] = Jt[0]; J[4] = Jt[1]; J[5] = Jt[2];
@@ -80,13 +82,14 @@ __device__ __forceinline__ void ll_neq_eval(const LLView &V, int s, const double
     }
 }
 
+template <bool DIST>
 __global__ __launch_bounds__(LL_BLOCK) void k_normal_equations(LLView V, int first, int count, int do_step)
 {
     if ((int)blockIdx.x >= count) return;
     const int s = first + blockIdx.x;
     __shared__ double red[LL_BLOCK / 64][LL_NACC];
     double *pose = V.pose + (size_t)s * 7, *out = V.neq + (size_t)s * LL_NEQ_STRIDE;
-    ll_neq_eval<LL_BLOCK>(V, s, pose, out, red);
+    ll_neq_eval<LL_BLOCK, DIST>(V, s, pose, out, red);
     if (threadIdx.x == 0 && do_step) {
         double H[36], g[6], d[6];
         for (int i = 0; i < 36; ++i) H[i] = out[i];
@@ -149,7 +152,8 @@ __global__ __launch_bounds__(LL_BLOCK) void k_rows(LLView V, int s, const double
 void ll_launch_normal_equations(const LLView &V, int first, int count, int do_step, hipStream_t st, LLProfiler *prof)
 {
     ll_prof_mark(prof, LL_K_NORMAL_EQ, st);
-    hipLaunchKernelGGL(k_normal_equations, dim3(count), dim3(LL_BLOCK), 0, st, V, first, count, do_step);
+    if (V.distortion) hipLaunchKernelGGL(k_normal_equations<true>, dim3(count), dim3(LL_BLOCK), 0, st, V, first, count, do_step);
+    else hipLaunchKernelGGL(k_normal_equations<false>, dim3(count), dim3(LL_BLOCK), 0, st, V, first, count, do_step);
     ll_prof_mark(prof, LL_K_END, st);
 }
 /* ------------------------------------------------------------------------------------------------------------------
@@ -188,6 +192,7 @@ __global__ void k_lm_accept(LLView V, int first, int count, LLLmOpt o)
  * the row-parallel mode, where an all-reduce sits between evaluate and accept): the results are bit-identical, the node-style
  * odometry frame drops from 48 dependent launches to 9.  The state and the last normal equations are left in V.lm / V.neq. */
 #define LL_LM_THREADS 512     /* the solve is a chain of 1 + max_num_iterations evaluations on ONE workgroup: twice the threads, half the chain */
+template <bool DIST>
 __global__ __launch_bounds__(LL_LM_THREADS) void k_lm_solve(LLView V, int first, int count, LLLmOpt o)
 {
     if ((int)blockIdx.x >= count) return;
@@ -198,12 +203,12 @@ __global__ __launch_bounds__(LL_LM_THREADS) void k_lm_solve(LLView V, int first,
     if (tid < 7) sp[tid] = V.pose[(size_t)s * 7 + tid];
     for (int k = tid; k < LL_LM_STRIDE; k += LL_LM_THREADS) sL[k] = 0.0;
     __syncthreads();
-    ll_neq_eval<LL_LM_THREADS>(V, s, sp, sneq, red);
+    ll_neq_eval<LL_LM_THREADS, DIST>(V, s, sp, sneq, red);
     if (tid == 0) ll_lm_begin_one(sL, sneq, sp, o);
     for (int it = 0; it < o.max_num_iterations; ++it) {
         if (tid == 0) ll_lm_propose_one(sL, sp, o);
         __syncthreads();
-        ll_neq_eval<LL_LM_THREADS>(V, s, sp, sneq, red);
+        ll_neq_eval<LL_LM_THREADS, DIST>(V, s, sp, sneq, red);
         if (tid == 0) ll_lm_accept_one(sL, sneq, sp, o);
     }
     __syncthreads();
@@ -214,7 +219,8 @@ __global__ __launch_bounds__(LL_LM_THREADS) void k_lm_solve(LLView V, int first,
 
 void ll_launch_lm_solve(const LLView &V, int first, int count, const LLLmOpt &o, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_lm_solve, dim3(count), dim3(LL_LM_THREADS), 0, st, V, first, count, o);
+    if (V.distortion) hipLaunchKernelGGL(k_lm_solve<true>, dim3(count), dim3(LL_LM_THREADS), 0, st, V, first, count, o);
+    else hipLaunchKernelGGL(k_lm_solve<false>, dim3(count), dim3(LL_LM_THREADS), 0, st, V, first, count, o);
 }
 void ll_launch_lm_begin(const LLView &V, int first, int count, const LLLmOpt &o, hipStream_t st)
 {
