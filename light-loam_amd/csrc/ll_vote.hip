@@ -17,16 +17,16 @@
 extern __shared__ __attribute__((aligned(16))) unsigned char ll_vsm[];
 
 /* stable compaction of valid_src[0..n) >= 0 by one workgroup; emit(i, pos) for every kept i; returns the total */
-template <typename F>
+template <int NT, typename F>
 __device__ __forceinline__ int ll_block_compact(int n, int *sc, F emit, const int *valid_src)
 {
     const int tid = threadIdx.x;
-    const int per = (n + LL_BLOCK - 1) / LL_BLOCK;
+    const int per = (n + NT - 1) / NT;
     const int a0 = min(n, tid * per), a1 = min(n, a0 + per);
     int c = 0;
     for (int i = a0; i < a1; ++i) c += valid_src[i] >= 0;
     int total = 0;
-    int pos = ll_block_exscan(c, sc, total);
+    int pos = ll_block_exscan_n<NT / 64>(c, sc, total);
     for (int i = a0; i < a1; ++i) if (valid_src[i] >= 0) emit(i, pos++);
     __syncthreads();
     return total;
@@ -38,14 +38,15 @@ __device__ __forceinline__ int ll_block_compact(int n, int *sc, F emit, const in
  * takes the partners at circular offsets 1 .. (m - 1) / 2 (and, for even m, the lower half takes offset m / 2), which
  * gives every lane the same trip count; an incompatible pair bumps the entry's own register count and the partner's
  * count in LDS (cntL, n_p ints, zeroed here).  Counts are integers, so the summation order does not matter. */
+template <int NT>
 __device__ __forceinline__ int ll_vote_core(const float *S3, const float *T3, int n_p, int number_of_region, int enable,
                                             int *vc, uint8_t *vs, float *vw, int *cntL)
 {
     const int chunk = n_p / number_of_region;                     /* cor_size_all / number_of_region (:202) */
-    for (int i = threadIdx.x; i < n_p; i += LL_BLOCK) cntL[i] = 0;
+    for (int i = threadIdx.x; i < n_p; i += NT) cntL[i] = 0;
     __syncthreads();
     if (enable) {
-        for (int i = threadIdx.x; i < n_p; i += LL_BLOCK) {
+        for (int i = threadIdx.x; i < n_p; i += NT) {
             const int rg = (chunk > 0) ? min(i / chunk, number_of_region - 1) : number_of_region - 1;
             const int b0 = chunk * rg, b1 = (rg == number_of_region - 1) ? n_p : chunk * (rg + 1);
             const int m = b1 - b0;
@@ -84,7 +85,7 @@ __device__ __forceinline__ int ll_vote_core(const float *S3, const float *T3, in
     }
     __syncthreads();
     int my_sel = 0;
-    for (int i = threadIdx.x; i < n_p; i += LL_BLOCK) {
+    for (int i = threadIdx.x; i < n_p; i += NT) {
         int cnt = 0, sel = 1; float w = 1.0f;
         if (enable) {
             const int rg = (chunk > 0) ? min(i / chunk, number_of_region - 1) : number_of_region - 1;
@@ -100,12 +101,17 @@ __device__ __forceinline__ int ll_vote_core(const float *S3, const float *T3, in
     return my_sel;
 }
 
-__global__ __launch_bounds__(LL_BLOCK) void k_vote(LLView V, int first, int count, int enable)
+/* LL_VT threads: the all-pairs loop is the serial work of a thread (72 k pair tests per scan pair: ~280 each with 256 threads);
+ * 256 / 512 / 1024 threads: 0.80 / 0.63 / 1.14 ms per 8192 scan pairs */
+#ifndef LL_VT
+#define LL_VT 512
+#endif
+__global__ __launch_bounds__(LL_VT) void k_vote(LLView V, int first, int count, int enable)
 {
     if ((int)blockIdx.x >= count) return;
     const int s = first + blockIdx.x;
     const int tid = threadIdx.x;
-    __shared__ int sc[LL_BLOCK + 1];
+    __shared__ int sc[LL_VT / 64 + 1];
     __shared__ int nsel_sh;
     const ScanHdr h = V.hdr[s];
     const bool ok = h.status == 0;
@@ -116,11 +122,11 @@ __global__ __launch_bounds__(LL_BLOCK) void k_vote(LLView V, int first, int coun
     /* edges (:574-617) */
     const int *eqa = V.eq_a + (size_t)s * V.cap_sharp, *eqb = V.eq_b + (size_t)s * V.cap_sharp;
     int *es = V.e_src + (size_t)s * V.cap_sharp, *ea = V.e_a + (size_t)s * V.cap_sharp, *eb = V.e_b + (size_t)s * V.cap_sharp;
-    const int n_e = ll_block_compact(ns, sc, [&](int i, int pos) { es[pos] = i; ea[pos] = eqa[i]; eb[pos] = eqb[i]; }, eqa);
+    const int n_e = ll_block_compact<LL_VT>(ns, sc, [&](int i, int pos) { es[pos] = i; ea[pos] = eqa[i]; eb[pos] = eqb[i]; }, eqa);
     /* planes (:745-790) */
     const int *pqa = V.pq_a + (size_t)s * V.cap_flat, *pqb = V.pq_b + (size_t)s * V.cap_flat, *pqc = V.pq_c + (size_t)s * V.cap_flat;
     int *ps = V.p_src + (size_t)s * V.cap_flat, *pa = V.p_a + (size_t)s * V.cap_flat, *pb = V.p_b + (size_t)s * V.cap_flat, *pc = V.p_c + (size_t)s * V.cap_flat;
-    const int n_p = ll_block_compact(nf, sc, [&](int i, int pos) { ps[pos] = i; pa[pos] = pqa[i]; pb[pos] = pqb[i]; pc[pos] = pqc[i]; }, pqa);
+    const int n_p = ll_block_compact<LL_VT>(nf, sc, [&](int i, int pos) { ps[pos] = i; pa[pos] = pqa[i]; pb[pos] = pqb[i]; pc[pos] = pqc[i]; }, pqa);
 
     /* stage Corre_Match.src (raw current point, :753) and .tgt (closest target point, :754) */
     float *S3 = (float *)ll_vsm;                 /* [n_p][6]: src xyz, tgt xyz */
@@ -128,13 +134,13 @@ __global__ __launch_bounds__(LL_BLOCK) void k_vote(LLView V, int first, int coun
     const float4 *flat = V.flat + (size_t)s * V.cap_flat;
     if (tid == 0) nsel_sh = 0;
     __syncthreads();
-    for (int i = tid; i < n_p; i += LL_BLOCK) {
+    for (int i = tid; i < n_p; i += LL_VT) {
         const float4 a = flat[ps[i]], b = surf[pa[i]];
         S3[6 * i] = a.x; S3[6 * i + 1] = a.y; S3[6 * i + 2] = a.z;
         S3[6 * i + 3] = b.x; S3[6 * i + 4] = b.y; S3[6 * i + 5] = b.z;
     }
     __syncthreads();
-    const int my_sel = ll_vote_core(S3, T3, n_p, 10 /* plane case (:186-187) */, enable,
+    const int my_sel = ll_vote_core<LL_VT>(S3, T3, n_p, 10 /* plane case (:186-187) */, enable,
                                     V.v_count + (size_t)s * V.cap_flat, V.v_sel + (size_t)s * V.cap_flat, V.v_w + (size_t)s * V.cap_flat,
                                     (int *)(T3 + 3 * (size_t)V.cap_flat));
     if (my_sel) atomicAdd(&nsel_sh, my_sel);
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(LL_BLOCK) void k_vote_points(const float4 *src, con
         S3[6 * i + 3] = b.x; S3[6 * i + 4] = b.y; S3[6 * i + 5] = b.z;
     }
     __syncthreads();
-    (void)ll_vote_core(S3, T3, n, regions, 1, vc, vs, vw, (int *)(T3 + 3 * (size_t)n));
+    (void)ll_vote_core<LL_BLOCK>(S3, T3, n, regions, 1, vc, vs, vw, (int *)(T3 + 3 * (size_t)n));
 }
 
 void ll_launch_vote(const LLView &V, int first, int count, int enable, hipStream_t st, LLProfiler *prof)
@@ -165,7 +171,7 @@ void ll_launch_vote(const LLView &V, int first, int count, int enable, hipStream
     static size_t attr_bytes[LL_MAX_DEVICES] = {0};
     ll_ensure_dynamic_lds(k_vote, lds, attr_bytes);
     ll_prof_mark(prof, LL_K_VOTE, st);
-    hipLaunchKernelGGL(k_vote, dim3(count), dim3(LL_BLOCK), lds, st, V, first, count, enable);
+    hipLaunchKernelGGL(k_vote, dim3(count), dim3(LL_VT), lds, st, V, first, count, enable);
     ll_prof_mark(prof, LL_K_END, st);
 }
 
