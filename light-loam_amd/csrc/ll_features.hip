@@ -47,6 +47,12 @@ __device__ __forceinline__ bool ll_xcd_map2(int id, int per_scan, int count, int
 #else
 #define LL_LOOKBACK_SPINS (1 << 24)    /* bounded so that a logic error ends in wrong results, not in a hung GPU */
 #endif
+#ifndef LL_PICK_PRIO
+#define LL_PICK_PRIO 3     /* wave priority during the pick (the workgroup's longest serial stretch) */
+#endif
+#ifndef LL_TAIL_PRIO
+#define LL_TAIL_PRIO 0     /* ... and after it */
+#endif
 #define LL_NLIST 176      /* per segment slots: sharp[6][2] lsharp[6][20] flat[6][4] + counters[6][3] */
 
 struct FeatLds {
@@ -426,7 +432,7 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : 1)) void k_ring_
     if (active) {
         constexpr int SR = (ROWS * LL_BLOCK + 383) / 384;
         int *donemask = L.sc + 60;
-        __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(LL_PICK_PRIO);
         /* the wave index is uniform; saying so keeps the segment bounds and every branch on them scalar */
         for (int j = __builtin_amdgcn_readfirstlane(tid >> 6); j < LL_SEGS; j += LL_BLOCK / 64) {
             const int sp = Lseg * j / 6, ep = Lseg * (j + 1) / 6 - 1;     /* record slots; = (:253-254) - S */
@@ -596,7 +602,7 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : 1)) void k_ring_
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) atomicOr(donemask, 1 << j);
         }
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(LL_TAIL_PRIO);
     }
     __syncthreads();
 
