@@ -588,8 +588,11 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
  * with the same 60 VGPRs and no scratch -- the kernel is latency-bound, one more wave per SIMD is worth 17 % (A/B, one box). */
 __global__ __launch_bounds__(LL_BLOCK, 8) void k_associate(LLView V, int first, int count, int qb_corner, int qb_plane, int qpb)
 {
+    /* All query blocks of a scan on ONE XCD (workgroup b runs on XCD b % 8): they search the same target grid, and an XCD's 4 MB L2 is
+     * private -- dealt round-robin over the XCDs, every scan's target would be fetched into all eight of them. */
     const int per = qb_corner + qb_plane;
-    const int sl = blockIdx.x / per, item = blockIdx.x % per;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int sl = (jb / per) * 8 + xcd, item = jb % per;
     if (sl >= count) return;
     const int s = first + sl;
     __shared__ float4 qs[LL_BLOCK];
@@ -631,6 +634,6 @@ void ll_launch_associate(const LLView &V, int first, int count, hipStream_t st, 
     const int qpb = (count <= 16) ? 32 : LL_BLOCK;
     const int qbc = (V.cap_sharp + qpb - 1) / qpb, qbp = (V.cap_flat + qpb - 1) / qpb;
     ll_prof_mark(prof, LL_K_ASSOCIATE, st);
-    hipLaunchKernelGGL(k_associate, dim3(count * (qbc + qbp)), dim3(LL_BLOCK), 0, st, V, first, count, qbc, qbp, qpb);
+    hipLaunchKernelGGL(k_associate, dim3(8 * (qbc + qbp) * ((count + 7) / 8)), dim3(LL_BLOCK), 0, st, V, first, count, qbc, qbp, qpb);
     ll_prof_mark(prof, LL_K_END, st);
 }
