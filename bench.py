@@ -203,7 +203,7 @@ def bench_stream(args, rank, local_rank, world):
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    B = args.batch if args.batch != 8192 else 2048            # default: 2048 slots (two halves of 1024)
+    B = args.batch if not args.batch_defaulted else 2048      # default: 2048 slots (two halves of 1024)
     B -= B % 2
     H = B // 2
     base, order, guesses = build_workload(synth, args.rings, B, args.distinct, 0x5EED0000 + rank)
@@ -359,7 +359,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8192, help="scans resident per GPU and processed per step (8192 S64 scans: 100 GB of the 288)")
+    ap.add_argument("--batch", type=int, default=0, help="scans resident per GPU and processed per step; 0 = by ring count: 16384 for 64 rings "
+                    "(189 GB of the 288; 8192: -2 %%), 4096 for more rings, 32768 for fewer; --stream-input: 2048")
     ap.add_argument("--chunk", type=int, default=0, help="scans per launch sequence inside a step (0 = whole batch)")
     ap.add_argument("--rings", type=int, default=64)
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic poses the batch cycles through")
@@ -381,6 +382,9 @@ def main():
     ap.add_argument("--max-ring-points", type=int, default=0,
                     help="ring capacity of the context (0: 2304, enough for the synthetic 2048-column scans; real HDL-64E data needs 4608)")
     args = ap.parse_args()
+    args.batch_defaulted = args.batch <= 0
+    if args.batch_defaulted:
+        args.batch = 16384 if args.rings == 64 else 4096 if args.rings > 64 else 32768
     if args.cpu_worker:
         if args.pin >= 0 and hasattr(os, "sched_setaffinity"):
             try:

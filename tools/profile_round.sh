@@ -13,7 +13,7 @@ rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o $TAG -- $B > $O/prof_$TAG.lo
 python3 tools/rocpd_summary.py $O/prof_$TAG/${TAG}_results.db > $O/${TAG}_kernel_stats.txt
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $O/pmc_fetch -o fetch -- $B > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d $O/pmc_write -o write -- $B > $O/pmc_write.log 2>&1
-python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write --batch ${BATCH:-8192} --rings 64 > $O/pmc_traffic.json
+python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write --batch ${BATCH:-16384} --rings 64 > $O/pmc_traffic.json
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY \
     --kernel-trace -f csv -d $O/pmc_sq -o sq -- $B > $O/pmc_sq.log 2>&1
 python3 tools/sq_summary.py $O/pmc_sq > $O/${TAG}_sq_counters.txt
