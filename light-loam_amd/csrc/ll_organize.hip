@@ -254,7 +254,11 @@ __global__ __launch_bounds__(LL_BLOCK, LL_OWAVES) void k_organize(LLView V, int 
 /* first kept point of each scan -> startOri (:114).  One workgroup per scan, 4 points per thread per round, stops at
  * the first round that keeps anything.  (With minimum_range 5 the first rings of a ring-major scan are dropped
  * entirely: the first kept point can be tens of thousands of points in.) */
-__global__ __launch_bounds__(LL_BLOCK) void k_first_kept(LLView V, int first, int count)
+/* This path serves calls of a few scans, where the chain of dependent rounds is what costs: 1024 threads x 16 points per round
+ * (with minimum_range 5 the first kept point of a 64-ring scan is ~20 k points in: two rounds instead of twenty) */
+#define LL_FK_THREADS 1024
+#define LL_FK_PER 16
+__global__ __launch_bounds__(LL_FK_THREADS) void k_first_kept(LLView V, int first, int count)
 {
     if ((int)blockIdx.x >= count) return;
     const int s = first + blockIdx.x;
@@ -264,12 +268,15 @@ __global__ __launch_bounds__(LL_BLOCK) void k_first_kept(LLView V, int first, in
     __shared__ int sh_first;
     if (tid == 0) sh_first = INT_MAX;
     __syncthreads();
-    for (int c = 0; c < n_in; c += LL_TILE) {
+    for (int c = 0; c < n_in; c += LL_FK_THREADS * LL_FK_PER) {
+        float4 p[LL_FK_PER];
+#pragma unroll
+        for (int k = 0; k < LL_FK_PER; ++k) { const int i = c + k * LL_FK_THREADS + tid; if (i < n_in) p[k] = raw[i]; }
         int mine = INT_MAX;
 #pragma unroll
-        for (int k = LL_TILE / LL_BLOCK - 1; k >= 0; --k) {
-            const int i = c + k * LL_BLOCK + tid;
-            if (i < n_in && ll_keep(raw[i], V.thres)) mine = i;
+        for (int k = LL_FK_PER - 1; k >= 0; --k) {
+            const int i = c + k * LL_FK_THREADS + tid;
+            if (i < n_in && ll_keep(p[k], V.thres)) mine = i;
         }
         if (__syncthreads_or(mine != INT_MAX ? 1 : 0)) {
             if (mine != INT_MAX) atomicMin(&sh_first, mine);
@@ -561,7 +568,7 @@ void ll_launch_organize(const LLView &V, int first, int count, hipStream_t st, L
     const int groups = (count + 7) / 8;
     const int grid = 8 * V.T * groups;
     ll_prof_mark(prof, LL_K_FIRST, st);
-    hipLaunchKernelGGL(k_first_kept, dim3(count), dim3(LL_BLOCK), 0, st, V, first, count);
+    hipLaunchKernelGGL(k_first_kept, dim3(count), dim3(LL_FK_THREADS), 0, st, V, first, count);
     ll_prof_mark(prof, LL_K_CLASSIFY, st);
     if (V.lut_nb > 0) hipLaunchKernelGGL(k_classify<true>, dim3(grid), dim3(LL_BLOCK), 0, st, V, first, count);
     else hipLaunchKernelGGL(k_classify<false>, dim3(grid), dim3(LL_BLOCK), 0, st, V, first, count);
