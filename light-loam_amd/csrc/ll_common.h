@@ -284,7 +284,8 @@ struct LLVoxWork {
 };
 size_t ll_vox_work_bytes(int cap, int max_seg);
 void ll_vox_work_carve(void *base, int cap, int max_seg, LLVoxWork *W);
-int ll_voxel_grid_segments(const float4 *pts, int n, int nseg, float leaf, const LLVoxWork &W, float4 *out, int *n_out_dev, hipStream_t st);   /* 0 = ok */
+int ll_voxel_grid_segments(const float4 *pts, int n, int nseg, float leaf, const LLVoxWork &W, float4 *out, int *n_out_dev, hipStream_t st,
+                           int max_seg_len = 0);   /* 0 = ok; max_seg_len: the longest segment when the host knows it (<= 8192: one sort launch) */
 void ll_device_exscan(int *data, int n, int *tile_sum, hipStream_t st);
 
 /* raise a kernel's dynamic-LDS limit once per (kernel, device): the cache is per device, so contexts on several GPUs of

@@ -378,7 +378,9 @@ extern "C" int ll_cubemap_update(ll_cubemap *cm, const double *pose_w7)
         std::vector<int> seg_count(cm->n_valid, 0); int n_out = 0;
         if (tot > 0) {
             CM_HIP(hipMemcpyAsync(cm->W.seg_off, seg_off.data(), seg_off.size() * sizeof(int), hipMemcpyHostToDevice, st));
-            if (ll_voxel_grid_segments(cm->d_work, (int)tot, cm->n_valid, cm->leaf[w], cm->W, cm->d_out, cm->d_nout, st)) { cm->err = "voxel filter: read-back failed"; return LL_ERR_HIP; }
+            int max_seg = 0;
+            for (int v = 0; v < cm->n_valid; ++v) max_seg = std::max(max_seg, seg_off[(size_t)v + 1] - seg_off[(size_t)v]);
+            if (ll_voxel_grid_segments(cm->d_work, (int)tot, cm->n_valid, cm->leaf[w], cm->W, cm->d_out, cm->d_nout, st, max_seg)) { cm->err = "voxel filter: read-back failed"; return LL_ERR_HIP; }
             /* seg_count and n_out in one page-locked read-back: n_out first, then the counts */
             {
                 int *pin = (int *)ll_pinned_scratch((size_t)(cm->n_valid + 1) * sizeof(int));

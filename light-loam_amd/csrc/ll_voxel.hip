@@ -260,8 +260,12 @@ __global__ __launch_bounds__(1024) void k_rs_scatter8(const unsigned long long *
 #define LL_RSS_ROWS 8
 #define LL_RSS_MAX (LL_RSS_ROWS * 1024)
 extern __shared__ __attribute__((aligned(16))) unsigned char ll_rss_smem[];
-__global__ __launch_bounds__(1024) void k_rs_small(unsigned long long *keys, int *vals, int n)
+/* seg_off != null: workgroup b sorts the pairs [seg_off[b], seg_off[b + 1]) on their own -- keys whose high part is the
+ * segment number are then in global order too (the voxel filter of all valid cubes: 75 small sorts in one launch instead of the
+ * device-wide sort's five passes of five launches) */
+__global__ __launch_bounds__(1024) void k_rs_small(unsigned long long *keys, int *vals, int n, const int *seg_off)
 {
+    if (seg_off) { const int base = seg_off[blockIdx.x]; n = seg_off[blockIdx.x + 1] - base; keys += base; vals += base; }
     unsigned long long *lk = (unsigned long long *)ll_rss_smem;           /* [LL_RSS_MAX] */
     int *lv = (int *)(lk + LL_RSS_MAX);                                     /* [LL_RSS_MAX] */
     int *cnt = lv + LL_RSS_MAX;                                             /* [16][LL_RSS_ROWS * 16] */
@@ -327,6 +331,16 @@ __global__ __launch_bounds__(1024) void k_rs_small(unsigned long long *keys, int
     }
 }
 
+/* every segment [seg_off[b], seg_off[b + 1]) of (keys, vals) sorted on its own, nseg <= 65535 segments of at most LL_RSS_MAX pairs */
+void ll_sort_pairs_segments(unsigned long long *keys, int *vals, const int *seg_off_dev, int nseg, hipStream_t st)
+{
+    if (nseg <= 0) return;
+    const size_t lds = (size_t)LL_RSS_MAX * 12 + 16 * LL_RSS_ROWS * 16 * sizeof(int);
+    static size_t attr_bytes[LL_MAX_DEVICES] = {0};
+    ll_ensure_dynamic_lds(k_rs_small, lds, attr_bytes);
+    hipLaunchKernelGGL(k_rs_small, dim3(nseg), dim3(1024), lds, st, keys, vals, 0, seg_off_dev);
+}
+
 /* sorts (keys, vals) by keys, stable; the result is in (keys, vals) again.  tmp_* hold n elements, hist 16 * ceil(n/4096)
  * ints, tile_sum as for ll_device_exscan of that, or_and_host is pinned host memory for the varying-bit mask */
 int ll_sort_pairs(unsigned long long *keys, int *vals, unsigned long long *tmp_keys, int *tmp_vals, int n, int *hist, int *tile_sum,
@@ -337,7 +351,7 @@ int ll_sort_pairs(unsigned long long *keys, int *vals, unsigned long long *tmp_k
         const size_t lds = (size_t)LL_RSS_MAX * 12 + 16 * LL_RSS_ROWS * 16 * sizeof(int);
         static size_t attr_bytes[LL_MAX_DEVICES] = {0};
         ll_ensure_dynamic_lds(k_rs_small, lds, attr_bytes);
-        hipLaunchKernelGGL(k_rs_small, dim3(1), dim3(1024), lds, st, keys, vals, n);
+        hipLaunchKernelGGL(k_rs_small, dim3(1), dim3(1024), lds, st, keys, vals, n, (const int *)nullptr);
         return 0;
     }
     unsigned long long oa[2];
@@ -444,7 +458,7 @@ void ll_vox_work_carve(void *base, int cap, int max_seg, LLVoxWork *W)
  * out: the filtered clouds back to back in segment order; seg_count (W.seg_count, device): points per filtered cloud;
  * *n_out_dev (device int, may alias nothing else): total.  Everything is enqueued on st except the sort's one
  * host read-back of the varying key bits.  Returns non-zero when that read-back failed (a HIP error the caller reports). */
-int ll_voxel_grid_segments(const float4 *pts, int n, int nseg, float leaf, const LLVoxWork &W, float4 *out, int *n_out_dev, hipStream_t st)
+int ll_voxel_grid_segments(const float4 *pts, int n, int nseg, float leaf, const LLVoxWork &W, float4 *out, int *n_out_dev, hipStream_t st, int max_seg_len)
 {
     const float inv = 1.0f / leaf;                                   /* inverse_leaf_size_ = Array4f::Ones() / leaf_size_ */
     const int nb = (max(n, nseg * 6) + LL_VB - 1) / LL_VB;
@@ -453,7 +467,9 @@ int ll_voxel_grid_segments(const float4 *pts, int n, int nseg, float leaf, const
     hipLaunchKernelGGL(k_vx_bbox, dim3((n + LL_VB - 1) / LL_VB), dim3(LL_VB), 0, st, pts, W.segid, n, W.bbox);
     hipLaunchKernelGGL(k_vx_params, dim3((nseg + 63) / 64), dim3(64), 0, st, W.bbox, W.seg_off, nseg, inv, W.sp);
     hipLaunchKernelGGL(k_vx_keys, dim3((n + LL_VB - 1) / LL_VB), dim3(LL_VB), 0, st, pts, W.segid, W.seg_off, W.sp, n, inv, W.keys, W.vals);
-    const int rc = ll_sort_pairs(W.keys, W.vals, W.tmp_keys, W.tmp_vals, n, W.hist, W.tile_sum, W.or_and, st);
+    int rc = 0;
+    if (nseg > 1 && max_seg_len > 0 && max_seg_len <= LL_RSS_MAX) ll_sort_pairs_segments(W.keys, W.vals, W.seg_off, nseg, st);   /* the keys lead with the segment */
+    else rc = ll_sort_pairs(W.keys, W.vals, W.tmp_keys, W.tmp_vals, n, W.hist, W.tile_sum, W.or_and, st);
     hipLaunchKernelGGL(k_vx_heads, dim3((max(n, nseg) + LL_VB - 1) / LL_VB), dim3(LL_VB), 0, st, W.keys, n, nseg, W.flag, W.seg_count);
     ll_copy_d2d(W.rank, W.flag, (size_t)n * sizeof(int), st);
     ll_fill_words(W.rank + n, 1, 0, 0, 1, st);
