@@ -5,7 +5,11 @@ One STEP = one pass of the hot path (extract + associate + vote + normal equatio
 BASELINE.json's metric unit) over a batch of synthetic KITTI-shape 64-ring scans that is already resident in
 HBM when the timed region starts.  `value` = scans processed by all ranks per second.
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU.  Started under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment) this
+process IS a rank; started as a plain command line it only LAUNCHES the N ranks as fresh child processes -- before it imports
+torch or makes any HIP call -- relays rank 0's JSON line as its own last line and returns the children's exit code.
 
 Scans shard across GPUs with no data-path collective (scan-parallel): every rank owns
 `--batch` scans, so scaling is weak.  torch is used for the process group (RCCL), the barrier and the device
@@ -23,7 +27,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md chip table: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md chip table: HBM3E 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0        # ... and the copy rate measured on the part (same table)
 
 
 def emit(out):
@@ -38,12 +43,26 @@ def emit(out):
     print(json.dumps(out), flush=True)
 
 
-def build_workload(synth, rings, batch, distinct, seed):
+def workload_source(args, seed):
+    """(scan(k) -> (n, 4) float32, pose(k) -> (x, y, yaw)) of the named workload.
+    synthetic: host/ll_synth.c, every ring on the bin centre of scanRegistration.cpp:162.
+    hdl64:     lightloam_amd/hdl64.py, the HDL-64E true laser table in a KITTI .bin's order (BASELINE config 3 stand-in:
+               elevations anywhere inside the bins, some bins hold two lasers -> ring capacity 4608)."""
+    if args.workload == "hdl64":
+        from lightloam_amd import hdl64
+        return (lambda k: hdl64.hdl64_scan(k, order="kitti", seed=64 + (seed & 0xffff))), (lambda k: hdl64.pose(k))
+    from lightloam_amd import synth
+    cfg = synth.default_cfg(args.rings, seed=seed)
+    return (lambda k: synth.scan(cfg, k)), (lambda k: synth.pose(cfg, k))
+
+
+def build_workload(args, batch, seed):
     """batch+1 scans: slot i (and the carry target, index -1) follow a ping-pong walk over `distinct`+1 consecutive
     poses, so every (slot k-1, slot k) pair is a pair of ADJACENT poses (one step forward or backward)."""
-    cfg = synth.default_cfg(rings, seed=seed)
-    base = [synth.scan(cfg, k) for k in range(distinct + 1)]
-    poses = [synth.pose(cfg, k) for k in range(distinct + 1)]
+    distinct = args.distinct
+    scan, pose = workload_source(args, seed)
+    base = [scan(k) for k in range(distinct + 1)]
+    poses = [pose(k) for k in range(distinct + 1)]
 
     def tri(i):
         period = 2 * distinct
@@ -62,6 +81,37 @@ def build_workload(synth, rings, batch, distinct, seed):
         yaw = dyaw * 0.9
         guesses[i] = [0.0, 0.0, np.sin(yaw / 2), np.cos(yaw / 2), t[0], t[1], t[2]]
     return base, order, guesses
+
+
+def ring_model_params(args):
+    """context / oracle parameters beyond the ring count: the linear ring model for ring counts the reference's switch does not
+    know (BASELINE config 5's 128 rings), the ring capacity"""
+    extra = dict(ring_model=1, lower_bound=-25.0, up_bound=15.0, minimum_range=0.3) if args.rings not in (16, 32, 64) else {}
+    return extra
+
+
+def metric_name(args, suffix=""):
+    return "scans/sec (feature-extract+match+one GN iter), %d-ring cloud%s" % (args.rings, suffix)
+
+
+def workload_name(args):
+    if args.workload == "hdl64":
+        return ("HDL-64E true laser table, KITTI .bin order (64 lasers in two blocks, ~1900 azimuths, per-laser mounting offsets; "
+                "elevations off the bin centres of scanRegistration.cpp:162, ring capacity %d)" % args.max_ring_points)
+    return ("HDL-64E / KITTI-shape scan (64 rings x 2048 azimuths, min_range 5 m)" if args.rings == 64 else
+            "dense 128-ring scan (128 rings x 2048 azimuths over [-25, +15] deg, linear ring model)" if args.rings == 128 else
+            "%d-ring synthetic scan" % args.rings)
+
+
+def source_digest():
+    """sha256 (16 hex digits) over the library's sources: what ties profiles/pmc_traffic.json to the code it was measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    for d, exts in ((os.path.join(ROOT, "light-loam_amd", "csrc"), (".hip", ".h")), (os.path.join(ROOT, "include"), (".h",))):
+        for f in sorted(os.listdir(d)):
+            if f.endswith(exts):
+                h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(orc, rings, base, order, guesses, budget_s=15.0):
@@ -125,7 +175,8 @@ def cpu_baseline_host(args, rank_seed):
         procs = []
         for i in range(n_proc):
             cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", "--rings", str(args.rings), "--batch", str(args.batch),
-                   "--distinct", str(args.distinct), "--cpu-budget", str(budget), "--seed", str(rank_seed), "--pin", str(cpus[i % len(cpus)])]
+                   "--distinct", str(args.distinct), "--cpu-budget", str(budget), "--seed", str(rank_seed), "--pin", str(cpus[i % len(cpus)]),
+                   "--workload", args.workload]
             procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
         res = []
         for p in procs:
@@ -199,15 +250,17 @@ def bench_stream(args, rank, local_rank, world):
     half's scans are copied in (copy stream), ordered by events only.  Reports the sustained scans/s including H2D, the
     copy-only and compute-only times of the same work, and checks the poses against the all-resident run bit for bit."""
     import torch
-    from lightloam_amd import api, synth
+    from lightloam_amd import api
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    B = args.batch if not args.batch_defaulted else 2048      # default: 2048 slots (two halves of 1024)
+    B = args.batch if not args.batch_defaulted else (2048 if args.rings <= 64 else 1024)      # default: 2048 slots (two halves of 1024)
     B -= B % 2
     H = B // 2
-    base, order, guesses = build_workload(synth, args.rings, B, args.distinct, 0x5EED0000 + rank)
-    extra = dict(ring_model=1, lower_bound=-25.0, up_bound=15.0, minimum_range=0.3) if args.rings not in (16, 32, 64) else {}
+    base, order, guesses = build_workload(args, B, 0x5EED0000 + rank)
+    extra = ring_model_params(args)
+    if args.max_ring_points > 0:
+        extra["max_ring_points"] = args.max_ring_points
     ctx = api.Context(api.default_params(args.rings, batch=B + 1, max_points=max(len(s) for s in base), **extra), device=local_rank)
     # the ingest buffer: one page-locked area with a slot per scan of the step (what a driver thread would fill from the sensor)
     NPs = (max(len(s) for s in base) + 63) // 64 * 64
@@ -257,11 +310,13 @@ def bench_stream(args, rank, local_rank, world):
     bad = [i for i in range(B) if ctx.scan_info(i).status != 0 or ctx.pair_info(i).n_plane_selected <= 0]
     assert not bad, bad[:5]
     nbytes = sum(int(staging.n[i]) * 16 for i in range(B))
-    out = {"metric": "scans/sec (feature-extract+match+one GN iter), %d-ring cloud, input streamed over PCIe" % args.rings,
+    out = {"metric": metric_name(args, ", input streamed over PCIe"),
            "value": B / t_stream, "unit": "scans/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t_stream,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
            "dtype": "f32 (features, association, vote) + f64 (residuals, Jacobians, normal equations)",
-           "config": {"workload": "the hot path with every scan copied from page-locked host memory inside the timed region, double-buffered slot halves",
+           "config": {"workload": workload_name(args) + ": the hot path with every scan copied from page-locked host memory inside the timed region, "
+                                  "double-buffered slot halves (the chained half votes through the dynamic-LDS k_vote path at 128 rings)",
+                      "points_per_scan_in": int(staging.n[0]),
                       "scans_per_step": B, "half": H, "h2d_bytes_per_step": nbytes, "distinct_scans": args.distinct + 1},
            "stream": {"ms_copy_only": 1e3 * t_copy, "ms_compute_only": 1e3 * t_compute, "ms_overlapped": 1e3 * t_stream,
                       "h2d_GBps_alone": nbytes / t_copy / 1e9, "h2d_GBps_sustained": nbytes / t_stream / 1e9,
@@ -280,7 +335,7 @@ def bench_map(args, rank, local_rank, world):
     every frame; a STEP is one frame.  All collectives run on device buffers on the library's stream (parallel.DeviceCollectives)."""
     import torch
     import torch.distributed as dist
-    from lightloam_amd import api, parallel, synth
+    from lightloam_amd import api, parallel
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -289,12 +344,14 @@ def bench_map(args, rank, local_rank, world):
         import socket
         s = socket.socket(); s.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(s.getsockname()[1]); s.close()
     dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    cfg = synth.default_cfg(args.rings, seed=0x5EED0000)
+    scan_of, pose_of = workload_source(args, 0x5EED0000)
     n_frames = args.warmup + args.steps
     distinct = min(n_frames, 40)
-    scans = [synth.scan(cfg, k) for k in range(distinct)]
-    poses = [synth.pose(cfg, k) for k in range(distinct)]
-    extra = dict(ring_model=1, lower_bound=-25.0, up_bound=15.0, minimum_range=0.3) if args.rings not in (16, 32, 64) else {}
+    scans = [scan_of(k) for k in range(distinct)]
+    poses = [pose_of(k) for k in range(distinct)]
+    extra = ring_model_params(args)
+    if args.max_ring_points > 0:
+        extra["max_ring_points"] = args.max_ring_points
     ctx = api.Context(api.default_params(args.rings, batch=distinct, max_points=max(map(len, scans)), **extra), device=local_rank)
     for k, sc in enumerate(scans):
         ctx.upload_scan(k, sc)
@@ -354,6 +411,41 @@ def bench_map(args, rank, local_rank, world):
     dist.barrier(); dist.destroy_process_group()
 
 
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh child processes of this same command line, one per GPU, with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (what torch.distributed.run would set), relay rank 0's stdout --
+    its last line is the JSON line -- and return the worst exit code.  The parent never imports torch and never touches HIP:
+    replacing or re-launching a process that has initialised the GPU is what this avoids."""
+    import socket
+    import subprocess
+    n = args.gpus
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in argv if a != "--dry-launch"]
+    envs = []
+    for r in range(n):
+        envs.append({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+    if args.dry_launch:
+        emit({"dry_launch": True, "n_ranks": n, "command": cmd, "rank_env": envs, "parent_imported_torch": "torch" in sys.modules})
+        return 0
+    procs = []
+    for r in range(n):
+        env = dict(os.environ); env.update(envs[r])
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    lines = [ln for ln in (out0 or "").splitlines() if ln.strip()]
+    for ln in lines[:-1]:
+        print(ln)
+    rc = next((c for c in rcs if c != 0), 0)
+    if lines:
+        sys.stdout.flush()
+        print(lines[-1], flush=True)                           # rank 0's JSON line is this process's last line
+    if rc != 0:
+        print(f"bench.py: rank exit codes {rcs}", file=sys.stderr)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -380,11 +472,28 @@ def main():
     ap.add_argument("--seed", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--pin", type=int, default=-1, help=argparse.SUPPRESS)                # cpu-worker: the logical cpu to run on
     ap.add_argument("--max-ring-points", type=int, default=0,
-                    help="ring capacity of the context (0: 2304, enough for the synthetic 2048-column scans; real HDL-64E data needs 4608)")
+                    help="ring capacity of the context (0: 2304, enough for the synthetic 2048-column scans; --workload hdl64: 4608)")
+    ap.add_argument("--workload", choices=["synthetic", "hdl64"], default="synthetic",
+                    help="synthetic: SURVEY.md section 8d's scans (every ring on its bin centre; the headline workload).  hdl64: BASELINE config 3's "
+                         "stand-in, the HDL-64E true laser table in KITTI .bin order (off-centre elevations, ring capacity 4608)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="process-group backend of the N > 1 run (nccl = RCCL; gloo only to exercise the multi-rank path where RCCL cannot run)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="N > 1 ranks all on device 0 (a one-GPU box exercising the multi-rank path; needs --backend gloo and a small --batch)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="--gpus N > 1 from a plain command line: print the N child command lines + rank environments as JSON and exit "
+                         "(nothing is started, torch is never imported)")
     args = ap.parse_args()
     args.batch_defaulted = args.batch <= 0
+    if args.workload == "hdl64":
+        if args.rings != 64:
+            raise SystemExit("--workload hdl64 is a 64-ring sensor")
+        if args.max_ring_points <= 0:
+            args.max_ring_points = 4608
     if args.batch_defaulted:
         args.batch = 16384 if args.rings == 64 else 4096 if args.rings > 64 else 32768
+        if args.max_ring_points > 2304:
+            args.batch = 8192                                  # laserCloud's ring stride doubles: 8192 slots of capacity 4608 are ~150 GB
     if args.cpu_worker:
         if args.pin >= 0 and hasattr(os, "sched_setaffinity"):
             try:
@@ -392,29 +501,31 @@ def main():
             except OSError:
                 pass
         import lightloam_amd  # noqa: F401
-        from lightloam_amd import synth
         from oracle import orc
-        base, order, guesses = build_workload(synth, args.rings, args.batch, args.distinct, args.seed)
+        base, order, guesses = build_workload(args, args.batch, args.seed)
         v, units, el = cpu_baseline(orc, args.rings, base, order, guesses, args.cpu_budget)
         print(json.dumps({"value": v, "units": units, "elapsed": el}), flush=True)
         return
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # a plain `python bench.py --gpus N`: this process only launches the ranks (it has made no HIP call and never will)
+        sys.exit(launch_ranks(args, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-        args.gpus = world
+        args.gpus = world                                      # the launcher's world size is the truth
+    if args.share_gpu:
+        local_rank = 0
 
     import lightloam_amd  # noqa: F401
-    from lightloam_amd import synth
     if args.mode == "map":
         return bench_map(args, rank, local_rank, world)
     if args.stream_input:
         return bench_stream(args, rank, local_rank, world)
     # every rank owns its own scans (different seed => different noise), same shape
-    base, order, guesses = build_workload(synth, args.rings, args.batch, args.distinct, 0x5EED0000 + rank)
+    base, order, guesses = build_workload(args, args.batch, 0x5EED0000 + rank)
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_host(args, 0x5EED0000 + rank)                              # before any HIP call in this process
@@ -427,11 +538,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend="gloo")
+    red_dev = "cuda" if args.backend == "nccl" else "cpu"      # where the timing reduction lives (gloo reduces host tensors)
 
     from lightloam_amd import api
     max_pts = max(len(s) for s in base)
-    extra = dict(ring_model=1, lower_bound=-25.0, up_bound=15.0, minimum_range=0.3) if args.rings not in (16, 32, 64) else {}
+    extra = ring_model_params(args)
     if args.max_ring_points > 0:
         extra["max_ring_points"] = args.max_ring_points
     prm = api.default_params(args.rings, batch=args.batch + 1, max_points=max_pts, chunk=args.chunk, **extra)
@@ -469,7 +584,7 @@ def main():
     prof = ctx.profile_read(reset=True)
     ctx.profile_enable(False)
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
@@ -521,33 +636,38 @@ def main():
         bytes_per_launch = kernel_bytes[dom] / launches_per_step
         avg_ms = dom_ms / max(1, dom_launches)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # HBM traffic of that kernel from the separate rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py)
-        traffic = None
+        # HBM traffic of that kernel from the separate rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py, stamped by
+        # tools/profile_round.sh): only when the file was measured on THIS code (source digest), ring count, workload and batch
+        traffic = None; traffic_note = "profiles/pmc_traffic.json absent"
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
                 T = json.load(open(tpath))
-                if dom in T.get("kernels", {}) and T.get("rings") == args.rings:
+                want = {"source_digest": source_digest(), "rings": args.rings, "batch": args.batch, "workload": args.workload}
+                diff = {k: (T.get(k), v) for k, v in want.items() if T.get(k) != v}
+                if diff:
+                    traffic_note = "profiles/pmc_traffic.json was measured on another " + ", ".join(sorted(diff)) + ": not used"
+                elif dom in T.get("kernels", {}):
                     traffic = T["kernels"][dom]["hbm_bytes_per_scan"] * args.batch / launches_per_step
-            except Exception:
-                traffic = None
+                    traffic_note = "rocprofv3 FETCH_SIZE + WRITE_SIZE passes of this command at this source digest (tools/profile_round.sh)"
+            except Exception as e:
+                traffic = None; traffic_note = "profiles/pmc_traffic.json unreadable: " + repr(e)[:80]
         out = {
-            "metric": "scans/sec (feature-extract+match+one GN iter), 64-ring cloud",
+            "metric": metric_name(args),
             "value": value, "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 (features, association, vote) + f64 (residuals, Jacobians, normal equations)",
             "data": "synthetic",
-            "config": {"workload": ("HDL-64E / KITTI-shape scan (64 rings x 2048 azimuths, min_range 5 m)" if args.rings == 64 else
-                                    "dense 128-ring scan (128 rings x 2048 azimuths over [-25, +15] deg, linear ring model)" if args.rings == 128 else
-                                    "%d-ring synthetic scan" % args.rings) + ", feature extraction "
-                                   "+ graph-match + one GN iteration per scan pair, inputs resident in HBM",
+            "config": {"workload": workload_name(args) + ", feature extraction + graph-match + one GN iteration per scan pair, inputs resident in HBM",
+                       "workload_id": args.workload, "max_ring_points": args.max_ring_points or 2304,
                        "scans_per_gpu_per_step": args.batch, "chunk": args.chunk or args.batch,
                        "distinct_scans": args.distinct + 1, "distinct_scan_pairs": len(pose_of_pair),
                        "self_check": "every slot: status 0, correspondences > 0, finite pose; equal scan pairs -> bit-identical poses",
                        "points_per_scan_in": int(info.n_in), "points_per_scan_kept": int(info.n),
                        "parallelism": f"scan-parallel x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
+                         "frac_of_measured_copy": achieved / HBM_COPY_GBS, "measured_copy_GBps": HBM_COPY_GBS,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "whole_path_algorithmic_GBps": (ab["ext"] + ab["assoc"] + ab["vote"] + ab["rj"]) * args.steps / elapsed / 1e9,
                          "kernel_ms_per_step": {k: v[0] / v[1] * launches_per_step for k, v in prof.items() if v[1]},
@@ -558,7 +678,7 @@ def main():
             out["cpu_baseline"] = cpu
     # RCCL sanity on every run (also N = 1): the 28-double all-reduce of the row-parallel mode (21 + 6 + 1 unique values of
     # JtJ, Jtr, cost) on a device buffer, checked against the closed form and timed.  Not part of `value`.
-    rccl = rccl_check(torch, dist, world, rank, local_rank)
+    rccl = rccl_check(torch, dist, world, rank, local_rank) if args.backend == "nccl" else {"rccl_world": None, "backend": "gloo (RCCL not exercised)"}
     ctx.close()
     import torch.distributed as tdist
     if tdist.is_initialized():

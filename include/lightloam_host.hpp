@@ -50,11 +50,14 @@ struct Error : std::runtime_error {
 class Context {
 public:
     /* distortion: the DISTORTION macro of laserOdometry.cpp:23 (0 in the reference's build; 1 = its per-point interpolation path) */
+    /* max_ring_points: capacity of one scan line (0: the library default, 2304 = a 2048-column sensor; real HDL-64E / KITTI data
+     * under the linear 64-ring model of scanRegistration.cpp:162 needs 4608 -- some bins hold two lasers) */
     explicit Context(int scan_line, int batch = 2, int device = 0, double minimum_range = -1.0,
-                     float lowerBound = -24.9f, float upBound = 2.0f, int distortion = 0) {
+                     float lowerBound = -24.9f, float upBound = 2.0f, int distortion = 0, int max_ring_points = 0) {
         ll_default_params(&p_, scan_line);
         p_.batch = batch;
         p_.distortion = distortion;
+        if (max_ring_points > 0) p_.max_ring_points = max_ring_points;
         if (minimum_range >= 0) p_.minimum_range = (float)minimum_range;       /* nh.param("minimum_range") :438 */
         p_.lower_bound = lowerBound; p_.up_bound = upBound;                     /* nh.param("lowerBound" / "upBound") :439-440 */
         const int rc = ll_create(device, &p_, &ctx_);

@@ -48,7 +48,8 @@ def build_hip(force=False, extra_flags=()):
     out = lib_path()
     hdrs = _all_files(_CSRC, (".h", ".hpp")) + [os.path.join(_ROOT, "include", "lightloam_hip.h")]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(_CSRC, "_obj" + ("_" + str(abs(hash(tuple(extra_flags))) % 10**8) if extra_flags else ""))
+    import hashlib                  # a stable name per flag set (hash() is salted per process: objects would never be reused)
+    objdir = os.path.join(_CSRC, "_obj" + ("_" + hashlib.sha256(" ".join(extra_flags).encode()).hexdigest()[:8] if extra_flags else ""))
     os.makedirs(objdir, exist_ok=True)
     cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags) + ["-I", os.path.join(_ROOT, "include"), "-I", _CSRC]
 

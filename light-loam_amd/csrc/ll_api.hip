@@ -71,7 +71,6 @@ extern "C" void ll_destroy(ll_ctx *ctx)
     if (ctx->ev_ok) for (auto &e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
     for (auto &e : ctx->ev_x) if (e) (void)hipEventDestroy(e);
-    if (ctx->h_n_in_pinned) (void)hipHostFree(ctx->h_n_in_pinned);
     for (auto &e : ctx->prof.ev) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -251,8 +250,23 @@ static int ensure_copy_stream(ll_ctx *ctx)
 {
     if (ctx->copy_stream) return LL_OK;
     LL_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-    LL_HIP(hipHostMalloc((void **)&ctx->h_n_in_pinned, (size_t)ctx->p.batch * sizeof(int), hipHostMallocDefault));
     return LL_OK;
+}
+
+/* The point counts of asynchronously uploaded scans travel BY VALUE, as kernel arguments of a launch on the copy stream: an
+ * asynchronous copy reads its host source when it RUNS, and a caller that is several generations ahead (the double buffer never
+ * blocks the host) would by then have overwritten a per-slot staging cell with a later generation's count. */
+#define LL_COUNTS_PER_LAUNCH 512
+struct LLCounts { int v[LL_COUNTS_PER_LAUNCH]; };
+__global__ void k_set_counts(int *dst, LLCounts c, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) dst[i] = c.v[i]; }
+static void enqueue_counts(ll_ctx *ctx, int first, const int *n, int count)
+{
+    for (int c0 = 0; c0 < count; c0 += LL_COUNTS_PER_LAUNCH) {
+        const int m = count - c0 < LL_COUNTS_PER_LAUNCH ? count - c0 : LL_COUNTS_PER_LAUNCH;
+        LLCounts c;
+        std::memcpy(c.v, n + c0, (size_t)m * sizeof(int));
+        hipLaunchKernelGGL(k_set_counts, dim3((m + 255) / 256), dim3(256), 0, ctx->copy_stream, const_cast<int *>(ctx->V.n_in) + first + c0, c, m);
+    }
 }
 
 extern "C" void *ll_host_alloc(size_t bytes)
@@ -271,8 +285,9 @@ extern "C" int ll_upload_scan_async(ll_ctx *ctx, int slot, const float *xyz4, in
     rc = ensure_copy_stream(ctx); if (rc) return rc;
     LLView &V = ctx->V;
     if (n > 0) LL_HIP(hipMemcpyAsync(const_cast<float4 *>(V.raw) + (size_t)slot * V.NP, xyz4, (size_t)n * 16, hipMemcpyHostToDevice, ctx->copy_stream));
-    ctx->n_in_host[slot] = n; ctx->h_n_in_pinned[slot] = n;
-    LL_HIP(hipMemcpyAsync(const_cast<int *>(V.n_in) + slot, ctx->h_n_in_pinned + slot, sizeof(int), hipMemcpyHostToDevice, ctx->copy_stream));
+    ctx->n_in_host[slot] = n;
+    enqueue_counts(ctx, slot, &n, 1);
+    LL_HIP(hipGetLastError());
     return LL_OK;
 }
 
@@ -296,13 +311,14 @@ extern "C" int ll_upload_scans_async_strided(ll_ctx *ctx, int first, int count, 
     for (int i = 0; i < count; ++i) {
         if (n[i] < 0 || n[i] > ctx->p.max_points || (size_t)n[i] * 16 > stride_bytes) { ctx->err = "scan larger than max_points / the stride"; return LL_ERR_CAPACITY; }
         nmax = n[i] > nmax ? n[i] : nmax;
-        ctx->n_in_host[first + i] = n[i]; ctx->h_n_in_pinned[first + i] = n[i];
+        ctx->n_in_host[first + i] = n[i];
     }
     LLView &V = ctx->V;
     if (nmax > 0)
         LL_HIP(hipMemcpy2DAsync(const_cast<float4 *>(V.raw) + (size_t)first * V.NP, (size_t)V.NP * 16, base, stride_bytes, (size_t)nmax * 16, (size_t)count,
                                 hipMemcpyHostToDevice, ctx->copy_stream));
-    LL_HIP(hipMemcpyAsync(const_cast<int *>(V.n_in) + first, ctx->h_n_in_pinned + first, (size_t)count * sizeof(int), hipMemcpyHostToDevice, ctx->copy_stream));
+    enqueue_counts(ctx, first, n, count);
+    LL_HIP(hipGetLastError());
     return LL_OK;
 }
 
@@ -927,6 +943,18 @@ static void map_lm_solve(ll_map *m, const LLLmOpt &o)
 {
     ll_map_launch_lm_solve(m->M, o, m->ctx->stream);          /* evaluate, begin, n x (propose, evaluate, accept): one launch */
 }
+/* A solve whose workgroups timed out on one another returns a NaN pose and leaves the round word at "everybody out"; stragglers may
+ * also have bumped the arrival counter after workgroup 0 reset it.  Left alone, the NEXT solve's workgroups would pass their
+ * waits at once and sum stale partials -- a wrong pose without an error.  Called where a solve's pose has just been read back
+ * (the stream is drained: no straggler is left): on NaN both words are zeroed again. */
+static void map_lm_repair(ll_map *m, const double *pose7)
+{
+    bool bad = false;
+    for (int k = 0; k < 7; ++k) bad = bad || std::isnan(pose7[k]);
+    if (!bad) return;
+    ll_fill_words((int *)m->M.lm_go, 1, 0, 0, 1, m->ctx->stream);
+    ll_fill_words((int *)m->M.neq_ticket, 1, 0, 0, 1, m->ctx->stream);
+}
 
 extern "C" int ll_map_set_row_shard(ll_map *m, int rank, int world)
 {
@@ -947,6 +975,7 @@ extern "C" int ll_map_solve(ll_map *m, double *pose_w7, const ll_lm_options *opt
     map_lm_solve(m, o);
     LLM_HIP(hipGetLastError());
     if (ll_read_back(pose_w7, m->M.pose, 7 * sizeof(double), m->ctx->stream)) { m->err = "read-back failed"; return LL_ERR_HIP; }
+    map_lm_repair(m, pose_w7);
     return LL_OK;
 }
 
@@ -969,6 +998,7 @@ extern "C" int ll_map_optimize(ll_map *m, double *pose_w7, int n_outer, const ll
     }
     LLM_HIP(hipGetLastError());
     if (ll_read_back(pose_w7, m->M.pose, 7 * sizeof(double), st)) { m->err = "read-back failed"; return LL_ERR_HIP; }
+    map_lm_repair(m, pose_w7);
     if (ran) *ran = 1;
     return LL_OK;
 }
@@ -1009,6 +1039,7 @@ extern "C" int ll_map_get_pose(ll_map *m, double *pose_w7)
     if (!m || !pose_w7) return LL_ERR_ARG;
     LLM_HIP(hipSetDevice(m->ctx->device));
     if (ll_read_back(pose_w7, m->M.pose, 7 * sizeof(double), m->ctx->stream)) { m->err = "read-back failed"; return LL_ERR_HIP; }
+    map_lm_repair(m, pose_w7);                                   /* this is where a caller of ll_map_solve_dev sees the result */
     return LL_OK;
 }
 
@@ -1114,6 +1145,9 @@ extern "C" int ll_map_solve_dev(ll_map *m, const ll_lm_options *opt)
     if (o.max_num_iterations < 0 || o.max_num_iterations > 64) { m->err = "max_num_iterations out of range"; return LL_ERR_ARG; }
     if (m->M.row_world > 1) { m->err = "the map sums a row shard: step with ll_map_evaluate_dev + all-reduce + ll_map_lm_*_dev"; return LL_ERR_STATE; }
     LLM_HIP(hipSetDevice(m->ctx->device));
+    /* no read-back here to notice a timed-out predecessor by: the hand-over words are zeroed on the stream before every solve */
+    ll_fill_words((int *)m->M.lm_go, 1, 0, 0, 1, m->ctx->stream);
+    ll_fill_words((int *)m->M.neq_ticket, 1, 0, 0, 1, m->ctx->stream);
     map_lm_solve(m, o);                                          /* from the pose on the device, result left there (ll_map_get_pose) */
     LLM_HIP(hipGetLastError());
     return LL_OK;
@@ -1183,6 +1217,9 @@ extern "C" int ll_download_cloud(ll_ctx *ctx, int slot, ll_point *cloud, int cap
     int rc = check_range(ctx, slot, 1); if (rc) return rc;
     ScanHdr h; rc = fetch_hdr(ctx, slot, &h); if (rc) return rc;
     LLView &V = ctx->V;
+    /* a slot the registration refused (a ring beyond max_ring_points: LL_ERR_CAPACITY) holds a truncated laserCloud whose gaps
+     * would come back as stale points: hand the status back instead of LL_OK */
+    if (h.status != 0 && h.status != LL_ERR_EMPTY) { ctx->err = "the slot's scan was refused (status " + std::to_string(h.status) + "): nothing to download"; return h.status; }
     if (cloud) {
         if (cap < h.n) { ctx->err = "cloud capacity too small"; return LL_ERR_CAPACITY; }
         ll_launch_cloud_flatten(V, slot, ctx->cloud_flat, ctx->stream);          /* the rings sit at a fixed stride on the device */
@@ -1203,6 +1240,7 @@ extern "C" int ll_download_labels(ll_ctx *ctx, int slot, int8_t *label, float *c
     int rc = check_range(ctx, slot, 1); if (rc) return rc;
     ScanHdr h; rc = fetch_hdr(ctx, slot, &h); if (rc) return rc;
     LLView &V = ctx->V;
+    if (h.status != 0 && h.status != LL_ERR_EMPTY) { ctx->err = "the slot's scan was refused (status " + std::to_string(h.status) + "): nothing to download"; return h.status; }
     if (cap < h.n) { ctx->err = "label capacity too small"; return LL_ERR_CAPACITY; }
     if (curvature && !V.write_curv) { ctx->err = "curvature requested but write_curvature = 0"; return LL_ERR_STATE; }
     rc = dl(ctx, label, V.label + (size_t)slot * V.NP, (size_t)h.n); if (rc) return rc;

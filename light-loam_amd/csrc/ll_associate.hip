@@ -425,7 +425,9 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
              * One 64-bit key per candidate: the distance's bits (non-negative floats order like their bits) above the packed
              * word index << 8 | ring, so "closer, or as close with the lower index" is one unsigned minimum, and the winner's
              * ring (closestPointScanID, :500 / :664) comes with it. */
-            const unsigned long long knone = ((unsigned long long)__float_as_uint(dmax) << 32) | 0xffffffffull;
+            /* "none yet" = (dmax, 0): only a candidate with d < dmax undercuts it -- one AT the limit has the same upper word and a
+             * lower word >= 0, so it does not (:497 / :659 accept d < DISTANCE_SQ_THRESHOLD only) */
+            const unsigned long long knone = (unsigned long long)__float_as_uint(dmax) << 32;
             unsigned long long kb = knone;
             /* The query's own cell and the four entries of Chebyshev ring 1 (row below, row above, left and right cell) serve
              * BOTH searches: lane e of the group fetches entry e's bounds once and keeps them in its registers, the scans get
@@ -466,7 +468,7 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
                             diff = q.y - p.y; d += diff * diff;
                             diff = q.z - p.z; d += diff * diff;
                             const unsigned long long k = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w);
-                            kb = (k < kb) ? k : kb;                           /* d < dmax is implied: kb starts at (dmax, ~0) */
+                            kb = (k < kb) ? k : kb;                           /* d < dmax is implied: kb starts at (dmax, 0) */
                         }
                     }
                 };
@@ -486,7 +488,7 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
                 const int jhi = (hi + 1 > LL_TAB) ? M : tab[max(hi + 1, 0)];                   /* first j with ring > hi */
                 const int jlo = (lo - 1 < 0) ? -1 : tab[LL_TAB + 1 + min(lo - 1, LL_TAB)];     /* last j with ring < lo */
                 const int c1 = c + 1, mc = M + c - 1;
-                const unsigned long long wnone = ((unsigned long long)__float_as_uint(dmax) << 32) | 0x7fffffffull;
+                const unsigned long long wnone = (unsigned long long)__float_as_uint(dmax) << 32;           /* (dmax, 0): strict d < dmax as above (:512, :520, :677 ...) */
                 unsigned long long k2 = wnone, k3 = wnone;
                 auto w_scan = [&](int st, int en) {
                         for (int k0 = st + sub; k0 < en; k0 += 8 * LL_SCAN_UN) {
@@ -631,7 +633,11 @@ void ll_launch_associate(const LLView &V, int first, int count, hipStream_t st, 
 {
     /* a node-style call (one scan pair) would put 9 workgroups of 8 sequential passes on a 256-CU chip: 217 us of dependent
      * loads; 32 queries per workgroup (one pass) spread the same work over 72 workgroups */
+#ifdef LL_ASSOC_QPB
+    const int qpb = (count <= 16) ? 32 : LL_ASSOC_QPB;         /* A/B builds (tools/make_ab_variant.sh) */
+#else
     const int qpb = (count <= 16) ? 32 : LL_BLOCK;
+#endif
     const int qbc = (V.cap_sharp + qpb - 1) / qpb, qbp = (V.cap_flat + qpb - 1) / qpb;
     ll_prof_mark(prof, LL_K_ASSOCIATE, st);
     hipLaunchKernelGGL(k_associate, dim3(8 * (qbc + qbp) * ((count + 7) / 8)), dim3(LL_BLOCK), 0, st, V, first, count, qbc, qbp, qpb);

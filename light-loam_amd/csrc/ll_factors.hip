@@ -188,9 +188,11 @@ __global__ void k_lm_accept(LLView V, int first, int count, LLLmOpt o)
 
 /* The whole solve of a slot in ONE launch: evaluate, begin, max_num_iterations x (propose, evaluate, accept) -- one workgroup per
  * slot, the steps of the single-thread trust-region logic on thread 0 between the workgroup-wide evaluations, the pose and the
- * normal equations handed over in LDS.  The same arithmetic in the same order as the launch-per-step sequence above (kept for
- * the row-parallel mode, where an all-reduce sits between evaluate and accept): the results are bit-identical, the node-style
- * odometry frame drops from 48 dependent launches to 9.  The state and the last normal equations are left in V.lm / V.neq. */
+ * normal equations handed over in LDS.  The same trust-region logic as the launch-per-step sequence above (kept for the
+ * row-parallel mode, where an all-reduce sits between evaluate and accept), but NOT bit-identical to it: the evaluation here
+ * sums the rows over 512 threads (ll_neq_eval<512>, stride-512 partition, eight waves), k_normal_equations over 256, so the f64
+ * sums differ in their last bits and the two paths agree to rounding only (tests compare them within tolerance).  The
+ * node-style odometry frame drops from 48 dependent launches to 9.  The state and the last normal equations are left in V.lm / V.neq. */
 #define LL_LM_THREADS 512     /* the solve is a chain of 1 + max_num_iterations evaluations on ONE workgroup: twice the threads, half the chain */
 template <bool DIST>
 __global__ __launch_bounds__(LL_LM_THREADS) void k_lm_solve(LLView V, int first, int count, LLLmOpt o)

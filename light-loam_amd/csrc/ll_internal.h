@@ -41,10 +41,9 @@ struct ll_ctx {
     int fb_n[3] = {0, 0, 0};
     double *d_fb_s = nullptr; size_t fb_s_cap = 0; bool fb_has_s = false;   /* per-block s of the edge / plane blocks (ll_factor_blocks_set_s) */
     /* streaming input (ll_upload_scan_async): a second stream for host -> device copies, ordered against the compute stream by
-     * ll_stream_fence; the per-slot point counts live in page-locked memory so that their copies are asynchronous too */
+     * ll_stream_record / ll_stream_wait; the point counts go down by value (k_set_counts), not from a staging cell */
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_x[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   /* ll_stream_record / ll_stream_wait */
-    int *h_n_in_pinned = nullptr;
 };
 
 

@@ -97,3 +97,44 @@ def test_exact_distance_ties_pick_lowest_index(pair, orc):
     c = np.repeat(pair["e0"]["less_sharp"], 2, axis=0)[:7680]
     s = np.repeat(pair["e0"]["less_flat"][:20000], 2, axis=0)
     run_case(pair, orc, c, s, [0, 0, 0, 1, 0.9, 0, 0])
+
+
+@pytest.mark.parametrize("monotone", [True, False], ids=["table-bounded search", "sequential-walk fallback"])
+def test_candidates_at_exactly_the_distance_limit_are_rejected(api, orc, monotone):
+    """laserOdometry.cpp:497/:502 (corners) and :659/:665 (planes) accept d < DISTANCE_SQ_THRESHOLD only: a target at exactly
+    5 m (3-4-0, d^2 = 25.0f) is no neighbour, and a second / third point at exactly 5 m is no partner.  Queries and targets are
+    crafted (ll_upload_features / ll_set_target) at the identity pose, so the distances are exact in f32; both the packed-key
+    grid search and the sequential fallback (ring ids made non-monotone) must agree with the oracle."""
+    F = lambda rows: np.array(rows, np.float32).reshape(-1, 4)
+    # corner queries (x, y, z, ring + relTime)
+    sharp = F([[0, 0, 0, 10.0], [30, 0, 0, 10.0], [-30, 0, 0, 10.0], [0, 30, 0, 10.0]])
+    corner = F([
+        [3, 4, 0, 10.0],                         # Q0: the only candidate sits at exactly 25 -> no nearest neighbour at all
+        [33, 3.9, 0, 10.0], [30, 5, 0, 11.0],    # Q1: neighbour inside, the only other-ring point at exactly 25 -> no pair
+        [-27, 3.9, 0, 10.0], [-30, 4.5, 0, 11.0],   # Q2: both inside -> a pair
+        [3, 34, 0, 10.0], [0, 30, 5, 12.0], [0, 30, 4.99, 12.5],   # Q3: neighbour just inside (ring 12), the only other-ring point at exactly 25 -> no pair
+    ])
+    flat = F([[0, -30, 0, 20.0], [40, 40, 0, 20.0], [-40, -40, 0, 20.0]])
+    surf = F([
+        [0, -30, 1, 20.0], [3, -26, 0, 20.2], [0, -25, 0, 21.0],          # P0: nn inside, b at exactly 25 (same ring), c at exactly 25
+        [40, 41, 0, 20.0], [40, 43, 0, 20.5], [44, 43, 0, 20.7], [40, 40, 3, 21.0], [43, 44, 0, 21.5],   # P1: b inside / at 25, c inside / at 25
+        [-40, -45, 0, 20.0],                                                # P2: nn at exactly 25 -> nothing
+    ])
+    if not monotone:        # ring ids no longer sorted: the ring tables are invalid, k_associate takes the sequential walk
+        corner = np.concatenate([corner, F([[90, 90, 0, 3.0]])]); surf = np.concatenate([surf, F([[90, 90, 0, 3.0]])])
+    ctx = api.Context(api.default_params(64, batch=1, max_points=4096))
+    ctx.upload_features(0, sharp, corner[:1], flat, surf[:1])       # the slot's own less-sharp / less-flat clouds are not used here
+    ctx.set_target(corner, surf)
+    pose = np.array([0, 0, 0, 1.0, 0, 0, 0])
+    ctx.associate(0, 1, pose)
+    ctx.vote(0, 1, False)
+    es, ea, eb = ctx.edge_corr(0)
+    ps, pa, pb, pc = ctx.plane_corr(0)
+    ctx.close()
+    q, t = pose[:4], pose[4:]
+    oes, oea, oeb = orc.associate_corner(q, t, sharp, corner)
+    ops, opa, opb, opc = orc.associate_plane(q, t, flat, surf)
+    assert oes.tolist() == [2] and oea.tolist() == [4] and oeb.tolist() == [3]               # what strict '<' gives (hand-checked)
+    assert ops.tolist() == [1] and opa.tolist() == [3] and opb.tolist() == [4] and opc.tolist() == [6]
+    for got, want, nm in ((es, oes, "e_src"), (ea, oea, "e_a"), (eb, oeb, "e_b"), (ps, ops, "p_src"), (pa, opa, "p_a"), (pb, opb, "p_b"), (pc, opc, "p_c")):
+        assert got.tolist() == want.tolist(), nm

@@ -532,3 +532,72 @@ def test_streamed_halves_equal_the_resident_batch(api, synth):
     for p in pinned + [junk]:
         p.close()
     staging.close(); ctx.close()
+
+
+def test_async_uploads_of_different_sizes_with_the_host_running_ahead(api, synth):
+    """The double buffer never blocks the host, so it can be several generations ahead of the copy stream.  One slot takes four
+    generations of scans of DIFFERENT sizes while the copy stream is still stalled behind earlier compute work: every
+    generation must be organised with ITS OWN point count (the counts travel by value with the launches, not through a
+    per-slot staging cell the host has meanwhile overwritten).  Each generation's features become the target of its own
+    consumer slot; the consumers' normal equations must equal those of the same sequence run synchronously, bit for bit."""
+    cfg = synth.default_cfg(16)
+    G, STALL = 4, 64
+    full = [synth.scan(cfg, k) for k in range(G + 1)]
+    gens = [full[g][: len(full[g]) - 1500 * g] for g in range(G)]          # 4 sizes; truncation keeps the scans valid (ring-major order)
+    B = 1 + G + STALL
+    guess = np.array([0, 0, 0, 1.0, 0.9, 0.0, 0.0])
+
+    def setup():
+        ctx = api.Context(api.default_params(16, batch=B, max_points=max(map(len, full))))
+        for g in range(G):
+            ctx.upload_scan(1 + g, full[G])
+        for i in range(STALL):
+            ctx.upload_scan(1 + G + i, full[i % (G + 1)])
+        ctx.extract(1, G)
+        ctx.set_pose_guess(1, G, guess)
+        ctx.synchronize()
+        return ctx
+
+    def consume(ctx, g):                                 # enqueue only: nothing here waits for the device
+        ctx.extract(0, 1)
+        ctx.set_target_from_slot(0)
+        ctx.associate(1 + g, 1, None)
+        ctx.vote(1 + g, 1, True)
+        ctx.normal_equations(1 + g, 1, None)
+
+    ref = setup()
+    want = []
+    for g in range(G):
+        ref.upload_scan(0, gens[g])
+        consume(ref, g); ref.synchronize()
+        want.append((ref.scan_info(0).n, ref.normal_equations_result(1 + g), ref.pair_info(1 + g).n_plane_selected))
+    ref.close()
+    assert len({w[0] for w in want}) == G               # the generations really differ in size
+
+    ctx = setup()
+    pinned = [api.PinnedScan(s) for s in gens]
+    COMPUTE, COPY = 0, 1
+    for _ in range(30):                                  # a few milliseconds of compute ...
+        ctx.extract(1 + G, STALL)
+    ctx.stream_record(COMPUTE, 7); ctx.stream_wait(COPY, 7)     # ... that the copy stream must wait for: the host runs ahead
+    for g in range(G):
+        ctx.stream_wait(COPY, 2)                         # slot 0 was last read by the compute work marked 2
+        ctx.upload_scan_async(0, pinned[g])
+        ctx.stream_record(COPY, 0); ctx.stream_wait(COMPUTE, 0)
+        consume(ctx, g)
+        ctx.stream_record(COMPUTE, 2)
+    ctx.synchronize_copy(); ctx.synchronize()
+    for g in range(G):
+        n, (H, gv, cost), nsel = want[g]
+        Hd, gd, cd = ctx.normal_equations_result(1 + g)
+        assert ctx.pair_info(1 + g).n_plane_selected == nsel > 10, g
+        assert (Hd == H).all() and (gd == gv).all() and cd == cost, g
+    assert ctx.scan_info(0).n == want[-1][0]
+    # the strided run of several slots goes the same way (one launch carries up to 512 counts)
+    staging = api.PinnedStaging(G, max(map(len, gens)) + 3)
+    for g in range(G):
+        staging.put(g, gens[g])
+    ctx.upload_staging_async(1, staging)
+    ctx.synchronize_copy(); ctx.extract(1, G); ctx.synchronize()
+    assert [ctx.scan_info(1 + g).n for g in range(G)] == [w[0] for w in want]
+    ctx.close()

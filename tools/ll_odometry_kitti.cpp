@@ -2,7 +2,9 @@
 // the way the reference's kittiHelper -> scanRegistration -> laserOdometry chain would process them, writing the
 // reference's trajectory-file format (laserMapping.cpp:2284-2325: 12 values of H_init^-1 * H per frame).
 //
-//   ll_odometry_kitti <scan_dir> <result_path> [scan_line = 64] [first-frame forward guess in metres = 0] [mapping = 0]
+//   ll_odometry_kitti <scan_dir> <result_path> [scan_line = 64] [first-frame forward guess in metres = 0] [mapping = 0] [max_ring_points = 0]
+//
+// max_ring_points: capacity of one scan line (0 = library default 2304; KITTI / HDL-64E data needs 4608, see lightloam_host.hpp).
 //
 // mapping = 1 adds the third node: every frame's odometry pose goes through laserMapping's scan-to-map refinement
 // (lightloam::LaserMapping, laserMapping.cpp:1581-2165) and the written trajectory is q_w_curr / t_w_curr, which is what
@@ -26,11 +28,12 @@
 
 int main(int argc, char **argv)
 {
-    if (argc < 3) { std::cerr << "usage: ll_odometry_kitti <scan_dir> <result_path> [scan_line] [first guess tx] [mapping]\n"; return 2; }
+    if (argc < 3) { std::cerr << "usage: ll_odometry_kitti <scan_dir> <result_path> [scan_line] [first guess tx] [mapping] [max_ring_points]\n"; return 2; }
     const std::string dir = argv[1], result = argv[2];
     const int scan_line = argc > 3 ? std::atoi(argv[3]) : 64;
     const double tx0 = argc > 4 ? std::atof(argv[4]) : 0.0;
     const bool mapping = argc > 5 && std::atoi(argv[5]) != 0;
+    const int max_ring_points = argc > 6 ? std::atoi(argv[6]) : 0;
     std::vector<std::string> files;
     if (DIR *d = opendir(dir.c_str())) {
         while (dirent *e = readdir(d)) {
@@ -44,12 +47,22 @@ int main(int argc, char **argv)
     try {
         using namespace lightloam;
         const int n = (int)files.size();
-        Context ctx(scan_line, n);
+        Context ctx(scan_line, n, 0, -1.0, -24.9f, 2.0f, 0, max_ring_points);
         for (int k = 0; k < n; ++k) {
             const std::vector<float> pts = read_lidar_data(files[k]);
             ctx.check(ll_upload_scan(ctx.get(), k, pts.data(), 4, (int)(pts.size() / 4)));
         }
         ctx.check(ll_extract_batch(ctx.get(), 0, n));                       // scanRegistration for every scan
+        for (int k = 0; k < n; ++k) {                                        // a scan the registration refused must not become a silent hole in the trajectory
+            ll_scan_info info;
+            ctx.check(ll_get_scan_info(ctx.get(), k, &info));
+            if (info.status == LL_ERR_CAPACITY) {
+                std::cerr << files[k] << ": a scan line holds " << info.max_ring << " points, beyond the ring capacity " << ctx.params().max_ring_points
+                          << " -- pass a larger max_ring_points (KITTI / HDL-64E: 4608)\n";
+                return 1;
+            }
+            if (info.status != LL_OK && info.status != LL_ERR_EMPTY) { std::cerr << files[k] << ": scan registration failed with status " << info.status << "\n"; return 1; }
+        }
         ctx.check(ll_set_target_from_slot(ctx.get(), 0));                   // frame 0 only initialises (laserOdometry.cpp:427-431)
         const double pose0[7] = {0, 0, 0, 1, tx0, 0, 0};
         const std::vector<double> rel = odometry_frames(ctx, 1, n - 1, pose0, 1);
@@ -105,7 +118,7 @@ int main(int argc, char **argv)
             for (int r = 0; r < tiles; ++r)
                 th.emplace_back([&, r] {
                     try {
-                        Context c(scan_line, 1);
+                        Context c(scan_line, 1, 0, -1.0, -24.9f, 2.0f, 0, max_ring_points);
                         LaserMapping shard(c, 0.4f, 0.8f, scan_line * 120 + 64, 400000, 1 << 22);
                         shard.set_shard(r, tiles);
                         for (int k = 0; k < n; ++k) {

@@ -44,7 +44,13 @@ def main():
     ap.add_argument("fetch_dir"); ap.add_argument("write_dir")
     ap.add_argument("--batch", type=int, required=True); ap.add_argument("--rings", type=int, default=64)
     ap.add_argument("--calib-bytes", type=float, default=float(1 << 30))
+    ap.add_argument("--workload", default="synthetic")
+    ap.add_argument("--source-digest", default=None, help="bench.py's source_digest() of the library the passes ran (default: computed from this tree)")
     args = ap.parse_args()
+    if args.source_digest is None:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        args.source_digest = bench.source_digest()
     fetch, fcalls = per_kernel(args.fetch_dir, "FETCH_SIZE")
     write, wcalls = per_kernel(args.write_dir, "WRITE_SIZE")
     cf = fetch.get("k_calib_copy", 0) / max(1, fcalls.get("k_calib_copy", 1)) * 1024.0
@@ -52,7 +58,7 @@ def main():
     if cf <= 0 or cw <= 0:
         raise SystemExit("k_calib_copy not found: run bench.py with --calibrate")
     kf, kw = args.calib_bytes / cf, args.calib_bytes / cw          # true bytes per reported byte
-    out = {"rings": args.rings, "batch": args.batch, "unit": "bytes",
+    out = {"rings": args.rings, "batch": args.batch, "workload": args.workload, "source_digest": args.source_digest, "unit": "bytes",
            "calibration": {"fetch_reported_per_true": 1.0 / kf, "write_reported_per_true": 1.0 / kw,
                            "note": "k_calib_copy: 1 GiB float4 read + 1 GiB float4 write; counters scaled by these factors"},
            "kernels": {}}
