@@ -4,6 +4,7 @@ Fails loudly when the HIP library is missing or no gfx950 device is usable: ther
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -166,9 +167,15 @@ class Context:
             raise LightLoamError(rc, self.lib.ll_last_error(None).decode())
         self.h = h
         self.R = params.n_scans
+        self._children = weakref.WeakSet()      # Map / CubeMap objects living on this context: destroyed before it
 
     def close(self):
         if getattr(self, "h", None):
+            for child in list(getattr(self, "_children", ())):   # a map outliving its context would free through a dangling pointer
+                try:
+                    child.close()
+                except Exception:
+                    pass
             self.lib.ll_destroy(self.h)
             self.h = None
 
@@ -426,6 +433,7 @@ class Map:
         rc = self.lib.ll_map_create(ctx.h, int(max_map_corner), int(max_map_surf), int(max_scan_corner), int(max_scan_surf), C.byref(self.h))
         if rc != LL_OK:
             raise LightLoamError(rc, ctx.lib.ll_last_error(ctx.h).decode())
+        ctx._children.add(self)
 
     def close(self):
         if getattr(self, "h", None):
@@ -593,6 +601,7 @@ class CubeMap:
                                         int(pool_points), C.byref(self.h))
         if rc != LL_OK:
             raise LightLoamError(rc, ctx.lib.ll_last_error(ctx.h).decode())
+        ctx._children.add(self)
 
     def close(self):
         if getattr(self, "h", None):
