@@ -150,6 +150,7 @@ extern "C" int ll_create(int device, const ll_params *p, ll_ctx **out)
     ok = ok && dev_alloc(ctx, V.cloud, (size_t)B * V.CS, false) && dev_alloc(ctx, ctx->cloud_flat, NP, false);
     ok = ok && dev_alloc(ctx, V.label, BN) && dev_alloc(ctx, V.curv, p->write_curvature ? BN : 1);
     ok = ok && dev_alloc(ctx, V.ring_pub, (size_t)B * R);
+    ok = ok && dev_alloc(ctx, V.stage_sf, p->max_ring_points > 2304 ? (size_t)B * R * LL_STAGE_SF : 1, false);
     {   /* ring thresholds of this sensor model (ll_exact_math.h), computed once with the same exact arithmetic */
         int *thr_dev = nullptr;
         std::vector<int32_t> thr((size_t)R + 1);

@@ -25,6 +25,7 @@
 #define LL_LSHARP_PER_SEG 20
 #define LL_FLAT_PER_SEG 4
 #define LL_SEGS 6
+#define LL_STAGE_SF (LL_SEGS * (LL_SHARP_PER_SEG + LL_FLAT_PER_SEG))      /* staged sharp + flat points per ring */
 /* nearest-neighbour cell grid over (x, y): 128 x 128 cells of 1 m centred on the sensor; farther points saturate into
  * the border cells, whose rectangles count as unbounded outwards */
 #define LL_GRID_G 128
@@ -81,6 +82,7 @@ struct LLView {
     int8_t *label; float *curv;
     /* features */
     unsigned long long *ring_pub;  /* [B][R] look-back word of every ring: launch tag << 40 | its four feature counts */
+    float4 *stage_sf;              /* [B][R][LL_STAGE_SF] staged sharp + flat lists of the rings longer than 2304 points (max_ring_points > 2304 only) */
     int epoch;                     /* the tag of the current k_ring_features launch (1 .. 2^24 - 2) */
     float4 *sharp, *lsharp, *flat, *lflat;
     /* targets */

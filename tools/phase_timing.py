@@ -7,13 +7,15 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-out = os.path.join(ROOT, "gpurun_out", "liblightloam_hip_phase.so")
+prebuilt = os.environ.get("LL_PHASE_LIB")           # an instrumented library built elsewhere (tools/make_ab_variant.sh x -DLL_PHASE_TIMING)
+out = prebuilt or os.path.join(ROOT, "gpurun_out", "liblightloam_hip_phase.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
 os.environ["LIGHTLOAM_HIP_LIB"] = out
 import lightloam_amd  # noqa: E402,F401
 from lightloam_amd import build, api, synth  # noqa: E402
 
-build.build_hip(force=True, extra_flags=["-DLL_PHASE_TIMING"])
+if not prebuilt:
+    build.build_hip(force=True, extra_flags=["-DLL_PHASE_TIMING"])
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 cfg = synth.default_cfg(64)
 scans = [synth.scan(cfg, k) for k in range(4)]
