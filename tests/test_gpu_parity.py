@@ -40,10 +40,8 @@ SHAPES = {
 RING_MODEL = {128: dict(ring_model=1, lower_bound=-25.0, up_bound=15.0, minimum_range=0.3)}
 
 
-@pytest.fixture(scope="module", params=[(s, o) for s in SHAPES for o in ("tiles", "walk")], ids=lambda p: f"{p[0]}-{p[1]}")
-def case(request, api, orc, synth):
+def _make_case(shape, org, api, orc, synth):
     from conftest import set_org_path
-    shape, org = request.param
     set_org_path(org)                # both organise paths (ll_organize.hip) see every shape
     kw = dict(SHAPES[shape]); rings = kw.pop("rings")
     extra_prm = {}
@@ -63,8 +61,24 @@ def case(request, api, orc, synth):
     ctx.extract(0, 3)
     ref = [orc.extract(s, P) for s in scans]
     set_org_path("tiles")
-    yield dict(name=f"{shape}-{org}", ctx=ctx, ref=ref, scans=scans, rings=rings)
-    ctx.close()
+    return dict(name=f"{shape}-{org}", ctx=ctx, ref=ref, scans=scans, rings=rings)
+
+
+@pytest.fixture(scope="module", params=[(s, o) for s in SHAPES for o in ("tiles", "walk")], ids=lambda p: f"{p[0]}-{p[1]}")
+def case(request, api, orc, synth):
+    """a1-a4 (organise, curvature, labels, feature clouds): every shape through BOTH organise paths of ll_organize.hip"""
+    c = _make_case(*request.param, api, orc, synth)
+    yield c
+    c["ctx"].close()
+
+
+@pytest.fixture(scope="module", params=list(SHAPES), ids=lambda p: p)
+def case_down(request, api, orc, synth):
+    """the stages downstream of the feature clouds (a5-a10): one organise path -- they read what test_feature_clouds_bit_exact
+    has just shown to be the same bytes on both (keeps the suite inside the driver's time limit)"""
+    c = _make_case(request.param, "tiles", api, orc, synth)
+    yield c
+    c["ctx"].close()
 
 
 def test_organize_bit_exact(case):
@@ -100,8 +114,9 @@ def test_feature_clouds_bit_exact(case):
 
 
 @pytest.fixture(scope="module")
-def odo(case, orc):
+def odo(case_down, orc):
     """scan 1 and 2 against their predecessors at a non-trivial pose guess."""
+    case = case_down
     ctx = case["ctx"]
     q = np.array([0.001, -0.002, 0.004, 1.0]); q /= np.linalg.norm(q)
     t = np.array([0.8, 0.02, -0.01])
@@ -121,7 +136,8 @@ def odo(case, orc):
     return dict(q=q, t=t, pose=pose, ref=out)
 
 
-def test_association_indices_exact(case, odo):
+def test_association_indices_exact(case_down, odo):
+    case = case_down
     """a5-a7: (src, a, b[, c]) index tuples in correspondence order."""
     for i, k in enumerate((1, 2)):
         r = odo["ref"][i]
@@ -133,7 +149,8 @@ def test_association_indices_exact(case, odo):
             assert len(got) == len(want) and (got == want).all(), f"{case['name']} scan {k} {nm}"
 
 
-def test_vote_exact(case, odo):
+def test_vote_exact(case_down, odo):
+    case = case_down
     """a8: incompatibility counts, selected set and weights."""
     for i, k in enumerate((1, 2)):
         r = odo["ref"][i]
@@ -154,7 +171,8 @@ def _oracle_neq(orc, odo, r):
                                 r["pc"][order], wmap[order], 0.1)
 
 
-def test_normal_equations(case, odo, orc):
+def test_normal_equations(case_down, odo, orc):
+    case = case_down
     """a9 + a10: H, g, cost (Huber 0.1) against Jet-autodiff blocks."""
     for i, k in enumerate((1, 2)):
         H, g, cost = case["ctx"].normal_equations_result(k)
@@ -163,7 +181,8 @@ def test_normal_equations(case, odo, orc):
         assert np.allclose(H, H.T)
 
 
-def test_residual_jacobian_rows(case, odo, orc):
+def test_residual_jacobian_rows(case_down, odo, orc):
+    case = case_down
     """What ceres::CostFunction::Evaluate would return per block: r, d r/d q (ambient xyzw), d r/d t."""
     k, r = 1, odo["ref"][0]
     rr, Jq, Jt = case["ctx"].residual_jacobian(k, odo["pose"])
@@ -182,7 +201,8 @@ def test_residual_jacobian_rows(case, odo, orc):
         close(rr[row], ro[0], "plane r"); close(Jq[row], Jqo[0], "plane Jq"); close(Jt[row], Jto[0], "plane Jt")
 
 
-def test_gn_step_pose(case, odo, orc):
+def test_gn_step_pose(case_down, odo, orc):
+    case = case_down
     """one Gauss-Newton iteration: Cholesky solve + EigenQuaternionManifold::Plus."""
     ctx = case["ctx"]
     ctx.gn_step(1, 2)
@@ -195,7 +215,8 @@ def test_gn_step_pose(case, odo, orc):
         close(p[:4], qo, "q"); close(p[4:], to, "t")
 
 
-def test_hot_path_matches_staged(case, odo):
+def test_hot_path_matches_staged(case_down, odo):
+    case = case_down
     """ll_hot_path_batch (one launch sequence, no host sync) == the staged calls."""
     ctx = case["ctx"]
     staged = [ctx.pose(k) for k in (1, 2)]
@@ -325,7 +346,8 @@ def test_voxel_runs_across_lanes_and_waves(api, orc, n_az, spread):
     assert len(ref["less_flat"]) * 8 < n_lf_in, "the construction must put many points into each voxel"
 
 
-def test_vote_disabled_keeps_all(case, odo):
+def test_vote_disabled_keeps_all(case_down, odo):
+    case = case_down
     """now_frame <= 5 branch (laserOdometry.cpp:781-787): every plane correspondence, weight 1."""
     ctx = case["ctx"]
     ctx.vote(1, 2, False)
@@ -601,3 +623,54 @@ def test_async_uploads_of_different_sizes_with_the_host_running_ahead(api, synth
     ctx.synchronize_copy(); ctx.extract(1, G); ctx.synchronize()
     assert [ctx.scan_info(1 + g).n for g in range(G)] == [w[0] for w in want]
     ctx.close()
+
+
+def test_streamed_halves_at_128_rings(api, synth):
+    """BASELINE config 5 as stated (a dense 128-ring STREAM): the double-buffered upload / compute pipeline of
+    test_streamed_halves_equal_the_resident_batch at 128 rings -- 3072 plane correspondences per scan put k_vote on its
+    86 KB dynamic-LDS launch, on the first half (ll_hot_path_batch) and on the chained half (ll_hot_path_chain) alike.
+    Poses, feature clouds and selected counts bit-identical to one resident batch."""
+    extra = RING_MODEL[128]
+    cfg = synth.default_cfg(128)
+    B, H = 8, 4
+    scans = [synth.scan(cfg, k % 5) for k in range(B + 1)]
+    prm = lambda: api.default_params(128, batch=B + 1, max_points=max(map(len, scans)), **extra)
+    guess = np.array([0, 0, 0, 1.0, 0.45, 0.0, 0.0])            # 20 Hz: half the 10 Hz step
+    res = api.Context(prm())
+    for k, s in enumerate(scans):
+        res.upload_scan(k, s)
+    res.extract(B, 1); res.set_target_from_slot(B)
+    res.set_pose_guess(0, B, guess)
+    res.hot_path(0, B, None, vote=True); res.synchronize()
+    want = [(res.pose(k).copy(), res.features(k), res.pair_info(k).n_plane_selected) for k in range(B)]
+    res.close()
+
+    ctx = api.Context(prm())
+    ctx.upload_scan(B, scans[B]); ctx.extract(B, 1); ctx.set_target_from_slot(B)
+    ctx.set_pose_guess(0, B, guess)
+    staging = api.PinnedStaging(B, max(map(len, scans)) + 5)
+    for i in range(B):
+        staging.put(i, scans[i])
+    COMPUTE, COPY = 0, 1
+    for rnd in range(3):
+        for h in (0, 1):
+            f = h * H
+            ctx.stream_wait(COPY, 2 + h)
+            ctx.upload_staging_async(f, staging, f, H)
+            ctx.stream_record(COPY, h)
+            ctx.stream_wait(COMPUTE, h)
+            if h == 0:
+                ctx.hot_path(0, H, None, vote=True)
+            else:
+                ctx.hot_path_chain(H, H, vote=True)
+            ctx.stream_record(COMPUTE, 2 + h)
+    ctx.synchronize_copy(); ctx.synchronize()
+    for k in range(B):
+        pose, feats, nsel = want[k]
+        assert (ctx.pose(k) == pose).all(), k
+        assert ctx.pair_info(k).n_plane_selected == nsel > 100, k
+        got = ctx.features(k)
+        for name in ("sharp", "less_sharp", "flat", "less_flat"):
+            assert_bit_equal(got[name], feats[name], f"slot {k} {name}")
+    assert ctx.scan_info(0).n_flat > 1800                         # well beyond the 64-ring capacity of 1536: the large-LDS vote path ran
+    staging.close(); ctx.close()

@@ -1,0 +1,30 @@
+"""Reduced soaks of the batch path (tools/soak_extract.py, tools/soak_extract_s64.py: the full runs' logs are kept under
+profiles/): many random irregular scans and synthetic 64-ring scans of three generator settings through k_organize + the ring
+kernel (more than 64 slots: the one-workgroup-per-scan organise path) against the oracle, bit for bit, plus association index
+tuples on every fifth scan."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(tool, arg):
+    env = dict(os.environ, GRAFT_REPO_ROOT=ROOT)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), str(arg)], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    return out.stdout
+
+
+def test_irregular_scans_soak_800():
+    out = _run("soak_extract.py", 2)                # 2 seeds x 400 scans (the committed log: 8 seeds)
+    assert "soak passed:" in out and int(out.strip().split("soak passed:")[1].split()[0]) > 700
+
+
+def test_s64_generator_settings_soak_72():
+    out = _run("soak_extract_s64.py", 24)           # 3 settings x 24 scans (the committed log: 3 x 96)
+    assert "soak passed: 72 scans" in out
