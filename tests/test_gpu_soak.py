@@ -13,8 +13,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(tool, arg):
-    env = dict(os.environ, GRAFT_REPO_ROOT=ROOT)
+def _run(tool, arg, **extra_env):
+    env = dict(os.environ, GRAFT_REPO_ROOT=ROOT, **extra_env)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), str(arg)], capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     return out.stdout
@@ -26,5 +26,7 @@ def test_irregular_scans_soak_800():
 
 
 def test_s64_generator_settings_soak_72():
-    out = _run("soak_extract_s64.py", 24)           # 3 settings x 24 scans (the committed log: 3 x 96)
+    # 3 settings x 24 scans (the committed log: 3 x 96 through the default dispatch); LIGHTLOAM_ORG_SMALL=0 sends these
+    # 24-scan calls through k_organize, the path batches of more than 64 scans take
+    out = _run("soak_extract_s64.py", 24, LIGHTLOAM_ORG_SMALL="0")
     assert "soak passed: 72 scans" in out
