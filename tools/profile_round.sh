@@ -1,8 +1,9 @@
 #!/bin/bash
 # The rocprofv3 passes behind profiles/<tag>_*.  Run on the GPU box from the repo root:
-#   gpurun --timeout 1500 -- 'bash tools/profile_round.sh r01'
+#   gpurun --timeout 2400 -- 'bash tools/profile_round.sh r03'
 # then copy gpurun_out/<tag>_* and gpurun_out/pmc_traffic.json into profiles/.
 # Counter passes are separate runs with --kernel-trace only (TCC has 4 PMC slots; FETCH_SIZE takes 3, WRITE_SIZE 2).
+# pmc_traffic.json is stamped with the library's source digest, ring count, workload and batch (bench.py uses it only on a match).
 TAG=${1:-r01}
 ROOT=$(pwd)
 O=$ROOT/gpurun_out
@@ -13,13 +14,25 @@ rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o $TAG -- $B > $O/prof_$TAG.lo
 python3 tools/rocpd_summary.py $O/prof_$TAG/${TAG}_results.db > $O/${TAG}_kernel_stats.txt
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $O/pmc_fetch -o fetch -- $B > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d $O/pmc_write -o write -- $B > $O/pmc_write.log 2>&1
-python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write --batch ${BATCH:-16384} --rings 64 > $O/pmc_traffic.json
+python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write --batch ${BATCH:-16384} --rings 64 --workload synthetic > $O/pmc_traffic.json
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY \
     --kernel-trace -f csv -d $O/pmc_sq -o sq -- $B > $O/pmc_sq.log 2>&1
 python3 tools/sq_summary.py $O/pmc_sq > $O/${TAG}_sq_counters.txt
-cp $O/pmc_traffic.json profiles/pmc_traffic.json          # bench.py reads roofline.traffic from here
+cp $O/pmc_traffic.json profiles/pmc_traffic.json          # bench.py reads roofline.traffic from here (when the stamp matches)
 python3 bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 python3 tools/phase_timing.py 2048 > $O/${TAG}_phase_timing.txt 2>&1
+# BASELINE config 3's stand-in (HDL-64E true laser table, ring capacity 4608): bench line + its kernel stats
+python3 bench.py --workload hdl64 --no-cpu-baseline > $O/${TAG}_bench_hdl64.json 2> $O/${TAG}_bench_hdl64.err
+rocprofv3 --kernel-trace --stats -d $O/prof_${TAG}_hdl64 -o ${TAG}h -- python3 bench.py --workload hdl64 --steps 5 --warmup 1 --no-cpu-baseline > $O/prof_${TAG}_hdl64.log 2>&1
+python3 tools/rocpd_summary.py $O/prof_${TAG}_hdl64/${TAG}h_results.db > $O/${TAG}_kernel_stats_hdl64.txt
+# the other shapes and BASELINE config 5 (stream of scans over PCIe, 64 and 128 rings)
+python3 bench.py --rings 128 --no-cpu-baseline > $O/${TAG}_bench_s128.json 2>/dev/null
+python3 bench.py --rings 16 --no-cpu-baseline > $O/${TAG}_bench_s16.json 2>/dev/null
+python3 bench.py --stream-input --no-cpu-baseline > $O/${TAG}_stream_input.json 2>/dev/null
+python3 bench.py --stream-input --rings 128 --no-cpu-baseline > $O/${TAG}_stream_input_s128.json 2>/dev/null
+# the full soaks behind tests/test_gpu_soak.py
+python3 tools/soak_extract.py 8 > $O/${TAG}_soak_extract.log 2>&1
+python3 tools/soak_extract_s64.py 96 > $O/${TAG}_soak_extract_s64.log 2>&1
 # keep what is merged back small: the raw counter tables and traces stay on the box
-rm -rf $O/prof_$TAG $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/liblightloam_hip_phase.so
+rm -rf $O/prof_$TAG $O/prof_${TAG}_hdl64 $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/liblightloam_hip_phase.so
 tail -n 3 $O/${TAG}_kernel_stats.txt; tail -c 600 $O/${TAG}_bench.json
