@@ -7,7 +7,7 @@
  *                       over the cloud's bounding box, cells >= 1.01 m.  The search below only has to be exact when the
  *                       fifth neighbour is closer than 1 m (:1884, :1952), and then all five lie in the 3 x 3 x 3 cells
  *                       around the query's cell (the 1 % margin absorbs the f32 rounding of the cell coordinate).
- *   k_map_knn<CORNER>   one thread per stack point: pointAssociateToMap (:125-134, f64 rotate + translate, f32 store),
+ *   k_map_knn           one thread per stack point (both stacks in one launch of 64-thread workgroups): pointAssociateToMap (:125-134, f64 rotate + translate, f32 store),
  *                       exact K = 5 by (FLANN L2_Simple f32 distance, index) -- PCL's kd-tree leaves equal distances
  *                       to traversal order, here and in the oracle the lower index wins -- then
  *                         corners (:1886-1921): mean, 3 x 3 covariance, symmetric eigen-decomposition (cyclic Jacobi in
@@ -251,20 +251,36 @@ __device__ __forceinline__ void ll_map_search5(const LLGrid3 &G, int n_map, cons
     if (n_map <= 0) return;
     int cx = (int)floorf((sx - G.org[0]) / G.cell), cy = (int)floorf((sy - G.org[1]) / G.cell), cz = (int)floorf((sz - G.org[2]) / G.cell);
     cx = min(max(cx, 0), G.dim[0] - 1); cy = min(max(cy, 0), G.dim[1] - 1); cz = min(max(cz, 0), G.dim[2] - 1);
-    for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) {
-        const int yy = cy + dy, zz = cz + dz;
-        if (yy < 0 || zz < 0 || yy >= G.dim[1] || zz >= G.dim[2]) continue;
-        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, G.dim[0] - 1);
-        const int row = (zz * G.dim[1] + yy) * G.dim[0];
-        const int st = G.start[row + x0], en = G.start[row + x1 + 1];          /* the three x-cells are contiguous */
-        for (int k = st; k < en; ++k) {
-            const float4 p = G.pts[k];
-            float diff = sx - p.x; float d = diff * diff;                  /* FLANN L2_Simple: a = query, b = data */
-            diff = sy - p.y; d += diff * diff;
-            diff = sz - p.z; d += diff * diff;
-            int j = __float_as_int(p.w);
-            if (WITH_PT && gid) j = gid[j];
-            ll_five_insert<WITH_PT>(bd, bi, bp, nb, d, j, p);
+    /* the nine (z, y) rows of the 27 cells: the three x-cells of a row are contiguous, so a row is one range.  All eighteen
+     * bounds first (independent loads), then the ranges in the same order as before, four points in flight: a thread's search
+     * is a chain of dependent round trips, and a frame's association is ~11 k of them on a chip that holds 65 k threads. */
+    int st[9], en[9];
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, G.dim[0] - 1);
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        const int yy = cy + (r % 3) - 1, zz = cz + (r / 3) - 1;
+        st[r] = 0; en[r] = 0;
+        if (yy >= 0 && zz >= 0 && yy < G.dim[1] && zz < G.dim[2]) {
+            const int row = (zz * G.dim[1] + yy) * G.dim[0];
+            st[r] = G.start[row + x0]; en[r] = G.start[row + x1 + 1];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        for (int k0 = st[r]; k0 < en[r]; k0 += 4) {
+            float4 p[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (k0 + u < en[r]) p[u] = G.pts[k0 + u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (k0 + u >= en[r]) break;
+                float diff = sx - p[u].x; float d = diff * diff;               /* FLANN L2_Simple: a = query, b = data */
+                diff = sy - p[u].y; d += diff * diff;
+                diff = sz - p[u].z; d += diff * diff;
+                int j = __float_as_int(p[u].w);
+                if (WITH_PT && gid) j = gid[j];
+                ll_five_insert<WITH_PT>(bd, bi, bp, nb, d, j, p[u]);
+            }
         }
     }
 }
@@ -313,11 +329,11 @@ __device__ __forceinline__ void ll_map_fit(const LLMapView &M, int i, const doub
     M.ok[which][i] = ok;
 }
 
+#define LL_KNNB 64            /* threads per workgroup of the searches: ~11 k stack points should spread over the chip, not fill 45 workgroups */
 template <bool CORNER>
-__global__ __launch_bounds__(LL_MAPB) void k_map_knn(LLMapView M)
+__device__ __forceinline__ void ll_map_knn_one(const LLMapView &M, int i)
 {
     const int which = CORNER ? 0 : 1;
-    const int i = blockIdx.x * LL_MAPB + threadIdx.x;
     if (i >= M.n_stk[which]) return;
     float sx, sy, sz;
     ll_map_to_world(M.pose, M.stk[which][i], sx, sy, sz);
@@ -331,14 +347,19 @@ __global__ __launch_bounds__(LL_MAPB) void k_map_knn(LLMapView M)
         ll_map_fit<CORNER>(M, i, P5);
     } else M.ok[which][i] = 0;
 }
+/* both stacks in ONE launch: the first blocks_corner workgroups take the corner points, the rest the surface points */
+__global__ __launch_bounds__(LL_KNNB) void k_map_knn(LLMapView M, int blocks_corner)
+{
+    if ((int)blockIdx.x < blocks_corner) ll_map_knn_one<true>(M, blockIdx.x * LL_KNNB + threadIdx.x);
+    else ll_map_knn_one<false>(M, ((int)blockIdx.x - blocks_corner) * LL_KNNB + threadIdx.x);
+}
 
 /* tile-parallel mapping: this rank's search clouds are the points of ITS cubes; per stack point the five
  * nearest of them go out as (x, y, z, distance) + global id, INFINITY / INT_MAX in the unused slots */
 template <bool CORNER>
-__global__ __launch_bounds__(LL_MAPB) void k_map_knn_partial(LLMapView M)
+__device__ __forceinline__ void ll_map_knn_partial_one(const LLMapView &M, int i)
 {
     const int which = CORNER ? 0 : 1;
-    const int i = blockIdx.x * LL_MAPB + threadIdx.x;
     if (i >= M.n_stk[which]) return;
     float sx, sy, sz;
     ll_map_to_world(M.pose, M.stk[which][i], sx, sy, sz);
@@ -349,6 +370,11 @@ __global__ __launch_bounds__(LL_MAPB) void k_map_knn_partial(LLMapView M)
         M.nn_pt[which][(size_t)i * 5 + j] = make_float4(bp[j].x, bp[j].y, bp[j].z, bd[j]);
         M.nn_id[which][(size_t)i * 5 + j] = bi[j];
     }
+}
+__global__ __launch_bounds__(LL_KNNB) void k_map_knn_partial(LLMapView M, int blocks_corner)
+{
+    if ((int)blockIdx.x < blocks_corner) ll_map_knn_partial_one<true>(M, blockIdx.x * LL_KNNB + threadIdx.x);
+    else ll_map_knn_partial_one<false>(M, ((int)blockIdx.x - blocks_corner) * LL_KNNB + threadIdx.x);
 }
 
 /* the candidates of all ranks ([part][stack point][5]) -> the five nearest overall -> the same fit as k_map_knn */
@@ -672,15 +698,15 @@ void ll_map_launch_build(const LLGrid3 &G, const float4 *pts, int n, int *tile_s
 
 void ll_map_launch_associate(const LLMapView &M, hipStream_t st)
 {
-    if (M.n_stk[0] > 0) hipLaunchKernelGGL(k_map_knn<true>, dim3((M.n_stk[0] + LL_MAPB - 1) / LL_MAPB), dim3(LL_MAPB), 0, st, M);
-    if (M.n_stk[1] > 0) hipLaunchKernelGGL(k_map_knn<false>, dim3((M.n_stk[1] + LL_MAPB - 1) / LL_MAPB), dim3(LL_MAPB), 0, st, M);
+    const int bc = (M.n_stk[0] + LL_KNNB - 1) / LL_KNNB, bs = (M.n_stk[1] + LL_KNNB - 1) / LL_KNNB;
+    if (bc + bs > 0) hipLaunchKernelGGL(k_map_knn, dim3(bc + bs), dim3(LL_KNNB), 0, st, M, bc);
     hipLaunchKernelGGL(k_map_compact, dim3(2), dim3(1024), 0, st, M);
 }
 
 void ll_map_launch_knn_partial(const LLMapView &M, hipStream_t st)
 {
-    if (M.n_stk[0] > 0) hipLaunchKernelGGL(k_map_knn_partial<true>, dim3((M.n_stk[0] + LL_MAPB - 1) / LL_MAPB), dim3(LL_MAPB), 0, st, M);
-    if (M.n_stk[1] > 0) hipLaunchKernelGGL(k_map_knn_partial<false>, dim3((M.n_stk[1] + LL_MAPB - 1) / LL_MAPB), dim3(LL_MAPB), 0, st, M);
+    const int bc = (M.n_stk[0] + LL_KNNB - 1) / LL_KNNB, bs = (M.n_stk[1] + LL_KNNB - 1) / LL_KNNB;
+    if (bc + bs > 0) hipLaunchKernelGGL(k_map_knn_partial, dim3(bc + bs), dim3(LL_KNNB), 0, st, M, bc);
 }
 
 void ll_map_launch_associate_merged(const LLMapView &M, int n_parts, const float4 *const pt_all[2], const int *const id_all[2], hipStream_t st)
