@@ -282,8 +282,10 @@ struct LLVoxWork {
     int cap, max_seg;
     int *segid, *bbox, *seg_off, *flag, *rank, *vals, *tmp_vals, *hist, *tile_sum, *seg_count;
     unsigned long long *keys, *tmp_keys, *or_and;
+    unsigned long long *pub;           /* [LL_VX_FUSED_WGS] k_vx_finish: valid bit | heads of workgroup b (zeroed by k_vx_keys) */
     LLVoxSeg *sp;
 };
+#define LL_VX_FUSED_WGS 256            /* k_vx_finish handles clouds of up to 256 workgroups x 256 points in one launch */
 size_t ll_vox_work_bytes(int cap, int max_seg);
 void ll_vox_work_carve(void *base, int cap, int max_seg, LLVoxWork *W);
 int ll_voxel_grid_segments(const float4 *pts, int n, int nseg, float leaf, const LLVoxWork &W, float4 *out, int *n_out_dev, hipStream_t st,

@@ -159,9 +159,11 @@ __global__ void k_vx_params(const int *bbox, const int *seg_off, int nseg, float
 }
 
 __global__ __launch_bounds__(LL_VB) void k_vx_keys(const float4 *pts, const int *segid, const int *seg_off, const LLVoxSeg *sp, int n, float inv,
-                                                  unsigned long long *keys, int *vals)
+                                                  unsigned long long *keys, int *vals, unsigned long long *pub, int *seg_count, int nseg)
 {
     const int i = blockIdx.x * LL_VB + threadIdx.x;
+    if (i < LL_VX_FUSED_WGS) pub[i] = 0ull;                          /* k_vx_finish's hand-over words: nothing published yet */
+    for (int j = i; j < nseg; j += gridDim.x * LL_VB) seg_count[j] = 0;   /* ... and its per-segment counters */
     if (i >= n) return;
     const int s = segid[i];
     const LLVoxSeg P = sp[s];
@@ -263,9 +265,10 @@ extern __shared__ __attribute__((aligned(16))) unsigned char ll_rss_smem[];
 /* seg_off != null: workgroup b sorts the pairs [seg_off[b], seg_off[b + 1]) on their own -- keys whose high part is the
  * segment number are then in global order too (the voxel filter of all valid cubes: 75 small sorts in one launch instead of the
  * device-wide sort's five passes of five launches) */
-__global__ __launch_bounds__(1024) void k_rs_small(unsigned long long *keys, int *vals, int n, const int *seg_off)
+__global__ __launch_bounds__(1024) void k_rs_small(unsigned long long *keys, int *vals, int n, const int *seg_off, int chunk)
 {
     if (seg_off) { const int base = seg_off[blockIdx.x]; n = seg_off[blockIdx.x + 1] - base; keys += base; vals += base; }
+    else if (chunk > 0) { const int base = blockIdx.x * chunk; n = min(chunk, n - base); keys += base; vals += base; }   /* workgroup b: the b-th chunk on its own */
     unsigned long long *lk = (unsigned long long *)ll_rss_smem;           /* [LL_RSS_MAX] */
     int *lv = (int *)(lk + LL_RSS_MAX);                                     /* [LL_RSS_MAX] */
     int *cnt = lv + LL_RSS_MAX;                                             /* [16][LL_RSS_ROWS * 16] */
@@ -331,6 +334,50 @@ __global__ __launch_bounds__(1024) void k_rs_small(unsigned long long *keys, int
     }
 }
 
+/* chunks of `chunk` pairs, each sorted: pair i goes to its rank among all of them (see ll_sort_pairs).  The searches in the
+ * other chunks advance together, one probe of every chunk per step: ~14 dependent round trips, not 14 per chunk. */
+#define LL_RSM_MAXC 8
+__global__ __launch_bounds__(256) void k_rs_merge(const unsigned long long *__restrict__ keys, const int *__restrict__ vals, int n, int chunk,
+                                                  unsigned long long *__restrict__ out_keys, int *__restrict__ out_vals)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long K = keys[i];
+    const int c = i / chunk;
+    int lo[LL_RSM_MAXC], hi[LL_RSM_MAXC];
+#pragma unroll
+    for (int cc = 0; cc < LL_RSM_MAXC; ++cc) {
+        lo[cc] = min(n, cc * chunk); hi[cc] = (cc == c) ? lo[cc] : min(n, lo[cc] + chunk);
+    }
+    for (int step = 0; step < 32; ++step) {
+        bool open = false;
+#pragma unroll
+        for (int cc = 0; cc < LL_RSM_MAXC; ++cc) open = open || lo[cc] < hi[cc];
+        if (!open) break;
+        unsigned long long km[LL_RSM_MAXC];
+#pragma unroll
+        for (int cc = 0; cc < LL_RSM_MAXC; ++cc) if (lo[cc] < hi[cc]) km[cc] = keys[(lo[cc] + hi[cc]) >> 1];
+#pragma unroll
+        for (int cc = 0; cc < LL_RSM_MAXC; ++cc)
+            if (lo[cc] < hi[cc]) {
+                const int mid = (lo[cc] + hi[cc]) >> 1;
+                const bool before = (cc < c) ? (km[cc] <= K) : (km[cc] < K);     /* does the probed pair go before pair i? */
+                if (before) lo[cc] = mid + 1; else hi[cc] = mid;
+            }
+    }
+    int rank = i - c * chunk;
+#pragma unroll
+    for (int cc = 0; cc < LL_RSM_MAXC; ++cc) if (cc != c) rank += lo[cc] - min(n, cc * chunk);
+    out_keys[rank] = K; out_vals[rank] = vals[i];
+}
+
+__global__ __launch_bounds__(256) void k_rs_copy_pairs(const unsigned long long *__restrict__ sk, const int *__restrict__ sv, int n,
+                                                       unsigned long long *__restrict__ dk, int *__restrict__ dv)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { dk[i] = sk[i]; dv[i] = sv[i]; }
+}
+
 /* every segment [seg_off[b], seg_off[b + 1]) of (keys, vals) sorted on its own, nseg <= 65535 segments of at most LL_RSS_MAX pairs */
 void ll_sort_pairs_segments(unsigned long long *keys, int *vals, const int *seg_off_dev, int nseg, hipStream_t st)
 {
@@ -338,7 +385,7 @@ void ll_sort_pairs_segments(unsigned long long *keys, int *vals, const int *seg_
     const size_t lds = (size_t)LL_RSS_MAX * 12 + 16 * LL_RSS_ROWS * 16 * sizeof(int);
     static size_t attr_bytes[LL_MAX_DEVICES] = {0};
     ll_ensure_dynamic_lds(k_rs_small, lds, attr_bytes);
-    hipLaunchKernelGGL(k_rs_small, dim3(nseg), dim3(1024), lds, st, keys, vals, 0, seg_off_dev);
+    hipLaunchKernelGGL(k_rs_small, dim3(nseg), dim3(1024), lds, st, keys, vals, 0, seg_off_dev, 0);
 }
 
 /* sorts (keys, vals) by keys, stable; the result is in (keys, vals) again.  tmp_* hold n elements, hist 16 * ceil(n/4096)
@@ -351,7 +398,21 @@ int ll_sort_pairs(unsigned long long *keys, int *vals, unsigned long long *tmp_k
         const size_t lds = (size_t)LL_RSS_MAX * 12 + 16 * LL_RSS_ROWS * 16 * sizeof(int);
         static size_t attr_bytes[LL_MAX_DEVICES] = {0};
         ll_ensure_dynamic_lds(k_rs_small, lds, attr_bytes);
-        hipLaunchKernelGGL(k_rs_small, dim3(1), dim3(1024), lds, st, keys, vals, n, (const int *)nullptr);
+        hipLaunchKernelGGL(k_rs_small, dim3(1), dim3(1024), lds, st, keys, vals, n, (const int *)nullptr, 0);
+        return 0;
+    }
+    if (n <= LL_RSM_MAXC * LL_RSS_MAX) {
+        /* up to 64 k pairs (a scan's less-flat cloud is ~33 k): every chunk of 8192 sorted in LDS by its own workgroup, then
+         * every pair placed by its rank among ALL chunks -- its place in its chunk plus, by binary search, the number of
+         * pairs of the other chunks that go before it (<= K in the chunks before its own, < K in those behind: stable).
+         * Three launches and no host read-back, against ~16 launches and one read-back for the device-wide passes. */
+        const size_t lds = (size_t)LL_RSS_MAX * 12 + 16 * LL_RSS_ROWS * 16 * sizeof(int);
+        static size_t attr_bytes[LL_MAX_DEVICES] = {0};
+        ll_ensure_dynamic_lds(k_rs_small, lds, attr_bytes);
+        const int nch = (n + LL_RSS_MAX - 1) / LL_RSS_MAX;
+        hipLaunchKernelGGL(k_rs_small, dim3(nch), dim3(1024), lds, st, keys, vals, n, (const int *)nullptr, LL_RSS_MAX);
+        hipLaunchKernelGGL(k_rs_merge, dim3((n + 255) / 256), dim3(256), 0, st, (const unsigned long long *)keys, (const int *)vals, n, LL_RSS_MAX, tmp_keys, tmp_vals);
+        hipLaunchKernelGGL(k_rs_copy_pairs, dim3((n + 255) / 256), dim3(256), 0, st, (const unsigned long long *)tmp_keys, (const int *)tmp_vals, n, keys, vals);
         return 0;
     }
     unsigned long long oa[2];
@@ -424,6 +485,66 @@ __global__ __launch_bounds__(LL_VB) void k_vx_centroid(const float4 *pts, const 
     }
 }
 
+/* k_vx_heads + the rank scan + k_vx_centroid in ONE launch for clouds of up to LL_VX_FUSED_WGS x LL_VB points (every cloud of the
+ * mapping stage's frame): a workgroup counts the run heads of its 256 sorted keys, publishes the count (valid bit | count, one
+ * 8-byte agent-scope atomic -- the data is the flag), sums the counts of the workgroups before it as they appear (they are
+ * all resident: at most 256 workgroups) and writes its centroids at their ranks.  seg_count must be zero on entry. */
+__global__ __launch_bounds__(LL_VB) void k_vx_finish(const float4 *pts, const unsigned long long *keys, const int *vals, int n, float4 *out,
+                                                    int *seg_count, int *n_out_dev, unsigned long long *pub)
+{
+    const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.x;
+    const int i = b * LL_VB + tid;
+    unsigned long long key = ~0ull;
+    bool head = false;
+    if (i < n) { key = keys[i]; head = (i == 0) || keys[i - 1] != key; }
+    __shared__ int sc[LL_VB / 64];
+    __shared__ int sbase;
+    int total;
+    const int lrank = ll_block_exscan_n<LL_VB / 64>(head ? 1 : 0, sc, total);
+    if (tid == 0) __hip_atomic_store(&pub[b], (1ull << 63) | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int before = 0;
+    for (int q = tid; q < b; q += LL_VB) {
+        unsigned long long w; int spins = 0;
+        while (!((w = __hip_atomic_load(&pub[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 63) && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(8);
+        if (!(w >> 63)) __builtin_trap();                             /* a workgroup before this one never published: abort the launch (a HIP error at the next synchronisation), never a silently wrong cloud */
+        before += (int)(w & 0xffffffffull);
+    }
+    before = ll_wave_sum_i32(before);
+    if (tid == 0) sbase = 0;
+    __syncthreads();
+    if (lane == 0 && before) atomicAdd(&sbase, before);
+    __syncthreads();
+    const int base = sbase;
+    int seg = -1;
+    if (head) {
+        seg = (int)(key >> 32);
+        int e = i + 1;
+        while (e < n && keys[e] == key) ++e;                          /* the run ends at the next head */
+        /* CentroidPoint<PointXYZI>: f32 sums from zero in input order, divided by float(n); four independent gathers in flight */
+        float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f;
+        for (int j = i; j < e; j += 4) {
+            int v[4]; float4 p[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (j + k < e) v[k] = vals[j + k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (j + k < e) p[k] = pts[v[k]];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (j + k < e) { sx += p[k].x; sy += p[k].y; sz += p[k].z; si += p[k].w; }
+        }
+        const float fn = (float)(e - i);
+        out[base + lrank] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
+    }
+    /* voxels per segment: one atomic per wave and segment (the keys are sorted by segment) */
+    unsigned long long todo = __ballot(head);
+    while (todo) {
+        const int s0 = __shfl(seg, __ffsll((long long)todo) - 1);
+        const unsigned long long same = __ballot(head && seg == s0);
+        if (lane == __ffsll((long long)same) - 1) atomicAdd(&seg_count[s0], __popcll(same));
+        todo &= ~same;
+    }
+    if (b == (int)gridDim.x - 1 && tid == 0) *n_out_dev = base + total;
+}
+
 /* workspace for up to cap points / max_seg segments: one device allocation carved into LLVoxWork (ll_common.h) */
 size_t ll_vox_work_bytes(int cap, int max_seg)
 {
@@ -434,8 +555,8 @@ size_t ll_vox_work_bytes(int cap, int max_seg)
     b += (size_t)max_seg * (6 + 1 + 1) * sizeof(int) + sizeof(int); /* bbox, seg_off (+1), seg_count */
     b += (size_t)max_seg * sizeof(LLVoxSeg);
     b += 256 * nblk * sizeof(int) + (256 * nblk / 4096 + 2) * sizeof(int) + ((size_t)cap / 4096 + 2) * sizeof(int);
-    b += 2 * sizeof(unsigned long long);
-    return b + 4096;
+    b += 2 * sizeof(unsigned long long) + LL_VX_FUSED_WGS * sizeof(unsigned long long);
+    return b + 8192;
 }
 
 void ll_vox_work_carve(void *base, int cap, int max_seg, LLVoxWork *W)
@@ -446,6 +567,7 @@ void ll_vox_work_carve(void *base, int cap, int max_seg, LLVoxWork *W)
     W->cap = cap; W->max_seg = max_seg;
     W->keys = (unsigned long long *)take((size_t)cap * 8); W->tmp_keys = (unsigned long long *)take((size_t)cap * 8);
     W->or_and = (unsigned long long *)take(16);
+    W->pub = (unsigned long long *)take(LL_VX_FUSED_WGS * 8);
     W->segid = (int *)take((size_t)cap * 4); W->flag = (int *)take((size_t)cap * 4); W->rank = (int *)take((size_t)cap * 4 + 4);
     W->vals = (int *)take((size_t)cap * 4); W->tmp_vals = (int *)take((size_t)cap * 4);
     W->bbox = (int *)take((size_t)max_seg * 24); W->seg_off = (int *)take((size_t)(max_seg + 1) * 4); W->seg_count = (int *)take((size_t)max_seg * 4);
@@ -466,10 +588,15 @@ int ll_voxel_grid_segments(const float4 *pts, int n, int nseg, float leaf, const
     if (n <= 0) { (void)hipMemsetAsync(W.seg_count, 0, (size_t)nseg * sizeof(int), st); (void)hipMemsetAsync(n_out_dev, 0, sizeof(int), st); return 0; }
     hipLaunchKernelGGL(k_vx_bbox, dim3((n + LL_VB - 1) / LL_VB), dim3(LL_VB), 0, st, pts, W.segid, n, W.bbox);
     hipLaunchKernelGGL(k_vx_params, dim3((nseg + 63) / 64), dim3(64), 0, st, W.bbox, W.seg_off, nseg, inv, W.sp);
-    hipLaunchKernelGGL(k_vx_keys, dim3((n + LL_VB - 1) / LL_VB), dim3(LL_VB), 0, st, pts, W.segid, W.seg_off, W.sp, n, inv, W.keys, W.vals);
+    hipLaunchKernelGGL(k_vx_keys, dim3((n + LL_VB - 1) / LL_VB), dim3(LL_VB), 0, st, pts, W.segid, W.seg_off, W.sp, n, inv, W.keys, W.vals, W.pub, W.seg_count, nseg);
     int rc = 0;
     if (nseg > 1 && max_seg_len > 0 && max_seg_len <= LL_RSS_MAX) ll_sort_pairs_segments(W.keys, W.vals, W.seg_off, nseg, st);   /* the keys lead with the segment */
     else rc = ll_sort_pairs(W.keys, W.vals, W.tmp_keys, W.tmp_vals, n, W.hist, W.tile_sum, W.or_and, st);
+    if (n <= LL_VX_FUSED_WGS * LL_VB) {
+        hipLaunchKernelGGL(k_vx_finish, dim3((n + LL_VB - 1) / LL_VB), dim3(LL_VB), 0, st, pts, (const unsigned long long *)W.keys, (const int *)W.vals, n, out,
+                           W.seg_count, n_out_dev, W.pub);
+        return rc;
+    }
     hipLaunchKernelGGL(k_vx_heads, dim3((max(n, nseg) + LL_VB - 1) / LL_VB), dim3(LL_VB), 0, st, W.keys, n, nseg, W.flag, W.seg_count);
     ll_copy_d2d(W.rank, W.flag, (size_t)n * sizeof(int), st);
     ll_fill_words(W.rank + n, 1, 0, 0, 1, st);
