@@ -746,20 +746,31 @@ static int map_upload(ll_map *m, float4 *dst, const ll_point *src, int n)
 }
 
 /* search grids over the clouds that already sit in d_map[0 / 1] (uploaded by ll_map_set_map, gathered by the cube map) */
+/* the search grids over the clouds already in d_map[], in two halves so that a caller with more to read back can share the
+ * one synchronisation: _begin enqueues the bounding boxes (m->d_bbox, 12 ints), _finish takes them on the host (the grid
+ * dimensions are launch parameters) and enqueues the builds */
+void ll_map_rebuild_begin(ll_map *m, int n_corner, int n_surf)
+{
+    const int n[2] = {n_corner, n_surf};
+    for (int w = 0; w < 2; ++w) {
+        m->M.n_map[w] = n[w];
+        ll_map_launch_bbox(m->d_map[w], n[w], m->d_bbox + 6 * w, m->ctx->stream);
+    }
+}
+void ll_map_rebuild_finish(ll_map *m, const int bbox_host[12])
+{
+    for (int w = 0; w < 2; ++w) {
+        ll_map_bbox_to_grid(bbox_host + 6 * w, m->M.n_map[w], m->max_cells, &m->M.grid[w]);
+        ll_map_launch_build(m->M.grid[w], m->d_map[w], m->M.n_map[w], m->d_tile, m->ctx->stream);
+    }
+}
 int ll_map_rebuild(ll_map *m, int n_corner, int n_surf)
 {
     hipStream_t st = m->ctx->stream;
-    const int n[2] = {n_corner, n_surf};
     int bbox[12];
-    for (int w = 0; w < 2; ++w) {
-        m->M.n_map[w] = n[w];
-        ll_map_launch_bbox(m->d_map[w], n[w], m->d_bbox + 6 * w, st);
-    }
+    ll_map_rebuild_begin(m, n_corner, n_surf);
     if (ll_read_back(bbox, m->d_bbox, sizeof(bbox), st)) { m->err = "read-back failed"; return LL_ERR_HIP; }   /* the grid dimensions are launch parameters */
-    for (int w = 0; w < 2; ++w) {
-        ll_map_bbox_to_grid(bbox + 6 * w, n[w], m->max_cells, &m->M.grid[w]);
-        ll_map_launch_build(m->M.grid[w], m->d_map[w], n[w], m->d_tile, st);
-    }
+    ll_map_rebuild_finish(m, bbox);
     LLM_HIP(hipGetLastError());
     return LL_OK;
 }

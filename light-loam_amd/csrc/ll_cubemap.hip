@@ -48,12 +48,15 @@ struct ll_cubemap {
     std::vector<int> off[2], cnt[2];
     int valid[125]; int n_valid = 0;
     int rank = 0, world = 1;                      /* tile shard: this map keeps the cubes with cm_owner() == rank */
-    float4 *d_last = nullptr, *d_tp = nullptr, *d_work = nullptr, *d_out = nullptr;
+    float4 *d_last = nullptr;
+    /* ll_cubemap_update runs both cloud types through every stage before it synchronises: one set of buffers per type */
+    float4 *d_tp[2] = {nullptr, nullptr}, *d_work[2] = {nullptr, nullptr}, *d_out[2] = {nullptr, nullptr};
     int cap_work = 0;
     CmOp *d_ops = nullptr;
-    int *d_addcnt = nullptr, *d_nout = nullptr;
-    unsigned long long *d_keys = nullptr; int *d_vals = nullptr;
-    void *vox_mem = nullptr; LLVoxWork W;
+    int *d_addcnt = nullptr, *d_nout = nullptr;   /* [2][CM_N + 1]; [4]: stack sizes of prepare, filtered sizes of update */
+    unsigned long long *d_keys[2] = {nullptr, nullptr}; int *d_vals[2] = {nullptr, nullptr};
+    void *vox_mem = nullptr; LLVoxWork W;         /* prepare's filters and update's corner filter */
+    void *vox_mem2 = nullptr; LLVoxWork W2;       /* update's surface filter */
     void *sort_mem = nullptr; LLVoxWork WS;       /* scratch of the by-cube sort (same layout, stack-sized) */
     std::vector<void *> allocs;
     std::string err;
@@ -167,15 +170,20 @@ extern "C" int ll_cubemap_create(ll_ctx *ctx, float line_res, float plane_res, i
         ok = ok && cm_alloc(cm, cm->pool[w][0], cm->cap_pool) && cm_alloc(cm, cm->pool[w][1], cm->cap_pool);
         cm->off[w].assign(CM_N, 0); cm->cnt[w].assign(CM_N, 0);
     }
-    ok = ok && cm_alloc(cm, cm->d_last, (size_t)mx_last) && cm_alloc(cm, cm->d_tp, (size_t)mx_last);
-    ok = ok && cm_alloc(cm, cm->d_work, (size_t)cm->cap_work) && cm_alloc(cm, cm->d_out, (size_t)cm->cap_work);
-    ok = ok && cm_alloc(cm, cm->d_ops, CM_MAX_OPS) && cm_alloc(cm, cm->d_addcnt, CM_N + 1) && cm_alloc(cm, cm->d_nout, 4);
-    ok = ok && cm_alloc(cm, cm->d_keys, (size_t)mx_last) && cm_alloc(cm, cm->d_vals, (size_t)mx_last);
+    ok = ok && cm_alloc(cm, cm->d_last, (size_t)mx_last);
+    for (int w = 0; w < 2; ++w) {
+        ok = ok && cm_alloc(cm, cm->d_tp[w], (size_t)mx_last) && cm_alloc(cm, cm->d_work[w], (size_t)cm->cap_work) && cm_alloc(cm, cm->d_out[w], (size_t)cm->cap_work);
+        ok = ok && cm_alloc(cm, cm->d_keys[w], (size_t)mx_last) && cm_alloc(cm, cm->d_vals[w], (size_t)mx_last);
+    }
+    ok = ok && cm_alloc(cm, cm->d_ops, CM_MAX_OPS) && cm_alloc(cm, cm->d_addcnt, 2 * (CM_N + 1)) && cm_alloc(cm, cm->d_nout, 4);
     if (ok) {
         const size_t vb = ll_vox_work_bytes(cm->cap_work, 128), sb = ll_vox_work_bytes(mx_last, 1);
-        unsigned char *p1 = nullptr, *p2 = nullptr;
-        ok = cm_alloc(cm, p1, vb) && cm_alloc(cm, p2, sb);
-        if (ok) { cm->vox_mem = p1; cm->sort_mem = p2; ll_vox_work_carve(p1, cm->cap_work, 128, &cm->W); ll_vox_work_carve(p2, mx_last, 1, &cm->WS); }
+        unsigned char *p1 = nullptr, *p2 = nullptr, *p3 = nullptr;
+        ok = cm_alloc(cm, p1, vb) && cm_alloc(cm, p2, sb) && cm_alloc(cm, p3, vb);
+        if (ok) {
+            cm->vox_mem = p1; cm->sort_mem = p2; cm->vox_mem2 = p3;
+            ll_vox_work_carve(p1, cm->cap_work, 128, &cm->W); ll_vox_work_carve(p2, mx_last, 1, &cm->WS); ll_vox_work_carve(p3, cm->cap_work, 128, &cm->W2);
+        }
     }
     if (!ok) { ctx->err = cm->err; ll_cubemap_destroy(cm); return LL_ERR_HIP; }
     *out = cm;
@@ -270,20 +278,27 @@ static int cm_prepare(ll_cubemap *cm, const double *t_w3, const ll_point *corner
         int rc = cm_run_ops(cm, ops, cm->pool[w][cm->cur[w]], nullptr, nullptr, cm->map->d_map[w], cm->world > 1 ? cm->map->d_gid[w] : nullptr); if (rc) return rc;
         n_from[w] = (int)tot;
     }
-    int rc = ll_map_rebuild(cm->map, n_from[0], n_from[1]);
-    if (rc) { cm->err = cm->map->err; return rc; }
-    /* laserCloudCornerStack / SurfStack: the scan's clouds down-sized (:1813-1821) */
+    ll_map_rebuild_begin(cm->map, n_from[0], n_from[1]);                           /* the clouds' bounding boxes: enqueued, read below */
+    /* laserCloudCornerStack / SurfStack: the scan's clouds down-sized (:1813-1821) -- both filters enqueued back to back */
     const ll_point *src[2] = {corner_last, surf_last}; const int n_in[2] = {n_corner, n_surf};
     for (int w = 0; w < 2; ++w) {
-        int n_out = 0;
         if (n_in[w] > 0) {
-            const int seg_off[2] = {0, n_in[w]};
             CM_HIP(hipMemcpyAsync(cm->d_last, src[w], (size_t)n_in[w] * sizeof(ll_point), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
-            CM_HIP(hipMemcpyAsync(cm->W.seg_off, seg_off, sizeof(seg_off), hipMemcpyHostToDevice, st));
-            if (ll_voxel_grid_segments(cm->d_last, n_in[w], 1, cm->leaf[w], cm->W, cm->map->d_stk[w], cm->d_nout, st)) { cm->err = "voxel filter: read-back failed"; return LL_ERR_HIP; }
-            if (ll_read_back(&n_out, cm->d_nout, sizeof(int), st)) { cm->err = "read-back failed"; return LL_ERR_HIP; }
+            ll_fill_words(cm->W.seg_off, 2, 0, n_in[w], 1, st);                    /* one segment: {0, n} */
+            if (ll_voxel_grid_segments(cm->d_last, n_in[w], 1, cm->leaf[w], cm->W, cm->map->d_stk[w], cm->d_nout + w, st)) { cm->err = "voxel filter: read-back failed"; return LL_ERR_HIP; }
         }
-        cm->map->M.n_stk[w] = n_out;
+    }
+    /* ONE synchronisation for everything the host needs from the above: the two boxes (grid dimensions) and the two sizes */
+    {
+        int *pin = (int *)ll_pinned_scratch(16 * sizeof(int));
+        if (!pin) { cm->err = "no page-locked scratch"; return LL_ERR_HIP; }
+        CM_HIP(hipMemcpyAsync(pin, cm->map->d_bbox, 12 * sizeof(int), hipMemcpyDeviceToHost, st));
+        CM_HIP(hipMemcpyAsync(pin + 12, cm->d_nout, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+        CM_HIP(hipStreamSynchronize(st));
+        int bbox[12];
+        for (int k = 0; k < 12; ++k) bbox[k] = pin[k];
+        for (int w = 0; w < 2; ++w) cm->map->M.n_stk[w] = n_in[w] > 0 ? pin[12 + w] : 0;
+        ll_map_rebuild_finish(cm->map, bbox);
     }
     CM_HIP(hipGetLastError());
     return LL_OK;
@@ -350,50 +365,68 @@ extern "C" int ll_cubemap_update(ll_cubemap *cm, const double *pose_w7)
      * stays as it was).  A HIP failure after it leaves the tables half-updated: the cube map is then marked unusable and
      * every later call returns LL_ERR_STATE instead of mapping on with an emptied neighbourhood. */
     struct Guard { ll_cubemap *cm; bool armed = false; ~Guard() { if (armed) cm->broken = true; } } guard{cm};
-    std::vector<int> addcnt(CM_N + 1), goff(CM_N + 2);
+    /* Three synchronisations per frame instead of six: both cloud types go through a stage before the host looks at what the
+     * stage produced.  Stage A: points -> cubes (k_cm_assign), sorted by cube.  Host: the cubes' new-point counts of both types. */
+    const LLVoxWork *VW[2] = {&cm->W, &cm->W2};
+    CM_HIP(hipMemsetAsync(cm->d_addcnt, 0, 2 * (CM_N + 1) * sizeof(int), st));
     for (int w = 0; w < 2; ++w) {
         const int ns = m->M.n_stk[w];
-        CM_HIP(hipMemsetAsync(cm->d_addcnt, 0, (CM_N + 1) * sizeof(int), st));
         if (ns > 0) {
             hipLaunchKernelGGL(k_cm_assign, dim3((ns + 255) / 256), dim3(256), 0, st, m->d_stk[w], ns, m->M.pose, cm->cen[0], cm->cen[1], cm->cen[2], cm->rank, cm->world,
-                               cm->d_tp, cm->d_keys, cm->d_vals, cm->d_addcnt);
-            if (ll_sort_pairs(cm->d_keys, cm->d_vals, cm->WS.keys, cm->WS.vals, ns, cm->WS.hist, cm->WS.tile_sum, cm->WS.or_and, st)) { cm->err = "sort by cube: read-back failed"; return LL_ERR_HIP; }   /* by cube, stack order kept */
+                               cm->d_tp[w], cm->d_keys[w], cm->d_vals[w], cm->d_addcnt + w * (CM_N + 1));
+            if (ll_sort_pairs(cm->d_keys[w], cm->d_vals[w], cm->WS.keys, cm->WS.vals, ns, cm->WS.hist, cm->WS.tile_sum, cm->WS.or_and, st)) { cm->err = "sort by cube: read-back failed"; return LL_ERR_HIP; }   /* by cube, stack order kept */
         }
-        if (ll_read_back(addcnt.data(), cm->d_addcnt, (CM_N + 1) * sizeof(int), st)) { cm->err = "read-back failed"; return LL_ERR_HIP; }
-        goff[0] = 0;
-        for (int c = 0; c < CM_N; ++c) goff[c + 1] = goff[c] + addcnt[c];              /* the new points of cube c in the sorted order */
-        /* one voxel-grid segment per valid cube: its cloud, then its new points (:2119-2125 push_back, :2151-2165 filter) */
-        std::vector<CmOp> ops; std::vector<int> seg_off(cm->n_valid + 1, 0); std::vector<char> is_valid(CM_N, 0);
-        size_t tot = 0;
+    }
+    std::vector<int> addcnt_all(2 * (CM_N + 1));
+    if (ll_read_back(addcnt_all.data(), cm->d_addcnt, addcnt_all.size() * sizeof(int), st)) { cm->err = "read-back failed"; return LL_ERR_HIP; }
+    /* Stage B: one voxel-grid segment per valid cube -- its cloud, then its new points (:2119-2125 push_back, :2151-2165 filter) */
+    std::vector<int> goff[2], seg_off[2]; std::vector<char> is_valid(CM_N, 0);
+    size_t tot[2] = {0, 0};
+    for (int v = 0; v < cm->n_valid; ++v) is_valid[cm->valid[v]] = 1;
+    for (int w = 0; w < 2; ++w) {
+        const int *addcnt = addcnt_all.data() + w * (CM_N + 1);
+        goff[w].assign(CM_N + 2, 0);
+        for (int c = 0; c < CM_N; ++c) goff[w][c + 1] = goff[w][c] + addcnt[c];        /* the new points of cube c in the sorted order */
+        std::vector<CmOp> ops; seg_off[w].assign(cm->n_valid + 1, 0);
         for (int v = 0; v < cm->n_valid; ++v) {
             const int c = cm->valid[v];
-            is_valid[c] = 1;
-            seg_off[v] = (int)tot;
-            if (cm->cnt[w][c] > 0) { ops.push_back({0, cm->off[w][c], cm->cnt[w][c], (int)tot, 0}); tot += (size_t)cm->cnt[w][c]; }
-            if (addcnt[c] > 0) { ops.push_back({1, goff[c], addcnt[c], (int)tot, 0}); tot += (size_t)addcnt[c]; }
+            seg_off[w][v] = (int)tot[w];
+            if (cm->cnt[w][c] > 0) { ops.push_back({0, cm->off[w][c], cm->cnt[w][c], (int)tot[w], 0}); tot[w] += (size_t)cm->cnt[w][c]; }
+            if (addcnt[c] > 0) { ops.push_back({1, goff[w][c], addcnt[c], (int)tot[w], 0}); tot[w] += (size_t)addcnt[c]; }
         }
-        seg_off[cm->n_valid] = (int)tot;
-        if (tot > (size_t)cm->cap_work) { cm->err = "the valid cubes hold more points than the filter workspace"; return LL_ERR_CAPACITY; }
-        int rc = cm_run_ops(cm, ops, cm->pool[w][cm->cur[w]], cm->d_tp, cm->d_vals, cm->d_work); if (rc) return rc;
-        std::vector<int> seg_count(cm->n_valid, 0); int n_out = 0;
-        if (tot > 0) {
-            CM_HIP(hipMemcpyAsync(cm->W.seg_off, seg_off.data(), seg_off.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        seg_off[w][cm->n_valid] = (int)tot[w];
+        if (tot[w] > (size_t)cm->cap_work) { cm->err = "the valid cubes hold more points than the filter workspace"; return LL_ERR_CAPACITY; }
+        int rc = cm_run_ops(cm, ops, cm->pool[w][cm->cur[w]], cm->d_tp[w], cm->d_vals[w], cm->d_work[w]); if (rc) return rc;
+        if (tot[w] > 0) {
+            CM_HIP(hipMemcpyAsync(VW[w]->seg_off, seg_off[w].data(), seg_off[w].size() * sizeof(int), hipMemcpyHostToDevice, st));   /* the vector lives until the synchronisation below */
             int max_seg = 0;
-            for (int v = 0; v < cm->n_valid; ++v) max_seg = std::max(max_seg, seg_off[(size_t)v + 1] - seg_off[(size_t)v]);
-            if (ll_voxel_grid_segments(cm->d_work, (int)tot, cm->n_valid, cm->leaf[w], cm->W, cm->d_out, cm->d_nout, st, max_seg)) { cm->err = "voxel filter: read-back failed"; return LL_ERR_HIP; }
-            /* seg_count and n_out in one page-locked read-back: n_out first, then the counts */
-            {
-                int *pin = (int *)ll_pinned_scratch((size_t)(cm->n_valid + 1) * sizeof(int));
-                if (!pin) { cm->err = "no page-locked scratch"; return LL_ERR_HIP; }
-                CM_HIP(hipMemcpyAsync(pin, cm->d_nout, sizeof(int), hipMemcpyDeviceToHost, st));
-                CM_HIP(hipMemcpyAsync(pin + 1, cm->W.seg_count, (size_t)cm->n_valid * sizeof(int), hipMemcpyDeviceToHost, st));
-                CM_HIP(hipStreamSynchronize(st));
-                n_out = pin[0];
-                for (int k = 0; k < cm->n_valid; ++k) seg_count[(size_t)k] = pin[1 + k];
-            }
+            for (int v = 0; v < cm->n_valid; ++v) max_seg = std::max(max_seg, seg_off[w][(size_t)v + 1] - seg_off[w][(size_t)v]);
+            if (ll_voxel_grid_segments(cm->d_work[w], (int)tot[w], cm->n_valid, cm->leaf[w], *VW[w], cm->d_out[w], cm->d_nout + 2 + w, st, max_seg)) { cm->err = "voxel filter: read-back failed"; return LL_ERR_HIP; }
         }
+    }
+    /* Host: both filtered sizes and both sets of per-cube counts in one page-locked read-back */
+    std::vector<int> seg_count[2]; int n_out[2] = {0, 0};
+    {
+        const size_t per = (size_t)cm->n_valid + 1;
+        int *pin = (int *)ll_pinned_scratch(2 * per * sizeof(int));
+        if (!pin) { cm->err = "no page-locked scratch"; return LL_ERR_HIP; }
+        for (int w = 0; w < 2; ++w)
+            if (tot[w] > 0) {
+                CM_HIP(hipMemcpyAsync(pin + w * per, cm->d_nout + 2 + w, sizeof(int), hipMemcpyDeviceToHost, st));
+                CM_HIP(hipMemcpyAsync(pin + w * per + 1, VW[w]->seg_count, (size_t)cm->n_valid * sizeof(int), hipMemcpyDeviceToHost, st));
+            }
+        CM_HIP(hipStreamSynchronize(st));
+        for (int w = 0; w < 2; ++w) {
+            seg_count[w].assign(cm->n_valid, 0);
+            if (tot[w] > 0) { n_out[w] = pin[w * per]; for (int k = 0; k < cm->n_valid; ++k) seg_count[w][(size_t)k] = pin[w * per + 1 + k]; }
+        }
+    }
+    /* Stage C: the pair tables, one cloud type after the other (a capacity overflow of the second leaves the first updated and
+     * the second as it was -- as when the types were processed one after the other) */
+    for (int w = 0; w < 2; ++w) {
+        const int *addcnt = addcnt_all.data() + w * (CM_N + 1);
         /* pool space: the filtered valid cubes + the grown clouds of the other cubes that received points */
-        size_t need = (size_t)n_out;
+        size_t need = (size_t)n_out[w];
         for (int c = 0; c < CM_N; ++c) if (!is_valid[c] && addcnt[c] > 0) need += (size_t)cm->cnt[w][c] + (size_t)addcnt[c];
         /* will it fit?  Decided BEFORE any table changes: a compaction keeps the clouds of the cubes outside the valid set only */
         if (cm->top[w] + need > cm->cap_pool * 3 / 4) {
@@ -404,23 +437,23 @@ extern "C" int ll_cubemap_update(ll_cubemap *cm, const double *pose_w7)
         /* ---- commit: the valid cubes' old clouds are dead from here on (not carried through a compaction) ---- */
         guard.armed = true;
         for (int v = 0; v < cm->n_valid; ++v) cm->cnt[w][cm->valid[v]] = 0;
-        rc = cm_reserve(cm, w, need); if (rc) return rc;
+        int rc = cm_reserve(cm, w, need); if (rc) return rc;
         float4 *pool = cm->pool[w][cm->cur[w]];
-        if (n_out > 0) ll_copy_d2d(pool + cm->top[w], cm->d_out, (size_t)n_out * sizeof(float4), st);
+        if (n_out[w] > 0) ll_copy_d2d(pool + cm->top[w], cm->d_out[w], (size_t)n_out[w] * sizeof(float4), st);
         size_t at = cm->top[w];
-        for (int v = 0; v < cm->n_valid; ++v) { const int c = cm->valid[v]; cm->off[w][c] = (int)at; cm->cnt[w][c] = seg_count[v]; at += (size_t)seg_count[v]; }
+        for (int v = 0; v < cm->n_valid; ++v) { const int c = cm->valid[v]; cm->off[w][c] = (int)at; cm->cnt[w][c] = seg_count[w][v]; at += (size_t)seg_count[w][v]; }
         std::vector<CmOp> grow;
         for (int c = 0; c < CM_N; ++c)
             if (!is_valid[c] && addcnt[c] > 0) {
                 if (cm->cnt[w][c] > 0) grow.push_back({0, cm->off[w][c], cm->cnt[w][c], (int)at, 0});
-                grow.push_back({1, goff[c], addcnt[c], (int)(at + (size_t)cm->cnt[w][c]), 0});
+                grow.push_back({1, goff[w][c], addcnt[c], (int)(at + (size_t)cm->cnt[w][c]), 0});
                 cm->off[w][c] = (int)at; cm->cnt[w][c] += addcnt[c]; at += (size_t)cm->cnt[w][c];
             }
-        rc = cm_run_ops(cm, grow, pool, cm->d_tp, cm->d_vals, pool); if (rc) return rc;
+        rc = cm_run_ops(cm, grow, pool, cm->d_tp[w], cm->d_vals[w], pool); if (rc) return rc;
         cm->top[w] = at;
-        CM_HIP(hipStreamSynchronize(st));
-        guard.armed = false;                                         /* this cloud type is consistent again */
     }
+    CM_HIP(hipStreamSynchronize(st));
+    guard.armed = false;                                             /* both cloud types are consistent again */
     CM_HIP(hipGetLastError());
     return LL_OK;
 }

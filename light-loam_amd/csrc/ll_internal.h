@@ -96,4 +96,6 @@ static inline bool map_alloc(ll_map *m, T *&ptr, size_t count)
 
 LLLmOpt ll_to_dev_opt(const ll_lm_options *opt);
 int ll_map_rebuild(ll_map *m, int n_corner, int n_surf);      /* grids over the clouds already in d_map[] */
+void ll_map_rebuild_begin(ll_map *m, int n_corner, int n_surf);       /* ... in two halves around the caller's own read-back */
+void ll_map_rebuild_finish(ll_map *m, const int bbox_host[12]);
 int ll_map_use_ids(ll_map *m, bool on);                       /* search ties by d_gid[] (a tile shard) or by position */
