@@ -730,6 +730,7 @@ extern "C" int ll_map_create(ll_ctx *ctx, int max_map_corner, int max_map_surf, 
         ok = ok && map_alloc(m, M.nn_pt[w], (size_t)m->cap_stk[w] * 5) && map_alloc(m, M.nn_id[w], (size_t)m->cap_stk[w] * 5);
     ok = ok && map_alloc(m, M.counts, 2) && map_alloc(m, M.pose, 7) && map_alloc(m, M.neq, LL_NEQ_STRIDE) && map_alloc(m, M.lm, LL_LM_STRIDE);
     ok = ok && map_alloc(m, M.neq_part, (size_t)LL_NEQ_NB * 28) && map_alloc(m, M.neq_ticket, 1) && map_alloc(m, M.lm_go, 1);
+    for (int w = 0; w < 2; ++w) ok = ok && map_alloc(m, M.cpub[w], (size_t)m->cap_stk[w] / 256 + 2);
     ok = ok && map_alloc(m, m->d_bbox, 12) && map_alloc(m, m->d_tile, (size_t)(m->max_cells + 1 + 4095) / 4096 + 1);
     if (!ok) { ctx->err = m->err; ll_map_destroy(m); return LL_ERR_HIP; }
     M.huber = ctx->V.huber;

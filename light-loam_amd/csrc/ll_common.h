@@ -255,6 +255,7 @@ struct LLMapView {
     int row_rank, row_world;                     /* k_map_normal_eq sums the blocks i with i % row_world == row_rank (0, 1: all) */
     double *neq_part; unsigned *neq_ticket;      /* k_map_normal_eq: per-workgroup partial sums [LL_NEQ_NB][28], arrival counter */
     unsigned *lm_go;                             /* k_map_lm_solve: the round workgroup 0 has released */
+    unsigned long long *cpub[2]; int cpub_tag;   /* k_map_compact: launch tag << 32 | valid blocks of workgroup b, per cloud type */
 };
 #define LL_NEQ_NB 16                             /* workgroups of k_map_normal_eq */
 /* device-to-device copy / small constant fill as kernel launches: on this stack an asynchronous copy costs the host ~26 us,

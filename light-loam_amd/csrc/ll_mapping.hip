@@ -25,6 +25,7 @@
 #include "ll_lm_step.h"
 #include <limits.h>
 #include <string.h>
+#include <atomic>
 
 #define LL_MAPB 256
 
@@ -405,32 +406,54 @@ __global__ __launch_bounds__(LL_MAPB) void k_map_fit_merged(LLMapView M, int n_p
 }
 
 /* per-query results -> residual blocks in stack order; one 1024-thread workgroup */
-__global__ __launch_bounds__(1024) void k_map_compact(LLMapView M)
+/* stack points that produced a residual block -> the block lists, in stack order.  One thread per stack point; a workgroup
+ * counts its valid points, publishes the count (launch tag << 32 | count: one 8-byte agent-scope atomic) and takes its offset
+ * from the counts of the workgroups before it as they appear (all of a frame's workgroups are resident).  The last workgroup
+ * of a cloud type writes the total. */
+#define LL_CMPB 256
+__global__ __launch_bounds__(LL_CMPB) void k_map_compact(LLMapView M, int blocks_corner)
 {
-    __shared__ int sc[16];
-    const int tid = threadIdx.x;
-    {
-        const int which = blockIdx.x;                                /* one workgroup per cloud type: they are independent */
-        const int n = M.n_stk[which];
-        const int per = (n + 1023) / 1024;
-        const int a0 = min(n, tid * per), a1 = min(n, a0 + per);
-        int c = 0;
-        for (int i = a0; i < a1; ++i) c += M.ok[which][i];
-        int total;
-        int pos = ll_block_exscan_n<16>(c, sc, total);
-        for (int i = a0; i < a1; ++i) {
-            if (!M.ok[which][i]) continue;
-            M.src[which][pos] = i;
-            if (which == 0) for (int k = 0; k < 3; ++k) { M.fa[(size_t)pos * 3 + k] = M.qa[(size_t)i * 3 + k]; M.fb[(size_t)pos * 3 + k] = M.qb[(size_t)i * 3 + k]; }
-            else { for (int k = 0; k < 3; ++k) M.fn[(size_t)pos * 3 + k] = M.qn[(size_t)i * 3 + k]; M.fd[pos] = M.qd[i]; }
-            ++pos;
-        }
-        if (tid == 0) M.counts[which] = total;
+    __shared__ int sc[LL_CMPB / 64];
+    __shared__ int sbase;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int which = (int)blockIdx.x < blocks_corner ? 0 : 1;
+    const int b = which ? (int)blockIdx.x - blocks_corner : (int)blockIdx.x;
+    const int nb = which ? (int)gridDim.x - blocks_corner : blocks_corner;
+    const int n = M.n_stk[which];
+    const int i = b * LL_CMPB + tid;
+    const bool ok = i < n && M.ok[which][i];
+    /* the block's data, fetched before the wait */
+    double v[7];
+    if (ok) {
+        if (which == 0) for (int k = 0; k < 3; ++k) { v[k] = M.qa[(size_t)i * 3 + k]; v[3 + k] = M.qb[(size_t)i * 3 + k]; }
+        else { for (int k = 0; k < 3; ++k) v[k] = M.qn[(size_t)i * 3 + k]; v[3] = M.qd[i]; }
     }
+    int total;
+    const int lpos = ll_block_exscan_n<LL_CMPB / 64>(ok ? 1 : 0, sc, total);
+    unsigned long long *pub = M.cpub[which];
+    const unsigned long long tag = (unsigned long long)(unsigned)M.cpub_tag << 32;
+    if (tid == 0) __hip_atomic_store(&pub[b], tag | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int before = 0;
+    for (int q = tid; q < b; q += LL_CMPB) {
+        unsigned long long w; int spins = 0;
+        while (((w = __hip_atomic_load(&pub[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != (unsigned)M.cpub_tag && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(8);
+        if ((w >> 32) != (unsigned)M.cpub_tag) __builtin_trap();       /* never published: abort the launch, never a silently wrong block list */
+        before += (int)(w & 0xffffffffull);
+    }
+    before = ll_wave_sum_i32(before);
+    if (tid == 0) sbase = 0;
+    __syncthreads();
+    if (lane == 0 && before) atomicAdd(&sbase, before);
+    __syncthreads();
+    const int pos = sbase + lpos;
+    if (ok) {
+        M.src[which][pos] = i;
+        if (which == 0) for (int k = 0; k < 3; ++k) { M.fa[(size_t)pos * 3 + k] = v[k]; M.fb[(size_t)pos * 3 + k] = v[3 + k]; }
+        else { for (int k = 0; k < 3; ++k) M.fn[(size_t)pos * 3 + k] = v[k]; M.fd[pos] = v[3]; }
+    }
+    if (b == nb - 1 && tid == 0) M.counts[which] = sbase + total;
 }
 
-/* Normal equations of the residual blocks at M.pose: LL_NEQ_NB workgroups accumulate their rows, the last one to arrive adds
- * the partial sums in workgroup order (a fixed order: the result does not depend on which workgroup came last). */
 __global__ __launch_bounds__(256) void k_map_normal_eq(LLMapView M)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -696,11 +719,20 @@ void ll_map_launch_build(const LLGrid3 &G, const float4 *pts, int n, int *tile_s
     if (n > 0) hipLaunchKernelGGL(k_map_scatter, dim3((n + LL_MAPB - 1) / LL_MAPB), dim3(LL_MAPB), 0, st, G, pts, n);
 }
 
+static void ll_map_launch_compact(const LLMapView &M, hipStream_t st)
+{
+    static std::atomic<unsigned> tag{0};                 /* distinguishes this launch's words from the previous launch's on the same map (never 0) */
+    LLMapView V = M;
+    V.cpub_tag = (int)(tag.fetch_add(1u) % 0x3fffffffu) + 1;
+    const int bc = max(1, (M.n_stk[0] + LL_CMPB - 1) / LL_CMPB), bs = max(1, (M.n_stk[1] + LL_CMPB - 1) / LL_CMPB);   /* >= 1: an empty stack still writes its count */
+    hipLaunchKernelGGL(k_map_compact, dim3(bc + bs), dim3(LL_CMPB), 0, st, V, bc);
+}
+
 void ll_map_launch_associate(const LLMapView &M, hipStream_t st)
 {
     const int bc = (M.n_stk[0] + LL_KNNB - 1) / LL_KNNB, bs = (M.n_stk[1] + LL_KNNB - 1) / LL_KNNB;
     if (bc + bs > 0) hipLaunchKernelGGL(k_map_knn, dim3(bc + bs), dim3(LL_KNNB), 0, st, M, bc);
-    hipLaunchKernelGGL(k_map_compact, dim3(2), dim3(1024), 0, st, M);
+    ll_map_launch_compact(M, st);
 }
 
 void ll_map_launch_knn_partial(const LLMapView &M, hipStream_t st)
@@ -713,7 +745,7 @@ void ll_map_launch_associate_merged(const LLMapView &M, int n_parts, const float
 {
     if (M.n_stk[0] > 0) hipLaunchKernelGGL(k_map_fit_merged<true>, dim3((M.n_stk[0] + LL_MAPB - 1) / LL_MAPB), dim3(LL_MAPB), 0, st, M, n_parts, pt_all[0], id_all[0]);
     if (M.n_stk[1] > 0) hipLaunchKernelGGL(k_map_fit_merged<false>, dim3((M.n_stk[1] + LL_MAPB - 1) / LL_MAPB), dim3(LL_MAPB), 0, st, M, n_parts, pt_all[1], id_all[1]);
-    hipLaunchKernelGGL(k_map_compact, dim3(2), dim3(1024), 0, st, M);
+    ll_map_launch_compact(M, st);
 }
 
 void ll_map_launch_normal_eq(const LLMapView &M, hipStream_t st)
