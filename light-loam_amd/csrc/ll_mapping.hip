@@ -253,8 +253,8 @@ __device__ __forceinline__ void ll_map_search5(const LLGrid3 &G, int n_map, cons
     int cx = (int)floorf((sx - G.org[0]) / G.cell), cy = (int)floorf((sy - G.org[1]) / G.cell), cz = (int)floorf((sz - G.org[2]) / G.cell);
     cx = min(max(cx, 0), G.dim[0] - 1); cy = min(max(cy, 0), G.dim[1] - 1); cz = min(max(cz, 0), G.dim[2] - 1);
     /* the nine (z, y) rows of the 27 cells: the three x-cells of a row are contiguous, so a row is one range.  All eighteen
-     * bounds first (independent loads), then the ranges in the same order as before, four points in flight: a thread's search
-     * is a chain of dependent round trips, and a frame's association is ~11 k of them on a chip that holds 65 k threads. */
+     * bounds first (independent loads): a thread's search is a chain of dependent round trips, and a frame's association is
+     * ~11 k of them on a chip that holds 65 k threads. */
     int st[9], en[9];
     const int x0 = max(cx - 1, 0), x1 = min(cx + 1, G.dim[0] - 1);
 #pragma unroll
@@ -266,22 +266,29 @@ __device__ __forceinline__ void ll_map_search5(const LLGrid3 &G, int n_map, cons
             st[r] = G.start[row + x0]; en[r] = G.start[row + x1 + 1];
         }
     }
+    /* all nine ranges advance together, two points of each per round: the five best are a total order on (distance, index), so
+     * the order of insertion does not matter, and a search is 2-3 round trips of up to eighteen loads instead of nine chains */
+    for (;;) {
+        float4 p[9][2];
+        bool any = false;
 #pragma unroll
-    for (int r = 0; r < 9; ++r) {
-        for (int k0 = st[r]; k0 < en[r]; k0 += 4) {
-            float4 p[4];
+        for (int r = 0; r < 9; ++r)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) if (k0 + u < en[r]) p[u] = G.pts[k0 + u];
+            for (int u = 0; u < 2; ++u) if (st[r] + u < en[r]) { p[r][u] = G.pts[st[r] + u]; any = true; }
+        if (!any) break;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (k0 + u >= en[r]) break;
-                float diff = sx - p[u].x; float d = diff * diff;               /* FLANN L2_Simple: a = query, b = data */
-                diff = sy - p[u].y; d += diff * diff;
-                diff = sz - p[u].z; d += diff * diff;
-                int j = __float_as_int(p[u].w);
+        for (int r = 0; r < 9; ++r) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (st[r] + u >= en[r]) continue;
+                float diff = sx - p[r][u].x; float d = diff * diff;            /* FLANN L2_Simple: a = query, b = data */
+                diff = sy - p[r][u].y; d += diff * diff;
+                diff = sz - p[r][u].z; d += diff * diff;
+                int j = __float_as_int(p[r][u].w);
                 if (WITH_PT && gid) j = gid[j];
-                ll_five_insert<WITH_PT>(bd, bi, bp, nb, d, j, p[u]);
+                ll_five_insert<WITH_PT>(bd, bi, bp, nb, d, j, p[r][u]);
             }
+            st[r] += 2;
         }
     }
 }

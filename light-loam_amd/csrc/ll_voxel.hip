@@ -258,7 +258,7 @@ __global__ __launch_bounds__(1024) void k_rs_scatter8(const unsigned long long *
 }
 
 /* the same sort for n <= 8192 pairs in ONE launch: one 1024-thread workgroup, keys and values in LDS between the
- * passes, digits that do not vary found on the device (no host read-back).  104 KB of dynamic LDS. */
+ * passes, digits that do not vary found on the device (no host read-back).  112 KB of dynamic LDS. */
 #define LL_RSS_ROWS 8
 #define LL_RSS_MAX (LL_RSS_ROWS * 1024)
 extern __shared__ __attribute__((aligned(16))) unsigned char ll_rss_smem[];
@@ -271,65 +271,80 @@ __global__ __launch_bounds__(1024) void k_rs_small(unsigned long long *keys, int
     else if (chunk > 0) { const int base = blockIdx.x * chunk; n = min(chunk, n - base); keys += base; vals += base; }   /* workgroup b: the b-th chunk on its own */
     unsigned long long *lk = (unsigned long long *)ll_rss_smem;           /* [LL_RSS_MAX] */
     int *lv = (int *)(lk + LL_RSS_MAX);                                     /* [LL_RSS_MAX] */
-    int *cnt = lv + LL_RSS_MAX;                                             /* [16][LL_RSS_ROWS * 16] */
+    int *cnt = lv + LL_RSS_MAX;                                             /* [16 waves][256 digits] */
     __shared__ int sc[16];
     __shared__ unsigned long long oa[2];
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    /* Record g lives in wave g / (64 nrows), row (g / 64) % nrows, lane g % 64: (wave, row, lane) is the input order.  A wave ranks
+     * its rows one after the other into its OWN 256 counters (its LDS operations execute in order, so a row reads what the rows
+     * before it added), the rank inside a row is a wave match-any, and one scan of the digit-major (digit, wave) table turns
+     * the counters into bases -- the scheme of k_ring_features' voxel sort: 8-bit digits, a third of the passes of a 4-bit
+     * sort with per-row counters. */
     const int nrows = (n + 1023) >> 10;
+    const int wbase = wave * nrows * 64;
     unsigned long long k[LL_RSS_ROWS]; int v[LL_RSS_ROWS];
     unsigned long long o = 0ull, a = ~0ull;
 #pragma unroll
     for (int r = 0; r < LL_RSS_ROWS; ++r) {
-        const int i = r * 1024 + tid;
+        const int i = wbase + r * 64 + lane;
         k[r] = ~0ull; v[r] = 0;
         if (r < nrows && i < n) { k[r] = keys[i]; v[r] = vals[i]; o |= k[r]; a &= k[r]; }
     }
     if (tid == 0) { oa[0] = 0ull; oa[1] = ~0ull; }
     __syncthreads();
     for (int s_ = 32; s_ > 0; s_ >>= 1) { o |= __shfl_xor(o, s_); a &= __shfl_xor(a, s_); }
-    if ((tid & 63) == 0) { atomicOr(&oa[0], o); atomicAnd(&oa[1], a); }
+    if (lane == 0) { atomicOr(&oa[0], o); atomicAnd(&oa[1], a); }
     __syncthreads();
     const unsigned long long vary = oa[0] ^ oa[1];
-    for (int shift = 0; shift < 64; shift += 4) {
-        if (((vary >> shift) & 15ull) == 0ull) continue;
-        cnt[tid] = 0; cnt[1024 + tid] = 0;
+    int *wc = cnt + wave * 256;
+    for (int shift = 0; shift < 64; shift += 8) {
+        if (((vary >> shift) & 255ull) == 0ull) continue;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cnt[u * 1024 + tid] = 0;
         __syncthreads();
         int rnk[LL_RSS_ROWS];
 #pragma unroll
         for (int r = 0; r < LL_RSS_ROWS; ++r) {
             rnk[r] = 0;
             if (r < nrows) {                                               /* the padding (all-ones keys) takes part and stays last */
-                const int d = (int)((k[r] >> shift) & 15ull);
+                const int d = (int)((k[r] >> shift) & 255ull);
                 unsigned mlo, mhi;
-                ll_match_any(d, 4, ~0ull, mlo, mhi);
-                rnk[r] = ll_match_rank(mlo, mhi);
-                if (rnk[r] == 0) cnt[d * (LL_RSS_ROWS * 16) + r * 16 + wave] = ll_match_count(mlo, mhi);
+                ll_match_any(d, 8, ~0ull, mlo, mhi);
+                const int rk = ll_match_rank(mlo, mhi);
+                const int pre = wc[d];                                     /* same digit, earlier rows of this wave */
+                if (rk == 0) atomicAdd(&wc[d], ll_match_count(mlo, mhi));
+                rnk[r] = pre + rk;
             }
         }
         __syncthreads();
-        {   /* exclusive scan of the 2048 digit-major counters: two consecutive ones per thread */
-            const int c0 = cnt[2 * tid], c1 = cnt[2 * tid + 1];
+        {   /* exclusive scan of the (digit, wave) table in digit-major order: thread d < 256 owns digit d */
+            int vv[16]; int s_ = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) { vv[w] = (tid < 256) ? cnt[w * 256 + tid] : 0; s_ += vv[w]; }
             int total;
-            const int ex = ll_block_exscan_n<16>(c0 + c1, sc, total);
-            cnt[2 * tid] = ex; cnt[2 * tid + 1] = ex + c0;
+            int run = ll_block_exscan_n<16>(s_, sc, total);
+            if (tid < 256) {
+#pragma unroll
+                for (int w = 0; w < 16; ++w) { cnt[w * 256 + tid] = run; run += vv[w]; }
+            }
         }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < LL_RSS_ROWS; ++r)
             if (r < nrows) {
-                const int d = (int)((k[r] >> shift) & 15ull);
-                const int pos = cnt[d * (LL_RSS_ROWS * 16) + r * 16 + wave] + rnk[r];
+                const int d = (int)((k[r] >> shift) & 255ull);
+                const int pos = wc[d] + rnk[r];
                 lk[pos] = k[r]; lv[pos] = v[r];
             }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < LL_RSS_ROWS; ++r)
-            if (r < nrows) { k[r] = lk[r * 1024 + tid]; v[r] = lv[r * 1024 + tid]; }
+            if (r < nrows) { k[r] = lk[wbase + r * 64 + lane]; v[r] = lv[wbase + r * 64 + lane]; }
         __syncthreads();
     }
 #pragma unroll
     for (int r = 0; r < LL_RSS_ROWS; ++r) {
-        const int i = r * 1024 + tid;
+        const int i = wbase + r * 64 + lane;
         if (r < nrows && i < n) { keys[i] = k[r]; vals[i] = v[r]; }
     }
 }
@@ -382,7 +397,7 @@ __global__ __launch_bounds__(256) void k_rs_copy_pairs(const unsigned long long 
 void ll_sort_pairs_segments(unsigned long long *keys, int *vals, const int *seg_off_dev, int nseg, hipStream_t st)
 {
     if (nseg <= 0) return;
-    const size_t lds = (size_t)LL_RSS_MAX * 12 + 16 * LL_RSS_ROWS * 16 * sizeof(int);
+    const size_t lds = (size_t)LL_RSS_MAX * 12 + 16 * 256 * sizeof(int);
     static size_t attr_bytes[LL_MAX_DEVICES] = {0};
     ll_ensure_dynamic_lds(k_rs_small, lds, attr_bytes);
     hipLaunchKernelGGL(k_rs_small, dim3(nseg), dim3(1024), lds, st, keys, vals, 0, seg_off_dev, 0);
@@ -395,7 +410,7 @@ int ll_sort_pairs(unsigned long long *keys, int *vals, unsigned long long *tmp_k
 {
     if (n <= 1) return 0;
     if (n <= LL_RSS_MAX) {
-        const size_t lds = (size_t)LL_RSS_MAX * 12 + 16 * LL_RSS_ROWS * 16 * sizeof(int);
+        const size_t lds = (size_t)LL_RSS_MAX * 12 + 16 * 256 * sizeof(int);
         static size_t attr_bytes[LL_MAX_DEVICES] = {0};
         ll_ensure_dynamic_lds(k_rs_small, lds, attr_bytes);
         hipLaunchKernelGGL(k_rs_small, dim3(1), dim3(1024), lds, st, keys, vals, n, (const int *)nullptr, 0);
@@ -406,7 +421,7 @@ int ll_sort_pairs(unsigned long long *keys, int *vals, unsigned long long *tmp_k
          * every pair placed by its rank among ALL chunks -- its place in its chunk plus, by binary search, the number of
          * pairs of the other chunks that go before it (<= K in the chunks before its own, < K in those behind: stable).
          * Three launches and no host read-back, against ~16 launches and one read-back for the device-wide passes. */
-        const size_t lds = (size_t)LL_RSS_MAX * 12 + 16 * LL_RSS_ROWS * 16 * sizeof(int);
+        const size_t lds = (size_t)LL_RSS_MAX * 12 + 16 * 256 * sizeof(int);
         static size_t attr_bytes[LL_MAX_DEVICES] = {0};
         ll_ensure_dynamic_lds(k_rs_small, lds, attr_bytes);
         const int nch = (n + LL_RSS_MAX - 1) / LL_RSS_MAX;
