@@ -782,3 +782,22 @@ def test_vote_against_independent_python_restatement(orc, n, outliers):
     assert dict(zip(idx.tolist(), w.tolist())) == wsel
     if n >= 95:
         assert 0 < len(idx) < n or outliers < 30
+
+
+def test_hdl64_generator_is_off_centre_and_deterministic(orc):
+    """The config-3 stand-in (lightloam_amd/hdl64.py): same bytes for the same (k, order, seed); the oracle accepts the scan;
+    some bin of the linear 64-ring model holds two lasers (a ring beyond the 2304-point default capacity, which is what makes
+    the HIP path's long-ring tiers run in tests/test_gpu_config3.py); KITTI order and firing order are the same point set."""
+    import scangen
+    a = scangen.hdl64_scan(2)
+    assert a.tobytes() == scangen.hdl64_scan(2).tobytes() and a.dtype == np.float32 and a.shape[1] == 4
+    f = orc.extract(a, orc.params(64))
+    assert f["rc"] == 0 and len(f["sharp"]) > 300 and len(f["less_flat"]) > 15000
+    ring_len = f["scan_end"] - f["scan_start"] + 11
+    assert ring_len.max() > 2304 and (ring_len > 2304).sum() >= 3
+    # elevations really fall off the bin centres: the fractional ring coordinate of scanRegistration.cpp:162 is spread out
+    ang = np.degrees(np.arctan2(a[:, 2], np.hypot(a[:, 0], a[:, 1])))
+    frac = ((ang + 24.9) * (63.0 / 26.9)) % 1.0
+    assert 0.2 < np.mean((frac > 0.25) & (frac < 0.75)) < 0.8
+    b = scangen.hdl64_scan(2, order="firing")
+    assert len(b) == len(a) and np.array_equal(np.sort(a.view(np.uint32).reshape(-1, 4), axis=0), np.sort(b.view(np.uint32).reshape(-1, 4), axis=0))
