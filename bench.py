@@ -411,6 +411,27 @@ def bench_map(args, rank, local_rank, world):
     dist.barrier(); dist.destroy_process_group()
 
 
+def traffic_from_profile(args, kernel, launches_per_step, path=None):
+    """(HBM bytes per launch of `kernel` or None, why) from profiles/pmc_traffic.json -- the separate rocprofv3 FETCH_SIZE / WRITE_SIZE
+    passes of this same command (tools/pmc_traffic.py, stamped by tools/profile_round.sh) -- used ONLY when the file was measured on
+    THIS code (source digest), ring count, workload and batch."""
+    tpath = path or os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(tpath):
+        return None, "profiles/pmc_traffic.json absent"
+    try:
+        T = json.load(open(tpath))
+        want = {"source_digest": source_digest(), "rings": args.rings, "batch": args.batch, "workload": args.workload}
+        diff = sorted(k for k, v in want.items() if T.get(k) != v)
+        if diff:
+            return None, "profiles/pmc_traffic.json was measured on another " + ", ".join(diff) + ": not used"
+        if kernel not in T.get("kernels", {}):
+            return None, "profiles/pmc_traffic.json has no entry for " + kernel
+        return (T["kernels"][kernel]["hbm_bytes_per_scan"] * args.batch / launches_per_step,
+                "rocprofv3 FETCH_SIZE + WRITE_SIZE passes of this command at this source digest (tools/profile_round.sh)")
+    except Exception as e:
+        return None, "profiles/pmc_traffic.json unreadable: " + repr(e)[:80]
+
+
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` without a launcher: start N fresh child processes of this same command line, one per GPU, with
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (what torch.distributed.run would set), relay rank 0's stdout --
@@ -636,22 +657,7 @@ def main():
         bytes_per_launch = kernel_bytes[dom] / launches_per_step
         avg_ms = dom_ms / max(1, dom_launches)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # HBM traffic of that kernel from the separate rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py, stamped by
-        # tools/profile_round.sh): only when the file was measured on THIS code (source digest), ring count, workload and batch
-        traffic = None; traffic_note = "profiles/pmc_traffic.json absent"
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                T = json.load(open(tpath))
-                want = {"source_digest": source_digest(), "rings": args.rings, "batch": args.batch, "workload": args.workload}
-                diff = {k: (T.get(k), v) for k, v in want.items() if T.get(k) != v}
-                if diff:
-                    traffic_note = "profiles/pmc_traffic.json was measured on another " + ", ".join(sorted(diff)) + ": not used"
-                elif dom in T.get("kernels", {}):
-                    traffic = T["kernels"][dom]["hbm_bytes_per_scan"] * args.batch / launches_per_step
-                    traffic_note = "rocprofv3 FETCH_SIZE + WRITE_SIZE passes of this command at this source digest (tools/profile_round.sh)"
-            except Exception as e:
-                traffic = None; traffic_note = "profiles/pmc_traffic.json unreadable: " + repr(e)[:80]
+        traffic, traffic_note = traffic_from_profile(args, dom, launches_per_step)
         out = {
             "metric": metric_name(args),
             "value": value, "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

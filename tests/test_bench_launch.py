@@ -79,3 +79,28 @@ def test_self_launched_two_ranks_share_the_gpu_over_gloo():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["scans_per_gpu_per_step"] == 256 and abs(d["value"] - 2 * 256 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
     assert d["metric"].endswith("64-ring cloud")
+
+
+def test_traffic_is_taken_from_the_profile_only_when_its_stamp_matches(tmp_path):
+    """roofline.traffic comes from profiles/pmc_traffic.json ONLY when that file was measured on this code (source digest), ring
+    count, workload and batch -- a stale file must not dress a new kernel in an old number."""
+    import argparse
+    sys.path.insert(0, ROOT)
+    import bench
+    args = argparse.Namespace(rings=64, batch=16384, workload="synthetic")
+    good = {"source_digest": bench.source_digest(), "rings": 64, "batch": 16384, "workload": "synthetic",
+            "kernels": {"k_ring_features": {"hbm_bytes_per_scan": 6.5e6}}}
+    p = tmp_path / "t.json"
+    p.write_text(json.dumps(good))
+    t, why = bench.traffic_from_profile(args, "k_ring_features", 1, str(p))
+    assert t == 6.5e6 * 16384 and "source digest" in why
+    for key, val in (("source_digest", "0" * 16), ("rings", 128), ("batch", 8192), ("workload", "hdl64")):
+        p.write_text(json.dumps(dict(good, **{key: val})))
+        t, why = bench.traffic_from_profile(args, "k_ring_features", 1, str(p))
+        assert t is None and key in why
+    t, why = bench.traffic_from_profile(args, "k_ring_features", 1, str(tmp_path / "absent.json"))
+    assert t is None and "absent" in why
+    # the committed file is the one tools/profile_round.sh stamped; whether it matches this tree is reported, never assumed
+    t, why = bench.traffic_from_profile(args, "k_ring_features", 1)
+    assert (t is None) == ("not used" in why or "absent" in why or "no entry" in why)
+    assert len(bench.source_digest()) == 16
