@@ -360,9 +360,11 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : ROWS <= 12 ? 5 :
     if (tid == 0) L.sc[60] = 0;                                       /* segments finished (bit j) */
     __syncthreads();
 
-    /* the picked points of the per-segment lists, fetched before the look-back wait: thread t holds entry t of each list
-     * and its position (segment, pick order) among the ring's sharp / less-sharp / flat points, -1 = no entry */
-    float4 fpt[3]; int fpos[3] = {-1, -1, -1};
+    /* the picked points of the per-segment lists: thread t holds the local index of entry t of each list and its position
+     * (segment, pick order) among the ring's sharp / less-sharp / flat points, -1 = no entry */
+    /* (only where the points ARE goes across the wait: the three points themselves, fetched ahead of it, used to live in
+     * scratch memory for its whole length -- 12 KB written and read back per ring, more than half of the kernel's write traffic) */
+    int fsrc0 = 0, fsrc1 = 0, fsrc2 = 0; int fpos[3] = {-1, -1, -1};
     auto gather_lists = [&]() __attribute__((always_inline)) {
         const int js = tid / LL_SHARP_PER_SEG, jl = tid / LL_LSHARP_PER_SEG, jf = tid / LL_FLAT_PER_SEG;
         int os = 0, ol = 0, of = 0;
@@ -371,9 +373,9 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : ROWS <= 12 ? 5 :
             if (j < jl) ol += L.lists[157 + j * 3];
             if (j < jf) of += L.lists[158 + j * 3];
         }
-        if (js < LL_SEGS && tid % LL_SHARP_PER_SEG < L.lists[156 + js * 3]) { fpos[0] = os + tid % LL_SHARP_PER_SEG; fpt[0] = cloud[off + L.lists[tid]]; }
-        if (jl < LL_SEGS && tid % LL_LSHARP_PER_SEG < L.lists[157 + jl * 3]) { fpos[1] = ol + tid % LL_LSHARP_PER_SEG; fpt[1] = cloud[off + L.lists[12 + tid]]; }
-        if (jf < LL_SEGS && tid % LL_FLAT_PER_SEG < L.lists[158 + jf * 3]) { fpos[2] = of + tid % LL_FLAT_PER_SEG; fpt[2] = cloud[off + L.lists[132 + tid]]; }
+        if (js < LL_SEGS && tid % LL_SHARP_PER_SEG < L.lists[156 + js * 3]) { fpos[0] = os + tid % LL_SHARP_PER_SEG; fsrc0 = L.lists[tid]; }
+        if (jl < LL_SEGS && tid % LL_LSHARP_PER_SEG < L.lists[157 + jl * 3]) { fpos[1] = ol + tid % LL_LSHARP_PER_SEG; fsrc1 = L.lists[12 + tid]; }
+        if (jf < LL_SEGS && tid % LL_FLAT_PER_SEG < L.lists[158 + jf * 3]) { fpos[2] = of + tid % LL_FLAT_PER_SEG; fsrc2 = L.lists[132 + tid]; }
     };
     auto write_labels = [&]() __attribute__((always_inline)) {
         int8_t *label = V.label + (size_t)s * V.NP + off;
@@ -796,14 +798,20 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : ROWS <= 12 ? 5 :
     seg_totals(ns, nls, nf);
     if (!looked_back) { publish(ns, nls, nf, n_lf_out); write_labels(); gather_lists(); if (!stage_only) prefix(roff); }   /* rings without a less-flat point */
     if (stage_only) {
-        if (fpos[0] >= 0) stage_sf[fpos[0]] = fpt[0];
-        if (fpos[1] >= 0) stage_ls[fpos[1]] = fpt[1];
-        if (fpos[2] >= 0) stage_sf[LL_SEGS * LL_SHARP_PER_SEG + fpos[2]] = fpt[2];
+        if (fpos[0] >= 0) stage_sf[fpos[0]] = cloud[off + fsrc0];
+        if (fpos[1] >= 0) stage_ls[fpos[1]] = cloud[off + fsrc1];
+        if (fpos[2] >= 0) stage_sf[LL_SEGS * LL_SHARP_PER_SEG + fpos[2]] = cloud[off + fsrc2];
         return;
     }
-    if (fpos[0] >= 0) V.sharp[(size_t)s * V.cap_sharp + roff[0] + fpos[0]] = fpt[0];
-    if (fpos[1] >= 0) V.lsharp[(size_t)s * V.cap_lsharp + roff[1] + fpos[1]] = fpt[1];
-    if (fpos[2] >= 0) V.flat[(size_t)s * V.cap_flat + roff[2] + fpos[2]] = fpt[2];
+    {   /* the three loads together, then the three stores */
+        float4 p0, p1, p2;
+        if (fpos[0] >= 0) p0 = cloud[off + fsrc0];
+        if (fpos[1] >= 0) p1 = cloud[off + fsrc1];
+        if (fpos[2] >= 0) p2 = cloud[off + fsrc2];
+        if (fpos[0] >= 0) V.sharp[(size_t)s * V.cap_sharp + roff[0] + fpos[0]] = p0;
+        if (fpos[1] >= 0) V.lsharp[(size_t)s * V.cap_lsharp + roff[1] + fpos[1]] = p1;
+        if (fpos[2] >= 0) V.flat[(size_t)s * V.cap_flat + roff[2] + fpos[2]] = p2;
+    }
     if (r == V.R - 1 && tid == 0) {                                            /* the scan's totals */
         ScanHdr *hh = &V.hdr[s];
         hh->n_sharp = roff[0] + ns; hh->n_less_sharp = roff[1] + nls; hh->n_flat = roff[2] + nf; hh->n_less_flat = roff[3] + n_lf_out;
