@@ -449,13 +449,38 @@ def launch_ranks(args, argv):
     if args.dry_launch:
         emit({"dry_launch": True, "n_ranks": n, "command": cmd, "rank_env": envs, "parent_imported_torch": "torch" in sys.modules})
         return 0
+    import tempfile
     procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")                   # rank 0's stdout (a file, not a pipe: nothing to drain while polling)
     for r in range(n):
         env = dict(os.environ); env.update(envs[r])
-        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    lines = [ln for ln in (out0 or "").splitlines() if ln.strip()]
+        procs.append(subprocess.Popen(cmd, env=env, stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
+    # a rank that dies (no such device, out of memory ...) would leave the others waiting in the rendezvous or a collective for
+    # minutes: the first non-zero exit ends the run -- the survivors get a moment to finish, then they are terminated (they are
+    # this process's own children, addressed by their exact pids)
+    rcs = [None] * n
+    failed_at = None
+    while any(c is None for c in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+        if failed_at is None and any(c not in (None, 0) for c in rcs):
+            failed_at = time.monotonic()
+        if failed_at is not None and time.monotonic() - failed_at > 15.0:
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    p.terminate()
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    try:
+                        rcs[r] = p.wait(timeout=10)
+                    except subprocess.TimeoutExpired:
+                        p.kill(); rcs[r] = p.wait()
+            break
+        time.sleep(0.1)
+    out0.seek(0)
+    lines = [ln for ln in out0.read().splitlines() if ln.strip()]
+    out0.close()
     for ln in lines[:-1]:
         print(ln)
     rc = next((c for c in rcs if c != 0), 0)
