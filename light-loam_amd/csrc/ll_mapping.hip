@@ -440,18 +440,28 @@ __global__ __launch_bounds__(LL_CMPB) void k_map_compact(LLMapView M, int blocks
     unsigned long long *pub = M.cpub[which];
     const unsigned long long tag = (unsigned long long)(unsigned)M.cpub_tag << 32;
     if (tid == 0) __hip_atomic_store(&pub[b], tag | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __shared__ int slost;
     int before = 0;
+    bool lost = false;
     for (int q = tid; q < b; q += LL_CMPB) {
         unsigned long long w; int spins = 0;
         while (((w = __hip_atomic_load(&pub[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != (unsigned)M.cpub_tag && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(8);
-        if ((w >> 32) != (unsigned)M.cpub_tag) __builtin_trap();       /* never published: abort the launch, never a silently wrong block list */
+        if ((w >> 32) != (unsigned)M.cpub_tag) lost = true;
         before += (int)(w & 0xffffffffull);
     }
     before = ll_wave_sum_i32(before);
-    if (tid == 0) sbase = 0;
+    if (tid == 0) { sbase = 0; slost = 0; }
     __syncthreads();
     if (lane == 0 && before) atomicAdd(&sbase, before);
+    if (lost) slost = 1;
     __syncthreads();
+    if (slost) {
+        /* an earlier block never published (a logic error, not a race: they are dispatched first): never a silently wrong block list --
+         * this block places nothing and poisons the pose, so that the solve that follows hands back NaN (what ll_map_solve's callers
+         * already have to check for, map_lm_repair) */
+        if (tid == 0) { M.pose[0] = __builtin_nan(""); if (b == nb - 1) M.counts[which] = 0; }
+        return;
+    }
     const int pos = sbase + lpos;
     if (ok) {
         M.src[which][pos] = i;

@@ -1,7 +1,8 @@
 """Reduced soaks of the batch path (tools/soak_extract.py, tools/soak_extract_s64.py: the full runs' logs are kept under
 profiles/): many random irregular scans and synthetic 64-ring scans of three generator settings through k_organize + the ring
 kernel (more than 64 slots: the one-workgroup-per-scan organise path) against the oracle, bit for bit, plus association index
-tuples on every fifth scan."""
+tuples on every fifth scan; and tools/soak_hot_path.py: the stages downstream of the feature clouds (association, vote, normal
+equations, Gauss-Newton step) on consecutive scans of four data shapes with a random pose guess per slot."""
 import os
 import subprocess
 import sys
@@ -30,3 +31,9 @@ def test_s64_generator_settings_soak_36():
     # 12-scan calls through k_organize, the path batches of more than 64 scans take
     out = _run("soak_extract_s64.py", 12, LIGHTLOAM_ORG_SMALL="0")
     assert "soak passed: 36 scans" in out
+
+
+def test_hot_path_soak_4_shapes_x_9_pairs():
+    # the committed log: 4 shapes x 255 pairs
+    out = _run("soak_hot_path.py", 10)
+    assert "hot-path soak passed: 36 scan pairs" in out
