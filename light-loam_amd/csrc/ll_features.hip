@@ -259,8 +259,7 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : ROWS <= 12 ? 5 :
     const int off = V.ring_off[(size_t)s * (V.R + 1) + r];
     const int nr = V.ring_off[(size_t)s * (V.R + 1) + r + 1] - off;
     if (h.status != 0) return;                                        /* every ring of the scan takes this exit: nobody waits */
-    if (nr <= ring_lo || (stage_only && nr > ring_hi)) return;        /* another tier's ring */
-    const bool placer = nr > ring_hi;                                 /* main launch, a ring that an earlier tier has staged */
+    if (nr <= ring_lo || nr > ring_hi) return;                        /* another tier's ring (a longer ring that an earlier tier has staged: k_ring_place moves it) */
     const int N = h.n;
     /* One 64-bit word per ring carries the four counts AND the launch tag, written and polled with relaxed atomics: no
      * release / acquire fence is needed (at agent scope those write back / invalidate the whole L2 on this chip). */
@@ -334,25 +333,6 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : ROWS <= 12 ? 5 :
     float4 *stage_lf = V.gpts_s + (size_t)s * V.NP + off;                                  /* less-flat: at the ring's laserCloud offset */
     float4 *stage_ls = V.gpts_c + (size_t)s * V.cap_lsharp + (size_t)r * (LL_SEGS * LL_LSHARP_PER_SEG);
     float4 *stage_sf = V.stage_sf + ((size_t)s * V.R + r) * LL_STAGE_SF;                   /* sharp [12], flat [24] */
-    if (placer) {
-        /* the ring's lists were staged and its counts published by an earlier launch: wait for the rings before it like
-         * everybody else, then move the lists to their place */
-        prefix(roff);
-        int c[4] = {0, 0, 0, 0};
-        if (tid == 0) { ll_poll(r, c); L.sc[32] = c[0]; L.sc[33] = c[1]; L.sc[34] = c[2]; L.sc[35] = c[3]; }
-        __syncthreads();
-        for (int k = 0; k < 4; ++k) c[k] = L.sc[32 + k];
-        if (tid < c[0]) V.sharp[(size_t)s * V.cap_sharp + roff[0] + tid] = stage_sf[tid];
-        if (tid < c[1]) V.lsharp[(size_t)s * V.cap_lsharp + roff[1] + tid] = stage_ls[tid];
-        if (tid < c[2]) V.flat[(size_t)s * V.cap_flat + roff[2] + tid] = stage_sf[LL_SEGS * LL_SHARP_PER_SEG + tid];
-        float4 *out = V.lflat + (size_t)s * V.NP + roff[3];
-        for (int i = tid; i < c[3]; i += LL_BLOCK) out[i] = stage_lf[i];
-        if (r == V.R - 1 && tid == 0) {
-            ScanHdr *hh = &V.hdr[s];
-            hh->n_sharp = roff[0] + c[0]; hh->n_less_sharp = roff[1] + c[1]; hh->n_flat = roff[2] + c[2]; hh->n_less_flat = roff[3] + c[3];
-        }
-        return;
-    }
     const int nwords = (nr + 31) / 32 + 1;
     for (int i = tid; i < nwords; i += LL_BLOCK) { L.picked[i] = 0; L.gapf[i] = 0; }
     for (int i = tid; i < (nr + 3) / 4; i += LL_BLOCK) ((unsigned *)L.lab)[i] = 0u;   /* labels, four at a time (the array is 4-byte aligned and padded) */
@@ -831,6 +811,48 @@ static void ll_launch_ring_features(const LLView &V, int first, int count, int g
     hipLaunchKernelGGL(k_ring_features<ROWS>, dim3(grid), dim3(LL_BLOCK), lds_bytes, st, V, first, count, ring_lo, ring_hi, stage_only);
 }
 
+/* The long rings' lists were staged and their counts published by the tier launches; the main launch's rings have looked back at those
+ * counts and stored around them.  One workgroup per scan -- on the XCD its rings ran on (scan sl <-> XCD sl % 8, ll_xcd_map2) -- reads all
+ * ring words (every ring has published: the launches before this one are complete), scans the four counts over the rings and moves the
+ * staged lists to their places.  (Until round 3 the long rings sat in the main launch as workgroups that did nothing but wait for their
+ * predecessors' counts -- a fifth of an HDL-64E scan's workgroups holding a slot of the CU for most of a ring's run time.) */
+__global__ __launch_bounds__(LL_BLOCK) void k_ring_place(LLView V, int first, int count, int ring_hi)
+{
+    const int sl = blockIdx.x;
+    if (sl >= count) return;
+    const int s = first + sl, tid = threadIdx.x, R = V.R;
+    ScanHdr *hh = &V.hdr[s];
+    if (hh->status != 0) return;
+    __shared__ int cnt[4][LL_MAX_RINGS], pre[4][LL_MAX_RINGS + 1];
+    __shared__ int lost;
+    const int *ro = V.ring_off + (size_t)s * (R + 1);
+    if (tid == 0) lost = 0;
+    __syncthreads();
+    if (tid < R) {
+        const unsigned long long w = __hip_atomic_load(&V.ring_pub[(size_t)s * R + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((w >> 40) != (unsigned long long)V.epoch) lost = 1;                           /* a ring that never published: fail loudly (LL_ERR_STATE) */
+        cnt[0][tid] = (int)(w & 15u); cnt[2][tid] = (int)((w >> 4) & 31u); cnt[1][tid] = (int)((w >> 9) & 127u); cnt[3][tid] = (int)((w >> 16) & 0xffffffu);
+    }
+    __syncthreads();
+    if (lost) { if (tid == 0) hh->status = -7; return; }
+    if (tid < 4) { int run = 0; for (int r = 0; r < R; ++r) { pre[tid][r] = run; run += cnt[tid][r]; } pre[tid][R] = run; }
+    __syncthreads();
+    for (int r = 0; r < R; ++r) {
+        const int off = ro[r], nr = ro[r + 1] - off;
+        if (nr <= ring_hi) continue;
+        const float4 *stage_lf = V.gpts_s + (size_t)s * V.NP + off;
+        const float4 *stage_ls = V.gpts_c + (size_t)s * V.cap_lsharp + (size_t)r * (LL_SEGS * LL_LSHARP_PER_SEG);
+        const float4 *stage_sf = V.stage_sf + ((size_t)s * R + r) * LL_STAGE_SF;
+        if (tid < cnt[0][r]) V.sharp[(size_t)s * V.cap_sharp + pre[0][r] + tid] = stage_sf[tid];
+        if (tid < cnt[1][r]) V.lsharp[(size_t)s * V.cap_lsharp + pre[1][r] + tid] = stage_ls[tid];
+        if (tid < cnt[2][r]) V.flat[(size_t)s * V.cap_flat + pre[2][r] + tid] = stage_sf[LL_SEGS * LL_SHARP_PER_SEG + tid];
+        float4 *out = V.lflat + (size_t)s * V.NP + pre[3][r];
+        for (int i = tid; i < cnt[3][r]; i += LL_BLOCK) out[i] = stage_lf[i];
+    }
+    /* the scan's totals are the last ring's offsets + counts: written by that ring in the main launch unless it is a long one */
+    if (tid == 0 && ro[R] - ro[R - 1] > ring_hi) { hh->n_sharp = pre[0][R]; hh->n_less_sharp = pre[1][R]; hh->n_flat = pre[2][R]; hh->n_less_flat = pre[3][R]; }
+}
+
 void ll_launch_features(const LLView &V, int first, int count, size_t /* LDS of the largest tier: checked by ll_create */, hipStream_t st, LLProfiler *prof)
 {
     const int groups = (count + 7) / 8;
@@ -842,5 +864,6 @@ void ll_launch_features(const LLView &V, int first, int count, size_t /* LDS of 
     if (cap > 3072) ll_launch_ring_features<18>(V, first, count, grid, 3072, cap < 4608 ? cap : 4608, 1, st);
     if (cap > 2304) ll_launch_ring_features<12>(V, first, count, grid, 2304, cap < 3072 ? cap : 3072, 1, st);   /* two lasers of a 64-beam sensor in one bin: five workgroups per CU */
     ll_launch_ring_features<9>(V, first, count, grid, INT_MIN, cap < 2304 ? cap : 2304, 0, st);
+    if (cap > 2304) hipLaunchKernelGGL(k_ring_place, dim3(count), dim3(LL_BLOCK), 0, st, V, first, count, 2304);
     ll_prof_mark(prof, LL_K_END, st);
 }
