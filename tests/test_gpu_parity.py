@@ -276,6 +276,24 @@ def _assert_extract_equal(api, orc, scan, rings, what, max_ring_points=2304, **p
     return ref
 
 
+@pytest.mark.parametrize("lengths", [
+    # VLP-16 rings (elevation -15 + 2 k deg); lengths beyond 2304 go through the 12- / 18-row tier launches, are staged and moved by
+    # k_ring_place; the others are extracted by the main launch around the long rings' published counts
+    pytest.param([2600, 900, 1200, 0, 3500, 1800, 2305, 2304, 700, 0, 1500, 3073, 3072, 1000, 800, 2900], id="last ring long: the placer writes the scan's totals"),
+    pytest.param([4400, 2400, 2500, 2600, 2700, 2800, 2900, 3000, 3100, 3200, 3300, 3400, 3500, 3600, 3700, 0], id="every ring long, last ring empty"),
+    pytest.param([1000, 1100, 1200, 1300, 3000, 1500, 1600, 1700, 1800, 1900, 2000, 2100, 2200, 2300, 4000, 500], id="two long rings among short ones"),
+])
+def test_rings_of_every_tier_in_one_scan(api, orc, lengths):
+    rng = np.random.default_rng(len(lengths) + sum(lengths))
+    rings = []
+    for k, n in enumerate(lengths):
+        if n == 0:
+            continue
+        az_r = 6.0 + 2.0 * np.sin(np.arange(n) * (2 * np.pi / n) * 3 + k) + (rng.random(n) < 0.02) * rng.uniform(0.3, 1.5, n) + rng.normal(0, 0.004, n)
+        rings.append(_vlp16_ring(-15 + 2 * k, n, az_r, phase=0.25 * (k % 4)))
+    _assert_extract_equal(api, orc, _ring_scan(rings), 16, "mixed tiers", max_ring_points=4608)
+
+
 def _square_room_ring(z, half=8.0, step=1.0 / 32, bump_every=16, bump=0.5):
     """One sweep (clockwise from azimuth 0) along the walls of a square room, points every `step`; every
     `bump_every`-th point is pushed `bump` outwards.  All coordinates are small multiples of 2^-5, so the 11-tap
