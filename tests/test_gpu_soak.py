@@ -14,9 +14,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(tool, arg, **extra_env):
+def _run(tool, *args, **extra_env):
     env = dict(os.environ, GRAFT_REPO_ROOT=ROOT, **extra_env)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), str(arg)], capture_output=True, text=True, env=env, timeout=900)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)] + [str(a) for a in args], capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     return out.stdout
 
@@ -37,3 +37,9 @@ def test_hot_path_soak_4_shapes_x_9_pairs():
     # the committed log: 4 shapes x 255 pairs
     out = _run("soak_hot_path.py", 10)
     assert "hot-path soak passed: 36 scan pairs" in out
+
+
+def test_frame_loops_soak_2_drives():
+    # odometry frame loop + free-running cube map on a synthetic and an HDL-64E drive (the committed log: 2 x 399 / 2 x 200 frames)
+    out = _run("soak_frames.py", 14, 8)
+    assert "frame-loop soak passed: 2 x 13 odometry frames, 2 x 8 mapping frames" in out

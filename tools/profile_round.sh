@@ -34,6 +34,7 @@ python3 bench.py --stream-input --rings 128 --no-cpu-baseline > $O/${TAG}_stream
 python3 tools/soak_extract.py 8 > $O/${TAG}_soak_extract.log 2>&1
 python3 tools/soak_extract_s64.py 96 > $O/${TAG}_soak_extract_s64.log 2>&1
 python3 tools/soak_hot_path.py 256 2>&1 | grep -v amdgpu.ids > $O/${TAG}_soak_hot_path.log
+python3 tools/soak_frames.py 120 60 2>&1 | grep -v "amdgpu.ids\|RuntimeWarning\|org_s" > $O/${TAG}_soak_frames_short.log
 # keep what is merged back small: the raw counter tables and traces stay on the box
 rm -rf $O/prof_$TAG $O/prof_${TAG}_hdl64 $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/liblightloam_hip_phase.so
 tail -n 3 $O/${TAG}_kernel_stats.txt; tail -c 600 $O/${TAG}_bench.json
