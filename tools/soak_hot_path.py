@@ -1,6 +1,6 @@
 """Soak of the stages DOWNSTREAM of the feature clouds through the batch hot path, against the oracle:
 N consecutive scans of four data shapes (three settings of the synthetic 64-ring generator, the HDL-64E true laser table in KITTI
-order at ring capacity 4608), every slot with its own randomly perturbed pose guess; for every slot k >= 1 (target = slot k - 1):
+order at ring capacity 4608; with LL_SOAK_ALL_SHAPES=1 also 16 / 32 / 128 rings and the HDL-64E table in firing order), every slot with its own randomly perturbed pose guess; for every slot k >= 1 (target = slot k - 1):
   association   (src, a, b[, c]) index tuples of corners and planes        exact
   vote          incompatibility counts, selected set, weights               exact
   H, g, cost    Huber(0.1) normal equations at the guess                    <= 1e-9 (relative to the largest entry)
@@ -44,27 +44,32 @@ def rel_guess(a, b, rng):
     return np.concatenate([q, t])
 
 
-shapes = [("synthetic ring-major", dict(), None),
-          ("synthetic azimuth-major, jitter, drops, NaN", dict(order=1, az_jitter_deg=0.4, drop_prob=0.03, emit_nan=1), None),
-          ("synthetic ring-major, jitter, 10 % drops", dict(az_jitter_deg=0.7, drop_prob=0.1), None),
-          ("HDL-64E table, KITTI order", None, 4608)]
+RING_MODEL = {128: dict(ring_model=1, lower_bound=-25.0, up_bound=15.0, minimum_range=0.3)}     # BASELINE config 5's 128 rings: the linear formula of :162
+shapes = [("synthetic ring-major", 64, dict(), None),
+          ("synthetic azimuth-major, jitter, drops, NaN", 64, dict(order=1, az_jitter_deg=0.4, drop_prob=0.03, emit_nan=1), None),
+          ("synthetic ring-major, jitter, 10 % drops", 64, dict(az_jitter_deg=0.7, drop_prob=0.1), None),
+          ("HDL-64E table, KITTI order", 64, "kitti", 4608)]
+if os.environ.get("LL_SOAK_ALL_SHAPES"):                  # the other ring counts and the raw firing order (the committed long log has them)
+    shapes += [("synthetic 16 rings", 16, dict(), None), ("synthetic 32 rings, jitter", 32, dict(az_jitter_deg=0.4), None),
+               ("synthetic 128 rings (linear ring model)", 128, dict(), None), ("HDL-64E table, firing order", 64, "firing", 4608)]
 rng = np.random.default_rng(20261002)
 total = 0
 worst = dict(H=0.0, g=0.0, cost=0.0, pose=0.0)
 t00 = time.time()
-for name, kw, cap in shapes:
-    if kw is not None:
-        cfg = synth.default_cfg(64, **kw)
+for name, rings, kw, cap in shapes:
+    if isinstance(kw, dict):
+        cfg = synth.default_cfg(rings, **kw)
         k0 = int(rng.integers(0, 400))
         scans = [synth.scan(cfg, k0 + k) for k in range(N)]
         poses = [synth.pose(cfg, k0 + k) for k in range(N)]
     else:
         k0 = int(rng.integers(0, 40))
-        scans = [hdl64.hdl64_scan(k0 + k, order="kitti") for k in range(N)]
+        scans = [hdl64.hdl64_scan(k0 + k, order=kw) for k in range(N)]
         poses = [hdl64.pose(k0 + k) for k in range(N)]
-    P = orc.params(64)
-    extra = {"max_ring_points": cap} if cap else {}
-    ctx = api.Context(api.default_params(64, batch=N, max_points=max(map(len, scans)) + 7, **extra))
+    model = RING_MODEL.get(rings, {})
+    P = orc.params(rings, **model)
+    extra = dict(model, **({"max_ring_points": cap} if cap else {}))
+    ctx = api.Context(api.default_params(rings, batch=N, max_points=max(map(len, scans)) + 7, **extra))
     for k, s in enumerate(scans):
         ctx.upload_scan(k, s)
     guesses = np.zeros((N, 7)); guesses[:, 3] = 1.0
