@@ -244,11 +244,12 @@ extern __shared__ __attribute__((aligned(16))) unsigned char ll_smem[];
 
 /* 2nd launch bound = waves per SIMD: six 256-thread workgroups per CU for the common 2304-point capacity (<= 80 VGPRs) */
 /* ring_lo < ring length <= ring_hi: the rings this launch extracts (ring_hi, a multiple of 256 <= 256 ROWS, also sizes its LDS).
- * stage_only: a tier of long rings, launched before the main one -- lists to the staging rows, counts published, no look-back.
- * The main launch (stage_only 0, ring_lo = INT_MIN) extracts its rings and places the staged lists of the longer ones. */
+ * stage_only (= more rows than the main launch's nine): a tier of long rings, launched before the main one -- lists to the staging rows,
+ * counts published, no look-back.  The main launch (ring_lo = INT_MIN) extracts its rings and places the staged lists of the longer ones. */
 template <int ROWS>
-__global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : ROWS <= 12 ? 5 : ROWS <= 18 ? 3 : 1)) void k_ring_features(LLView V, int first, int count, int ring_lo, int ring_hi, int stage_only)
+__global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : ROWS <= 12 ? 5 : ROWS <= 18 ? 3 : 1)) void k_ring_features(LLView V, int first, int count, int ring_lo, int ring_hi)
 {
+    constexpr int stage_only = ROWS > 9 ? 1 : 0;                      /* the tiers of long rings are the instantiations with more rows than the main launch's */
     static_assert(ROWS <= 32, "lfm / headm / endm hold one bit per row of a thread");
     int sl, r;
     if (!ll_xcd_map2(blockIdx.x, V.R, count, sl, r)) return;
@@ -803,12 +804,12 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : ROWS <= 12 ? 5 :
 }
 
 template <int ROWS>
-static void ll_launch_ring_features(const LLView &V, int first, int count, int grid, int ring_lo, int ring_hi, int stage_only, hipStream_t st)
+static void ll_launch_ring_features(const LLView &V, int first, int count, int grid, int ring_lo, int ring_hi, hipStream_t st)
 {
     static size_t attr_bytes[LL_MAX_DEVICES] = {0};
     const size_t lds_bytes = ll_features_lds_bytes(ring_hi);
     ll_ensure_dynamic_lds(k_ring_features<ROWS>, lds_bytes, attr_bytes);
-    hipLaunchKernelGGL(k_ring_features<ROWS>, dim3(grid), dim3(LL_BLOCK), lds_bytes, st, V, first, count, ring_lo, ring_hi, stage_only);
+    hipLaunchKernelGGL(k_ring_features<ROWS>, dim3(grid), dim3(LL_BLOCK), lds_bytes, st, V, first, count, ring_lo, ring_hi);
 }
 
 /* The long rings' lists were staged and their counts published by the tier launches; the main launch's rings have looked back at those
@@ -860,10 +861,10 @@ void ll_launch_features(const LLView &V, int first, int count, size_t /* LDS of 
     ll_prof_mark(prof, LL_K_RING_FEATURES, st);                /* V.epoch: the caller's per-context tag of this extract call (ll_next_epoch) */
     const int cap = (V.max_ring + 255) / 256 * 256;
     /* the tiers of long rings first (they wait for nobody), the main launch last: its look-back finds their counts published */
-    if (cap > 4608) ll_launch_ring_features<32>(V, first, count, grid, 4608, cap, 1, st);   /* <= 8192 points: the per-thread row masks are 32 bits wide */
-    if (cap > 3072) ll_launch_ring_features<18>(V, first, count, grid, 3072, cap < 4608 ? cap : 4608, 1, st);
-    if (cap > 2304) ll_launch_ring_features<12>(V, first, count, grid, 2304, cap < 3072 ? cap : 3072, 1, st);   /* two lasers of a 64-beam sensor in one bin: five workgroups per CU */
-    ll_launch_ring_features<9>(V, first, count, grid, INT_MIN, cap < 2304 ? cap : 2304, 0, st);
+    if (cap > 4608) ll_launch_ring_features<32>(V, first, count, grid, 4608, cap, st);   /* <= 8192 points: the per-thread row masks are 32 bits wide */
+    if (cap > 3072) ll_launch_ring_features<18>(V, first, count, grid, 3072, cap < 4608 ? cap : 4608, st);
+    if (cap > 2304) ll_launch_ring_features<12>(V, first, count, grid, 2304, cap < 3072 ? cap : 3072, st);   /* two lasers of a 64-beam sensor in one bin: five workgroups per CU */
+    ll_launch_ring_features<9>(V, first, count, grid, INT_MIN, cap < 2304 ? cap : 2304, st);
     if (cap > 2304) hipLaunchKernelGGL(k_ring_place, dim3(count), dim3(LL_BLOCK), 0, st, V, first, count, 2304);
     ll_prof_mark(prof, LL_K_END, st);
 }
