@@ -7,7 +7,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 _HOST = os.path.join(_HERE, "host")
 _ROOT = os.path.dirname(_HERE)
 
-HIP_SOURCES = ["ll_api.hip", "ll_organize.hip", "ll_features.hip", "ll_associate.hip", "ll_vote.hip", "ll_factors.hip", "ll_mapping.hip", "ll_voxel.hip", "ll_cubemap.hip", "ll_functors.hip"]
+HIP_SOURCES = ["ll_api.hip", "ll_organize.hip", "ll_features.hip", "ll_pick.hip", "ll_associate.hip", "ll_vote.hip", "ll_factors.hip", "ll_mapping.hip", "ll_voxel.hip", "ll_cubemap.hip", "ll_functors.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                # parity: the reference build has no FMA (baseline x86-64); contraction would change f32 results
                "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",

@@ -10,7 +10,7 @@
 #include <cmath>
 
 static const char *const kKernelNames[LL_K_COUNT] = {"k_classify", "k_offsets", "k_scatter", "k_ring_features", "k_organize",
-                                                     "k_associate", "k_vote", "k_normal_equations", "k_gn_step", "k_build_grid", "k_first_kept"};
+                                                     "k_associate", "k_vote", "k_normal_equations", "k_gn_step", "k_build_grid", "k_first_kept", "k_ring_pick"};
 
 void ll_prof_mark(LLProfiler *p, int kernel_id, hipStream_t st)
 {
@@ -151,6 +151,9 @@ extern "C" int ll_create(int device, const ll_params *p, ll_ctx **out)
     ok = ok && dev_alloc(ctx, V.label, BN) && dev_alloc(ctx, V.curv, p->write_curvature ? BN : 1);
     ok = ok && dev_alloc(ctx, V.ring_pub, (size_t)B * R);
     ok = ok && dev_alloc(ctx, V.stage_sf, p->max_ring_points > 2304 ? (size_t)B * R * LL_STAGE_SF : 1, false);
+    ok = ok && dev_alloc(ctx, V.ring_rec, (size_t)B * R * LL_REC_U16) && dev_alloc(ctx, V.ring_cnt, (size_t)B * R) && dev_alloc(ctx, V.ring_box, (size_t)B * R * 8);
+    V.ring_split = 1;
+    if (const char *e = std::getenv("LIGHTLOAM_RING_SPLIT")) V.ring_split = std::atoi(e) ? 1 : 0;   /* A/B: 0 = the fused kernel of rounds 1-3 */
     {   /* ring thresholds of this sensor model (ll_exact_math.h), computed once with the same exact arithmetic */
         int *thr_dev = nullptr;
         std::vector<int32_t> thr((size_t)R + 1);

@@ -26,6 +26,11 @@
 #define LL_FLAT_PER_SEG 4
 #define LL_SEGS 6
 #define LL_STAGE_SF (LL_SEGS * (LL_SHARP_PER_SEG + LL_FLAT_PER_SEG))      /* staged sharp + flat points per ring */
+/* what k_ring_pick (ll_pick.hip) hands to k_ring_features (ll_features.hip), per ring: the picked points' local indices --
+ * sharp [0, 12), less-sharp [12, 132), flat [132, 156), entry = segment * per-segment capacity + pick order -- and the per-segment
+ * counts (n_sharp, n_less_sharp, n_flat) x 6 at [156, 174) */
+#define LL_REC_U16 176
+#define LL_PK_WAVES 4         /* rings (independent waves) per k_ring_pick workgroup */
 /* nearest-neighbour cell grid over (x, y): 128 x 128 cells of 1 m centred on the sensor; farther points saturate into
  * the border cells, whose rectangles count as unbounded outwards */
 #define LL_GRID_G 128
@@ -84,6 +89,10 @@ struct LLView {
     unsigned long long *ring_pub;  /* [B][R] look-back word of every ring: launch tag << 40 | its four feature counts */
     float4 *stage_sf;              /* [B][R][LL_STAGE_SF] staged sharp + flat lists of the rings longer than 2304 points (max_ring_points > 2304 only) */
     int epoch;                     /* the tag of the current k_ring_features launch (1 .. 2^24 - 2) */
+    int ring_split;                /* 1: k_ring_pick + k_ring_features<split> (two launches); 0: the fused kernel of rounds 1-3 (A/B reference) */
+    unsigned short *ring_rec;      /* [B][R][LL_REC_U16] k_ring_pick's lists of one ring */
+    unsigned *ring_cnt;            /* [B][R] n_sharp | n_less_sharp << 8 | n_flat << 16 | 1 << 31 (the ring has segments) */
+    float *ring_box;               /* [B][R][8] min x, y, z, max x, y, z of the ring's segment points */
     float4 *sharp, *lsharp, *flat, *lflat;
     /* targets */
     float4 *carry_corner, *carry_surf; int *carry_cnt;    /* carry_cnt[2] */
@@ -231,7 +240,7 @@ __device__ __forceinline__ void ll_targets(const LLView &V, int s, const float4 
 
 /* per-kernel HIP-event profiler (ll_api.hip); mark(id) = "kernel id starts here, the previous one ended" */
 enum { LL_K_CLASSIFY = 0, LL_K_OFFSETS, LL_K_SCATTER, LL_K_RING_FEATURES, LL_K_ORGANIZE, LL_K_ASSOCIATE, LL_K_VOTE,
-       LL_K_NORMAL_EQ, LL_K_GN_STEP, LL_K_GRID, LL_K_FIRST, LL_K_COUNT, LL_K_END = -1 };
+       LL_K_NORMAL_EQ, LL_K_GN_STEP, LL_K_GRID, LL_K_FIRST, LL_K_PICK, LL_K_COUNT, LL_K_END = -1 };
 /* ---- mapping stage (ll_mapping.hip): one scan against the clouds gathered from the cube map ---- */
 struct LLGrid3 {                       /* dense cell grid over a cloud's bounding box */
     float org[3]; float cell; int dim[3]; int ncell;
@@ -311,6 +320,7 @@ void ll_prof_mark(LLProfiler *p, int kernel_id, hipStream_t st);
 void ll_launch_organize(const LLView &V, int first, int count, hipStream_t st, LLProfiler *prof);
 void ll_launch_cloud_flatten(const LLView &V, int slot, float4 *dst, hipStream_t st);
 void ll_launch_features(const LLView &V, int first, int count, size_t lds_bytes, hipStream_t st, LLProfiler *prof);
+void ll_launch_pick(const LLView &V, int first, int count, hipStream_t st);
 void ll_launch_associate(const LLView &V, int first, int count, hipStream_t st, LLProfiler *prof);
 void ll_launch_build_grid(const LLView &V, int first, int count, int carry, hipStream_t st, LLProfiler *prof);
 void ll_launch_vote(const LLView &V, int first, int count, int enable, hipStream_t st, LLProfiler *prof);

@@ -246,7 +246,8 @@ extern __shared__ __attribute__((aligned(16))) unsigned char ll_smem[];
 /* ring_lo < ring length <= ring_hi: the rings this launch extracts (ring_hi, a multiple of 256 <= 256 ROWS, also sizes its LDS).
  * stage_only (= more rows than the main launch's nine): a tier of long rings, launched before the main one -- lists to the staging rows,
  * counts published, no look-back.  The main launch (ring_lo = INT_MIN) extracts its rings and places the staged lists of the longer ones. */
-template <int ROWS>
+/* SPLIT: phases 1-3 ran in k_ring_pick (ll_pick.hip): this launch starts from its lists (ring_rec) and does phases 4-5 only. */
+template <int ROWS, bool SPLIT>
 __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : ROWS <= 12 ? 5 : ROWS <= 18 ? 3 : 1)) void k_ring_features(LLView V, int first, int count, int ring_lo, int ring_hi)
 {
     constexpr int stage_only = ROWS > 9 ? 1 : 0;                      /* the tiers of long rings are the instantiations with more rows than the main launch's */
@@ -359,6 +360,7 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : ROWS <= 12 ? 5 :
         if (jf < LL_SEGS && tid % LL_FLAT_PER_SEG < L.lists[158 + jf * 3]) { fpos[2] = of + tid % LL_FLAT_PER_SEG; fsrc2 = L.lists[132 + tid]; }
     };
     auto write_labels = [&]() __attribute__((always_inline)) {
+        if (SPLIT) return;                                            /* k_ring_pick wrote cloudLabel */
         int8_t *label = V.label + (size_t)s * V.NP + off;
         for (int i = tid; i < nr; i += LL_BLOCK) label[i] = L.lab[i];
     };
@@ -368,6 +370,18 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : ROWS <= 12 ? 5 :
     };
 
     LL_PHASE_BEGIN();
+    if constexpr (SPLIT) {
+        /* the pick's lists of this ring: local indices + per-segment counts -> L.lists; the less-sharp picks (label 1 / 2) -> bitmap:
+         * less-flat = every segment point that is not one of them (:361-367) */
+        const unsigned short *rec = V.ring_rec + ((size_t)s * V.R + r) * LL_REC_U16;
+        if (tid < 174) L.lists[tid] = (int)rec[tid];
+        __syncthreads();
+        if (tid < LL_SEGS * LL_LSHARP_PER_SEG && tid % LL_LSHARP_PER_SEG < L.lists[157 + (tid / LL_LSHARP_PER_SEG) * 3]) {
+            const int li = L.lists[12 + tid];
+            atomicOr(&L.picked[li >> 5], 1u << (li & 31));
+        }
+        __syncthreads();
+    } else {
     /* ---------------- phase 1: curvature + gap flags + sort records ---------------- */
     constexpr int TLOADS = (LL_FTILE + 10 + LL_BLOCK - 1) / LL_BLOCK;
     /* TWO tiles' points in flight during the math (preA: even tiles, preB: odd tiles): one tile ahead leaves a workgroup
@@ -622,6 +636,7 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : ROWS <= 12 ? 5 :
         __builtin_amdgcn_s_setprio(LL_TAIL_PRIO);
     }
     __syncthreads();
+    }   /* !SPLIT */
 
     LL_PHASE(2);
     /* ---------------- phase 4: less-flat compaction + VoxelGrid (:361-376) ----------------
@@ -641,7 +656,7 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : ROWS <= 12 ? 5 :
             if (u < per && q < a1) {
                 const float4 p = cloud[off + q + 5];
                 px[u] = p.x; py[u] = p.y; pz[u] = p.z;
-                if (L.lab[q + 5] <= 0) lfm |= 1u << u;
+                if (SPLIT ? !ll_bit(L.picked, q + 5) : (L.lab[q + 5] <= 0)) lfm |= 1u << u;
             }
         }
         float mnx = INFINITY, mny = INFINITY, mnz = INFINITY, mxx = -INFINITY, mxy = -INFINITY, mxz = -INFINITY;
@@ -803,13 +818,13 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : ROWS <= 12 ? 5 :
 #endif
 }
 
-template <int ROWS>
+template <int ROWS, bool SPLIT>
 static void ll_launch_ring_features(const LLView &V, int first, int count, int grid, int ring_lo, int ring_hi, hipStream_t st)
 {
     static size_t attr_bytes[LL_MAX_DEVICES] = {0};
     const size_t lds_bytes = ll_features_lds_bytes(ring_hi);
-    ll_ensure_dynamic_lds(k_ring_features<ROWS>, lds_bytes, attr_bytes);
-    hipLaunchKernelGGL(k_ring_features<ROWS>, dim3(grid), dim3(LL_BLOCK), lds_bytes, st, V, first, count, ring_lo, ring_hi);
+    ll_ensure_dynamic_lds(k_ring_features<ROWS, SPLIT>, lds_bytes, attr_bytes);
+    hipLaunchKernelGGL((k_ring_features<ROWS, SPLIT>), dim3(grid), dim3(LL_BLOCK), lds_bytes, st, V, first, count, ring_lo, ring_hi);
 }
 
 /* The long rings' lists were staged and their counts published by the tier launches; the main launch's rings have looked back at those
@@ -858,13 +873,23 @@ void ll_launch_features(const LLView &V, int first, int count, size_t /* LDS of 
 {
     const int groups = (count + 7) / 8;
     const int grid = 8 * V.R * groups;
-    ll_prof_mark(prof, LL_K_RING_FEATURES, st);                /* V.epoch: the caller's per-context tag of this extract call (ll_next_epoch) */
     const int cap = (V.max_ring + 255) / 256 * 256;
+    if (V.ring_split) {
+        ll_prof_mark(prof, LL_K_PICK, st);
+        ll_launch_pick(V, first, count, st);
+        ll_prof_mark(prof, LL_K_RING_FEATURES, st);            /* V.epoch: the caller's per-context tag of this extract call (ll_next_epoch) */
+        if (cap > 4608) ll_launch_ring_features<32, true>(V, first, count, grid, 4608, cap, st);
+        if (cap > 3072) ll_launch_ring_features<18, true>(V, first, count, grid, 3072, cap < 4608 ? cap : 4608, st);
+        if (cap > 2304) ll_launch_ring_features<12, true>(V, first, count, grid, 2304, cap < 3072 ? cap : 3072, st);
+        ll_launch_ring_features<9, true>(V, first, count, grid, INT_MIN, cap < 2304 ? cap : 2304, st);
+    } else {
+    ll_prof_mark(prof, LL_K_RING_FEATURES, st);
     /* the tiers of long rings first (they wait for nobody), the main launch last: its look-back finds their counts published */
-    if (cap > 4608) ll_launch_ring_features<32>(V, first, count, grid, 4608, cap, st);   /* <= 8192 points: the per-thread row masks are 32 bits wide */
-    if (cap > 3072) ll_launch_ring_features<18>(V, first, count, grid, 3072, cap < 4608 ? cap : 4608, st);
-    if (cap > 2304) ll_launch_ring_features<12>(V, first, count, grid, 2304, cap < 3072 ? cap : 3072, st);   /* two lasers of a 64-beam sensor in one bin: five workgroups per CU */
-    ll_launch_ring_features<9>(V, first, count, grid, INT_MIN, cap < 2304 ? cap : 2304, st);
+    if (cap > 4608) ll_launch_ring_features<32, false>(V, first, count, grid, 4608, cap, st);   /* <= 8192 points: the per-thread row masks are 32 bits wide */
+    if (cap > 3072) ll_launch_ring_features<18, false>(V, first, count, grid, 3072, cap < 4608 ? cap : 4608, st);
+    if (cap > 2304) ll_launch_ring_features<12, false>(V, first, count, grid, 2304, cap < 3072 ? cap : 3072, st);   /* two lasers of a 64-beam sensor in one bin: five workgroups per CU */
+    ll_launch_ring_features<9, false>(V, first, count, grid, INT_MIN, cap < 2304 ? cap : 2304, st);
+    }
     if (cap > 2304) hipLaunchKernelGGL(k_ring_place, dim3(count), dim3(LL_BLOCK), 0, st, V, first, count, 2304);
     ll_prof_mark(prof, LL_K_END, st);
 }
