@@ -23,21 +23,26 @@
 #include <limits.h>
 #include <type_traits>
 
+typedef float ll_f4 __attribute__((ext_vector_type(4)));
+typedef float ll_f2 __attribute__((ext_vector_type(2)));
 #define LL_PK_TR 3                              /* rows of 64 segment points per curvature tile */
 #define LL_PK_TILE (LL_PK_TR * 64 + 10)         /* + 5 halo points either side */
 #define LL_PK_COMPACT 96                       /* corner candidates compacted to the front rows when at most this many */
 
-typedef float ll_f4 __attribute__((ext_vector_type(4)));
-typedef float ll_f2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void ll_lds_void;
 typedef const __attribute__((address_space(1))) void ll_glb_void;
 
 template <int SR>
 struct PickLds {
-    float4 tile[LL_PK_TILE + 6];                 /* 16-byte records: ds_read_b128 taps */
-    unsigned wkey[LL_PK_COMPACT], wli[LL_PK_COMPACT];   /* compacted corner candidates: curvature bits; local index | extents << 16 */
-    unsigned char lab[SR * 64 + 16];            /* the segment's labels, row layout */
+    union {
+        ll_f4 tile[LL_PK_TILE + 6];             /* 16-byte records: ds_read_b128 taps */
+        struct { unsigned wkey[LL_PK_COMPACT], wli[LL_PK_COMPACT]; } c;   /* compacted corner candidates (between the segment's last tap and the
+                                                                         * next segment's first tile): curvature bits; local index | extents << 16 */
+    };
     unsigned picked[(SR * 64 * 6 + 16 + 31) / 32 + 2];   /* cloudNeighborPicked over the ring's local indices */
+    unsigned lab2[(SR * 64 * 6 + 16 + 15) / 16 + 2];     /* cloudLabel, two bits per local index: 0, 1, 2, 3 = -1 */
+    unsigned short rec[LL_REC_U16];             /* the ring's lists (ring_rec layout); stored when the ring is done: no store inside the
+                                                 * segment loop, so every vmcnt wait there is a wait for a tile and nothing else */
     unsigned gw[2 * (SR + 2) + 2];              /* gap flags of the segment: 64-bit word k + 1 = bit l <-> local index sp + k * 64 + l + 5, k = -1 .. SR */
 };
 
@@ -80,7 +85,7 @@ __device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, in
     if (h.status != 0) return;
     if (nr <= ring_lo || nr > ring_hi) return;                        /* another tier's ring */
     PickLds<SR> &L = lds_all[wave];
-    unsigned short *rec = V.ring_rec + ((size_t)s * V.R + r) * LL_REC_U16;
+    unsigned short *rec_g = V.ring_rec + ((size_t)s * V.R + r) * LL_REC_U16;
     unsigned *rcnt = V.ring_cnt + (size_t)s * V.R + r;
     int8_t *label = V.label + (size_t)s * V.NP + off;
     const int N = h.n;
@@ -123,16 +128,16 @@ __device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, in
     }
     if (!active) {                                                    /* no segments: every label 0, no features (also nr <= 0) */
         for (int i = lane; i < nr; i += 64) label[i] = 0;
-        if (lane < 3 * LL_SEGS) rec[156 + lane] = 0;
+        if (lane < 3 * LL_SEGS) rec_g[156 + lane] = 0;
         if (lane == 0) *rcnt = 0u;
         return;
     }
-    if (lane < 5) label[lane] = 0;                                    /* the points outside the segments */
-    if (lane < 6) label[nr - 6 + lane] = 0;
     {
         const int nwords = (nr + 31) / 32 + 1;
         for (int i = lane; i < nwords; i += 64) L.picked[i] = 0;
+        for (int i = lane; i < 2 * nwords; i += 64) L.lab2[i] = 0;   /* the points outside the segments keep label 0 */
     }
+    unsigned short *rec = L.rec;
 
     /* the tile of rows [k0, k0 + TR) of segment [sp, sp + len): tile[t] = ring[sp + k0 * 64 + t], t < TR * 64 + 10, as far as the
      * segment + halo reaches (sp + len + 9 <= nr - 2) */
@@ -151,7 +156,7 @@ __device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, in
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
     auto gap_at = [&](int t) -> bool {                                /* (:290-293) squared distance of tile point t to its predecessor > 0.05 */
-        const float4 a = L.tile[t], b = L.tile[t - 1];
+        const ll_f4 a = L.tile[t], b = L.tile[t - 1];
         const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
         return dx * dx + dy * dy + dz * dz > V.gap_gt;
     };
@@ -186,7 +191,7 @@ __device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, in
                     const int k = k0 + kk;
                     if (k < SR && k < nrows) {
                         const int q = k * 64 + lane;
-                        const ll_f4 *C = (const ll_f4 *)L.tile + kk * 64 + lane + 5;
+                        const ll_f4 *C = L.tile + kk * 64 + lane + 5;
                         /* :225-235, strict left to right.  Every tap is one ds_read_b128 (4 LDS cycles; the 12-byte read the compiler
                          * picks when w is unused takes 8) and two packed adds -- (x, y) and (z, w): the w lane rides along and is
                          * "used" once at the end so that the reads stay 16 bytes wide.  Six taps in flight, then five. */
@@ -229,10 +234,8 @@ __device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, in
                 for (int kk = 0; kk < LL_PK_TR; ++kk) if (k0 + kk < SR) cb[k0 + kk] = 0u;
             }
         }
-        /* the next segment's first tile travels during the pick (the tile is dead until then: every tap has been read) */
-        __builtin_amdgcn_s_waitcnt(0xc07f);                           /* lgkmcnt(0) */
+        __builtin_amdgcn_s_waitcnt(0xc07f);                           /* lgkmcnt(0): every tap has been read, the tile is dead */
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        if (j + 1 < LL_SEGS) { const int sp1 = ep + 1, ep1 = Lseg * (j + 2) / 6 - 1; tile_dma(sp1, ep1 - sp1 + 1, 0); }
 
         /* ---------------- suppression extents (:288-311) ----------------
          * A pick at local index li marks li - bn .. li + fn: fn / bn = how far the forward / backward walk gets before a
@@ -278,8 +281,8 @@ __device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, in
                 const unsigned long long m = __ballot(c);
                 const int pos = nc + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                 if (c && pos < LL_PK_COMPACT) {
-                    L.wkey[pos] = cb[k];
-                    L.wli[pos] = (unsigned)(li0 + k * 64) | (((exw[k >> 2] >> ((k & 3) * 8)) & 0xffu) << 16);
+                    L.c.wkey[pos] = cb[k];
+                    L.c.wli[pos] = (unsigned)(li0 + k * 64) | (((exw[k >> 2] >> ((k & 3) * 8)) & 0xffu) << 16);
                 }
                 nc += __popcll(m);
             }
@@ -291,10 +294,12 @@ __device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, in
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             ck[rr] = 0u; cli[rr] = 0;
-            if (compact && rr < ncr && rr * 64 + lane < nc) { ck[rr] = L.wkey[rr * 64 + lane]; cli[rr] = (int)L.wli[rr * 64 + lane]; }
+            if (compact && rr < ncr && rr * 64 + lane < nc) { ck[rr] = L.c.wkey[rr * 64 + lane]; cli[rr] = (int)L.c.wli[rr * 64 + lane]; }
         }
-        /* labels of the segment, row layout */
-        for (int i = lane; i < (len + 3) / 4; i += 64) ((unsigned *)L.lab)[i] = 0u;
+        /* the next segment's first tile travels during the pick (the candidates are in registers, their LDS rows are dead) */
+        __builtin_amdgcn_s_waitcnt(0xc07f);                           /* lgkmcnt(0) */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (j + 1 < LL_SEGS) { const int sp1 = ep + 1, ep1 = Lseg * (j + 2) / 6 - 1; tile_dma(sp1, ep1 - sp1 + 1, 0); }
         int nrec[2] = {0, 0};
         for (int pass = 0; pass < 2; ++pass) {
             int npick = 0;
@@ -391,11 +396,13 @@ __device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, in
             nrec[pass] = nr_;
             if (lane < nr_) {
                 const int sel = (int)(myrec & 0xffffu), e = (int)(myrec >> 16);
+                unsigned code;                                        /* cloudLabel (:271, :276, :323) */
                 if (pass == 0) {
-                    if (lane < LL_SHARP_PER_SEG) { L.lab[sel - sp - 5] = 2; rec[j * LL_SHARP_PER_SEG + lane] = (unsigned short)sel; }
-                    else L.lab[sel - sp - 5] = 1;
+                    if (lane < LL_SHARP_PER_SEG) { code = 2u; rec[j * LL_SHARP_PER_SEG + lane] = (unsigned short)sel; }
+                    else code = 1u;
                     rec[12 + j * LL_LSHARP_PER_SEG + lane] = (unsigned short)sel;
-                } else { L.lab[sel - sp - 5] = (unsigned char)0xff; rec[132 + j * LL_FLAT_PER_SEG + lane] = (unsigned short)sel; }
+                } else { code = 3u; rec[132 + j * LL_FLAT_PER_SEG + lane] = (unsigned short)sel; }
+                atomicOr(&L.lab2[sel >> 4], code << ((sel & 15) * 2));
                 /* marks into the bitmap: a corner pick's whole range from this segment's first index on (the flat pass reads it
                  * back), a flat pick's only beyond this segment (inside it the flat pass keeps them in registers) */
                 const int shi = sel + (e >> 4), f0 = max(sel - (e & 15), pass == 0 ? sp + 5 : ep + 6);
@@ -408,12 +415,15 @@ __device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, in
         }
         if (lane < 3) rec[156 + j * 3 + lane] = (unsigned short)(lane == 0 ? min(nrec[0], LL_SHARP_PER_SEG) : lane == 1 ? nrec[0] : nrec[1]);
         segc += (unsigned)min(nrec[0], LL_SHARP_PER_SEG) | ((unsigned)nrec[0] << 8) | ((unsigned)nrec[1] << 16);
-        /* cloudLabel of the segment (:271, :276, :323) */
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-        for (int k = 0; k < SR; ++k) if (k < nrows && k * 64 + lane < len) label[li0 + k * 64] = (int8_t)L.lab[k * 64 + lane];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        /* the next segment clears the labels: after these reads */
     }
+    /* the ring is done: labels, lists, counts */
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int li = lane; li < nr; li += 64) {
+        const unsigned c = (L.lab2[li >> 4] >> ((li & 15) * 2)) & 3u;
+        label[li] = (int8_t)(c == 3u ? -1 : (int)c);
+    }
+    if (lane < LL_REC_U16 / 2) ((unsigned *)rec_g)[lane] = ((const unsigned *)L.rec)[lane];
+    if (lane + 64 < LL_REC_U16 / 2) ((unsigned *)rec_g)[lane + 64] = ((const unsigned *)L.rec)[lane + 64];
     if (lane == 0) *rcnt = segc | 0x80000000u;                        /* the ring's counts */
 }
 
