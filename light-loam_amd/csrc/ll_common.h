@@ -30,7 +30,9 @@
  * sharp [0, 12), less-sharp [12, 132), flat [132, 156), entry = segment * per-segment capacity + pick order -- and the per-segment
  * counts (n_sharp, n_less_sharp, n_flat) x 6 at [156, 174) */
 #define LL_REC_U16 176
-#define LL_PK_WAVES 4         /* rings (independent waves) per k_ring_pick workgroup */
+#ifndef LL_PK_WAVES
+#define LL_PK_WAVES 1         /* rings (independent waves) per k_ring_pick workgroup */
+#endif
 /* nearest-neighbour cell grid over (x, y): 128 x 128 cells of 1 m centred on the sensor; farther points saturate into
  * the border cells, whose rectangles count as unbounded outwards */
 #define LL_GRID_G 128

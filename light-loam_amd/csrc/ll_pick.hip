@@ -25,8 +25,14 @@
 
 typedef float ll_f4 __attribute__((ext_vector_type(4)));
 typedef float ll_f2 __attribute__((ext_vector_type(2)));
-#define LL_PK_TR 3                              /* rows of 64 segment points per curvature tile */
-#define LL_PK_TILE (LL_PK_TR * 64 + 10)         /* + 5 halo points either side */
+/* rows of 64 segment points per curvature tile (+ 5 halo points either side): the whole segment by default -- it comes in during
+ * the previous segment's pick, when the tile is dead, and the curvature phase waits for memory once; LL_PK_TILE_ROWS < SR: smaller
+ * tiles (less LDS, more waves per SIMD), every tile after a segment's first is waited for in the open */
+#ifndef LL_PK_TILE_ROWS
+#define LL_PK_TILE_ROWS 3
+#endif
+#define LL_PK_TR (SR < LL_PK_TILE_ROWS ? SR : LL_PK_TILE_ROWS)
+#define LL_PK_TILE (LL_PK_TR * 64 + 10)
 #define LL_PK_COMPACT 96                       /* corner candidates compacted to the front rows when at most this many */
 
 typedef __attribute__((address_space(3))) void ll_lds_void;
@@ -41,6 +47,12 @@ struct PickLds {
     };
     unsigned picked[(SR * 64 * 6 + 16 + 31) / 32 + 2];   /* cloudNeighborPicked over the ring's local indices */
     unsigned lab2[(SR * 64 * 6 + 16 + 15) / 16 + 2];     /* cloudLabel, two bits per local index: 0, 1, 2, 3 = -1 */
+#ifdef LL_PK_LDS_PAD
+    unsigned char pad[LL_PK_LDS_PAD];           /* timing builds: fewer waves per SIMD */
+#endif
+#ifdef LL_PK_FLAT_T
+    unsigned fkey[64], fli[64];                  /* the flat pass's compacted candidates (the tile is already filling with the next segment) */
+#endif
     unsigned short rec[LL_REC_U16];             /* the ring's lists (ring_rec layout); stored when the ring is done: no store inside the
                                                  * segment loop, so every vmcnt wait there is a wait for a tile and nothing else */
     unsigned gw[2 * (SR + 2) + 2];              /* gap flags of the segment: 64-bit word k + 1 = bit l <-> local index sp + k * 64 + l + 5, k = -1 .. SR */
@@ -147,7 +159,11 @@ __device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, in
 #pragma unroll
         for (int u = 0; u <= LL_PK_TR; ++u) {
             const int t = u * 64 + lane;
+#ifndef LL_PK_TIMING_NODMA
             if (u * 64 < lim && t < LL_PK_TILE && t < lim)
+#else
+            if (false)
+#endif
                 __builtin_amdgcn_global_load_lds((ll_glb_void *)(src + t), (ll_lds_void *)(L.tile + u * 64), 16, 0, 0);
         }
     };
@@ -162,6 +178,7 @@ __device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, in
     };
 
     unsigned segc = 0;                                                /* scalar: n_sharp, n_lsharp, n_flat totals, 8 bits each */
+    [[maybe_unused]] unsigned flat_T = 0x3b83126fu;                                    /* 0.004f: the flat pass's first threshold guess; afterwards the ring's last good one */
     /* lane constants of the extents window: bits [60 + lane, 70 + lane) of the 192-bit string word[k-1] : word[k] : word[k+1] */
     const int wsh = (60 + lane) & 31, wwi = (60 + lane) >> 5;         /* first 32-bit word of the window: 1, 2 or 3 */
 
@@ -301,7 +318,13 @@ __device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, in
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         if (j + 1 < LL_SEGS) { const int sp1 = ep + 1, ep1 = Lseg * (j + 2) / 6 - 1; tile_dma(sp1, ep1 - sp1 + 1, 0); }
         int nrec[2] = {0, 0};
+#ifdef LL_PK_TIMING_NOPICK
+        for (int pass = 0; pass < 0; ++pass) {
+#elif defined(LL_PK_TIMING_NOFLAT)
+        for (int pass = 0; pass < 1; ++pass) {
+#else
         for (int pass = 0; pass < 2; ++pass) {
+#endif
             int npick = 0;
             unsigned myrec = 0;                                       /* lane n: pick n + 1 as li | extents << 16 */
             /* non-negative float bits order like the floats; the flats maximise the complement */
@@ -312,13 +335,10 @@ __device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, in
 #pragma unroll
                 for (int k = 0; k < SR; ++k) if (k < nrows && k * 64 + lane < len && ll_pk_bit(L.picked, li0 + k * 64)) sup |= 1u << k;
             }
-#pragma unroll
-            for (int k = 0; k < SR; ++k)
-                mk[k] = pass == 1 ? ((((candf & ~sup) >> k) & 1u) ? ~cb[k] : 0u) : ((!compact && ((candc >> k) & 1u)) ? cb[k] : 0u);
             /* one pick loop, instantiated for the rows it scans: COMPACT -- the corner pass over the compacted candidates (NR = 1 or 2
              * rows of ck / cli); otherwise the segment's own rows (mk): the flat pass, or the corner pass of a segment with more than
              * LL_PK_COMPACT candidates */
-            auto pick_loop = [&](auto nr_tag, auto corner_tag, auto compact_tag, auto &key) __attribute__((always_inline)) {
+            auto pick_loop = [&](auto nr_tag, auto corner_tag, auto compact_tag, auto &key, int (&cli)[2]) __attribute__((always_inline)) {
                 constexpr int NR = decltype(nr_tag)::value;
                 constexpr bool CORNER = decltype(corner_tag)::value;
                 constexpr bool COMPACT = decltype(compact_tag)::value;
@@ -335,10 +355,11 @@ __device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, in
                     if (kmax == 0u) break;                            /* nothing eligible is left */
                     const unsigned long long bal = __ballot(best == kmax);
                     int selp;                                         /* row * 64 + lane of the choice */
-                    if (CORNER && NR == 1) {
+                    if (COMPACT && NR == 1) {
                         /* one row of candidates in ascending index: among equal curvatures the highest lane is the largest
-                         * index, which the descending walk meets first -- no tie path */
-                        selp = 63 - __builtin_clzll(bal);
+                         * index, which the descending walk of the corners meets first, the lowest lane the smallest, which the
+                         * ascending walk of the flats meets first -- no tie path */
+                        selp = CORNER ? 63 - __builtin_clzll(bal) : __ffsll((long long)bal) - 1;
                     } else if (__popcll(bal) == 1) {
                         const int f = __ffsll((long long)bal) - 1;
                         selp = (NR > 1 ? __builtin_amdgcn_readlane(row_l, f) * 64 : 0) + f;
@@ -385,12 +406,106 @@ __device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, in
                     }
                 }
             };
+            /* The corner pass over at most 64 candidates WITHOUT the arg-max chain: rank them once (descending curvature; the
+             * candidates sit in ascending index, so "larger index first" among equal curvatures would be the higher lane --
+             * equal curvatures are left to the arg-max loop instead), bring candidate number i of that order to lane i, and
+             * walk a scalar eligibility mask: the next pick is its lowest set bit, a pick clears the lanes whose index lies in
+             * its suppression range.  Per pick two v_readlane, one range compare and a handful of scalar instructions instead of
+             * six dependent DPP steps with their wait states.  Returns false (nothing done) when two candidates tie. */
+            auto sorted_walk = [&]() __attribute__((always_inline)) -> bool {
+                const unsigned key0 = ck[0];
+                int rank = 0;
+                for (int t = 0; t < nc; t += 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const unsigned kt = (unsigned)__builtin_amdgcn_readlane((int)key0, t + u);   /* lanes beyond nc hold 0: never greater */
+                        rank += (kt > key0) ? 1 : 0;
+                    }
+                }
+                rank = (lane < nc) ? rank : lane;                     /* the idle lanes keep their places */
+                const int sA = __builtin_amdgcn_ds_permute(rank * 4, cli[0]);   /* lane rank <- (local index | extents << 16); 0 where nobody wrote */
+                const unsigned long long got = __ballot(sA != 0);
+                if (__popcll(got) != nc) return false;                /* two lanes with one rank: equal curvatures */
+                const int selv = sA & 0xffff;
+                const int sB = (selv - ((sA >> 16) & 15)) | ((((sA >> 16) & 15) + (sA >> 20)) << 16);   /* first marked index | marks beyond it << 16 */
+                unsigned long long elig = got;
+                while (elig) {
+                    const int i = __ffsll((long long)elig) - 1;
+                    const int a_p = __builtin_amdgcn_readlane(sA, i), b_p = __builtin_amdgcn_readlane(sB, i);
+                    npick++;
+                    if (npick > LL_LSHARP_PER_SEG) break;             /* :281-284 */
+                    myrec = (lane == npick - 1) ? (unsigned)a_p : myrec;
+                    const unsigned long long hit = __ballot((unsigned)(selv - (b_p & 0xffff)) <= (unsigned)(b_p >> 16));
+                    elig &= ~hit;                                     /* the pick itself is in its range */
+                }
+                return true;
+            };
             using std::integral_constant;
             using std::true_type; using std::false_type;
-            if (pass == 1) pick_loop(integral_constant<int, SR>{}, false_type{}, false_type{}, mk);
-            else if (!compact) pick_loop(integral_constant<int, SR>{}, true_type{}, false_type{}, mk);
-            else if (ncr <= 1) pick_loop(integral_constant<int, 1>{}, true_type{}, true_type{}, ck);
-            else pick_loop(integral_constant<int, 2>{}, true_type{}, true_type{}, ck);
+            if (pass == 1) {
+                /* The flat pass takes four picks, and a pick suppresses at most ten others: whatever happens, the four lie among the
+                 * 34 smallest eligible curvatures.  So: a threshold T with 34 .. 64 eligible points at or below it (bisection on the
+                 * float bits, a count = one ballot per row; the ring's last T is the first guess), those compacted to one row in
+                 * ascending index, and four rounds of the one-row arg-min.  No T found (equal values around the cut): the rows. */
+                const unsigned fm = candf & ~sup;
+                int nf = 0;
+#pragma unroll
+                for (int k = 0; k < SR; ++k) if (k < nrows) nf += __popcll(__ballot((fm >> k) & 1u));
+                [[maybe_unused]] auto count_le = [&](unsigned T) __attribute__((always_inline)) {
+                    int c = 0;
+#pragma unroll
+                    for (int k = 0; k < SR; ++k) if (k < nrows) c += __popcll(__ballot(((fm >> k) & 1u) && cb[k] <= T));
+                    return c;
+                };
+                [[maybe_unused]] bool have = nf > 0;
+                [[maybe_unused]] unsigned T = 0x7fffffffu;
+#ifndef LL_PK_FLAT_T
+                have = false;
+#else
+                if (nf > 64) {
+                    unsigned lo = 0u, hi = ll_f2u(V.curv_lt);         /* count(lo) = 0 < 34 (a curvature of +0 counts as above lo: see below), count(hi) = nf > 64 */
+                    T = flat_T;
+                    have = false;
+                    for (int it = 0; it < 16; ++it) {
+                        if (T <= lo || T >= hi) T = lo + (hi - lo) / 2;
+                        if (T <= lo) break;                           /* hi - lo <= 1: more than 64 equal values at the cut */
+                        const int c = count_le(T);
+                        if (c > 64) hi = T; else if (c < 34) lo = T; else { have = true; break; }
+                        T = lo + (hi - lo) / 2;
+                    }
+                    if (have) flat_T = T;
+                }
+#endif
+#ifdef LL_PK_FLAT_T
+                if (have) {
+                    int n2 = 0;
+#pragma unroll
+                    for (int k = 0; k < SR; ++k) {
+                        if (k < nrows) {
+                            const bool c = ((fm >> k) & 1u) && cb[k] <= T;
+                            const unsigned long long m = __ballot(c);
+                            const int pos = n2 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                            if (c) { L.fkey[pos] = ~cb[k]; L.fli[pos] = (unsigned)(li0 + k * 64) | (((exw[k >> 2] >> ((k & 3) * 8)) & 0xffu) << 16); }
+                            n2 += __popcll(m);
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    unsigned fk[2] = {0u, 0u}; int fi[2] = {0, 0};
+                    if (lane < n2) { fk[0] = L.fkey[lane]; fi[0] = (int)L.fli[lane]; }
+                    pick_loop(integral_constant<int, 1>{}, false_type{}, true_type{}, fk, fi);
+                } else
+#endif
+                if (nf > 0) {
+#pragma unroll
+                    for (int k = 0; k < SR; ++k) mk[k] = ((fm >> k) & 1u) ? ~cb[k] : 0u;
+                    pick_loop(integral_constant<int, SR>{}, false_type{}, false_type{}, mk, cli);
+                }
+            } else if (!compact) {
+#pragma unroll
+                for (int k = 0; k < SR; ++k) mk[k] = ((candc >> k) & 1u) ? cb[k] : 0u;
+                pick_loop(integral_constant<int, SR>{}, true_type{}, false_type{}, mk, cli);
+            } else if (ncr <= 1) { if (nc > 0 && !sorted_walk()) pick_loop(integral_constant<int, 1>{}, true_type{}, true_type{}, ck, cli); }
+            else pick_loop(integral_constant<int, 2>{}, true_type{}, true_type{}, ck, cli);
             /* the picked records, lane-parallel: labels, list entries, marks */
             const int nr_ = pass == 0 ? min(npick, LL_LSHARP_PER_SEG) : npick;
             nrec[pass] = nr_;
@@ -431,10 +546,22 @@ __device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, in
 #define LL_PICK_KERNEL(SR, WAVES, NVGPR)                                                                              \
     __global__ __launch_bounds__(64 * LL_PK_WAVES, WAVES) __attribute__((amdgpu_num_vgpr(NVGPR)))                      \
     void k_ring_pick##SR(LLView V, int first, int count, int ring_lo, int ring_hi) { ll_ring_pick_body<SR>(V, first, count, ring_lo, ring_hi); }
+#if defined(LL_PK_W6_WAVES)
+LL_PICK_KERNEL(6, LL_PK_W6_WAVES, LL_PK_W6_VGPRS)
+LL_PICK_KERNEL(8, 6, 80)
+LL_PICK_KERNEL(12, 4, 128)
+LL_PICK_KERNEL(22, 2, 256)
+#elif LL_PK_TILE_ROWS >= 6
+LL_PICK_KERNEL(6, 5, 96)         /* 7.7 KB of LDS per wave: five waves per SIMD */
+LL_PICK_KERNEL(8, 4, 128)
+LL_PICK_KERNEL(12, 2, 128)
+LL_PICK_KERNEL(22, 1, 256)
+#else
 LL_PICK_KERNEL(6, 8, 64)
 LL_PICK_KERNEL(8, 6, 80)
 LL_PICK_KERNEL(12, 4, 128)
 LL_PICK_KERNEL(22, 2, 256)
+#endif
 
 template <typename K>
 static void ll_launch_ring_pick(K kernel, const LLView &V, int first, int count, int ring_lo, int ring_hi, hipStream_t st)

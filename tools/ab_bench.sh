@@ -4,7 +4,7 @@
 # variation does not hide a few-percent difference.
 fmt='import sys,json
 d=json.loads(sys.stdin.read()); k=d["roofline"]["kernel_ms_per_step"]
-print("%.0f scans/s  %.2f ms/step | " % (d["value"], d["ms_per_step"]) + " ".join("%s=%.2f" % (a[2:6],b) for a,b in k.items()))'
+print("%.0f scans/s  %.2f ms/step | " % (d["value"], d["ms_per_step"]) + " ".join("%s=%.2f" % (a[2:10],b) for a,b in k.items()))'
 for rep in 1 2; do
   for v in $GRAFT_REPO_ROOT/_ab/*.so tree; do
     if [ $v = tree ]; then unset LIGHTLOAM_HIP_LIB; else export LIGHTLOAM_HIP_LIB=$v; fi
