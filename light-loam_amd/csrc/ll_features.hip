@@ -126,8 +126,9 @@ __device__ __forceinline__ FeatLds ll_carve(unsigned char *base, int max_ring)
  * The last row is padded with all-ones keys that take part like records (they stay at the end, no per-record guards);
  * rows beyond it are skipped.  Keys must be < 0xffffffff.  Stability makes the result ordered by (k32, original
  * position): exactly the (voxel, input order) order the oracle defines. */
-template <int ROWS>
-__device__ __forceinline__ void ll_radix_sort(unsigned *k32, unsigned short *k16, int n, int key_bits, int *cnt, int *sc, int tid)
+template <int ROWS, bool PRELOADED = false>
+__device__ __forceinline__ void ll_radix_sort(unsigned *k32, unsigned short *k16, int n, int key_bits, int *cnt, int *sc, int tid,
+                                              const unsigned *pre32 = nullptr, const unsigned short *pre16 = nullptr)
 {
     constexpr int NW = LL_BLOCK / 64;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      /* uniform: scalar registers / branches */
@@ -139,7 +140,8 @@ __device__ __forceinline__ void ll_radix_sort(unsigned *k32, unsigned short *k16
     for (int k = 0; k < ROWS; ++k) {
         const int g = wbase + k * 64 + lane;
         e32[k] = 0xffffffffu; e16[k] = 0;
-        if (k < myrows && g < n) { e32[k] = k32[g]; e16[k] = k16[g]; }
+        if (PRELOADED) { if (k < myrows && g < n) { e32[k] = pre32[k]; e16[k] = pre16[k]; } }     /* the caller's registers, this layout */
+        else if (k < myrows && g < n) { e32[k] = k32[g]; e16[k] = k16[g]; }
     }
     if (key_bits <= 0) return;                                  /* one voxel (or none): already in order */
     const int lo = 0, hi = key_bits;                            /* the caller's bound on the keys: no reduction over them to find the varying bits */
@@ -646,6 +648,91 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : ROWS <= 12 ? 5 :
      * prefetches every thread's points before the left-to-right f32 centroid sums. */
     int n_lf_out = 0;
     if (active) {
+        int m = 0;
+        bool sorted_ok = false;
+        if constexpr (SPLIT) {
+            /* The segment points go to the sort as they lie, in the sort's own (wave, row, lane) order -- coalesced rows, no compaction
+             * scan, no trip through LDS: a less-sharp pick (not less-flat, :361-367) just carries the all-ones key that the padding
+             * of the last row carries and ends up behind the m real records. */
+            const int nrows_w = (Lseg + LL_BLOCK - 1) / LL_BLOCK;                  /* rows per wave, uniform */
+            const int wbase = __builtin_amdgcn_readfirstlane(tid >> 6) * nrows_w * 64;
+            float px[ROWS], py[ROWS], pz[ROWS];
+            unsigned mem = 0;                                                        /* bit k: record wbase + k * 64 + lane is less-flat */
+#pragma unroll
+            for (int k = 0; k < ROWS; ++k) {
+                const int g = wbase + k * 64 + lane;
+                if (k < nrows_w && g < Lseg) {
+                    const float4 p = cloud[off + g + 5];
+                    px[k] = p.x; py[k] = p.y; pz[k] = p.z;
+                    if (!ll_bit(L.picked, g + 5)) mem |= 1u << k;
+                }
+            }
+            float mnx = INFINITY, mny = INFINITY, mnz = INFINITY, mxx = -INFINITY, mxy = -INFINITY, mxz = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < ROWS; ++k)
+                if (k < nrows_w && ((mem >> k) & 1u)) {
+                    mnx = fminf(mnx, px[k]); mny = fminf(mny, py[k]); mnz = fminf(mnz, pz[k]);
+                    mxx = fmaxf(mxx, px[k]); mxy = fmaxf(mxy, py[k]); mxz = fmaxf(mxz, pz[k]);
+                }
+            mnx = ll_wave_min_f32(mnx); mny = ll_wave_min_f32(mny); mnz = ll_wave_min_f32(mnz);
+            mxx = ll_wave_max_f32(mxx); mxy = ll_wave_max_f32(mxy); mxz = ll_wave_max_f32(mxz);
+            if (lane == 0) { float *w = fs + (tid >> 6) * 6; w[0] = mnx; w[1] = mny; w[2] = mnz; w[3] = mxx; w[4] = mxy; w[5] = mxz; }
+            { int nls_ = 0; for (int j = 0; j < LL_SEGS; ++j) nls_ += L.lists[157 + j * 3]; m = Lseg - nls_; }   /* every pick is a segment point */
+            __syncthreads();
+            float mn[3] = {fs[0], fs[1], fs[2]}, mx[3] = {fs[3], fs[4], fs[5]};
+            for (int w = 1; w < LL_BLOCK / 64; ++w)
+                for (int c = 0; c < 3; ++c) { mn[c] = fminf(mn[c], fs[w * 6 + c]); mx[c] = fmaxf(mx[c], fs[w * 6 + 3 + c]); }
+            if (m > 0) {
+                /* pcl::VoxelGrid::applyFilter (PCL 1.10), restated */
+                const float inv = V.inv_leaf;
+                long long d[3]; int min_b[3], div_b[3];
+                for (int c = 0; c < 3; ++c) {
+                    d[c] = (long long)((mx[c] - mn[c]) * inv) + 1;
+                    min_b[c] = (int)floorf(mn[c] * inv);
+                    div_b[c] = (int)floorf(mx[c] * inv) - min_b[c] + 1;
+                }
+                const bool too_small = d[0] * d[1] * d[2] > (long long)INT_MAX;        /* "leaf size too small": output = input */
+                /* every real key is below key_end; the digit range covers key_end itself so that all-ones in it is above every real key */
+                const long long key_end = too_small ? (long long)m : (long long)div_b[0] * div_b[1] * div_b[2];
+                const int key_bits = min(32, 64 - __clzll(key_end));
+                const int mul1 = div_b[0], mul2 = div_b[0] * div_b[1];
+                const float fb0 = (float)min_b[0], fb1 = (float)min_b[1], fb2 = (float)min_b[2];
+                int rank_base = 0;                                                   /* too_small only: less-flat points before this wave's rows */
+                if (too_small) {                                                     /* uniform; the key is the point's place among the less-flat points */
+                    int wtot = 0;
+#pragma unroll
+                    for (int k = 0; k < ROWS; ++k) if (k < nrows_w) wtot += __popcll(__ballot((mem >> k) & 1u));
+                    __syncthreads();
+                    if (lane == 0) L.sc[tid >> 6] = wtot;
+                    __syncthreads();
+                    for (int w = 0; w < (tid >> 6); ++w) rank_base += L.sc[w];
+                }
+                unsigned e32[ROWS]; unsigned short e16[ROWS];
+#pragma unroll
+                for (int k = 0; k < ROWS; ++k) {
+                    e32[k] = 0xffffffffu; e16[k] = 0;
+                    if (k < nrows_w) {
+                        const bool mb = (mem >> k) & 1u;
+                        if (too_small) {
+                            const unsigned long long bal = __ballot(mb);
+                            if (mb) e32[k] = (unsigned)(rank_base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u)));
+                            rank_base += __popcll(bal);
+                        } else if (mb) {
+                            const int i0 = (int)(floorf(px[k] * inv) - fb0);
+                            const int i1 = (int)(floorf(py[k] * inv) - fb1);
+                            const int i2 = (int)(floorf(pz[k] * inv) - fb2);
+                            e32[k] = (unsigned)(i0 + i1 * mul1 + i2 * mul2);
+                        }
+                        e16[k] = (unsigned short)(wbase + k * 64 + lane + 5);       /* payload: local index */
+                    }
+                }
+                LL_PHASE(3);
+                ll_radix_sort<ROWS, true>(L.k32, L.k16, Lseg, key_bits, L.cnt, L.sc, tid, e32, e16);
+                LL_PHASE(4);
+                __syncthreads();
+                sorted_ok = true;
+            }
+        } else {
         const int per = (Lseg + LL_BLOCK - 1) / LL_BLOCK;                        /* <= ROWS; uniform: the row loops below skip the rows beyond it by scalar branches */
         const int a0 = min(Lseg, tid * per), a1 = min(Lseg, a0 + per);          /* slots -> local index slot + 5 */
         float px[ROWS], py[ROWS], pz[ROWS];
@@ -670,7 +757,6 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : ROWS <= 12 ? 5 :
         mnx = ll_wave_min_f32(mnx); mny = ll_wave_min_f32(mny); mnz = ll_wave_min_f32(mnz);
         mxx = ll_wave_max_f32(mxx); mxy = ll_wave_max_f32(mxy); mxz = ll_wave_max_f32(mxz);
         if (lane == 0) { float *w = fs + (tid >> 6) * 6; w[0] = mnx; w[1] = mny; w[2] = mnz; w[3] = mxx; w[4] = mxy; w[5] = mxz; }
-        int m = 0;
         int pos = ll_block_exscan(__popc(lfm), L.sc, m);             /* barriers inside also publish fs[] */
         float mn[3] = {fs[0], fs[1], fs[2]}, mx[3] = {fs[3], fs[4], fs[5]};
         for (int w = 1; w < LL_BLOCK / 64; ++w)
@@ -709,6 +795,10 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : ROWS <= 12 ? 5 :
             ll_radix_sort<ROWS>(L.k32, L.k16, m, key_bits, L.cnt, L.sc, tid);
             LL_PHASE(4);
             __syncthreads();
+            sorted_ok = true;
+        }
+        }
+        if (sorted_ok) {
             /* voxel runs -> centroids.  Thread t owns sorted positions [t*perm, (t+1)*perm): its points are fetched up
              * front, a run is summed by the thread that owns its head and may continue into the following threads' range */
             const int perm = (m + LL_BLOCK - 1) / LL_BLOCK;                          /* <= ROWS */
