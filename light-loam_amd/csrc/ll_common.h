@@ -331,4 +331,5 @@ void ll_launch_normal_equations(const LLView &V, int first, int count, int do_st
 void ll_launch_gn_step(const LLView &V, int first, int count, hipStream_t st, LLProfiler *prof);
 void ll_launch_rows(const LLView &V, int slot, const double *pose7_dev, double *r, double *Jq, double *Jt, hipStream_t st);
 size_t ll_features_lds_bytes(int max_ring);
+size_t ll_features_lds_bytes(int max_ring, int split);
 void ll_launch_debug_exact_math(const LLView &V, int op, const float *a, const float *b, const float *c, int n, float *out, hipStream_t st);

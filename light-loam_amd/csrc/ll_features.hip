@@ -47,6 +47,9 @@ __device__ __forceinline__ bool ll_xcd_map2(int id, int per_scan, int count, int
 #ifndef LL_FWAVES
 #define LL_FWAVES 6
 #endif
+#ifndef LL_FWAVES_SPLIT
+#define LL_FWAVES_SPLIT 6     /* the voxel-only kernel of the split pipeline */
+#endif
 #ifdef LL_PHASE_STOP
 #define LL_LOOKBACK_SPINS 1            /* instruction-count builds return early and never publish: do not wait for them */
 #else
@@ -80,32 +83,34 @@ static size_t ll_feat_tile_bytes(size_t rows)
     return m > c ? m : c;
 }
 
-size_t ll_features_lds_bytes(int max_ring)      /* max_ring: the ring capacity of the LAUNCH (a tier of ll_launch_features) */
+size_t ll_features_lds_bytes(int max_ring, int split)      /* max_ring: the ring capacity of the LAUNCH (a tier of ll_launch_features) */
 {
     const size_t mr = (size_t)((max_ring + 255) / 256 * 256);
     const size_t rows = (mr / 256 <= 9) ? 9 : (mr / 256 <= 12) ? 12 : (mr / 256 <= 18) ? 18 : 32;     /* the ROWS instantiation that will run */
     size_t b = 4 * mr + 2 * mr;              /* k32 + k16 */
-    b += ll_feat_tile_bytes(rows);           /* tile / pick scratch */
-    b += 2 * 4 * (mr / 32 + 2);              /* bitmaps */
-    b += mr;                                 /* labels */
+    b += split ? 4 * (32 * rows * 4 + 4) : ll_feat_tile_bytes(rows);   /* radix counters | tile / pick scratch / radix counters */
+    b += (split ? 1 : 2) * 4 * (mr / 32 + 2);   /* bitmaps */
+    if (!split) b += mr;                     /* labels */
     b += 4 * LL_NLIST;
     b += 4 * 64;
     return (b + 15) / 16 * 16 + 64;
 }
+size_t ll_features_lds_bytes(int max_ring) { return ll_features_lds_bytes(max_ring, 0); }   /* the larger of the two: ll_create's capacity check */
 
+template <bool SPLIT>
 __device__ __forceinline__ FeatLds ll_carve(unsigned char *base, int max_ring)
 {
     const size_t mr = (size_t)((max_ring + 255) / 256 * 256);
     const size_t rows = (mr / 256 <= 9) ? 9 : (mr / 256 <= 12) ? 12 : (mr / 256 <= 18) ? 18 : 32;     /* the ROWS instantiation that will run */
     const size_t tile = 3 * 4 * (size_t)(LL_FTILE + 16), wscr = 4 * 64 * ((rows * 256 + 383) / 384) * 2, cbytes = 4 * (32 * rows * 4 + 4);
-    const size_t tile_bytes = (tile > wscr ? tile : wscr) > cbytes ? (tile > wscr ? tile : wscr) : cbytes;
+    const size_t tile_bytes = SPLIT ? cbytes : ((tile > wscr ? tile : wscr) > cbytes ? (tile > wscr ? tile : wscr) : cbytes);
     FeatLds L;
     unsigned char *p = base;
     L.k32 = (unsigned *)p; p += 4 * mr;
     L.tx = (float *)p; L.ty = L.tx + (LL_FTILE + 16); L.tz = L.ty + (LL_FTILE + 16);
     p += tile_bytes;
     L.picked = (unsigned *)p; p += 4 * (mr / 32 + 2);
-    L.gapf = (unsigned *)p; p += 4 * (mr / 32 + 2);
+    L.gapf = (unsigned *)p; if (!SPLIT) p += 4 * (mr / 32 + 2);       /* split: never touched */
     L.lists = (int *)p; p += 4 * LL_NLIST;
     L.cnt = (int *)L.tx;                      /* radix counters of phase 4 share the tile region */
     L.sc = (int *)p; p += 4 * 64;
@@ -250,7 +255,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char ll_smem[];
  * counts published, no look-back.  The main launch (ring_lo = INT_MIN) extracts its rings and places the staged lists of the longer ones. */
 /* SPLIT: phases 1-3 ran in k_ring_pick (ll_pick.hip): this launch starts from its lists (ring_rec) and does phases 4-5 only. */
 template <int ROWS, bool SPLIT>
-__global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : ROWS <= 12 ? 5 : ROWS <= 18 ? 3 : 1)) void k_ring_features(LLView V, int first, int count, int ring_lo, int ring_hi)
+__global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? (SPLIT ? LL_FWAVES_SPLIT : LL_FWAVES) : ROWS <= 12 ? 5 : ROWS <= 18 ? 3 : 1)) void k_ring_features(LLView V, int first, int count, int ring_lo, int ring_hi)
 {
     constexpr int stage_only = ROWS > 9 ? 1 : 0;                      /* the tiers of long rings are the instantiations with more rows than the main launch's */
     static_assert(ROWS <= 32, "lfm / headm / endm hold one bit per row of a thread");
@@ -311,7 +316,7 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : ROWS <= 12 ? 5 :
         else { int c = nr; do { l -= c; ++q; c = ro[q + 1] - ro[q]; } while (l >= c); }
         return slot_cloud[(size_t)q * V.ring_cap + l];
     };
-    FeatLds L = ll_carve(ll_smem, ring_hi);
+    FeatLds L = ll_carve<SPLIT>(ll_smem, ring_hi);
     float *fs = (float *)(L.sc + 32);                                 /* 24 floats: per-wave bounds */
 
     /* Decoupled look-back over the rings of the scan (they run on one XCD, dispatched in ring order): publish() this
@@ -338,8 +343,11 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES : ROWS <= 12 ? 5 :
     float4 *stage_ls = V.gpts_c + (size_t)s * V.cap_lsharp + (size_t)r * (LL_SEGS * LL_LSHARP_PER_SEG);
     float4 *stage_sf = V.stage_sf + ((size_t)s * V.R + r) * LL_STAGE_SF;                   /* sharp [12], flat [24] */
     const int nwords = (nr + 31) / 32 + 1;
-    for (int i = tid; i < nwords; i += LL_BLOCK) { L.picked[i] = 0; L.gapf[i] = 0; }
-    for (int i = tid; i < (nr + 3) / 4; i += LL_BLOCK) ((unsigned *)L.lab)[i] = 0u;   /* labels, four at a time (the array is 4-byte aligned and padded) */
+    if constexpr (SPLIT) { for (int i = tid; i < nwords; i += LL_BLOCK) L.picked[i] = 0; }
+    else {
+        for (int i = tid; i < nwords; i += LL_BLOCK) { L.picked[i] = 0; L.gapf[i] = 0; }
+        for (int i = tid; i < (nr + 3) / 4; i += LL_BLOCK) ((unsigned *)L.lab)[i] = 0u;   /* labels, four at a time (the array is 4-byte aligned and padded) */
+    }
     if (tid < 3 * LL_SEGS) L.lists[156 + tid] = 0;                    /* per segment: n_sharp, n_lsharp, n_flat */
     if (tid == 0) L.sc[60] = 0;                                       /* segments finished (bit j) */
     __syncthreads();
@@ -912,7 +920,7 @@ template <int ROWS, bool SPLIT>
 static void ll_launch_ring_features(const LLView &V, int first, int count, int grid, int ring_lo, int ring_hi, hipStream_t st)
 {
     static size_t attr_bytes[LL_MAX_DEVICES] = {0};
-    const size_t lds_bytes = ll_features_lds_bytes(ring_hi);
+    const size_t lds_bytes = ll_features_lds_bytes(ring_hi, SPLIT ? 1 : 0);
     ll_ensure_dynamic_lds(k_ring_features<ROWS, SPLIT>, lds_bytes, attr_bytes);
     hipLaunchKernelGGL((k_ring_features<ROWS, SPLIT>), dim3(grid), dim3(LL_BLOCK), lds_bytes, st, V, first, count, ring_lo, ring_hi);
 }
