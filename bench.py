@@ -29,6 +29,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md chip table: HBM3E 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0        # ... and the copy rate measured on the part (same table)
+N_SIMD = 1024                # 256 CUs x 4 SIMD-32 (same table)
+CLOCK_GHZ = 2.4              # peak engine clock; the board sits at 2.34-2.35 GHz during the bench (tools/sample_clocks.sh)
+VALU_CYCLES = 2.2            # cycles a SIMD needs per wave64 vector instruction with >= 4 waves feeding it (tools/ubench/valu_rate.hip)
 
 
 def emit(out):
@@ -415,7 +418,7 @@ def traffic_from_profile(args, kernel, launches_per_step, path=None):
     """(HBM bytes per launch of `kernel` or None, why) from profiles/pmc_traffic.json -- the separate rocprofv3 FETCH_SIZE / WRITE_SIZE
     passes of this same command (tools/pmc_traffic.py, stamped by tools/profile_round.sh) -- used ONLY when the file was measured on
     THIS code (source digest), ring count, workload and batch."""
-    tpath = path or os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    tpath = path or os.path.join(ROOT, "profiles", "pmc_traffic.json" if args.workload == "synthetic" else "pmc_traffic_%s.json" % args.workload)
     if not os.path.exists(tpath):
         return None, "profiles/pmc_traffic.json absent"
     try:
@@ -430,6 +433,27 @@ def traffic_from_profile(args, kernel, launches_per_step, path=None):
                 "rocprofv3 FETCH_SIZE + WRITE_SIZE passes of this command at this source digest (tools/profile_round.sh)")
     except Exception as e:
         return None, "profiles/pmc_traffic.json unreadable: " + repr(e)[:80]
+
+
+def issue_from_profile(args, kernels, path=None):
+    """Instruction-issue figures of `kernels` from profiles/sq_issue.json -- SQ_INSTS_VALU / SQ_INSTS_SALU / SQ_INSTS_LDS per full-batch
+    launch, collected by tools/profile_round.sh (rocprofv3 --pmc, its own pass) and stamped like pmc_traffic.json; used only when
+    the stamp matches this code, ring count, workload and batch.  (dict or None, why)"""
+    ipath = path or os.path.join(ROOT, "profiles", "sq_issue.json" if args.workload == "synthetic" else "sq_issue_%s.json" % args.workload)
+    if not os.path.exists(ipath):
+        return None, "profiles/sq_issue.json absent"
+    try:
+        T = json.load(open(ipath))
+        want = {"source_digest": source_digest(), "rings": args.rings, "batch": args.batch, "workload": args.workload}
+        diff = sorted(k for k, v in want.items() if T.get(k) != v)
+        if diff:
+            return None, "profiles/sq_issue.json was measured on another " + ", ".join(diff) + ": not used"
+        got = {k: T["kernels"][k] for k in kernels if k in T.get("kernels", {})}
+        if len(got) != len(kernels):
+            return None, "profiles/sq_issue.json lacks " + ", ".join(k for k in kernels if k not in got)
+        return got, "rocprofv3 SQ_INSTS_VALU / SQ_INSTS_SALU / SQ_INSTS_LDS pass of this command at this source digest (tools/profile_round.sh)"
+    except Exception as e:
+        return None, "profiles/sq_issue.json unreadable: " + repr(e)[:80]
 
 
 def launch_ranks(args, argv):
@@ -501,7 +525,8 @@ def main():
                     "(189 GB of the 288; 8192: -2 %%), 4096 for more rings, 32768 for fewer; --stream-input: 2048")
     ap.add_argument("--chunk", type=int, default=0, help="scans per launch sequence inside a step (0 = whole batch)")
     ap.add_argument("--rings", type=int, default=64)
-    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic poses the batch cycles through")
+    ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic poses the batch cycles through (65 scans, 128 scan pairs: "
+                    "ring lengths, pick counts and search depths differ from slot to slot)")
     ap.add_argument("--mode", choices=["hot", "map"], default="hot",
                     help="hot: the headline metric (scans/s of the per-scan hot path, scan-parallel).  map: BASELINE config 4, laserMapping "
                          "frames/s with the voxel-tiled map sharded over the GPUs and the RCCL all-reduce of JtJ / Jtr (strong scaling)")
@@ -611,6 +636,18 @@ def main():
     def step():
         ctx.hot_path(0, args.batch, None, vote=True)     # pose restarts from the stored guess, device-to-device
 
+    # box calibration: a FIXED micro-run (the extract stage of the first 512 slots, three times, untimed warm-up first), HIP-event time
+    # of the ring kernels -- the boxes of the pool differ by up to 30 % in exactly these kernels, so a slow
+    # draw shows here instead of looking like a regression of the headline
+    calib_n = min(512, args.batch)
+    ctx.extract(0, calib_n); ctx.synchronize()
+    ctx.profile_enable(True); ctx.profile_read(reset=True)
+    for _ in range(3):
+        ctx.extract(0, calib_n)
+    cprof = ctx.profile_read(reset=True)
+    ctx.profile_enable(False)
+    box_calibration_ms = sum(cprof[k][0] / max(1, cprof[k][1]) for k in ("k_ring_pick", "k_ring_features") if k in cprof and cprof[k][1])
+
     def barrier():
         if dist is not None:
             dist.barrier()
@@ -658,12 +695,16 @@ def main():
         tot["ne"] += pi.n_edge; tot["np_"] += pi.n_plane; tot["nsel"] += pi.n_plane_selected
     if bad and not os.environ.get("LL_BENCH_TIMING_BUILD"):     # set only by tools/ that time deliberately incomplete builds
         raise SystemExit(f"bench self-check failed on rank {rank}: {len(bad)} slot(s), first {bad[:5]}")
+    split = os.environ.get("LIGHTLOAM_RING_SPLIT", "1") != "0"
     kernel_bytes = {
         "k_first_kept": 0.0, "k_offsets": 0.0, "k_gn_step": 0.0,
         "k_organize": 16.0 * tot["n_in"] + 16.0 * tot["n"],          # read the raw scan, write laserCloud (one pass)
         "k_classify": 16.0 * tot["n_in"],                            # (tile-parallel path of small calls) read the raw scan
         "k_scatter": 16.0 * tot["n"],                                # (tile-parallel path) write laserCloud
-        "k_ring_features": 17.0 * tot["n"] + 16.0 * tot["feat"],     # read laserCloud, write labels + the four feature clouds
+        # the ring stage is two launches since round 4 (ll_pick.hip, ll_features.hip); LIGHTLOAM_RING_SPLIT=0 runs the fused kernel of
+        # rounds 1-3, which then carries the whole stage: 17 n + 16 feat
+        "k_ring_pick": 17.0 * tot["n"],                               # read laserCloud, write labels (+ 352 B of lists per ring)
+        "k_ring_features": (16.0 * tot["n"] + 16.0 * tot["feat"]) if split else (17.0 * tot["n"] + 16.0 * tot["feat"]),   # read laserCloud (again), write the four feature clouds
         "k_build_grid": 16.0 * (tot["lsharp"] + tot["lflat"]),       # read the target clouds once
         "k_associate": 16.0 * tot["q"] + 8.0 * tot["ne"] + 12.0 * tot["np_"],
         "k_vote": 32.0 * tot["np_"] + 8.0 * tot["nsel"],
@@ -683,6 +724,30 @@ def main():
         avg_ms = dom_ms / max(1, dom_launches)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic, traffic_note = traffic_from_profile(args, dom, launches_per_step)
+        ms_of = {k: v[0] / v[1] * launches_per_step for k, v in prof.items() if v[1]}
+        # the ring stage = what rounds 1-3 ran as ONE kernel: laserCloud counted once (17 n + 16 feat)
+        stage_kernels = [k for k in ("k_ring_pick", "k_ring_features") if k in ms_of]
+        stage_ms = sum(ms_of[k] for k in stage_kernels)
+        stage_bytes = 17.0 * tot["n"] + 16.0 * tot["feat"]
+        stage_gbps = stage_bytes / (stage_ms * 1e-3) / 1e9 if stage_ms > 0 else 0.0
+        # which wall: vector / scalar instruction issue against bytes, from the stamped counter pass
+        issue, issue_note = issue_from_profile(args, stage_kernels)
+        issue_out = {"source": issue_note}
+        bound = "hbm"
+        if issue is not None:
+            simd_slots = N_SIMD * CLOCK_GHZ * 1e9 / VALU_CYCLES                   # wave64 vector instructions per second, whole chip
+            scalar_slots = (N_SIMD / 4) * CLOCK_GHZ * 1e9                          # one scalar unit per CU, one instruction per cycle
+            for k in stage_kernels:
+                t = ms_of[k] / launches_per_step * 1e-3
+                issue_out[k] = {"valu_wave_insts_per_launch": issue[k]["valu"], "salu_wave_insts_per_launch": issue[k]["salu"],
+                                "lds_wave_insts_per_launch": issue[k].get("lds"),
+                                "valu_busy": issue[k]["valu"] / (simd_slots * t), "salu_busy": issue[k]["salu"] / (scalar_slots * t),
+                                "hbm_frac": kernel_bytes[k] / launches_per_step / t / 1e9 / HBM_PEAK_GBS}
+            d = issue_out.get(dom)
+            if d and max(d["valu_busy"], d["salu_busy"]) > d["hbm_frac"]:
+                bound = "issue (vector %.0f %%, scalar %.0f %% busy; bytes %.0f %% of the HBM peak)" % (100 * d["valu_busy"], 100 * d["salu_busy"], 100 * d["hbm_frac"])
+            issue_out["model"] = ("valu_busy = SQ_INSTS_VALU / (%d SIMDs x %.1f GHz / %.1f cycles x launch time); salu_busy = SQ_INSTS_SALU / "
+                                  "(%d scalar units x %.1f GHz x launch time)" % (N_SIMD, CLOCK_GHZ, VALU_CYCLES, N_SIMD // 4, CLOCK_GHZ))
         out = {
             "metric": metric_name(args),
             "value": value, "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -693,15 +758,23 @@ def main():
                        "workload_id": args.workload, "max_ring_points": args.max_ring_points or 2304,
                        "scans_per_gpu_per_step": args.batch, "chunk": args.chunk or args.batch,
                        "distinct_scans": args.distinct + 1, "distinct_scan_pairs": len(pose_of_pair),
+                       "box_calibration_ms": box_calibration_ms,
+                       "box_calibration": "HIP-event time of the ring kernels over the first %d slots (fixed micro-run before the timed region)" % calib_n,
+                       "ring_pipeline": "k_ring_pick + k_ring_features (split)" if split else "k_ring_features (fused, LIGHTLOAM_RING_SPLIT=0)",
                        "self_check": "every slot: status 0, correspondences > 0, finite pose; equal scan pairs -> bit-identical poses",
                        "points_per_scan_in": int(info.n_in), "points_per_scan_kept": int(info.n),
                        "parallelism": f"scan-parallel x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": bound, "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "frac_of_measured_copy": achieved / HBM_COPY_GBS, "measured_copy_GBps": HBM_COPY_GBS,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "whole_path_algorithmic_GBps": (ab["ext"] + ab["assoc"] + ab["vote"] + ab["rj"]) * args.steps / elapsed / 1e9,
-                         "kernel_ms_per_step": {k: v[0] / v[1] * launches_per_step for k, v in prof.items() if v[1]},
+                         "issue": issue_out,
+                         "ring_stage": {"kernels": stage_kernels, "ms_per_step": stage_ms, "algorithmic_bytes_per_step": stage_bytes,
+                                        "achieved": stage_gbps, "frac": stage_gbps / HBM_PEAK_GBS,
+                                        "note": "the stage rounds 1-3 ran as one kernel: laserCloud counted once (17 n + 16 features); each kernel's own "
+                                                "figure above counts what that launch must read and write"},
+                         "kernel_ms_per_step": ms_of,
                          "kernel_algorithmic_GBps": {k: kernel_bytes[k] / (v[0] / v[1] * launches_per_step * 1e-3) / 1e9
                                                      for k, v in prof.items() if v[1] and kernel_bytes.get(k)}},
         }

@@ -19,23 +19,30 @@ import sys
 from collections import defaultdict
 
 
+
+def kernel_name(raw):
+    """k_foo<9, true>(LLView, ...) -> k_foo; the per-row-count kernels k_ring_pick6 / 8 / 12 / 22 -> k_ring_pick (bench.py's name)"""
+    n = raw.split("(")[0].replace("void ", "").split("<")[0].strip()
+    return "k_ring_pick" if n.startswith("k_ring_pick") else n
+
+
 def per_kernel(dirpath, counter):
     files = glob.glob(os.path.join(dirpath, "**", "*counter_collection.csv"), recursive=True)
     if not files:
         raise SystemExit(f"no counter_collection.csv under {dirpath}")
-    rows = defaultdict(list)
+    inst = defaultdict(list)                   # per instantiation (template arguments kept): the tier launches of one kernel are summed below
     for f in files:
         for row in csv.DictReader(open(f)):
             if row.get("Counter_Name") != counter:
                 continue
-            name = row["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].strip()
-            rows[name].append((float(row["Counter_Value"]), float(row.get("Grid_Size", 0) or 0)))
+            inst[row["Kernel_Name"].split("(")[0].replace("void ", "").strip()].append((float(row["Counter_Value"]), float(row.get("Grid_Size", 0) or 0)))
     tot = defaultdict(float); calls = defaultdict(int)
-    for name, lst in rows.items():
+    for raw, lst in inst.items():
+        name = kernel_name(raw)
         gmax = max(g for _, g in lst)
-        for v, g in lst:                       # only full-batch launches (the carry / set-up launches cover one scan)
-            if g >= 0.5 * gmax:
-                tot[name] += v; calls[name] += 1
+        big = [v for v, g in lst if g >= 0.5 * gmax]     # only full-batch launches (the carry / set-up launches cover one scan)
+        # per-step figure of this instantiation = its per-launch average; tot / calls below is again "per launch of the kernel"
+        tot[name] += sum(big) / len(big); calls[name] = 1
     return tot, calls
 
 

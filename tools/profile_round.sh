@@ -18,9 +18,25 @@ python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write --batch ${BATCH:-16384} -
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY \
     --kernel-trace -f csv -d $O/pmc_sq -o sq -- $B > $O/pmc_sq.log 2>&1
 python3 tools/sq_summary.py $O/pmc_sq > $O/${TAG}_sq_counters.txt
+python3 tools/sq_issue.py $O/pmc_sq --batch ${BATCH:-16384} --rings 64 --workload synthetic > $O/sq_issue.json
 cp $O/pmc_traffic.json profiles/pmc_traffic.json          # bench.py reads roofline.traffic from here (when the stamp matches)
+cp $O/sq_issue.json profiles/sq_issue.json                # ... and roofline.issue from here
+# the same three counter passes for BASELINE config 3's stand-in (bench.py --workload hdl64: 8192 scans per step, ring capacity 4608)
+BH="python3 bench.py --workload hdl64 --steps 5 --warmup 1 --no-cpu-baseline --calibrate"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $O/pmc_fetch_h -o fetch -- $BH > $O/pmc_fetch_h.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d $O/pmc_write_h -o write -- $BH > $O/pmc_write_h.log 2>&1
+python3 tools/pmc_traffic.py $O/pmc_fetch_h $O/pmc_write_h --batch 8192 --rings 64 --workload hdl64 > $O/pmc_traffic_hdl64.json
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY \
+    --kernel-trace -f csv -d $O/pmc_sq_h -o sq -- $BH > $O/pmc_sq_h.log 2>&1
+python3 tools/sq_summary.py $O/pmc_sq_h > $O/${TAG}_sq_counters_hdl64.txt
+python3 tools/sq_issue.py $O/pmc_sq_h --batch 8192 --rings 64 --workload hdl64 > $O/sq_issue_hdl64.json
+cp $O/pmc_traffic_hdl64.json profiles/pmc_traffic_hdl64.json
+cp $O/sq_issue_hdl64.json profiles/sq_issue_hdl64.json
 python3 bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
-python3 tools/phase_timing.py 2048 > $O/${TAG}_phase_timing.txt 2>&1
+# fused ring kernel of rounds 1-3 beside the split pipeline, same box
+LIGHTLOAM_RING_SPLIT=0 python3 bench.py --no-cpu-baseline > $O/${TAG}_bench_fused_ring_kernel.json 2>/dev/null
+# 9 distinct scans (the default of rounds 1-3) beside the 65 of the headline: what slot-to-slot diversity costs
+python3 bench.py --distinct 8 --no-cpu-baseline > $O/${TAG}_bench_distinct8.json 2>/dev/null
 # BASELINE config 3's stand-in (HDL-64E true laser table, ring capacity 4608): bench line + its kernel stats
 python3 bench.py --workload hdl64 --no-cpu-baseline > $O/${TAG}_bench_hdl64.json 2> $O/${TAG}_bench_hdl64.err
 rocprofv3 --kernel-trace --stats -d $O/prof_${TAG}_hdl64 -o ${TAG}h -- python3 bench.py --workload hdl64 --steps 5 --warmup 1 --no-cpu-baseline > $O/prof_${TAG}_hdl64.log 2>&1
@@ -36,5 +52,5 @@ python3 tools/soak_extract_s64.py 96 > $O/${TAG}_soak_extract_s64.log 2>&1
 python3 tools/soak_hot_path.py 256 2>&1 | grep -v amdgpu.ids > $O/${TAG}_soak_hot_path.log
 python3 tools/soak_frames.py 120 60 2>&1 | grep -v "amdgpu.ids\|RuntimeWarning\|org_s" > $O/${TAG}_soak_frames_short.log
 # keep what is merged back small: the raw counter tables and traces stay on the box
-rm -rf $O/prof_$TAG $O/prof_${TAG}_hdl64 $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/liblightloam_hip_phase.so
+rm -rf $O/prof_$TAG $O/prof_${TAG}_hdl64 $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_fetch_h $O/pmc_write_h $O/pmc_sq_h $O/liblightloam_hip_phase.so
 tail -n 3 $O/${TAG}_kernel_stats.txt; tail -c 600 $O/${TAG}_bench.json

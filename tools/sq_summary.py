@@ -3,11 +3,18 @@
 import csv, glob, os, sys
 from collections import defaultdict
 
+
+def kernel_name(raw):
+    """k_foo<9, true>(LLView, ...) -> k_foo; the per-row-count kernels k_ring_pick6 / 8 / 12 / 22 -> k_ring_pick (bench.py's name)"""
+    n = raw.split("(")[0].replace("void ", "").split("<")[0].strip()
+    return "k_ring_pick" if n.startswith("k_ring_pick") else n
+
+
 d = sys.argv[1]
 rows = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].strip()
+        name = kernel_name(r["Kernel_Name"])
         if name.startswith("k_"):
             rows[name][r["Counter_Name"]].append((float(r["Counter_Value"]), float(r["Grid_Size"]), float(r["End_Timestamp"]) - float(r["Start_Timestamp"])))
 for name in sorted(rows):
