@@ -468,8 +468,10 @@ def launch_ranks(args, argv):
     cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in argv if a != "--dry-launch"]
     envs = []
     for r in range(n):
-        envs.append({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
-                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        e = {"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)}
+        if "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ:           # the ranks see what a torchrun-launched rank would see: the parent's setting, if any
+            e["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ["HSA_ENABLE_IPC_MODE_LEGACY"]
+        envs.append(e)
     if args.dry_launch:
         emit({"dry_launch": True, "n_ranks": n, "command": cmd, "rank_env": envs, "parent_imported_torch": "torch" in sys.modules})
         return 0
@@ -484,12 +486,18 @@ def launch_ranks(args, argv):
     # this process's own children, addressed by their exact pids)
     rcs = [None] * n
     failed_at = None
+    started = time.monotonic()
+    timed_out = False
     while any(c is None for c in rcs):
         for r, p in enumerate(procs):
             if rcs[r] is None:
                 rcs[r] = p.poll()
         if failed_at is None and any(c not in (None, 0) for c in rcs):
             failed_at = time.monotonic()
+        if not timed_out and args.launch_timeout > 0 and time.monotonic() - started > args.launch_timeout:
+            # every rank alive but nothing moves (a rendezvous or a collective that never completes): end the run, never re-launch
+            timed_out = True
+            failed_at = time.monotonic() - 16.0
         if failed_at is not None and time.monotonic() - failed_at > 15.0:
             for r, p in enumerate(procs):
                 if rcs[r] is None:
@@ -507,12 +515,13 @@ def launch_ranks(args, argv):
     out0.close()
     for ln in lines[:-1]:
         print(ln)
-    rc = next((c for c in rcs if c != 0), 0)
+    rc = 0 if all(c == 0 for c in rcs) and not timed_out else 1   # a signal-killed child reports a negative code: any failure is exit code 1
     if lines:
         sys.stdout.flush()
         print(lines[-1], flush=True)                           # rank 0's JSON line is this process's last line
     if rc != 0:
-        print(f"bench.py: rank exit codes {rcs}", file=sys.stderr)
+        print(f"bench.py: rank exit codes {rcs}" + (f" (no progress within --launch-timeout {args.launch_timeout:.0f} s: ranks terminated)" if timed_out else ""),
+              file=sys.stderr)
     return rc
 
 
@@ -551,11 +560,18 @@ def main():
                     help="process-group backend of the N > 1 run (nccl = RCCL; gloo only to exercise the multi-rank path where RCCL cannot run)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="N > 1 ranks all on device 0 (a one-GPU box exercising the multi-rank path; needs --backend gloo and a small --batch)")
+    ap.add_argument("--launch-timeout", type=float, default=1800.0,
+                    help="--gpus N > 1 from a plain command line: seconds after which ranks that are all alive but not finished are terminated "
+                         "(exit code 1; 0 = wait for ever)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="--gpus N > 1 from a plain command line: print the N child command lines + rank environments as JSON and exit "
                          "(nothing is started, torch is never imported)")
     args = ap.parse_args()
     args.batch_defaulted = args.batch <= 0
+    if args.share_gpu and args.backend != "gloo":
+        raise SystemExit("--share-gpu puts every rank on device 0: RCCL cannot run there, use --backend gloo")
+    if args.mode == "map" and (args.share_gpu or args.backend != "nccl"):
+        raise SystemExit("--mode map runs its collectives on device buffers over RCCL: --backend nccl, one GPU per rank (no --share-gpu)")
     if args.workload == "hdl64":
         if args.rings != 64:
             raise SystemExit("--workload hdl64 is a 64-ring sensor")

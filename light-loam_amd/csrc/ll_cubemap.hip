@@ -421,19 +421,25 @@ extern "C" int ll_cubemap_update(ll_cubemap *cm, const double *pose_w7)
             if (tot[w] > 0) { n_out[w] = pin[w * per]; for (int k = 0; k < cm->n_valid; ++k) seg_count[w][(size_t)k] = pin[w * per + 1 + k]; }
         }
     }
-    /* Stage C: the pair tables, one cloud type after the other (a capacity overflow of the second leaves the first updated and
-     * the second as it was -- as when the types were processed one after the other) */
+    /* Stage C: the pair tables.  Will it fit?  Decided for BOTH cloud types BEFORE any table changes (a compaction keeps the clouds
+     * of the cubes outside the valid set only): a pool that is too small for either type leaves the whole cube map as it was, with
+     * nothing of this stage enqueued, and the call can be repeated with a larger pool_points. */
+    size_t need_w[2] = {0, 0};
     for (int w = 0; w < 2; ++w) {
         const int *addcnt = addcnt_all.data() + w * (CM_N + 1);
         /* pool space: the filtered valid cubes + the grown clouds of the other cubes that received points */
         size_t need = (size_t)n_out[w];
         for (int c = 0; c < CM_N; ++c) if (!is_valid[c] && addcnt[c] > 0) need += (size_t)cm->cnt[w][c] + (size_t)addcnt[c];
-        /* will it fit?  Decided BEFORE any table changes: a compaction keeps the clouds of the cubes outside the valid set only */
+        need_w[w] = need;
         if (cm->top[w] + need > cm->cap_pool * 3 / 4) {
             size_t live = 0;
             for (int c = 0; c < CM_N; ++c) if (!is_valid[c]) live += (size_t)cm->cnt[w][c];
             if (live + need > cm->cap_pool) { cm->err = "cube map pool exhausted (pool_points too small)"; return LL_ERR_CAPACITY; }
         }
+    }
+    for (int w = 0; w < 2; ++w) {
+        const int *addcnt = addcnt_all.data() + w * (CM_N + 1);
+        const size_t need = need_w[w];
         /* ---- commit: the valid cubes' old clouds are dead from here on (not carried through a compaction) ---- */
         guard.armed = true;
         for (int v = 0; v < cm->n_valid; ++v) cm->cnt[w][cm->valid[v]] = 0;

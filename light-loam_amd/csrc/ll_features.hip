@@ -166,7 +166,8 @@ __device__ __forceinline__ void ll_radix_sort(unsigned *k32, unsigned short *k16
                 unsigned mlo, mhi;
                 ll_match_any(d, BITS, ~0ull, mlo, mhi);
                 rnk[k] = ll_match_rank(mlo, mhi);
-                pre[k] = wc[d];                                 /* records of the earlier rows of this wave with digit d ... */
+                pre[k] = __hip_atomic_load(&wc[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   /* records of the earlier rows of this wave with digit d ... (an
+                                                                                 * atomic load: it must see the rows' adds, whatever the compiler would like to merge) */
                 if (rnk[k] == 0) atomicAdd(&wc[d], ll_match_count(mlo, mhi));   /* ... bumped by an LDS add that does not wait for the read:
                                                                                  * the wave's LDS operations execute in order, so the next row's read sees it */
             }

@@ -311,7 +311,9 @@ __global__ __launch_bounds__(1024) void k_rs_small(unsigned long long *keys, int
                 unsigned mlo, mhi;
                 ll_match_any(d, 8, ~0ull, mlo, mhi);
                 const int rk = ll_match_rank(mlo, mhi);
-                const int pre = wc[d];                                     /* same digit, earlier rows of this wave */
+                /* same digit, earlier rows of this wave: the read must see the adds of the rows before it -- an atomic load, so that
+                 * neither the language's memory model nor a merged / hoisted load of a later row stands between the two */
+                const int pre = __hip_atomic_load(&wc[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (rk == 0) atomicAdd(&wc[d], ll_match_count(mlo, mhi));
                 rnk[r] = pre + rk;
             }
