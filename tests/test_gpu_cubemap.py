@@ -115,27 +115,27 @@ def test_process_slot_equals_process_with_downloaded_clouds(api, synth):
     a.close(); b.close(); ctx.close()
 
 
-def test_a_pool_too_small_for_the_surface_cloud_only_leaves_the_map_as_it_was(api, orc, frames):
+def test_a_pool_too_small_for_the_surface_cloud_only_leaves_the_map_as_it_was(api, orc, synth):
     """ll_cubemap_update decides the pool capacity of BOTH cloud types before it commits either (round-3 advice): with a pool that
     holds the corner cloud of the first frame but not its surface cloud the update fails with LL_ERR_CAPACITY, nothing has changed --
     every cube still empty, the map not marked broken -- and the same call fails the same way again instead of with LL_ERR_STATE."""
-    f = frames[0]
-    nc, ns = len(f["corner"]), len(f["surf"])
-    assert ns > 2 * nc, (nc, ns)
-    ctx = api.Context(api.default_params(16, batch=1, max_points=4096))
+    cfg = synth.default_cfg(64)
+    fe = orc.extract(synth.scan(cfg, 0), orc.params(64))
+    corner, surf = fe["less_sharp"], fe["less_flat"]
+    pose = _pose7(synth.pose(cfg, 0))
     oc = orc.CubeMap()
-    pose = _pose7(f["pose3"])
-    oc.prepare(pose[4:], f["corner"], f["surf"])
+    oc.prepare(pose[4:], corner, surf)
     stack_c, stack_s = len(oc.cloud(2)), len(oc.cloud(3))                       # the down-sized scan: what the update files into the cubes
     oc.close()
-    assert stack_s > stack_c + 64
+    assert stack_s > stack_c + 64 and stack_c + stack_s > 2 * 4096, (stack_c, stack_s)
     pool = (stack_c + stack_s) // 2                                             # corner fits, surface does not
-    dc = api.CubeMap(ctx, 4096, 32768, pool_points=pool)
-    dc.prepare(pose[4:], f["corner"], f["surf"])
+    ctx = api.Context(api.default_params(64, batch=1, max_points=4096))
+    dc = api.CubeMap(ctx, 16384, 65536, pool_points=pool)
+    dc.prepare(pose[4:], corner, surf)
     for attempt in range(2):
         with pytest.raises(api.LightLoamError) as e:
             dc.update(pose)
         assert e.value.code == -4, (attempt, e.value)                          # LL_ERR_CAPACITY, not -7 (LL_ERR_STATE)
     assert all(len(dc.cube(s, i, cap=1 << 16)) == 0 for s in (0, 1) for i in range(0, 4851, 7))
-    dc.prepare(pose[4:], f["corner"], f["surf"])                                # still usable: not LL_ERR_STATE
+    dc.prepare(pose[4:], corner, surf)                                          # still usable: not LL_ERR_STATE
     dc.close(); ctx.close()
