@@ -116,26 +116,36 @@ def test_process_slot_equals_process_with_downloaded_clouds(api, synth):
 
 
 def test_a_pool_too_small_for_the_surface_cloud_only_leaves_the_map_as_it_was(api, orc, synth):
-    """ll_cubemap_update decides the pool capacity of BOTH cloud types before it commits either (round-3 advice): with a pool that
-    holds the corner cloud of the first frame but not its surface cloud the update fails with LL_ERR_CAPACITY, nothing has changed --
-    every cube still empty, the map not marked broken -- and the same call fails the same way again instead of with LL_ERR_STATE."""
+    """ll_cubemap_update decides the pool capacity of BOTH cloud types before it commits either (round-3 advice).  A pool just large
+    enough for one scan fills up as the vehicle moves on (every frame 60 m further: new cubes each time); the surface cloud -- three
+    times the corner cloud -- runs out first.  That update fails with LL_ERR_CAPACITY, nothing has changed (the cubes filled so far
+    still hold what they held, corner AND surface), the map is not marked broken, and the same call fails the same way again."""
     cfg = synth.default_cfg(64)
     fe = orc.extract(synth.scan(cfg, 0), orc.params(64))
     corner, surf = fe["less_sharp"], fe["less_flat"]
-    pose = _pose7(synth.pose(cfg, 0))
-    oc = orc.CubeMap()
-    oc.prepare(pose[4:], corner, surf)
-    stack_c, stack_s = len(oc.cloud(2)), len(oc.cloud(3))                       # the down-sized scan: what the update files into the cubes
-    oc.close()
-    assert stack_s > stack_c + 64 and stack_c + stack_s > 2 * 4096, (stack_c, stack_s)
-    pool = (stack_c + stack_s) // 2                                             # corner fits, surface does not
+    assert len(surf) > 2 * len(corner)
     ctx = api.Context(api.default_params(64, batch=1, max_points=4096))
-    dc = api.CubeMap(ctx, 16384, 65536, pool_points=pool)
-    dc.prepare(pose[4:], corner, surf)
-    for attempt in range(2):
-        with pytest.raises(api.LightLoamError) as e:
+    cap_s = len(surf) + 64
+    dc = api.CubeMap(ctx, len(corner) + 64, cap_s, pool_points=cap_s)
+    x0, y0, yaw = synth.pose(cfg, 0)
+    failed_at = None
+    before = None
+    for k in range(12):
+        pose = _pose7((x0 + 60.0 * k, y0, yaw))
+        dc.prepare(pose[4:], corner, surf)
+        snapshot = [dc.cube(s, i, cap=1 << 17).copy() for s in (0, 1) for i in range(0, 4851, 3)]
+        try:
             dc.update(pose)
-        assert e.value.code == -4, (attempt, e.value)                          # LL_ERR_CAPACITY, not -7 (LL_ERR_STATE)
-    assert all(len(dc.cube(s, i, cap=1 << 16)) == 0 for s in (0, 1) for i in range(0, 4851, 7))
-    dc.prepare(pose[4:], corner, surf)                                          # still usable: not LL_ERR_STATE
+        except api.LightLoamError as e:
+            assert e.code == -4, e                                              # LL_ERR_CAPACITY
+            failed_at, before = k, snapshot
+            break
+    assert failed_at is not None and failed_at >= 1, "the pool never filled up"
+    assert sum(len(c) for c in before) > 0
+    with pytest.raises(api.LightLoamError) as e2:
+        dc.update(pose)
+    assert e2.value.code == -4, e2.value                                        # again LL_ERR_CAPACITY, not -7 (LL_ERR_STATE)
+    after = [dc.cube(s, i, cap=1 << 17) for s in (0, 1) for i in range(0, 4851, 3)]
+    assert all(a.tobytes() == b_.tobytes() for a, b_ in zip(after, before))     # neither cloud type was touched
+    dc.prepare(pose[4:], corner, surf)                                          # still usable
     dc.close(); ctx.close()

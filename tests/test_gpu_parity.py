@@ -72,13 +72,11 @@ def case(request, api, orc, synth):
     c["ctx"].close()
 
 
-@pytest.fixture(scope="module", params=list(SHAPES), ids=lambda p: p)
-def case_down(request, api, orc, synth):
-    """the stages downstream of the feature clouds (a5-a10): one organise path -- they read what test_feature_clouds_bit_exact
-    has just shown to be the same bytes on both (keeps the suite inside the driver's time limit)"""
-    c = _make_case(request.param, "tiles", api, orc, synth)
-    yield c
-    c["ctx"].close()
+@pytest.fixture(scope="module")
+def case_down(case):
+    """the stages downstream of the feature clouds (a5-a10) run on the slots of BOTH organise paths again (round 3 had thinned them to
+    one: the suite takes a fraction of the driver's limit, and a change the size of round 4's ring-kernel split needs the wide net)"""
+    return case
 
 
 def test_organize_bit_exact(case):

@@ -43,3 +43,9 @@ def test_frame_loops_soak_2_drives():
     # odometry frame loop + free-running cube map on a synthetic and an HDL-64E drive (the committed log: 2 x 399 / 2 x 200 frames)
     out = _run("soak_frames.py", 14, 8)
     assert "frame-loop soak passed: 2 x 13 odometry frames, 2 x 8 mapping frames" in out
+
+
+def test_hot_path_soak_all_8_shapes_x_5_pairs():
+    # also 16 / 32 / 128 rings and the HDL-64E table in firing order (the committed log: 8 shapes x 383 pairs)
+    out = _run("soak_hot_path.py", 6, LL_SOAK_ALL_SHAPES="1")
+    assert "hot-path soak passed: 40 scan pairs" in out
