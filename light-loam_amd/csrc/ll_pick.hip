@@ -33,7 +33,10 @@ typedef float ll_f2 __attribute__((ext_vector_type(2)));
 #endif
 #define LL_PK_TR (SR < LL_PK_TILE_ROWS ? SR : LL_PK_TILE_ROWS)
 #define LL_PK_TILE (LL_PK_TR * 64 + 10)
-#define LL_PK_COMPACT 96                       /* corner candidates compacted to the front rows when at most this many */
+#ifndef LL_PK_CROWS
+#define LL_PK_CROWS 3                            /* rows of compacted corner candidates the pick knows how to scan */
+#endif
+#define LL_PK_COMPACT (64 * LL_PK_CROWS)                       /* corner candidates compacted to the front rows when at most this many */
 
 typedef __attribute__((address_space(3))) void ll_lds_void;
 typedef const __attribute__((address_space(1))) void ll_glb_void;
@@ -307,9 +310,9 @@ __device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, in
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         const bool compact = nc <= LL_PK_COMPACT;                     /* else: a segment full of corners, its rows as they are */
         const int ncr = (nc + 63) >> 6;
-        unsigned ck[2]; int cli[2];                                   /* masked key (0 = not eligible); local index | suppression extents << 16 */
+        unsigned ck[LL_PK_CROWS]; int cli[LL_PK_CROWS];               /* masked key (0 = not eligible); local index | suppression extents << 16 */
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
+        for (int rr = 0; rr < LL_PK_CROWS; ++rr) {
             ck[rr] = 0u; cli[rr] = 0;
             if (compact && rr < ncr && rr * 64 + lane < nc) { ck[rr] = L.c.wkey[rr * 64 + lane]; cli[rr] = (int)L.c.wli[rr * 64 + lane]; }
         }
@@ -338,7 +341,7 @@ __device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, in
             /* one pick loop, instantiated for the rows it scans: COMPACT -- the corner pass over the compacted candidates (NR = 1 or 2
              * rows of ck / cli); otherwise the segment's own rows (mk): the flat pass, or the corner pass of a segment with more than
              * LL_PK_COMPACT candidates */
-            auto pick_loop = [&](auto nr_tag, auto corner_tag, auto compact_tag, auto &key, int (&cli)[2]) __attribute__((always_inline)) {
+            auto pick_loop = [&](auto nr_tag, auto corner_tag, auto compact_tag, auto &key, int (&cli)[LL_PK_CROWS]) __attribute__((always_inline)) {
                 constexpr int NR = decltype(nr_tag)::value;
                 constexpr bool CORNER = decltype(corner_tag)::value;
                 constexpr bool COMPACT = decltype(compact_tag)::value;
@@ -373,7 +376,8 @@ __device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, in
                     int e = 0;                                        /* its suppression extents: bn | fn << 4 */
                     if (COMPACT) {                                    /* compacted layout -> the element's own index, its extents with it */
                         int slv = __builtin_amdgcn_readlane(cli[0], selp & 63);
-                        if (NR > 1 && (selp >> 6) == 1) slv = __builtin_amdgcn_readlane(cli[1], selp & 63);
+#pragma unroll
+                        for (int rr = 1; rr < NR; ++rr) if ((selp >> 6) == rr) slv = __builtin_amdgcn_readlane(cli[rr], selp & 63);
                         sel = slv & 0xffff;
                         e = slv >> 16;
                     } else sel = sp + selp + 5;
@@ -490,7 +494,7 @@ __device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, in
                         }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                    unsigned fk[2] = {0u, 0u}; int fi[2] = {0, 0};
+                    unsigned fk[LL_PK_CROWS] = {}; int fi[LL_PK_CROWS] = {};
                     if (lane < n2) { fk[0] = L.fkey[lane]; fi[0] = (int)L.fli[lane]; }
                     pick_loop(integral_constant<int, 1>{}, false_type{}, true_type{}, fk, fi);
                 } else
@@ -505,7 +509,8 @@ __device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, in
                 for (int k = 0; k < SR; ++k) mk[k] = ((candc >> k) & 1u) ? cb[k] : 0u;
                 pick_loop(integral_constant<int, SR>{}, true_type{}, false_type{}, mk, cli);
             } else if (ncr <= 1) { if (nc > 0 && !sorted_walk()) pick_loop(integral_constant<int, 1>{}, true_type{}, true_type{}, ck, cli); }
-            else pick_loop(integral_constant<int, 2>{}, true_type{}, true_type{}, ck, cli);
+            else if (ncr <= 2) pick_loop(integral_constant<int, 2>{}, true_type{}, true_type{}, ck, cli);
+            else pick_loop(integral_constant<int, LL_PK_CROWS>{}, true_type{}, true_type{}, ck, cli);
             /* the picked records, lane-parallel: labels, list entries, marks */
             const int nr_ = pass == 0 ? min(npick, LL_LSHARP_PER_SEG) : npick;
             nrec[pass] = nr_;
