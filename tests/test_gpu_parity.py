@@ -292,6 +292,33 @@ def test_rings_of_every_tier_in_one_scan(api, orc, lengths):
     _assert_extract_equal(api, orc, _ring_scan(rings), 16, "mixed tiers", max_ring_points=4608)
 
 
+def test_many_long_rings_in_every_tier_of_a_64_ring_scan(api, orc):
+    """A 64-ring scan with 21 rings of 2305 .. 3072 points and 19 of 3073 .. 4608 around short and empty ones: every tier launch of the
+    pick and of the voxel kernel carries a third of the scan, the main launch looks back across all of them.  (Written for round 4's
+    compact tier launches -- 16 workgroups per scan and tier, the last one looping over the overflow -- which measured slower than the
+    dense launches and were dropped; the scan stays as a parity case.)"""
+    rng = np.random.default_rng(64)
+    lengths = []
+    for k in range(64):
+        if k % 3 == 0:
+            lengths.append(2305 + 36 * (k // 3))              # 22 rings: 2305 .. 3061 (one of them is dropped below)
+        elif k % 3 == 1 and k < 58:
+            lengths.append(3073 + 80 * (k // 3))              # 19 rings: 3073 .. 4513
+        else:
+            lengths.append(0 if k % 7 == 0 else 600 + 23 * k)
+    lengths[63] = 0
+    assert sum(2304 < n <= 3072 for n in lengths) > 16 and sum(3072 < n <= 4608 for n in lengths) > 16
+    rings = []
+    for k, n in enumerate(lengths):
+        if n == 0:
+            continue
+        elev = -24.9 + 26.9 * k / 63.0                          # the bin centres of scanRegistration.cpp:162
+        az = -(np.arange(n) + 0.25 * (k % 4)) * (2 * np.pi / n)
+        rad = 9.0 + 2.0 * np.sin(np.arange(n) * (2 * np.pi / n) * 3 + k) + (rng.random(n) < 0.02) * rng.uniform(0.3, 1.5, n) + rng.normal(0, 0.004, n)
+        rings.append(np.stack([rad * np.cos(az), rad * np.sin(az), rad * np.tan(np.deg2rad(elev))], axis=1))
+    _assert_extract_equal(api, orc, _ring_scan(rings), 64, "many long rings", max_ring_points=4608)
+
+
 def _square_room_ring(z, half=8.0, step=1.0 / 32, bump_every=16, bump=0.5):
     """One sweep (clockwise from azimuth 0) along the walls of a square room, points every `step`; every
     `bump_every`-th point is pushed `bump` outwards.  All coordinates are small multiples of 2^-5, so the 11-tap
