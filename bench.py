@@ -419,6 +419,8 @@ def traffic_from_profile(args, kernel, launches_per_step, path=None):
     passes of this same command (tools/pmc_traffic.py, stamped by tools/profile_round.sh) -- used ONLY when the file was measured on
     THIS code (source digest), ring count, workload and batch."""
     tpath = path or os.path.join(ROOT, "profiles", "pmc_traffic.json" if args.workload == "synthetic" else "pmc_traffic_%s.json" % args.workload)
+    if os.environ.get("LIGHTLOAM_RING_SPLIT", "1") == "0":
+        return None, "the counter passes ran the split ring pipeline, this run the fused kernel (LIGHTLOAM_RING_SPLIT=0): not used"
     if not os.path.exists(tpath):
         return None, "profiles/pmc_traffic.json absent"
     try:
@@ -440,6 +442,8 @@ def issue_from_profile(args, kernels, path=None):
     launch, collected by tools/profile_round.sh (rocprofv3 --pmc, its own pass) and stamped like pmc_traffic.json; used only when
     the stamp matches this code, ring count, workload and batch.  (dict or None, why)"""
     ipath = path or os.path.join(ROOT, "profiles", "sq_issue.json" if args.workload == "synthetic" else "sq_issue_%s.json" % args.workload)
+    if os.environ.get("LIGHTLOAM_RING_SPLIT", "1") == "0":
+        return None, "the counter pass ran the split ring pipeline, this run the fused kernel (LIGHTLOAM_RING_SPLIT=0): not used"
     if not os.path.exists(ipath):
         return None, "profiles/sq_issue.json absent"
     try:
