@@ -921,11 +921,7 @@ template <int ROWS, bool SPLIT>
 static void ll_launch_ring_features(const LLView &V, int first, int count, int grid, int ring_lo, int ring_hi, hipStream_t st)
 {
     static size_t attr_bytes[LL_MAX_DEVICES] = {0};
-#ifdef LL_FEAT_LDS_PAD                         /* timing / A-B builds: fewer workgroups per CU (their rings then fit the XCD's L2 between the two passes) */
-    const size_t lds_bytes = ll_features_lds_bytes(ring_hi, SPLIT ? 1 : 0) + (ROWS <= 9 ? LL_FEAT_LDS_PAD : 0);
-#else
     const size_t lds_bytes = ll_features_lds_bytes(ring_hi, SPLIT ? 1 : 0);
-#endif
     ll_ensure_dynamic_lds(k_ring_features<ROWS, SPLIT>, lds_bytes, attr_bytes);
     hipLaunchKernelGGL((k_ring_features<ROWS, SPLIT>), dim3(grid), dim3(LL_BLOCK), lds_bytes, st, V, first, count, ring_lo, ring_hi);
 }
