@@ -35,6 +35,8 @@ cp $O/sq_issue_hdl64.json profiles/sq_issue_hdl64.json
 python3 bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 # fused ring kernel of rounds 1-3 beside the split pipeline, same box
 LIGHTLOAM_RING_SPLIT=0 python3 bench.py --no-cpu-baseline > $O/${TAG}_bench_fused_ring_kernel.json 2>/dev/null
+# the self-launching N-rank path on the one GPU of this pool (two ranks on device 0, gloo for the timing reduction: RCCL cannot share a device)
+python3 bench.py --gpus 2 --backend gloo --share-gpu --batch 2048 --no-cpu-baseline > $O/${TAG}_bench_gpus2_gloo_share_gpu.json 2>/dev/null
 # 9 distinct scans (the default of rounds 1-3) beside the 65 of the headline: what slot-to-slot diversity costs
 python3 bench.py --distinct 8 --no-cpu-baseline > $O/${TAG}_bench_distinct8.json 2>/dev/null
 # BASELINE config 3's stand-in (HDL-64E true laser table, ring capacity 4608): bench line + its kernel stats
