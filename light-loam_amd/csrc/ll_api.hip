@@ -963,13 +963,17 @@ static void map_lm_solve(ll_map *m, const LLLmOpt &o)
  * also have bumped the arrival counter after workgroup 0 reset it.  Left alone, the NEXT solve's workgroups would pass their
  * waits at once and sum stale partials -- a wrong pose without an error.  Called where a solve's pose has just been read back
  * (the stream is drained: no straggler is left): on NaN both words are zeroed again. */
-static void map_lm_repair(ll_map *m, const double *pose7)
+/* Returns true when the pose was NaN -- a solve that timed out, or k_map_compact's lost-predecessor path, which poisons the pose -- after
+ * the repair; the callers then return LL_ERR_STATE instead of handing a NaN pose back with LL_OK (round-3 advice). */
+static bool map_lm_repair(ll_map *m, const double *pose7)
 {
     bool bad = false;
     for (int k = 0; k < 7; ++k) bad = bad || std::isnan(pose7[k]);
-    if (!bad) return;
+    if (!bad) return false;
     ll_fill_words((int *)m->M.lm_go, 1, 0, 0, 1, m->ctx->stream);
     ll_fill_words((int *)m->M.neq_ticket, 1, 0, 0, 1, m->ctx->stream);
+    m->err = "the mapping solve returned an undefined pose (a workgroup never heard from its predecessors, or the input pose was NaN): set a pose and solve again";
+    return true;
 }
 
 extern "C" int ll_map_set_row_shard(ll_map *m, int rank, int world)
@@ -991,7 +995,7 @@ extern "C" int ll_map_solve(ll_map *m, double *pose_w7, const ll_lm_options *opt
     map_lm_solve(m, o);
     LLM_HIP(hipGetLastError());
     if (ll_read_back(pose_w7, m->M.pose, 7 * sizeof(double), m->ctx->stream)) { m->err = "read-back failed"; return LL_ERR_HIP; }
-    map_lm_repair(m, pose_w7);
+    if (map_lm_repair(m, pose_w7)) return LL_ERR_STATE;
     return LL_OK;
 }
 
@@ -1014,7 +1018,7 @@ extern "C" int ll_map_optimize(ll_map *m, double *pose_w7, int n_outer, const ll
     }
     LLM_HIP(hipGetLastError());
     if (ll_read_back(pose_w7, m->M.pose, 7 * sizeof(double), st)) { m->err = "read-back failed"; return LL_ERR_HIP; }
-    map_lm_repair(m, pose_w7);
+    if (map_lm_repair(m, pose_w7)) return LL_ERR_STATE;
     if (ran) *ran = 1;
     return LL_OK;
 }
@@ -1055,7 +1059,7 @@ extern "C" int ll_map_get_pose(ll_map *m, double *pose_w7)
     if (!m || !pose_w7) return LL_ERR_ARG;
     LLM_HIP(hipSetDevice(m->ctx->device));
     if (ll_read_back(pose_w7, m->M.pose, 7 * sizeof(double), m->ctx->stream)) { m->err = "read-back failed"; return LL_ERR_HIP; }
-    map_lm_repair(m, pose_w7);                                   /* this is where a caller of ll_map_solve_dev sees the result */
+    if (map_lm_repair(m, pose_w7)) return LL_ERR_STATE;          /* this is where a caller of ll_map_solve_dev sees the result */
     return LL_OK;
 }
 

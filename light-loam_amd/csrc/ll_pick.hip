@@ -25,18 +25,12 @@
 
 typedef float ll_f4 __attribute__((ext_vector_type(4)));
 typedef float ll_f2 __attribute__((ext_vector_type(2)));
-/* rows of 64 segment points per curvature tile (+ 5 halo points either side): the whole segment by default -- it comes in during
- * the previous segment's pick, when the tile is dead, and the curvature phase waits for memory once; LL_PK_TILE_ROWS < SR: smaller
- * tiles (less LDS, more waves per SIMD), every tile after a segment's first is waited for in the open */
+/* rows of 64 segment points per curvature tile (+ 5 halo points either side): three -- 4.6 KB of LDS per wave, eight waves per SIMD;
+ * a segment's first tile comes in during the previous segment's pick, its second is waited for in the open.  Whole-segment tiles
+ * (LL_PK_TILE_ROWS >= 6: one wait per segment, 7.7 KB, five waves per SIMD) and double-buffered tiles measured slower. */
 #ifndef LL_PK_TILE_ROWS
 #define LL_PK_TILE_ROWS 3
 #endif
-/* LL_PK_DBUF: two tile buffers; the next tile of a segment is in flight while the current one is worked on (a tile's
- * latency hides behind the rows of the tile before it, the segment's first tile behind the previous segment's pick) */
-#ifndef LL_PK_DBUF
-#define LL_PK_DBUF 0
-#endif
-#define LL_PK_NBUF (LL_PK_DBUF ? 2 : 1)
 #define LL_PK_TR (SR < LL_PK_TILE_ROWS ? SR : LL_PK_TILE_ROWS)
 #define LL_PK_TILE (LL_PK_TR * 64 + 10)
 #ifndef LL_PK_CROWS
@@ -50,7 +44,7 @@ typedef const __attribute__((address_space(1))) void ll_glb_void;
 template <int SR>
 struct PickLds {
     union {
-        ll_f4 tile[LL_PK_NBUF][LL_PK_TILE + 6]; /* 16-byte records: ds_read_b128 taps */
+        ll_f4 tile[LL_PK_TILE + 6];             /* 16-byte records: ds_read_b128 taps */
         struct { unsigned wkey[LL_PK_COMPACT], wli[LL_PK_COMPACT]; } c;   /* compacted corner candidates (between the segment's last tap and the
                                                                          * next segment's first tile): curvature bits; local index | extents << 16 */
     };
@@ -58,9 +52,6 @@ struct PickLds {
     unsigned lab2[(SR * 64 * 6 + 16 + 15) / 16 + 2];     /* cloudLabel, two bits per local index: 0, 1, 2, 3 = -1 */
 #ifdef LL_PK_LDS_PAD
     unsigned char pad[LL_PK_LDS_PAD];           /* timing builds: fewer waves per SIMD */
-#endif
-#ifdef LL_PK_FLAT_T
-    unsigned fkey[64], fli[64];                  /* the flat pass's compacted candidates (the tile is already filling with the next segment) */
 #endif
     unsigned short rec[LL_REC_U16];             /* the ring's lists (ring_rec layout); stored when the ring is done: no store inside the
                                                  * segment loop, so every vmcnt wait there is a wait for a tile and nothing else */
@@ -162,7 +153,7 @@ __device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, in
 
     /* the tile of rows [k0, k0 + TR) of segment [sp, sp + len): tile[t] = ring[sp + k0 * 64 + t], t < TR * 64 + 10, as far as the
      * segment + halo reaches (sp + len + 9 <= nr - 2) */
-    auto tile_dma = [&](int sp, int len, int k0, int tb) __attribute__((always_inline)) {
+    auto tile_dma = [&](int sp, int len, int k0) __attribute__((always_inline)) {
         const int lim = len + 10 - k0 * 64;                           /* tile slots that exist */
         const float4 *src = ring + sp + k0 * 64;
 #pragma unroll
@@ -173,26 +164,24 @@ __device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, in
 #else
             if (false)
 #endif
-                __builtin_amdgcn_global_load_lds((ll_glb_void *)(src + t), (ll_lds_void *)(L.tile[tb] + u * 64), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((ll_glb_void *)(src + t), (ll_lds_void *)(L.tile + u * 64), 16, 0, 0);
         }
     };
     auto tile_wait = [&]() __attribute__((always_inline)) {
         __builtin_amdgcn_s_waitcnt(0x0f70);                           /* vmcnt(0): the LDS-DMA has landed */
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    auto gap_at = [&](int t, int tb) -> bool {                        /* (:290-293) squared distance of tile point t to its predecessor > 0.05 */
-        const ll_f4 a = L.tile[tb][t], b = L.tile[tb][t - 1];
+    auto gap_at = [&](int t) -> bool {                                /* (:290-293) squared distance of tile point t to its predecessor > 0.05 */
+        const ll_f4 a = L.tile[t], b = L.tile[t - 1];
         const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
         return dx * dx + dy * dy + dz * dz > V.gap_gt;
     };
 
     unsigned segc = 0;                                                /* scalar: n_sharp, n_lsharp, n_flat totals, 8 bits each */
-    [[maybe_unused]] unsigned flat_T = 0x3b83126fu;                                    /* 0.004f: the flat pass's first threshold guess; afterwards the ring's last good one */
     /* lane constants of the extents window: bits [60 + lane, 70 + lane) of the 192-bit string word[k-1] : word[k] : word[k+1] */
     const int wsh = (60 + lane) & 31, wwi = (60 + lane) >> 5;         /* first 32-bit word of the window: 1, 2 or 3 */
 
-    int tb = 0;                                                       /* the buffer the next tile to be worked on sits in (or travels to) */
-    tile_dma(0, Lseg * 1 / 6, 0, tb);                                 /* segment 0: sp = 0, len = ep + 1 */
+    tile_dma(0, Lseg * 1 / 6, 0);                                     /* segment 0: sp = 0, len = ep + 1 */
     for (int j = 0; j < LL_SEGS; ++j) {
         const int sp = Lseg * j / 6, ep = Lseg * (j + 1) / 6 - 1;     /* record slots; = (:253-254) - S */
         const int len = ep - sp + 1;
@@ -207,14 +196,10 @@ __device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, in
 #pragma unroll
         for (int k0 = 0; k0 < SR; k0 += LL_PK_TR) {
             if (k0 < nrows) {
-                if (!LL_PK_DBUF && k0 > 0) tile_dma(sp, len, k0, tb);
+                if (k0 > 0) tile_dma(sp, len, k0);
                 tile_wait();
-                if (LL_PK_DBUF && k0 + LL_PK_TR < nrows) {            /* the segment's next tile, into the other buffer (its last reader: the tile before this one) */
-                    __builtin_amdgcn_s_waitcnt(0xc07f);               /* lgkmcnt(0) */
-                    tile_dma(sp, len, k0 + LL_PK_TR, tb ^ 1);
-                }
                 if (k0 == 0) {                                        /* the four flags below the first centre: local index sp + 1 .. sp + 4 */
-                    const bool g = (lane >= 1 && lane < 5) ? gap_at(lane, tb) : false;
+                    const bool g = (lane >= 1 && lane < 5) ? gap_at(lane) : false;
                     gw_put(0, __ballot(g) << 59);                     /* lane 1 -> bit 60 (= centre -4) */
                 }
 #pragma unroll
@@ -222,7 +207,7 @@ __device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, in
                     const int k = k0 + kk;
                     if (k < SR && k < nrows) {
                         const int q = k * 64 + lane;
-                        const ll_f4 *C = L.tile[tb] + kk * 64 + lane + 5;
+                        const ll_f4 *C = L.tile + kk * 64 + lane + 5;
                         /* :225-235, strict left to right.  Every tap is one ds_read_b128 (4 LDS cycles; the 12-byte read the compiler
                          * picks when w is unused takes 8) and two packed adds -- (x, y) and (z, w): the w lane rides along and is
                          * "used" once at the end so that the reads stay 16 bytes wide.  Six taps in flight, then five. */
@@ -257,10 +242,9 @@ __device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, in
                 }
                 if (k0 + LL_PK_TR >= nrows) {                         /* the last tile: flags beyond the last row's centres, local index sp + nrows * 64 + 5 .. ep + 10 */
                     const int b = nrows * 64 + 5 + lane;              /* relative to sp */
-                    const bool g = (lane < 5 && b <= len + 9) ? gap_at(b - k0 * 64, tb) : false;
+                    const bool g = (lane < 5 && b <= len + 9) ? gap_at(b - k0 * 64) : false;
                     gw_put(nrows + 1, __ballot(g));
                 }
-                if (LL_PK_DBUF) tb ^= 1;
             } else {
 #pragma unroll
                 for (int kk = 0; kk < LL_PK_TR; ++kk) if (k0 + kk < SR) cb[k0 + kk] = 0u;
@@ -331,7 +315,7 @@ __device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, in
         /* the next segment's first tile travels during the pick (the candidates are in registers, their LDS rows are dead) */
         __builtin_amdgcn_s_waitcnt(0xc07f);                           /* lgkmcnt(0) */
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        if (j + 1 < LL_SEGS) { const int sp1 = ep + 1, ep1 = Lseg * (j + 2) / 6 - 1; tile_dma(sp1, ep1 - sp1 + 1, 0, tb); }
+        if (j + 1 < LL_SEGS) { const int sp1 = ep + 1, ep1 = Lseg * (j + 2) / 6 - 1; tile_dma(sp1, ep1 - sp1 + 1, 0); }
         int nrec[2] = {0, 0};
 #ifdef LL_PK_TIMING_NOPICK
         for (int pass = 0; pass < 0; ++pass) {
@@ -459,58 +443,12 @@ __device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, in
             using std::integral_constant;
             using std::true_type; using std::false_type;
             if (pass == 1) {
-                /* The flat pass takes four picks, and a pick suppresses at most ten others: whatever happens, the four lie among the
-                 * 34 smallest eligible curvatures.  So: a threshold T with 34 .. 64 eligible points at or below it (bisection on the
-                 * float bits, a count = one ballot per row; the ring's last T is the first guess), those compacted to one row in
-                 * ascending index, and four rounds of the one-row arg-min.  No T found (equal values around the cut): the rows. */
+                /* the flat pass over the segment's own rows (two threshold-compacted variants -- the four picks lie among the 34 smallest
+                 * eligible curvatures -- measured slower: DESIGN.md 13.3 liii) */
                 const unsigned fm = candf & ~sup;
                 int nf = 0;
 #pragma unroll
                 for (int k = 0; k < SR; ++k) if (k < nrows) nf += __popcll(__ballot((fm >> k) & 1u));
-                [[maybe_unused]] auto count_le = [&](unsigned T) __attribute__((always_inline)) {
-                    int c = 0;
-#pragma unroll
-                    for (int k = 0; k < SR; ++k) if (k < nrows) c += __popcll(__ballot(((fm >> k) & 1u) && cb[k] <= T));
-                    return c;
-                };
-                [[maybe_unused]] bool have = nf > 0;
-                [[maybe_unused]] unsigned T = 0x7fffffffu;
-#ifndef LL_PK_FLAT_T
-                have = false;
-#else
-                if (nf > 64) {
-                    unsigned lo = 0u, hi = ll_f2u(V.curv_lt);         /* count(lo) = 0 < 34 (a curvature of +0 counts as above lo: see below), count(hi) = nf > 64 */
-                    T = flat_T;
-                    have = false;
-                    for (int it = 0; it < 16; ++it) {
-                        if (T <= lo || T >= hi) T = lo + (hi - lo) / 2;
-                        if (T <= lo) break;                           /* hi - lo <= 1: more than 64 equal values at the cut */
-                        const int c = count_le(T);
-                        if (c > 64) hi = T; else if (c < 34) lo = T; else { have = true; break; }
-                        T = lo + (hi - lo) / 2;
-                    }
-                    if (have) flat_T = T;
-                }
-#endif
-#ifdef LL_PK_FLAT_T
-                if (have) {
-                    int n2 = 0;
-#pragma unroll
-                    for (int k = 0; k < SR; ++k) {
-                        if (k < nrows) {
-                            const bool c = ((fm >> k) & 1u) && cb[k] <= T;
-                            const unsigned long long m = __ballot(c);
-                            const int pos = n2 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                            if (c) { L.fkey[pos] = ~cb[k]; L.fli[pos] = (unsigned)(li0 + k * 64) | (((exw[k >> 2] >> ((k & 3) * 8)) & 0xffu) << 16); }
-                            n2 += __popcll(m);
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                    unsigned fk[LL_PK_CROWS] = {}; int fi[LL_PK_CROWS] = {};
-                    if (lane < n2) { fk[0] = L.fkey[lane]; fi[0] = (int)L.fli[lane]; }
-                    pick_loop(integral_constant<int, 1>{}, false_type{}, true_type{}, fk, fi);
-                } else
-#endif
                 if (nf > 0) {
 #pragma unroll
                     for (int k = 0; k < SR; ++k) mk[k] = ((fm >> k) & 1u) ? ~cb[k] : 0u;

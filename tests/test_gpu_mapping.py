@@ -202,3 +202,21 @@ def test_row_parallel_two_ranks_match_one():
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == "ok" for r in res), res
+
+
+def test_an_undefined_pose_is_an_error_not_a_result(scene, api):
+    """Round-3 advice: a solve that ends with a NaN pose (k_map_compact's lost-predecessor path poisons the pose; a NaN guess does the
+    same from outside) used to hand that pose back with LL_OK.  Now ll_map_optimize / ll_map_solve / ll_map_get_pose return
+    LL_ERR_STATE, the hand-over words are repaired, and the next solve with a proper guess gives the usual answer."""
+    ctx = api.Context(api.default_params(scene["rings"], batch=1, max_points=4096))
+    m = api.Map(ctx, len(scene["corner_map"]) + 8, len(scene["surf_map"]) + 8, len(scene["corner_stack"]) + 8, len(scene["surf_stack"]) + 8)
+    m.set_map(scene["corner_map"], scene["surf_map"]); m.set_scan(scene["corner_stack"], scene["surf_stack"])
+    good, ran = m.optimize(scene["guess"])
+    assert ran and np.isfinite(good).all()
+    bad = scene["guess"].copy(); bad[5] = np.nan
+    with pytest.raises(api.LightLoamError) as e:
+        m.optimize(bad)
+    assert e.value.code == -7, e.value                                           # LL_ERR_STATE
+    again, ran = m.optimize(scene["guess"])
+    assert ran and again.tobytes() == good.tobytes()
+    m.close(); ctx.close()
