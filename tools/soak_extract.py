@@ -10,7 +10,8 @@ import test_gpu_parity as T
 from conftest import assert_bit_equal
 api.load_library(); orc.build()
 bad = 0; checked = 0
-for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
+FIRST = int(sys.argv[2]) if len(sys.argv) > 2 else 0           # soak_extract.py <seeds> [first seed]
+for seed in range(FIRST, FIRST + (int(sys.argv[1]) if len(sys.argv) > 1 else 6)):
     rng = np.random.default_rng(777 + seed)
     scans = []
     for s in range(400):
