@@ -52,7 +52,7 @@ shapes = [("synthetic ring-major", 64, dict(), None),
 if os.environ.get("LL_SOAK_ALL_SHAPES"):                  # the other ring counts and the raw firing order (the committed long log has them)
     shapes += [("synthetic 16 rings", 16, dict(), None), ("synthetic 32 rings, jitter", 32, dict(az_jitter_deg=0.4), None),
                ("synthetic 128 rings (linear ring model)", 128, dict(), None), ("HDL-64E table, firing order", 64, "firing", 4608)]
-rng = np.random.default_rng(20261002)
+rng = np.random.default_rng(int(os.environ.get("LL_SOAK_SEED", "20261002")))   # LL_SOAK_SEED: other guesses, other scans of the streams
 total = 0
 worst = dict(H=0.0, g=0.0, cost=0.0, pose=0.0)
 t00 = time.time()
