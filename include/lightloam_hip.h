@@ -227,6 +227,8 @@ int ll_map_set_scan(ll_map *m, const ll_point *host_corner_stack, int n_corner, 
  * index, unit norm, negative_OA_dot_norm).                                                                           */
 int ll_map_associate(ll_map *m, const double *pose_w7);
 int ll_map_get_counts(ll_map *m, int *n_edge, int *n_plane);
+/* laserCloudCornerFromMap->points.size() / laserCloudSurfFromMap->points.size() (:1822: the block runs only above 10 / 50) */
+int ll_map_get_map_sizes(ll_map *m, int *n_corner_from_map, int *n_surf_from_map);
 int ll_map_download_edges(ll_map *m, int *src, double *a3, double *b3, int cap);
 int ll_map_download_planes(ll_map *m, int *src, double *norm3, double *d, int cap);
 /* H (6x6 row-major over the manifold tangent + t), g, cost of the current blocks at pose_w (NULL = current pose),
@@ -238,7 +240,8 @@ int ll_map_normal_equations(ll_map *m, const double *pose_w7, double *H36, doubl
 int ll_map_residual_jacobian(ll_map *m, const double *pose_w7, double *r, double *Jq, double *Jt, int cap_rows);
 /* The whole block :1822-2095: if the map holds > 10 corner and > 50 surf points, n_outer (2, :1832) x { associate,
  * ceres::Solve restated (LM, <= 4 iterations; opt NULL = ll_lm_default_options) }.  pose_w7 in/out; *ran = 0 when the
- * map is too small (the reference then keeps the odometry guess, :2096-2100).                                        */
+ * map is too small (the reference then keeps the odometry guess, :2096-2100).  LL_ERR_STATE: the solve left an
+ * undefined (NaN) pose -- a lost hand-over inside the launch -- or the map holds a row / tile shard.                  */
 int ll_map_optimize(ll_map *m, double *pose_w7, int n_outer, const ll_lm_options *opt, int *ran);
 
 /* Row-parallel use over several GPUs (BASELINE config 4): every rank holds the same map and its share of the
@@ -249,7 +252,7 @@ int ll_map_optimize(ll_map *m, double *pose_w7, int n_outer, const ll_lm_options
  *     associate;  evaluate -> all-reduce -> lm_begin;  repeat max_num_iterations x { lm_propose; evaluate -> all-reduce -> lm_accept }
  * ll_map_optimize is exactly this sequence on one rank without the all-reduce.                                          */
 int ll_map_set_pose(ll_map *m, const double *pose_w7);
-int ll_map_get_pose(ll_map *m, double *pose_w7);
+int ll_map_get_pose(ll_map *m, double *pose_w7);                                        /* LL_ERR_STATE: the pose on the device is undefined (NaN) */
 int ll_map_evaluate(ll_map *m, double *neq44);                                           /* at the map's current pose */
 int ll_map_lm_begin(ll_map *m, const double *neq44_sum, const ll_lm_options *opt);
 int ll_map_lm_propose(ll_map *m, const ll_lm_options *opt);                               /* current pose <- candidate (or unchanged) */
@@ -270,7 +273,7 @@ int ll_map_set_map_ids(ll_map *m, const int *corner_gid, const int *surf_gid);
 int ll_map_knn_partial(ll_map *m, const double *pose_w7, float *corner_nn, int *corner_id, float *surf_nn, int *surf_id);
 int ll_map_associate_merged(ll_map *m, const double *pose_w7, int n_parts, const float *corner_nn, const int *corner_id,
                             const float *surf_nn, const int *surf_id);
-int ll_map_solve(ll_map *m, double *pose_w7, const ll_lm_options *opt);
+int ll_map_solve(ll_map *m, double *pose_w7, const ll_lm_options *opt);                 /* LL_ERR_STATE: row shard set, or an undefined (NaN) pose came out */
 /* Device-resident variants of the same steps for the collectives: every pointer is a DEVICE pointer on the context's GPU, the
  * calls only enqueue on ll_stream(ctx) (no host hop, no synchronisation) and work at the pose already on the device
  * (ll_map_set_pose before, ll_map_get_pose after).  The caller's RCCL all-reduce (44 doubles, of which 28 matter) /

@@ -25,7 +25,7 @@ EXPORTS = [
     "ll_residual_jacobian", "ll_hot_path_batch", "ll_algorithmic_bytes", "ll_profile_enable", "ll_profile_read", "ll_set_pose_guess", "ll_debug_counters", "ll_vote_host", "ll_debug_calibration_copy", "ll_debug_exact_math", "ll_upload_scan_async", "ll_upload_scans_async", "ll_upload_scans_async_strided", "ll_stream_record", "ll_stream_wait", "ll_hot_path_chain", "ll_synchronize_copy", "ll_host_alloc", "ll_host_free",
     "ll_lm_default_options", "ll_lm_solve_batch", "ll_odometry_frames",
     "ll_map_create", "ll_map_destroy", "ll_map_last_error", "ll_map_set_map", "ll_map_set_scan", "ll_map_associate",
-    "ll_map_residual_jacobian", "ll_map_get_counts", "ll_map_download_edges", "ll_map_download_planes", "ll_map_normal_equations", "ll_map_optimize",
+    "ll_map_residual_jacobian", "ll_map_get_counts", "ll_map_get_map_sizes", "ll_map_download_edges", "ll_map_download_planes", "ll_map_normal_equations", "ll_map_optimize",
     "ll_cubemap_create", "ll_cubemap_destroy", "ll_cubemap_last_error", "ll_cubemap_prepare", "ll_cubemap_optimize", "ll_cubemap_update",
     "ll_cubemap_process", "ll_cubemap_process_slot", "ll_cubemap_info", "ll_cubemap_download_cloud", "ll_cubemap_download_cube",
     "ll_map_set_map_ids", "ll_map_knn_partial", "ll_map_associate_merged", "ll_map_solve", "ll_map_set_row_shard", "ll_cubemap_set_shard", "ll_cubemap_map",
@@ -474,6 +474,12 @@ class Map:
         ne, npl = C.c_int(0), C.c_int(0)
         self._ck(self.lib.ll_map_get_counts(self.h, C.byref(ne), C.byref(npl)))
         return ne.value, npl.value
+
+    def map_sizes(self):
+        """(laserCloudCornerFromMap, laserCloudSurfFromMap) sizes: what laserMapping.cpp:1822 tests before it optimises."""
+        nc, ns = C.c_int(0), C.c_int(0)
+        self._ck(self.lib.ll_map_get_map_sizes(self.h, C.byref(nc), C.byref(ns)))
+        return nc.value, ns.value
 
     def edges(self):
         ne, _ = self.counts()

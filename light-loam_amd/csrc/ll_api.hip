@@ -835,6 +835,16 @@ extern "C" int ll_map_get_counts(ll_map *m, int *n_edge, int *n_plane)
     return LL_OK;
 }
 
+/* the sizes of laserCloudCornerFromMap / laserCloudSurfFromMap as the map holds them: what laserMapping.cpp:1822 tests before it
+ * optimises at all (host state: no device round trip) */
+extern "C" int ll_map_get_map_sizes(ll_map *m, int *n_corner_from_map, int *n_surf_from_map)
+{
+    if (!m) return LL_ERR_ARG;
+    if (n_corner_from_map) *n_corner_from_map = m->M.n_map[0];
+    if (n_surf_from_map) *n_surf_from_map = m->M.n_map[1];
+    return LL_OK;
+}
+
 extern "C" int ll_map_download_edges(ll_map *m, int *src, double *a3, double *b3, int cap)
 {
     int ne = 0; int rc = ll_map_get_counts(m, &ne, nullptr); if (rc) return rc;
@@ -1077,6 +1087,7 @@ static int map_lm_stage(ll_map *m, int stage, const double *neq44_sum, const ll_
 {
     if (!m || (stage != 1 && !neq44_sum)) return LL_ERR_ARG;
     const LLLmOpt o = ll_to_dev_opt(opt);
+    if (o.max_num_iterations < 0 || o.max_num_iterations > 64) { m->err = "max_num_iterations out of range"; return LL_ERR_ARG; }   /* as ll_map_optimize */
     LLM_HIP(hipSetDevice(m->ctx->device));
     hipStream_t st = m->ctx->stream;
     if (neq44_sum) LLM_HIP(hipMemcpyAsync(m->M.neq, neq44_sum, LL_NEQ_STRIDE * sizeof(double), hipMemcpyHostToDevice, st));
@@ -1112,6 +1123,7 @@ static int map_lm_stage_dev(ll_map *m, int stage, const double *neq44_sum_dev, c
 {
     if (!m || (stage != 1 && !neq44_sum_dev)) return LL_ERR_ARG;
     const LLLmOpt o = ll_to_dev_opt(opt);
+    if (o.max_num_iterations < 0 || o.max_num_iterations > 64) { m->err = "max_num_iterations out of range"; return LL_ERR_ARG; }   /* as ll_map_optimize */
     LLM_HIP(hipSetDevice(m->ctx->device));
     hipStream_t st = m->ctx->stream;
     if (neq44_sum_dev) ll_copy_d2d(m->M.neq, neq44_sum_dev, LL_NEQ_STRIDE * sizeof(double), st);

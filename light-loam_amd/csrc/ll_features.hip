@@ -700,7 +700,11 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? (SPLIT ? LL_FWAVES_SPLIT : L
                     min_b[c] = (int)floorf(mn[c] * inv);
                     div_b[c] = (int)floorf(mx[c] * inv) - min_b[c] + 1;
                 }
-                const bool too_small = d[0] * d[1] * d[2] > (long long)INT_MAX;        /* "leaf size too small": output = input */
+                /* "leaf size too small": output = input.  Also taken where PCL's int voxel index would wrap (div_b is up to d + 1 per axis, so
+                 * the product of the three can pass 2^32 - 1 while d's stays below INT_MAX -- undefined in the reference; not reachable for a
+                 * ring of one laser, whose points share an elevation): a wrapped key could equal the all-ones padding key and sort among the
+                 * padding.  oracle/ll_oracle.c takes the same exit. */
+                const bool too_small = d[0] * d[1] * d[2] > (long long)INT_MAX || (long long)div_b[0] * div_b[1] * div_b[2] > 0xffffffffLL;
                 /* every real key is below key_end; the digit range covers key_end itself so that all-ones in it is above every real key */
                 const long long key_end = too_small ? (long long)m : (long long)div_b[0] * div_b[1] * div_b[2];
                 const int key_bits = min(32, 64 - __clzll(key_end));

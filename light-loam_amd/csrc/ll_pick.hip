@@ -79,6 +79,7 @@ template <int SR>
 __device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, int count, int ring_lo, int ring_hi)
 {
     static_assert(SR <= 32, "row bitmasks are 32 bits wide");
+    static_assert(2 * (SR + 2) + 2 <= 64, "the segment's gap words (L.gw) are cleared by one lane each");
     __shared__ __attribute__((aligned(16))) PickLds<SR> lds_all[LL_PK_WAVES];
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
     const int groups = (V.R + LL_PK_WAVES - 1) / LL_PK_WAVES;

@@ -60,9 +60,14 @@ def map_optimize_row_parallel(m, pose_w, n_outer=2, max_num_iterations=4, opt=No
     """laserMapping's optimisation (api.Map.optimize) with the scan's stack points split over the ranks of `group`:
     every rank holds the same map and ITS slice of the stack clouds in `m`; per evaluation one all-reduce of the
     normal equations (44 doubles; RCCL when `device` is a GPU device, gloo on CPU tensors), identical LM state on all
-    ranks.  Returns the optimised pose (the same on every rank)."""
+    ranks.  Returns the optimised pose (the same on every rank); the guess itself when the map is below laserMapping.cpp:1822's
+    sizes (every rank holds the same map, so every rank takes that exit before the first collective)."""
     import torch
     import torch.distributed as dist
+
+    nc, ns = m.map_sizes()
+    if not (nc > 10 and ns > 50):
+        return np.ascontiguousarray(pose_w, np.float64).copy()
 
     def reduced():
         buf = torch.from_numpy(m.evaluate())
@@ -217,6 +222,9 @@ def map_optimize_row_parallel_dev(m, coll, pose_w, n_outer=2, max_num_iterations
     (the result); everything between is enqueued."""
     if opt is not None:
         max_num_iterations = opt.max_num_iterations
+    nc, ns = m.map_sizes()
+    if not (nc > 10 and ns > 50):                               # laserMapping.cpp:1822, the same on every rank: no collective yet
+        return np.ascontiguousarray(pose_w, np.float64).copy()
     m.set_pose(pose_w)
     for _ in range(n_outer):
         m.associate()                                           # at the device pose, asynchronous

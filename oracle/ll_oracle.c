@@ -190,6 +190,10 @@ int orc_voxel_grid(const orc_point *in, int n, float leaf, orc_point *out, int *
         max_b[k] = (int)floorf(mx[k] * inv);
         div_b[k] = max_b[k] - min_b[k] + 1;
     }
+    if ((int64_t)div_b[0] * div_b[1] * div_b[2] > (int64_t)0xffffffffLL) {   /* PCL's int index would wrap here (undefined in the reference;
+                                                                              * coordinates ~1e8 m apart): defined as the exit above, like the HIP path */
+        memcpy(out, in, (size_t)n * sizeof(orc_point)); *n_out = n; return ORC_OK;
+    }
     mul[0] = 1; mul[1] = div_b[0]; mul[2] = div_b[0] * div_b[1];
     vox_key *keys = (vox_key *)malloc((size_t)n * sizeof(vox_key));
     for (int i = 0; i < n; ++i) {

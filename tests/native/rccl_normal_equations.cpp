@@ -82,6 +82,37 @@ int main(int argc, char **argv)
             for (auto &t : th) t.join();
             for (int r = 0; r < world; ++r) if (!err[(size_t)r].empty()) { std::cerr << "row-parallel rank " << r << ": " << err[(size_t)r] << "\n"; return 1; }
         }
+        // ---- the helper's exits: a map below laserMapping.cpp:1822's sizes -> false on every rank, no collective issued; a step that
+        // fails locally (max_num_iterations < 0 is refused by ll_map_lm_begin_dev) -> every rank still walks the whole sequence of
+        // collectives and THEN throws: nobody is left waiting in ncclAllReduce ----
+        {
+            std::vector<int> small_ok((size_t)world, 0), failed((size_t)world, 0);
+            std::vector<std::thread> th;
+            for (int r = 0; r < world; ++r)
+                th.emplace_back([&, r] {
+                    try {
+                        Context ctx(16, 1, r);
+                        MapOptimizer mo(ctx, (int)mc.size() + 16, (int)ms.size() + 16, (int)sc.size() + 16, (int)ss.size() + 16);
+                        RcclRank rk(rw.comm(r), ctx.get(), r);
+                        double p[7]; std::memcpy(p, guess, sizeof(p));
+                        mo.setInputClouds(std::vector<PointXYZI>(mc.begin(), mc.begin() + 8), ms);      // 8 corner points: too small
+                        mo.setScan(sc, ss);
+                        const long before = rk.n_allreduce;
+                        const bool ran = map_optimize_row_parallel(mo.get(), rk, p, 2, nullptr);
+                        small_ok[(size_t)r] = (!ran && rk.n_allreduce == before && std::memcmp(p, guess, sizeof(p)) == 0) ? 1 : 0;
+                        mo.setInputClouds(mc, ms);
+                        ll_lm_options bad; ll_lm_default_options(&bad); bad.max_num_iterations = -1;
+                        try { (void)map_optimize_row_parallel(mo.get(), rk, p, 2, &bad); }
+                        catch (const RcclError &) { failed[(size_t)r] = (rk.n_allreduce == before + 2 && !rk.aborted()) ? 1 : 0; }   // both outer rounds' all-reduces were issued
+                    } catch (const std::exception &e) { err[(size_t)r] = e.what(); }
+                });
+            for (auto &t : th) t.join();
+            for (int r = 0; r < world; ++r) {
+                if (!err[(size_t)r].empty()) { std::cerr << "row-parallel exits, rank " << r << ": " << err[(size_t)r] << "\n"; return 1; }
+                if (!small_ok[(size_t)r]) { std::cerr << "rank " << r << ": a map below the :1822 sizes was optimised against, or a collective was issued\n"; return 1; }
+                if (!failed[(size_t)r]) { std::cerr << "rank " << r << ": a failing local step did not end in an exception after the full collective sequence\n"; return 1; }
+            }
+        }
         double ref[7]; std::memcpy(ref, guess, sizeof(ref));
         {
             Context ctx(16, 1, 0);
