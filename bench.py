@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md chip table: HBM3E 8.0 TB/s spec
-HBM_COPY_GBS = 6290.0        # ... and the copy rate measured on the part (same table)
+HBM_COPY_GBS = 6290.0        # ... and the float4 copy rate the guide quotes for the part (same table); stream_rates() has what THIS tree measured
 N_SIMD = 1024                # 256 CUs x 4 SIMD-32 (same table)
 CLOCK_GHZ = 2.4              # peak engine clock; the board sits at 2.34-2.35 GHz during the bench (tools/sample_clocks.sh)
 VALU_CYCLES = 2.2            # cycles a SIMD needs per wave64 vector instruction with >= 4 waves feeding it (tools/ubench/valu_rate.hip)
@@ -414,13 +414,19 @@ def bench_map(args, rank, local_rank, world):
     dist.barrier(); dist.destroy_process_group()
 
 
+def profile_suffix(args):
+    """which counter files describe this workload: pmc_traffic.json / sq_issue.json for the 64-ring headline, _hdl64 for BASELINE config 3's
+    stand-in, _s128 / _s16 for the other synthetic ring counts (tools/profile_round.sh writes them all)"""
+    if args.workload != "synthetic":
+        return "_" + args.workload
+    return "" if args.rings == 64 else "_s%d" % args.rings
+
+
 def traffic_from_profile(args, kernel, launches_per_step, path=None):
     """(HBM bytes per launch of `kernel` or None, why) from profiles/pmc_traffic.json -- the separate rocprofv3 FETCH_SIZE / WRITE_SIZE
     passes of this same command (tools/pmc_traffic.py, stamped by tools/profile_round.sh) -- used ONLY when the file was measured on
     THIS code (source digest), ring count, workload and batch."""
-    tpath = path or os.path.join(ROOT, "profiles", "pmc_traffic.json" if args.workload == "synthetic" else "pmc_traffic_%s.json" % args.workload)
-    if os.environ.get("LIGHTLOAM_RING_SPLIT", "1") == "0":
-        return None, "the counter passes ran the split ring pipeline, this run the fused kernel (LIGHTLOAM_RING_SPLIT=0): not used"
+    tpath = path or os.path.join(ROOT, "profiles", "pmc_traffic%s.json" % profile_suffix(args))
     if not os.path.exists(tpath):
         return None, "profiles/pmc_traffic.json absent"
     try:
@@ -437,13 +443,42 @@ def traffic_from_profile(args, kernel, launches_per_step, path=None):
         return None, "profiles/pmc_traffic.json unreadable: " + repr(e)[:80]
 
 
+def stream_rates(path=None):
+    """What tools/ubench/stream_rate.hip measured on an MI355X of this pool on the library's own strides (rows of ring_cap float4,
+    ~1650 used): the best read-only, write-only and copy rate over 1..8 loads in flight per lane and 2..8 workgroups per CU.
+    These are the ceilings the streaming kernels are read against -- not the 4.6 TB/s of the naive
+    calibration copy.  {} when the file is absent."""
+    spath = path or os.path.join(ROOT, "profiles", "r05_stream_rate.json")
+    try:
+        R = json.load(open(spath))["stream_rate"]["results"]
+    except Exception:
+        return {}
+    best = {}
+    for r in R:
+        if r["pattern"] != "rows":
+            continue
+        k = "read" if r["mode"].startswith("read") else r["mode"]
+        best[k] = max(best.get(k, 0.0), float(r["GBps"]))
+    return {"read_GBps": best.get("read"), "write_GBps": best.get("write"), "copy_GBps": best.get("copy"),
+            "source": "profiles/r05_stream_rate.json (tools/stream_rate.sh: laserCloud's row stride, best of 1-8 loads in flight x 2-8 workgroups per CU)"}
+
+
+def all_traffic_from_profile(args, kernels, launches_per_step):
+    """Counter bytes per step of every kernel in `kernels` (same file and stamp rule as traffic_from_profile); None unless all are there."""
+    tot = 0.0
+    for k in kernels:
+        t, _ = traffic_from_profile(args, k, launches_per_step)
+        if t is None:
+            return None
+        tot += t * launches_per_step
+    return tot
+
+
 def issue_from_profile(args, kernels, path=None):
     """Instruction-issue figures of `kernels` from profiles/sq_issue.json -- SQ_INSTS_VALU / SQ_INSTS_SALU / SQ_INSTS_LDS per full-batch
     launch, collected by tools/profile_round.sh (rocprofv3 --pmc, its own pass) and stamped like pmc_traffic.json; used only when
     the stamp matches this code, ring count, workload and batch.  (dict or None, why)"""
-    ipath = path or os.path.join(ROOT, "profiles", "sq_issue.json" if args.workload == "synthetic" else "sq_issue_%s.json" % args.workload)
-    if os.environ.get("LIGHTLOAM_RING_SPLIT", "1") == "0":
-        return None, "the counter pass ran the split ring pipeline, this run the fused kernel (LIGHTLOAM_RING_SPLIT=0): not used"
+    ipath = path or os.path.join(ROOT, "profiles", "sq_issue%s.json" % profile_suffix(args))
     if not os.path.exists(ipath):
         return None, "profiles/sq_issue.json absent"
     try:
@@ -692,7 +727,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
 
-    # sanity on the result of the timed work (not timed): EVERY slot extracted (status 0; a look-back time-out would be -7),
+    # sanity on the result of the timed work (not timed): EVERY slot extracted (status 0),
     # found correspondences and solved to a finite pose; slots that hold the same (previous, current) pair of scans and the
     # same guess must give bit-identical poses (the batch cycles through `distinct`+1 scans)
     info = ctx.scan_info(0)
@@ -715,16 +750,14 @@ def main():
         tot["ne"] += pi.n_edge; tot["np_"] += pi.n_plane; tot["nsel"] += pi.n_plane_selected
     if bad and not os.environ.get("LL_BENCH_TIMING_BUILD"):     # set only by tools/ that time deliberately incomplete builds
         raise SystemExit(f"bench self-check failed on rank {rank}: {len(bad)} slot(s), first {bad[:5]}")
-    split = os.environ.get("LIGHTLOAM_RING_SPLIT", "1") != "0"
     kernel_bytes = {
         "k_first_kept": 0.0, "k_offsets": 0.0, "k_gn_step": 0.0,
         "k_organize": 16.0 * tot["n_in"] + 16.0 * tot["n"],          # read the raw scan, write laserCloud (one pass)
         "k_classify": 16.0 * tot["n_in"],                            # (tile-parallel path of small calls) read the raw scan
         "k_scatter": 16.0 * tot["n"],                                # (tile-parallel path) write laserCloud
-        # the ring stage is two launches since round 4 (ll_pick.hip, ll_features.hip); LIGHTLOAM_RING_SPLIT=0 runs the fused kernel of
-        # rounds 1-3, which then carries the whole stage: 17 n + 16 feat
+        # the ring stage is two launches since round 4 (ll_pick.hip, ll_features.hip)
         "k_ring_pick": 17.0 * tot["n"],                               # read laserCloud, write labels (+ 352 B of lists per ring)
-        "k_ring_features": (16.0 * tot["n"] + 16.0 * tot["feat"]) if split else (17.0 * tot["n"] + 16.0 * tot["feat"]),   # read laserCloud (again), write the four feature clouds
+        "k_ring_features": 16.0 * tot["n"] + 16.0 * tot["feat"],   # read laserCloud (again), write the four feature clouds
         "k_build_grid": 16.0 * (tot["lsharp"] + tot["lflat"]),       # read the target clouds once
         "k_associate": 16.0 * tot["q"] + 8.0 * tot["ne"] + 12.0 * tot["np_"],
         "k_vote": 32.0 * tot["np_"] + 8.0 * tot["nsel"],
@@ -750,14 +783,17 @@ def main():
         stage_ms = sum(ms_of[k] for k in stage_kernels)
         stage_bytes = 17.0 * tot["n"] + 16.0 * tot["feat"]
         stage_gbps = stage_bytes / (stage_ms * 1e-3) / 1e9 if stage_ms > 0 else 0.0
-        # which wall: vector / scalar instruction issue against bytes, from the stamped counter pass
-        issue, issue_note = issue_from_profile(args, stage_kernels)
+        # which wall: vector / scalar instruction issue against bytes, from the stamped counter pass -- for EVERY kernel of the step, so
+        # that whichever kernel dominates (the ring kernels on 64 rings, k_associate on 128) is read against its own counters
+        all_kernels = [k for k in ms_of if kernel_bytes.get(k)]
+        issue, issue_note = issue_from_profile(args, all_kernels)
         issue_out = {"source": issue_note}
-        bound = "hbm"
+        bound = "unknown (no counter pass of this code, workload and batch: %s)" % issue_note
+        sr = stream_rates()
         if issue is not None:
             simd_slots = N_SIMD * CLOCK_GHZ * 1e9 / VALU_CYCLES                   # wave64 vector instructions per second, whole chip
             scalar_slots = (N_SIMD / 4) * CLOCK_GHZ * 1e9                          # one scalar unit per CU, one instruction per cycle
-            for k in stage_kernels:
+            for k in all_kernels:
                 t = ms_of[k] / launches_per_step * 1e-3
                 issue_out[k] = {"valu_wave_insts_per_launch": issue[k]["valu"], "salu_wave_insts_per_launch": issue[k]["salu"],
                                 "lds_wave_insts_per_launch": issue[k].get("lds"),
@@ -765,18 +801,29 @@ def main():
                                 "hbm_frac": kernel_bytes[k] / launches_per_step / t / 1e9 / HBM_PEAK_GBS}
             d = issue_out.get(dom)
             # the kernel answers to the LARGEST of: vector issue, scalar issue, and the bytes it actually moves across the L2 <-> fabric
-            # boundary (counter traffic, not the algorithmic bytes: re-reads count) against the HBM peak
+            # boundary (counter traffic, not the algorithmic bytes: re-reads count) against what the chip streams (stream_rates(), else the peak)
             t_dom = avg_ms * 1e-3
+            stream_ceiling = (sr.get("copy_GBps") or HBM_PEAK_GBS)
             traffic_frac = (traffic / t_dom / 1e9 / HBM_PEAK_GBS) if (traffic and t_dom > 0) else None
-            if d and max(d["valu_busy"], d["salu_busy"]) > max(d["hbm_frac"], traffic_frac or 0.0):
-                bound = "issue (vector %.0f %%, scalar %.0f %% busy; bytes %.0f %% of the HBM peak)" % (100 * d["valu_busy"], 100 * d["salu_busy"], 100 * d["hbm_frac"])
+            traffic_of_stream = (traffic / t_dom / 1e9 / stream_ceiling) if (traffic and t_dom > 0) else None
+            if d:
+                byte_frac = max(d["hbm_frac"] * HBM_PEAK_GBS / stream_ceiling, traffic_of_stream or 0.0)
+                if max(d["valu_busy"], d["salu_busy"]) > byte_frac:
+                    bound = "issue (vector %.0f %%, scalar %.0f %% busy; bytes %.0f %% of the HBM peak)" % (100 * d["valu_busy"], 100 * d["salu_busy"], 100 * d["hbm_frac"])
+                else:
+                    bound = "hbm"
             issue_out["decision"] = {"valu_busy": d["valu_busy"] if d else None, "salu_busy": d["salu_busy"] if d else None,
                                      "algorithmic_bytes_frac_of_hbm_peak": d["hbm_frac"] if d else None,
                                      "counter_traffic_frac_of_hbm_peak": traffic_frac,
-                                     "rule": "bound = hbm when the counter traffic's (or the algorithmic bytes') fraction of the HBM peak is the largest of the four, "
-                                             "else issue; kernels of this path that move only algorithmic bytes (k_organize) top out at 0.55-0.59 of the peak"}
+                                     "counter_traffic_frac_of_measured_stream_rate": traffic_of_stream,
+                                     "rule": "bound = hbm when the counter traffic's (or the algorithmic bytes') fraction of the measured streaming rate "
+                                             "(profiles/r05_stream_rate.json; the 8 TB/s peak without it) is the largest of the four, else issue; "
+                                             "unknown without a counter pass of this code"}
             issue_out["model"] = ("valu_busy = SQ_INSTS_VALU / (%d SIMDs x %.1f GHz / %.1f cycles x launch time); salu_busy = SQ_INSTS_SALU / "
                                   "(%d scalar units x %.1f GHz x launch time)" % (N_SIMD, CLOCK_GHZ, VALU_CYCLES, N_SIMD // 4, CLOCK_GHZ))
+        whole_alg_bytes_per_step = ab["ext"] + ab["assoc"] + ab["vote"] + ab["rj"]
+        whole_alg_gbps = whole_alg_bytes_per_step * args.steps / elapsed / 1e9
+        counter_bytes_per_step = all_traffic_from_profile(args, all_kernels, launches_per_step)
         out = {
             "metric": metric_name(args),
             "value": value, "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -789,16 +836,21 @@ def main():
                        "distinct_scans": args.distinct + 1, "distinct_scan_pairs": len(pose_of_pair),
                        "box_calibration_ms": box_calibration_ms,
                        "box_calibration": "HIP-event time of the ring kernels over the first %d slots (fixed micro-run before the timed region)" % calib_n,
-                       "ring_pipeline": "k_ring_pick + k_ring_features (split)" if split else "k_ring_features (fused, LIGHTLOAM_RING_SPLIT=0)",
+                       "ring_pipeline": "k_ring_pick + k_ring_features; ring-strided less-flat cloud, no hand-over between the rings of a scan",
                        "self_check": "every slot: status 0, correspondences > 0, finite pose; equal scan pairs -> bit-identical poses",
                        "points_per_scan_in": int(info.n_in), "points_per_scan_kept": int(info.n),
                        "parallelism": f"scan-parallel x{world}, no data-path collective"},
             "roofline": {"bound": bound, "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "traffic_GBps": (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and avg_ms > 0) else None,
-                         "frac_of_measured_copy": achieved / HBM_COPY_GBS, "measured_copy_GBps": HBM_COPY_GBS,
+                         "frac_of_measured_copy": achieved / (sr.get("copy_GBps") or HBM_COPY_GBS), "measured_copy_GBps": sr.get("copy_GBps") or HBM_COPY_GBS,
+                         "measured_stream": sr,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "whole_path_algorithmic_GBps": (ab["ext"] + ab["assoc"] + ab["vote"] + ab["rj"]) * args.steps / elapsed / 1e9,
+                         "whole_path_algorithmic_GBps": whole_alg_gbps,
+                         # comparable across rounds (BASELINE.md's own definition: B x scans/s / peak, the whole path, every array counted once)
+                         "frac_whole_path": whole_alg_gbps / HBM_PEAK_GBS,
+                         # sum of the kernels' counter bytes / sum of the algorithmic bytes (1.0 = nothing re-read); null without a counter pass of this code
+                         "wasted_traffic": (counter_bytes_per_step / whole_alg_bytes_per_step) if counter_bytes_per_step else None,
                          "issue": issue_out,
                          "ring_stage": {"kernels": stage_kernels, "ms_per_step": stage_ms, "algorithmic_bytes_per_step": stage_bytes,
                                         "achieved": stage_gbps, "frac": stage_gbps / HBM_PEAK_GBS,

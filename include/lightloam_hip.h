@@ -144,7 +144,10 @@ int ll_download_features(ll_ctx *ctx, int slot,
  * for pairs (slot k, its target).  Targets of slot k are the less-sharp / less-flat clouds of slot k-1;
  * slot `first`'s target is the ctx "carry" target (the previous batch's last scan, or whatever
  * ll_set_target uploaded).  pose_guess: count x 7 doubles (qx,qy,qz,qw,tx,ty,tz) = para_q/para_t at entry
- * (:61-62); NULL = identity.                                                                           */
+ * (:61-62); NULL = identity.
+ * The association FIXES a slot's target: ll_vote_batch, ll_normal_equations_batch, ll_residual_jacobian and the solves read
+ * whose points the slot's correspondences name from what ll_associate_batch recorded, so a later call over any sub-range
+ * (e.g. ll_vote_batch(k, 1)) refers to the same clouds.                                                                */
 int ll_set_target(ll_ctx *ctx, const ll_point *host_corner_last, int m_c, const ll_point *host_surf_last, int m_s);
 /* The four feature clouds of a scan from host memory into a slot, in place of ll_extract_batch: what a separate
  * laserOdometry process receives on /laser_cloud_sharp, _less_sharp, _flat, _less_flat (laserOdometry.cpp:116-150,

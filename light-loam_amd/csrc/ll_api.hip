@@ -149,11 +149,9 @@ extern "C" int ll_create(int device, const ll_params *p, ll_ctx **out)
     V.ring_cap = p->max_ring_points < NP ? p->max_ring_points : NP; V.CS = R * V.ring_cap;
     ok = ok && dev_alloc(ctx, V.cloud, (size_t)B * V.CS, false) && dev_alloc(ctx, ctx->cloud_flat, NP, false);
     ok = ok && dev_alloc(ctx, V.label, BN) && dev_alloc(ctx, V.curv, p->write_curvature ? BN : 1);
-    ok = ok && dev_alloc(ctx, V.ring_pub, (size_t)B * R);
-    ok = ok && dev_alloc(ctx, V.stage_sf, p->max_ring_points > 2304 ? (size_t)B * R * LL_STAGE_SF : 1, false);
-    ok = ok && dev_alloc(ctx, V.ring_rec, (size_t)B * R * LL_REC_U16) && dev_alloc(ctx, V.ring_cnt, (size_t)B * R) && dev_alloc(ctx, V.ring_box, (size_t)B * R * 8);
-    V.ring_split = 1;
-    if (const char *e = std::getenv("LIGHTLOAM_RING_SPLIT")) V.ring_split = std::atoi(e) ? 1 : 0;   /* A/B: 0 = the fused kernel of rounds 1-3 */
+    ok = ok && dev_alloc(ctx, V.ring_rec, (size_t)B * R * LL_REC_U16) && dev_alloc(ctx, V.ring_cnt, (size_t)B * R);
+    ok = ok && dev_alloc(ctx, V.ring_nlf, (size_t)B * R) && dev_alloc(ctx, V.lf_pre, (size_t)B * (R + 1));
+    if (p->max_ring_points > 2304) ok = ok && dev_alloc(ctx, V.tier_cnt, 4) && dev_alloc(ctx, V.tier_list, (size_t)3 * B * R, false);   /* else both stay null: no tiers */
     {   /* ring thresholds of this sensor model (ll_exact_math.h), computed once with the same exact arithmetic */
         int *thr_dev = nullptr;
         std::vector<int32_t> thr((size_t)R + 1);
@@ -171,7 +169,9 @@ extern "C" int ll_create(int device, const ll_params *p, ll_ctx **out)
         V.ring_lut = lut_dev;
     }
     ok = ok && dev_alloc(ctx, V.sharp, (size_t)B * V.cap_sharp, false) && dev_alloc(ctx, V.lsharp, (size_t)B * V.cap_lsharp, false) &&
-         dev_alloc(ctx, V.flat, (size_t)B * V.cap_flat, false) && dev_alloc(ctx, V.lflat, BN, false);
+         dev_alloc(ctx, V.flat, (size_t)B * V.cap_flat, false);
+    V.LFS = V.CS > NP ? V.CS : NP;                                                /* ring-strided rows of an extracted scan, or an uploaded contiguous cloud */
+    ok = ok && dev_alloc(ctx, V.lflat, (size_t)B * V.LFS, false);
     ok = ok && dev_alloc(ctx, V.carry_corner, V.cap_lsharp) && dev_alloc(ctx, V.carry_surf, NP) && dev_alloc(ctx, V.carry_cnt, 2);
     ok = ok && dev_alloc(ctx, V.gstart, (size_t)B * 2 * LL_GSTRIDE) && dev_alloc(ctx, V.gpts_c, (size_t)B * V.cap_lsharp, false) && dev_alloc(ctx, V.gpts_s, BN, false);
     ok = ok && dev_alloc(ctx, V.carry_gstart, (size_t)2 * LL_GSTRIDE) && dev_alloc(ctx, V.carry_gpts_c, V.cap_lsharp, false) && dev_alloc(ctx, V.carry_gpts_s, NP, false);
@@ -182,7 +182,9 @@ extern "C" int ll_create(int device, const ll_params *p, ll_ctx **out)
     ok = ok && dev_alloc(ctx, V.v_count, (size_t)B * V.cap_flat) && dev_alloc(ctx, V.v_sel, (size_t)B * V.cap_flat) && dev_alloc(ctx, V.v_w, (size_t)B * V.cap_flat);
     ok = ok && dev_alloc(ctx, V.pair, B) && dev_alloc(ctx, V.pose, (size_t)B * 7) && dev_alloc(ctx, V.pose_guess, (size_t)B * 7) && dev_alloc(ctx, V.neq, (size_t)B * LL_NEQ_STRIDE);
     ok = ok && dev_alloc(ctx, ctx->d_tmp_pose, 7) && dev_alloc(ctx, V.dbg, 16) && dev_alloc(ctx, V.lm, (size_t)B * LL_LM_STRIDE);
+    ok = ok && dev_alloc(ctx, V.assoc_tgt, B, false);
     if (!ok) { ll_destroy(ctx); return LL_ERR_HIP; }
+    if (hipMemset(V.assoc_tgt, 0x80, (size_t)B * sizeof(int)) != hipSuccess) { g_create_err = "hipMemset failed"; ll_destroy(ctx); return LL_ERR_HIP; }   /* < -1: never associated */
     ctx->feat_lds = ll_features_lds_bytes(p->max_ring_points);
     if (ctx->feat_lds > 160 * 1024) { g_create_err = "max_ring_points needs more than 160 KiB of LDS"; ll_destroy(ctx); return LL_ERR_ARG; }
     /* identity pose guesses; status = "nothing extracted yet" */
@@ -362,7 +364,6 @@ extern "C" int ll_extract_batch(ll_ctx *ctx, int first, int count)
 {
     int rc = check_range(ctx, first, count); if (rc) return rc;
     ll_launch_organize(ctx->V, first, count, ctx->stream, &ctx->prof);
-    ll_next_epoch(ctx);
     ll_launch_features(ctx->V, first, count, ctx->feat_lds, ctx->stream, &ctx->prof);
     ll_launch_build_grid(ctx->V, first, count, 0, ctx->stream, &ctx->prof);
     LL_HIP(hipGetLastError());
@@ -410,12 +411,12 @@ extern "C" int ll_upload_features(ll_ctx *ctx, int slot, const ll_point *sharp, 
     if (ns) LL_HIP(hipMemcpyAsync(V.sharp + (size_t)slot * V.cap_sharp, sharp, (size_t)ns * 16, hipMemcpyHostToDevice, ctx->stream));
     if (nls) LL_HIP(hipMemcpyAsync(V.lsharp + (size_t)slot * V.cap_lsharp, lsharp, (size_t)nls * 16, hipMemcpyHostToDevice, ctx->stream));
     if (nf) LL_HIP(hipMemcpyAsync(V.flat + (size_t)slot * V.cap_flat, flat, (size_t)nf * 16, hipMemcpyHostToDevice, ctx->stream));
-    if (nlf) LL_HIP(hipMemcpyAsync(V.lflat + (size_t)slot * V.NP, lflat, (size_t)nlf * 16, hipMemcpyHostToDevice, ctx->stream));
+    if (nlf) LL_HIP(hipMemcpyAsync(V.lflat + (size_t)slot * V.LFS, lflat, (size_t)nlf * 16, hipMemcpyHostToDevice, ctx->stream));
     ScanHdr h;
     std::memset(&h, 0, sizeof(h));
     h.first_kept = 0; h.last_kept = -1; h.half_idx = 0;
     h.n_sharp = ns; h.n_less_sharp = nls; h.n_flat = nf; h.n_less_flat = nlf;
-    h.status = 0;
+    h.status = 0; h.lf_strided = 0;                         /* the caller's cloud as it is: contiguous, place = index */
     LL_HIP(hipMemcpyAsync(V.hdr + slot, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
     /* the slot may become the target of slot + 1 (ll_associate_batch / ll_odometry_frames over a range): its search grid and
      * ring tables are part of "serving like an extracted slot" */
@@ -426,13 +427,24 @@ extern "C" int ll_upload_features(ll_ctx *ctx, int slot, const ll_point *sharp, 
     return LL_OK;
 }
 
+/* the slot's less-sharp / less-flat clouds become the carry target: contiguous copies (the less-flat rows of an extracted slot are
+ * closed up through lf_pre, which k_build_grid wrote when the slot was extracted) */
 __global__ void k_copy_carry(LLView V, int slot)
 {
     const ScanHdr h = V.hdr[slot];
     const int mc = h.status == 0 ? h.n_less_sharp : 0, ms = h.status == 0 ? h.n_less_flat : 0;
     const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
     for (int i = gtid; i < mc; i += gsz) V.carry_corner[i] = V.lsharp[(size_t)slot * V.cap_lsharp + i];
-    for (int i = gtid; i < ms; i += gsz) V.carry_surf[i] = V.lflat[(size_t)slot * V.NP + i];
+    const float4 *lf = V.lflat + (size_t)slot * V.LFS;
+    if (!h.lf_strided) { for (int i = gtid; i < ms; i += gsz) V.carry_surf[i] = lf[i]; }
+    else {
+        const int *pre = V.lf_pre + (size_t)slot * (V.R + 1);
+        const int wave = gtid >> 6, nwaves = gsz >> 6, lane = gtid & 63;
+        for (int r = wave; r < V.R; r += nwaves) {                       /* a wave per ring row */
+            const int o = pre[r], n = pre[r + 1] - o;
+            for (int i = lane; i < n; i += 64) V.carry_surf[o + i] = lf[(size_t)r * V.ring_cap + i];
+        }
+    }
     if (gtid == 0) { V.carry_cnt[0] = mc; V.carry_cnt[1] = ms; }
 }
 
@@ -606,7 +618,6 @@ static int hot_path(ll_ctx *ctx, int first, int count, const double *host_pose_g
     for (int c0 = 0; c0 < count; c0 += chunk) {
         const int f = first + c0, n = (count - c0 < chunk) ? count - c0 : chunk;
         ll_launch_organize(ctx->V, f, n, ctx->stream, &ctx->prof);
-        ll_next_epoch(ctx);
         ll_launch_features(ctx->V, f, n, ctx->feat_lds, ctx->stream, &ctx->prof);
         ll_launch_build_grid(ctx->V, f, n, 0, ctx->stream, &ctx->prof);
         ll_launch_associate(ctx->V, f, n, ctx->stream, &ctx->prof);
@@ -1292,7 +1303,12 @@ extern "C" int ll_download_features(ll_ctx *ctx, int slot, ll_point *sharp, int 
     rc = dl(ctx, sharp, V.sharp + (size_t)slot * V.cap_sharp, (size_t)h.n_sharp * 16); if (rc) return rc;
     rc = dl(ctx, less_sharp, V.lsharp + (size_t)slot * V.cap_lsharp, (size_t)h.n_less_sharp * 16); if (rc) return rc;
     rc = dl(ctx, flat, V.flat + (size_t)slot * V.cap_flat, (size_t)h.n_flat * 16); if (rc) return rc;
-    rc = dl(ctx, less_flat, V.lflat + (size_t)slot * V.NP, (size_t)h.n_less_flat * 16); if (rc) return rc;
+    if (less_flat && h.n_less_flat > 0) {
+        if (h.lf_strided) {                                              /* ring rows -> the reference's contiguous cloud, on the device */
+            ll_launch_lflat_flatten(V, slot, ctx->cloud_flat, ctx->stream);
+            rc = dl(ctx, less_flat, ctx->cloud_flat, (size_t)h.n_less_flat * 16); if (rc) return rc;
+        } else { rc = dl(ctx, less_flat, V.lflat + (size_t)slot * V.LFS, (size_t)h.n_less_flat * 16); if (rc) return rc; }
+    }
     LL_HIP(hipStreamSynchronize(ctx->stream));
     return LL_OK;
 }
@@ -1335,7 +1351,25 @@ extern "C" int ll_download_plane_corr(ll_ctx *ctx, int slot, int *src, int *a, i
     rc = dl(ctx, a, V.p_a + o, by); if (rc) return rc;
     rc = dl(ctx, b, V.p_b + o, by); if (rc) return rc;
     rc = dl(ctx, c, V.p_c + o, by); if (rc) return rc;
+    /* inside the library a less-flat target point is named by its PLACE in the target slot (ll_common.h); the reference's
+     * closestPointInd / minPointInd2 / minPointInd3 (laserOdometry.cpp:661-721) are indices into the contiguous cloud */
+    std::vector<int> pre;
+    int stride = 0;
+    if (p.target_slot >= 0 && p.n_plane > 0) {
+        ScanHdr th; rc = fetch_hdr(ctx, p.target_slot, &th); if (rc) return rc;
+        if (th.lf_strided) {
+            pre.resize((size_t)V.R + 1); stride = V.ring_cap;
+            rc = dl(ctx, pre.data(), V.lf_pre + (size_t)p.target_slot * (V.R + 1), pre.size() * sizeof(int)); if (rc) return rc;
+        }
+    }
     LL_HIP(hipStreamSynchronize(ctx->stream));
+    if (stride) {
+        int *arr[3] = {a, b, c};
+        for (int *x : arr) {
+            if (!x) continue;
+            for (int i = 0; i < p.n_plane; ++i) if (x[i] >= 0) { const int r = x[i] / stride; x[i] = pre[(size_t)r] + (x[i] - r * stride); }
+        }
+    }
     return LL_OK;
 }
 

@@ -32,12 +32,6 @@
 #include <limits.h>
 #include <type_traits>
 
-__device__ __forceinline__ int ll_cell_coord(float v)
-{
-    const int c = (int)floorf((v + LL_GRID_ORG) * (1.0f / LL_GRID_CELL));
-    return min(max(c, 0), LL_GRID_G - 1);
-}
-
 /* walk bounds of a start ring rc: the up-walk stops at the first ring > rc + NEARBY_SCAN, the down-walk at the
  * first ring < rc - NEARBY_SCAN (compared in double like the reference); for integer rings that is > hi / < lo */
 __device__ __forceinline__ int ll_ring_hi(int rc, double nearby) { return (int)floor((double)rc + nearby); }
@@ -54,26 +48,29 @@ extern __shared__ __attribute__((aligned(16))) unsigned char ll_gsm[];
 #define LL_GPHASE(i) do {} while (0)
 #endif
 
-/* grid + ring tables of a target cloud; carry != 0: the carry clouds, else slot first + blockIdx/2 */
+/* grid + ring tables of a target cloud; carry != 0: the carry clouds, else slot first + blockIdx/2.
+ *
+ * The cloud is read as CHUNKS of 64 consecutive points, one chunk per wave and load: a contiguous cloud (less-sharp; the carry; an
+ * uploaded less-flat cloud) is chunk c = points [64 c, 64 c + 64); the ring-strided less-flat cloud of an extracted slot
+ * (ll_common.h) is, ring after ring, the ceil(ring_nlf[r] / 64) chunks of ring r's row; the chunks are dealt to the sixteen waves in
+ * equal blocks, so all of them stay busy whatever the rings' lengths.  A point is named by its PLACE (float4 offset inside the slot's
+ * array; = index for a contiguous cloud): place order = index order, and every consumer of the grid only compares.
+ * For an extracted slot this kernel is also where the scan's totals become known: the workgroup of the less-flat cloud scans the
+ * per-ring counts into lf_pre and writes the four totals of the header (no ring of k_ring_features waited for another to learn them). */
 #define LL_GB 1024      /* threads: the kernel is a chain of latency-bound sweeps and LDS (68 KB) allows two workgroups per CU */
-__global__ __launch_bounds__(LL_GB) void k_build_grid(LLView V, int first, int count, int carry)
+/* Two 1024-thread workgroups per CU are 8 waves per SIMD, and the hardware admits the eighth wave only below 81 SGPRs
+ * (MI355X_MICROARCH.md, residency: floor(800 / (ceil(sgpr / 16) * 16 + 16)) waves per SIMD; the occupancy query says 8 up to 96).
+ * Rounds 1-4 compiled this kernel to 82 SGPRs without the bound: ONE workgroup per CU was resident. */
+#ifndef LL_GRID_WAVES
+#define LL_GRID_WAVES 8
+#endif
+static size_t ll_grid_lds_bytes(const LLView &) { return (LL_GRID_NC + LL_GRID_NC / 16) * sizeof(int); }
+__global__ __launch_bounds__(LL_GB, LL_GRID_WAVES) void k_build_grid(LLView V, int first, int count, int carry)
 {
     const int which = blockIdx.x & 1, sl = blockIdx.x >> 1;
     if (sl >= count) return;
-    const int tid = threadIdx.x;
-    const float4 *pts; int m; int *gstart; float4 *gpts;
-    if (carry) {
-        pts = which ? V.carry_surf : V.carry_corner; m = V.carry_cnt[which];
-        gstart = V.carry_gstart + (size_t)which * LL_GSTRIDE;
-        gpts = which ? V.carry_gpts_s : V.carry_gpts_c;
-    } else {
-        const int s = first + sl;
-        const ScanHdr h = V.hdr[s];
-        pts = which ? V.lflat + (size_t)s * V.NP : V.lsharp + (size_t)s * V.cap_lsharp;
-        m = (h.status != 0) ? 0 : (which ? h.n_less_flat : h.n_less_sharp);
-        gstart = V.gstart + ((size_t)s * 2 + which) * LL_GSTRIDE;
-        gpts = which ? V.gpts_s + (size_t)s * V.NP : V.gpts_c + (size_t)s * V.cap_lsharp;
-    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NW = LL_GB / 64;
     /* cell c lives at hist[c + (c >> 4)]: the per-thread scan below walks 16 consecutive cells per lane, and the
      * one-word skew per 16 cells spreads the lanes over all LDS banks instead of putting them on two */
 #define LL_HI(c) ((c) + ((c) >> 4))
@@ -81,35 +78,130 @@ __global__ __launch_bounds__(LL_GB) void k_build_grid(LLView V, int first, int c
     __shared__ int sc[LL_GB / 64];
     __shared__ int feq[LL_TAB + 1], leq[LL_TAB + 1];
     __shared__ int okflag;
+    __shared__ int rcnt[LL_MAX_RINGS], pre[LL_MAX_RINGS + 1], cpre[LL_MAX_RINGS + 1];   /* per ring: points, index of the first, chunk of the first */
+    __shared__ int tot3[3];
     for (int i = tid; i < LL_GRID_NC + LL_GRID_NC / 16; i += LL_GB) hist[i] = 0;
     for (int i = tid; i <= LL_TAB; i += LL_GB) { feq[i] = INT_MAX; leq[i] = -1; }
     if (tid == 0) okflag = (V.nearby >= 0.0) ? 1 : 0;
+    if (tid < 3) tot3[tid] = 0;
+
+    const float4 *pts; int m = 0; int *gstart; float4 *gpts;
+    bool extracted = false;                                /* an extracted slot: the counts are per ring, the totals not yet known */
+    int s = 0;
+    if (carry) {
+        pts = which ? V.carry_surf : V.carry_corner; m = V.carry_cnt[which];
+        gstart = V.carry_gstart + (size_t)which * LL_GSTRIDE;
+        gpts = which ? V.carry_gpts_s : V.carry_gpts_c;
+    } else {
+        s = first + sl;
+        const ScanHdr h = V.hdr[s];
+        pts = which ? V.lflat + (size_t)s * V.LFS : V.lsharp + (size_t)s * V.cap_lsharp;
+        gstart = V.gstart + ((size_t)s * 2 + which) * LL_GSTRIDE;
+        gpts = which ? V.gpts_s + (size_t)s * V.NP : V.gpts_c + (size_t)s * V.cap_lsharp;
+        if (h.status != 0) m = 0;
+        else if (!h.lf_strided) m = which ? h.n_less_flat : h.n_less_sharp;         /* ll_upload_features: the caller's counts */
+        else extracted = true;
+    }
     __syncthreads();
+    if (extracted) {
+        /* the rings' counts: less-flat points (k_ring_features) or less-sharp picks (k_ring_pick) of every ring; the workgroup of
+         * the less-flat cloud also sums the three small clouds' counts for the header */
+        const int R = V.R;
+        if (tid < LL_MAX_RINGS) {
+            const unsigned pc = tid < R ? V.ring_cnt[(size_t)s * R + tid] : 0u;
+            rcnt[tid] = which ? (tid < R ? V.ring_nlf[(size_t)s * R + tid] : 0) : (int)((pc >> 8) & 0xffu);
+            if (which) {
+                const int a = ll_wave_sum_i32((int)(pc & 0xffu)), b = ll_wave_sum_i32((int)((pc >> 8) & 0xffu)), c = ll_wave_sum_i32((int)((pc >> 16) & 0xffu));
+                if (lane == 0) { atomicAdd(&tot3[0], a); atomicAdd(&tot3[1], b); atomicAdd(&tot3[2], c); }
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {                                    /* wave 0: exclusive prefixes of the points and of the 64-point chunks, two halves */
+            int carry_p = 0, carry_c = 0;
+#pragma unroll
+            for (int half = 0; half < LL_MAX_RINGS / 64; ++half) {
+                const int q = half * 64 + lane;
+                const int v = rcnt[q], c = (v + 63) >> 6;
+                const int ip = ll_wave_incl_scan(v), ic = ll_wave_incl_scan(c);
+                pre[q] = carry_p + ip - v; cpre[q] = carry_c + ic - c;
+                carry_p += __builtin_amdgcn_readlane(ip, 63); carry_c += __builtin_amdgcn_readlane(ic, 63);
+            }
+            if (lane == 0) { pre[LL_MAX_RINGS] = carry_p; cpre[LL_MAX_RINGS] = carry_c; }
+        }
+        __syncthreads();
+        m = pre[LL_MAX_RINGS];
+        if (which) {
+            /* rings beyond R hold no point: pre[R] = the total.  lf_pre: what turns a place into the reference's index (C ABI, carry copy) */
+            if (tid <= R) V.lf_pre[(size_t)s * (R + 1) + tid] = pre[tid];
+            if (tid == 0) { ScanHdr *hh = &V.hdr[s]; hh->n_sharp = tot3[0]; hh->n_less_sharp = tot3[1]; hh->n_flat = tot3[2]; hh->n_less_flat = m; }
+        }
+        __syncthreads();
+    }
+    const bool strided = extracted && which != 0;
+    const int stride = V.ring_cap;
+    const int pend = strided ? V.R * stride : m;           /* one past the last place */
+    const int nch = strided ? cpre[LL_MAX_RINGS] : (m + 63) >> 6;
+    /* Every wave takes a BLOCK of consecutive chunks and walks it with a cursor (ring q, chunk k of that ring, the ring's length): the
+     * next chunk is k + 1 or the first chunk of the next ring that holds a point -- scalar arithmetic, one LDS read per ring crossed,
+     * nothing per chunk (a per-chunk lookup table cost the sweeps 15 % of their time). */
+    const int per_wave = (nch + NW - 1) / NW;
+    const int cw0 = min(nch, wave * per_wave), cw1 = min(nch, cw0 + per_wave);
+    struct Cursor { int q, k, len; };
+    auto cursor_at = [&](int c) __attribute__((always_inline)) -> Cursor {       /* chunk c of the cloud (c < nch) */
+        Cursor cu; cu.q = 0; cu.k = c; cu.len = m;
+        if (strided) {
+            int lo = 0, hi = LL_MAX_RINGS;                                        /* the last ring whose first chunk is <= c and that holds a chunk */
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (__builtin_amdgcn_readfirstlane(cpre[mid]) <= c) lo = mid; else hi = mid; }
+            cu.q = lo; cu.k = c - __builtin_amdgcn_readfirstlane(cpre[lo]); cu.len = __builtin_amdgcn_readfirstlane(rcnt[lo]);
+        }
+        return cu;
+    };
+    /* the cursor's chunk -> its first place and the points it holds; then on to the next chunk */
+    auto take = [&](Cursor &cu, int &place0, int &nv) __attribute__((always_inline)) {
+        if (strided) {
+            place0 = cu.q * stride + cu.k * 64; nv = cu.len - cu.k * 64;
+            if (++cu.k * 64 >= cu.len) {
+                cu.k = 0;
+                do { ++cu.q; cu.len = cu.q < LL_MAX_RINGS ? __builtin_amdgcn_readfirstlane(rcnt[cu.q]) : 1; } while (cu.len == 0);
+            }
+        } else { place0 = cu.k * 64; nv = m - cu.k * 64; ++cu.k; }
+    };
     LL_GPHASE_BEGIN();
 #ifndef LL_GRID_UN
-#define LL_GRID_UN 8
+#define LL_GRID_UN 4
 #endif
-    constexpr int UN = LL_GRID_UN;                   /* independent loads in flight per thread: the kernel is latency-bound */
-    const int lane = tid & 63;
+    constexpr int UN = LL_GRID_UN;                   /* independent loads in flight per lane: the kernel is latency-bound, and UN = 4 is what keeps it
+                                                       * at two workgroups per CU without scratch */
+#define LL_WSHR1(x) __builtin_amdgcn_update_dpp(0, (int)(x), 0x138, 0xf, 0xf, false)      /* wave_shr:1: lane i <- lane i - 1 */
+#define LL_WSHL1(x) __builtin_amdgcn_update_dpp(0, (int)(x), 0x130, 0xf, 0xf, false)      /* wave_shl:1: lane i <- lane i + 1 */
     bool bad = false;
-    for (int i0 = tid; i0 < m; i0 += LL_GB * UN) {
-        float4 p[UN];
+    /* histogram + ring tables from a chunk's keys (cell | ring value << 16) */
+    auto count_chunk = [&](unsigned kv, int place0, int nv) __attribute__((always_inline)) {
+        const bool in = lane < nv;
+        if (in) atomicAdd(&hist[LL_HI((int)(kv & 0xFFFFu))], 1);
+        /* ring tables, same sweep: first / last place of every ring value (only run boundaries touch LDS) */
+        const int r = in ? (int)(kv >> 16) : 0;
+        const bool oob = in && r >= LL_TAB;                                   /* 0xFF: int(intensity) outside [0, LL_TAB) */
+        if (oob) bad = true;
+        const int rprev = LL_WSHR1(r), rnext = LL_WSHL1(r);
+        if (in && !oob) {
+            const int place = place0 + lane;
+            if (lane == 0 || r != rprev) atomicMin(&feq[r], place);
+            if (lane == 63 || lane == nv - 1 || r != rnext) atomicMax(&leq[r], place);
+        }
+    };
+    if (cw0 < cw1) {
+        Cursor cu = cursor_at(cw0);
+        for (int c = cw0; c < cw1; c += UN) {
+            float4 p[UN]; int pl[UN], nv[UN];
 #pragma unroll
-        for (int u = 0; u < UN; ++u) { const int i = i0 + u * LL_GB; if (i < m) p[u] = pts[i]; }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int i = i0 + u * LL_GB;
-            const bool in = i < m;
-            if (in) { const int c = ll_cell_coord(p[u].y) * LL_GRID_G + ll_cell_coord(p[u].x); atomicAdd(&hist[LL_HI(c)], 1); }
-            /* ring tables, same sweep: first / last index of every ring value (only run boundaries touch LDS) */
-            const int r = in ? (int)p[u].w : 0;
-            const bool oob = in && (r < 0 || r >= LL_TAB);
-            if (oob) bad = true;
-            const int rprev = __shfl_up(r, 1), rnext = __shfl_down(r, 1);
-            if (in && !oob) {
-                if (lane == 0 || r != rprev) atomicMin(&feq[r], i);
-                if (lane == 63 || i == m - 1 || r != rnext) atomicMax(&leq[r], i);
+            for (int u = 0; u < UN; ++u) {
+                pl[u] = 0; nv[u] = 0;
+                if (c + u < cw1) take(cu, pl[u], nv[u]);
+                if (lane < nv[u]) p[u] = pts[pl[u] + lane];
             }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) count_chunk(lane < nv[u] ? ll_grid_key(p[u]) : 0u, pl[u], nv[u]);
         }
     }
     if (bad) okflag = 0;
@@ -124,46 +216,53 @@ __global__ __launch_bounds__(LL_GB) void k_build_grid(LLView V, int first, int c
     if (tid == LL_GB - 1) gstart[LL_GRID_NC] = total;
     __syncthreads();
     LL_GPHASE(9);
-    for (int i0 = tid; i0 < m; i0 += LL_GB * UN) {
-        float4 p[UN]; int pos[UN];
+    if (cw0 < cw1) {
+        Cursor cu = cursor_at(cw0);
+        for (int c = cw0; c < cw1; c += UN) {
+            float4 p[UN]; int pl[UN], nv[UN], pos[UN];
 #pragma unroll
-        for (int u = 0; u < UN; ++u) { const int i = i0 + u * LL_GB; if (i < m) p[u] = pts[i]; }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int i = i0 + u * LL_GB;
-            if (i < m) { const int c = ll_cell_coord(p[u].y) * LL_GRID_G + ll_cell_coord(p[u].x); pos[u] = atomicAdd(&hist[LL_HI(c)], 1); }
-        }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int i = i0 + u * LL_GB;
-            if (i < m) {
-                const int r = (int)p[u].w;                                   /* int(intensity): the walk's scan id */
-                gpts[pos[u]] = make_float4(p[u].x, p[u].y, p[u].z, __int_as_float((i << 8) | (r & 0xFF)));   /* i < 2^24 */
+            for (int u = 0; u < UN; ++u) {
+                pl[u] = 0; nv[u] = 0;
+                if (c + u < cw1) take(cu, pl[u], nv[u]);
+                if (lane < nv[u]) p[u] = pts[pl[u] + lane];
             }
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+                if (lane < nv[u]) { const int cc = ll_cell_coord(p[u].y) * LL_GRID_G + ll_cell_coord(p[u].x); pos[u] = atomicAdd(&hist[LL_HI(cc)], 1); }
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+                if (lane < nv[u]) {
+                    const int r = (int)p[u].w;                                   /* int(intensity): the walk's scan id */
+                    gpts[pos[u]] = make_float4(p[u].x, p[u].y, p[u].z, __int_as_float(((pl[u] + lane) << 8) | (r & 0xFF)));   /* place < 2^24 */
+                }
         }
     }
 #undef LL_HI
+#undef LL_WSHR1
+#undef LL_WSHL1
 
     LL_GPHASE(10);
-    /* ---- ring tables + validity.  The tables first_ge / last_le reproduce the reference's sequential walk bounds for
-     * EVERY start index iff no point lies before a point whose up-window it exceeds and none after a point whose
+    /* ---- ring tables + validity.  The tables first_ge / last_le (in places) reproduce the reference's sequential walk bounds for
+     * EVERY start point iff no point lies before a point whose up-window it exceeds and none after a point whose
      * down-window it undercuts:
      *   exists j < c with ring_j > hi(ring_c)   <=>   exists value b:  first_ge[hi(b) + 1] < last_eq[b]
      *   exists j > c with ring_j < lo(ring_c)   <=>   exists value b:  last_le[lo(b) - 1]  > first_eq[b]
-     * so validity is a check on the two 160-entry tables, no per-point scan. ---- */
+     * so validity is a check on the two 160-entry tables, no per-point scan.  The same tables say whether the ring values never
+     * decrease along the cloud (first_ge[b + 1] > last_eq[b] for every value b): the extract stage's clouds are like that, and
+     * k_associate's second / third-point search then needs neither the direction of the walk nor the place window per candidate. ---- */
     LL_GPHASE(11);
     __syncthreads();
-    int *tab = gstart + LL_GRID_NC + 1;              /* first_ge[LL_TAB+1], last_le[LL_TAB+1], ok, m */
-    /* first_ge = suffix minimum of the first indices, last_le = prefix maximum of the last ones: wave 0, three
+    int *tab = gstart + LL_GRID_NC + 1;              /* first_ge[LL_TAB+1], last_le[LL_TAB+1], flags, m, one past the last place */
+    /* first_ge = suffix minimum of the first places, last_le = prefix maximum of the last ones: wave 0, three
      * 64-entry chunks with shuffle scans, the running value carried between chunks */
     __shared__ int fge[LL_TAB + 1], lle[LL_TAB + 1];
     if (tid < 64) {
         constexpr int NCH = (LL_TAB + 1 + 63) / 64;
-        int carry_min = m;
+        int carry_min = pend;
         for (int ch = NCH - 1; ch >= 0; --ch) {
             const int v = ch * 64 + lane;
-            int x = (v <= LL_TAB && feq[v] != INT_MAX) ? feq[v] : m;
-            x = min(x, m);
+            int x = (v <= LL_TAB && feq[v] != INT_MAX) ? feq[v] : pend;
+            x = min(x, pend);
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_down(x, o); if (lane + o < 64) x = min(x, t); }
             x = min(x, carry_min);
@@ -181,25 +280,29 @@ __global__ __launch_bounds__(LL_GB) void k_build_grid(LLView V, int first, int c
             carry_max = __shfl(x, 63);
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        bool viol = false;
+        bool viol = false, unsorted = false;
         for (int ch = 0; ch < NCH; ++ch) {
             const int bv = ch * 64 + lane;
             if (bv < LL_TAB && feq[bv] != INT_MAX) {
                 const int hi = ll_ring_hi(bv, V.nearby), lo = ll_ring_lo(bv, V.nearby);
-                const int fg = (hi + 1 > LL_TAB) ? m : fge[max(hi + 1, 0)];
+                const int fg = (hi + 1 > LL_TAB) ? pend : fge[max(hi + 1, 0)];
                 const int ll = (lo - 1 < 0) ? -1 : lle[min(lo - 1, LL_TAB)];
                 if (fg < leq[bv] || ll > feq[bv]) viol = true;
+                if (fge[bv + 1] < leq[bv]) unsorted = true;                 /* a larger ring value before the last point of value bv */
             }
         }
-        const bool any_viol = __ballot(viol) != 0ull;
+        const bool any_viol = __ballot(viol) != 0ull, any_unsorted = __ballot(unsorted) != 0ull;
         if (lane == 0) {
-            tab[2 * (LL_TAB + 1)] = (okflag && !any_viol) ? 1 : 0;
+            const int ok = (okflag && !any_viol) ? 1 : 0;
+            tab[2 * (LL_TAB + 1)] = ok | ((ok && !any_unsorted) ? 2 : 0);
             tab[2 * (LL_TAB + 1) + 1] = m;
+            tab[2 * (LL_TAB + 1) + 2] = pend;
         }
     }
 }
 
-struct TargetRef { const float4 *pts; int m; const int *gstart; const float4 *gpts; const int *tab; };
+struct TargetRef { const float4 *pts; int m; const int *gstart; const float4 *gpts; const int *tab;
+                   const int *pre; int stride; };   /* pre != null: pts is ring-strided (ll_common.h), index = pre[ring] + place - ring * stride */
 
 __device__ __forceinline__ TargetRef ll_target(const LLView &V, int s, int which)
 {
@@ -208,11 +311,14 @@ __device__ __forceinline__ TargetRef ll_target(const LLView &V, int s, int which
         T.pts = which ? V.carry_surf : V.carry_corner; T.m = V.carry_cnt[which];
         T.gstart = V.carry_gstart + (size_t)which * LL_GSTRIDE;
         T.gpts = which ? V.carry_gpts_s : V.carry_gpts_c;
+        T.pre = nullptr; T.stride = 0;
     } else {
         const int t = s - 1;
         const ScanHdr h = V.hdr[t];
-        T.pts = which ? V.lflat + (size_t)t * V.NP : V.lsharp + (size_t)t * V.cap_lsharp;
+        T.pts = which ? V.lflat + (size_t)t * V.LFS : V.lsharp + (size_t)t * V.cap_lsharp;
         T.m = (h.status != 0) ? 0 : (which ? h.n_less_flat : h.n_less_sharp);
+        const bool strided = which != 0 && h.lf_strided != 0;
+        T.pre = strided ? V.lf_pre + (size_t)t * (V.R + 1) : nullptr; T.stride = strided ? V.ring_cap : 0;
         T.gstart = V.gstart + ((size_t)t * 2 + which) * LL_GSTRIDE;
         T.gpts = which ? V.gpts_s + (size_t)t * V.NP : V.gpts_c + (size_t)t * V.cap_lsharp;
     }
@@ -353,12 +459,20 @@ __device__ __forceinline__ void ll_grid_search(const int *gstart, float qx, floa
     }
 }
 
-template <bool PLANE>
+template <bool PLANE, bool MONO>
 __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int qblock, int qpb,
                                                    const float4 *queries, int nq, const TargetRef T,
                                                    int *out_a, int *out_b, int *out_c, float4 *qs, int *nn, int *rb, int *rcl, int *cellb_all, int *tab, unsigned char *perm, int *hist)
 {
     const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < LL_TAB_WORDS; i += LL_BLOCK) tab[i] = T.tab[i];             /* the ring tables: read by every query */
+    __syncthreads();
+    {   /* which of the two launches serves this target (uniform): the one compiled for clouds whose ring values never decrease -- every
+         * cloud the extract stage makes -- or the general one (arbitrary uploaded targets; tables that do not bound the walks) */
+        const int fl = tab[2 * (LL_TAB + 1)];
+        const bool fast = (fl & 3) == 3 && tab[2 * (LL_TAB + 1) + 1] == T.m;
+        if (fast != MONO) return;
+    }
     const int qi = qblock * qpb + tid;                        /* qpb queries per workgroup: 256 in a batch, 32 (one pass) when few scans must fill the chip */
     const bool have = tid < qpb && qi < nq;
     /* a5: TransformToStart (s = 1 with DISTORTION 0, the reference's build): f64 rotate + translate, f32 store */
@@ -380,7 +494,6 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
         }
     }
     qs[tid] = make_float4(sx, sy, sz, have ? 1.0f : 0.0f);
-    for (int i = tid; i < 2 * (LL_TAB + 1) + 2; i += LL_BLOCK) tab[i] = T.tab[i];      /* the ring tables: read by every query */
     if (tid < 64) hist[tid] = 0;
     __syncthreads();
     /* The eight queries of a wave advance in lockstep, so they should cost about the same: the block's queries are dealt to
@@ -414,7 +527,8 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
     const int rmax = (int)ceilf(sqrtf(V.nn_max) / LL_GRID_CELL) + 1;
     const float4 *gpts = T.gpts; const int *gstart = T.gstart;
     const float4 *tgt = T.pts; const int M = T.m;
-    const bool tab_ok = tab[2 * (LL_TAB + 1)] != 0 && tab[2 * (LL_TAB + 1) + 1] == M;
+    const bool tab_ok = (tab[2 * (LL_TAB + 1)] & 1) != 0 && tab[2 * (LL_TAB + 1) + 1] == M;
+    const int PEND = tab[2 * (LL_TAB + 1) + 2];                  /* one past the last place of the target cloud (= M when it is contiguous) */
     const float dmax = V.nn_max;
 #ifdef LL_ASSOC_STATS   /* tools/assoc_stats.py: candidates scanned by the two searches, sweep rounds, queries -> V.dbg[0..3] corners, [4..7] planes */
     unsigned long long st_nn = 0, st_w = 0, st_sync = 0, st_q = 0;
@@ -493,9 +607,9 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
             if (closest >= 0 && tab_ok) {
                 const int c = closest;
                 const int hi = ll_ring_hi(rc, V.nearby), lo = ll_ring_lo(rc, V.nearby);
-                const int jhi = (hi + 1 > LL_TAB) ? M : tab[max(hi + 1, 0)];                   /* first j with ring > hi */
+                const int jhi = (hi + 1 > LL_TAB) ? PEND : tab[max(hi + 1, 0)];                /* first j with ring > hi */
                 const int jlo = (lo - 1 < 0) ? -1 : tab[LL_TAB + 1 + min(lo - 1, LL_TAB)];     /* last j with ring < lo */
-                const int c1 = c + 1, mc = M + c - 1;
+                const int c1 = c + 1, mc = PEND + c - 1;                                       /* c, j, jlo, jhi: PLACES in the target cloud (their order is the index order) */
                 const unsigned long long wnone = (unsigned long long)__float_as_uint(dmax) << 32;           /* (dmax, 0): strict d < dmax as above (:512, :520, :677 ...) */
                 unsigned long long k2 = wnone, k3 = wnone;
                 auto w_scan = [&](int st, int en) {
@@ -529,10 +643,71 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
                     };
                 auto w_bound = [&]() { const unsigned h2 = (unsigned)(k2 >> 32), h3 = (unsigned)(k3 >> 32); return __uint_as_float(PLANE ? max(h2, h3) : h2); };
                 auto w_sync = [&]() { k2 = ll_min8_u64(k2); if (PLANE) k3 = ll_min8_u64(k3); if (sub == 0) LL_STAT(st_sync); };
+                auto index_of = [&](unsigned long long k) { const int ord = (int)(unsigned)k; return (k == wnone) ? -1 : (ord < PEND ? c1 + ord : mc - ord); };   /* up: ord = j - c1 < PEND, down: ord = mc - j >= PEND */
+                if (MONO) {
+                    /* The ring values never decrease along the target (every cloud the extract stage makes; k_build_grid checked it):
+                     * j beyond c has ring >= rc and j before c ring <= rc, so "the walk's own ring" is rj == rc whatever the direction,
+                     * "another ring" is rj != rc, and the place window (jlo, jhi) is the ring window lo <= rj <= hi.  The candidate's
+                     * direction and visiting order are then needed only to break a tie between EQUAL distances: the loop keeps a 32-bit
+                     * key (the distance bits) and the place beside it, and the order is computed where two equal distances meet and
+                     * where the eight lanes share their best. */
+                    const unsigned dnone = __float_as_uint(dmax);
+                    unsigned d2 = dnone, d3 = dnone; int j2 = -1, j3 = -1;            /* (dmax, none): only d < dmax undercuts it */
+                    const unsigned wc = ((unsigned)c << 8) | (unsigned)rc;            /* the closest point's own packed word */
+                    const unsigned wspan = (unsigned)(hi - lo);
+                    auto ord_of = [&](int j) -> unsigned { return j < 0 ? 0u : (unsigned)(j > c ? j - c1 : mc - j); };   /* "none" goes first: nothing ties it away */
+                    auto m_scan = [&](int st, int en) {
+                        for (int k0 = st + sub; k0 < en; k0 += 8 * LL_SCAN_UN) {
+                          float4 pp[LL_SCAN_UN];
+#pragma unroll
+                          for (int u = 0; u < LL_SCAN_UN; ++u) if (k0 + 8 * u < en) pp[u] = gpts[k0 + 8 * u];
+#pragma unroll
+                          for (int u = 0; u < LL_SCAN_UN; ++u) {
+                            if (k0 + 8 * u >= en) break;
+                            const float4 p = pp[u];
+                            LL_STAT(st_w);
+                            const unsigned w = (unsigned)__float_as_int(p.w);
+                            const unsigned rj = w & 0xFFu;
+                            const bool in = (rj - (unsigned)lo) <= wspan && w != wc;
+                            const unsigned d = __float_as_uint(ll_walk_d2(p, q.x, q.y, q.z));
+                            const bool same = rj == (unsigned)rc;
+                            const int j = (int)(w >> 8);
+                            if (PLANE) {
+                                const bool ma = in && same, mb = in && !same;
+                                bool ta = ma && d < d2, tb = mb && d < d3;
+                                if ((ma && d == d2) || (mb && d == d3)) {             /* equal distances: the walk's order decides (rare) */
+                                    if (ma && d == d2 && ord_of(j) < ord_of(j2)) ta = true;
+                                    if (mb && d == d3 && ord_of(j) < ord_of(j3)) tb = true;
+                                }
+                                d2 = ta ? d : d2; j2 = ta ? j : j2;
+                                d3 = tb ? d : d3; j3 = tb ? j : j3;
+                            } else {
+                                const bool ma = in && !same;
+                                bool ta = ma && d < d2;
+                                if (ma && d == d2 && ord_of(j) < ord_of(j2)) ta = true;
+                                d2 = ta ? d : d2; j2 = ta ? j : j2;
+                            }
+                          }
+                        }
+                    };
+                    auto m_bound = [&]() { return __uint_as_float(PLANE ? max(d2, d3) : d2); };
+                    auto m_sync = [&]() {                                            /* the group's best = the lexicographic minimum of (distance, order) */
+                        unsigned long long k = ll_min8_u64(((unsigned long long)d2 << 32) | ord_of(j2));
+                        d2 = (unsigned)(k >> 32); j2 = index_of(k == ((unsigned long long)dnone << 32) ? wnone : k);
+                        if (PLANE) {
+                            k = ll_min8_u64(((unsigned long long)d3 << 32) | ord_of(j3));
+                            d3 = (unsigned)(k >> 32); j3 = index_of(k == ((unsigned long long)dnone << 32) ? wnone : k);
+                        }
+                        if (sub == 0) LL_STAT(st_sync);
+                    };
+                    scan_near(m_scan, m_bound, m_sync);
+                    ll_grid_search(gstart, q.x, q.y, rmax, cellb, sub, 2, m_scan, m_bound, m_sync);
+                    res_b = j2; res_c = PLANE ? j3 : -1;
+                } else {
                 scan_near(w_scan, w_bound, w_sync);
                 ll_grid_search(gstart, q.x, q.y, rmax, cellb, sub, 2, w_scan, w_bound, w_sync);
-                auto index_of = [&](unsigned long long k) { const int ord = (int)(unsigned)k; return (k == wnone) ? -1 : (ord < M ? c1 + ord : mc - ord); };   /* up: ord = j - c1 < M, down: ord = mc - j >= M */
                 res_b = index_of(k2); res_c = PLANE ? index_of(k3) : -1;
+                }
             }
         }
         if (sub == 0) { nn[ql] = closest; rb[ql] = res_b; rcl[ql] = res_c; }
@@ -545,19 +720,31 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
     const int closest = have ? nn[tid] : -1;
     int res_b = rb[tid], res_c = rcl[tid];
 
-    if (!tab_ok) {
-        /* fallback: the reference's sequential walks, one query at a time per wave */
+    if (!MONO && !tab_ok) {
+        /* fallback: the reference's sequential walks, one query at a time per wave.  They run over INDICES; a ring-strided target
+         * (an extracted slot -- whose tables can only fail on degenerate intensities) is addressed through its prefix table:
+         * place -> index by a division, index -> place by a search.  Rare by construction, exact always. */
+        const int *tpre = T.pre; const int tstride = T.stride, RR = V.R;
+        auto to_index = [&](int place) -> int { if (!tpre) return place; const int q = place / tstride; return tpre[q] + (place - q * tstride); };
+        auto to_place = [&](int idx) -> int {
+            if (!tpre) return idx;
+            int lo = 0, hi = RR;                                       /* the last ring q with pre[q] <= idx that holds a point */
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tpre[mid] <= idx) lo = mid; else hi = mid; }
+            return lo * tstride + (idx - tpre[lo]);
+        };
         res_b = -1; res_c = -1;
         for (int qq = 0; qq < 64; ++qq) {
-            const int c = __shfl(closest, qq);
-            if (c < 0) continue;
+            const int cp = __shfl(closest, qq);
+            if (cp < 0) continue;
+            const int c = to_index(cp);
             const float qx = __shfl(sx, qq), qy = __shfl(sy, qq), qz = __shfl(sz, qq);
-            const int rc = (int)tgt[c].w;
+            const int rc = (int)tgt[cp].w;
             Best b2 = {dmax, INT_MAX, -1}, b3 = {dmax, INT_MAX, -1};
             for (int j0 = c + 1; j0 < M; j0 += 64) {
                 const int j = j0 + lane;
                 const bool in = j < M;
-                const float4 p = in ? tgt[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int jp = in ? to_place(j) : 0;
+                const float4 p = in ? tgt[jp] : make_float4(0.f, 0.f, 0.f, 0.f);
                 const int rj = (int)p.w;
                 const bool stop = in && ((double)rj > (double)rc + V.nearby);
                 const unsigned long long sm = __ballot(stop);
@@ -565,15 +752,16 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
                 if (ok) {
                     const float d = ll_walk_d2(p, qx, qy, qz);
                     const int ord = j - c - 1;
-                    if (PLANE) { if (rj <= rc) ll_best_take(b2, d, ord, j, dmax); else ll_best_take(b3, d, ord, j, dmax); }
-                    else if (rj > rc) ll_best_take(b2, d, ord, j, dmax);
+                    if (PLANE) { if (rj <= rc) ll_best_take(b2, d, ord, jp, dmax); else ll_best_take(b3, d, ord, jp, dmax); }
+                    else if (rj > rc) ll_best_take(b2, d, ord, jp, dmax);
                 }
                 if (sm) break;
             }
             for (int j0 = c - 1; j0 >= 0; j0 -= 64) {
                 const int j = j0 - lane;
                 const bool in = j >= 0;
-                const float4 p = in ? tgt[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int jp = in ? to_place(j) : 0;
+                const float4 p = in ? tgt[jp] : make_float4(0.f, 0.f, 0.f, 0.f);
                 const int rj = (int)p.w;
                 const bool stop = in && ((double)rj < (double)rc - V.nearby);
                 const unsigned long long sm = __ballot(stop);
@@ -581,8 +769,8 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
                 if (ok) {
                     const float d = ll_walk_d2(p, qx, qy, qz);
                     const int ord = M + (c - 1 - j);
-                    if (PLANE) { if (rj >= rc) ll_best_take(b2, d, ord, j, dmax); else ll_best_take(b3, d, ord, j, dmax); }
-                    else if (rj < rc) ll_best_take(b2, d, ord, j, dmax);
+                    if (PLANE) { if (rj >= rc) ll_best_take(b2, d, ord, jp, dmax); else ll_best_take(b3, d, ord, jp, dmax); }
+                    else if (rj < rc) ll_best_take(b2, d, ord, jp, dmax);
                 }
                 if (sm) break;
             }
@@ -600,7 +788,12 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
 }
 
 /* 2nd launch bound = waves per SIMD.  Left alone the compiler spends 106 SGPRs and lands on 7; asked for 8 it fits in 78
- * with the same 60 VGPRs and no scratch -- the kernel is latency-bound, one more wave per SIMD is worth 17 % (A/B, one box). */
+ * with the same 60 VGPRs and no scratch -- the kernel is latency-bound, one more wave per SIMD is worth 17 % (A/B, one box).
+ * MONO: the instantiation for targets whose ring values never decrease along the cloud (k_build_grid's flag 2: every cloud the extract
+ * stage makes); the general instantiation -- direction and place window per candidate, and the sequential walks as the always-exact
+ * fallback -- is a launch of its own behind it whose workgroups leave at once for such a target.  One kernel holding both paid for the
+ * rarely used one in the hot one: 120 bytes of scratch per lane against 12, twice the code. */
+template <bool MONO>
 __global__ __launch_bounds__(LL_BLOCK, 8) void k_associate(LLView V, int first, int count, int qb_corner, int qb_plane, int qpb)
 {
     /* All query blocks of a scan on ONE XCD (workgroup b runs on XCD b % 8): they search the same target grid, and an XCD's 4 MB L2 is
@@ -610,10 +803,11 @@ __global__ __launch_bounds__(LL_BLOCK, 8) void k_associate(LLView V, int first, 
     const int sl = (jb / per) * 8 + xcd, item = jb % per;
     if (sl >= count) return;
     const int s = first + sl;
+    if (MONO && item == 0 && threadIdx.x == 0) V.assoc_tgt[s] = (s == V.carry_slot) ? -1 : s - 1;   /* whose points this slot's correspondences name from now on */
     __shared__ float4 qs[LL_BLOCK];
     __shared__ int nn[LL_BLOCK], rb[LL_BLOCK], rcl[LL_BLOCK];
     __shared__ int cellb[(LL_BLOCK / 8) * 3 * LL_RING_CELLS];
-    __shared__ int tab[2 * (LL_TAB + 1) + 2];
+    __shared__ int tab[LL_TAB_WORDS];
     __shared__ unsigned char perm[LL_BLOCK];
     __shared__ int hist[64];
     const ScanHdr h = V.hdr[s];
@@ -621,24 +815,25 @@ __global__ __launch_bounds__(LL_BLOCK, 8) void k_associate(LLView V, int first, 
     if (item < qb_corner) {
         const int nq = ok ? h.n_sharp : 0;
         if (item * qpb >= nq) return;
-        ll_associate_block<false>(V, s, item, qpb, V.sharp + (size_t)s * V.cap_sharp, nq, ll_target(V, s, 0),
-                                  V.eq_a + (size_t)s * V.cap_sharp, V.eq_b + (size_t)s * V.cap_sharp, nullptr, qs, nn, rb, rcl, cellb, tab, perm, hist);
+        ll_associate_block<false, MONO>(V, s, item, qpb, V.sharp + (size_t)s * V.cap_sharp, nq, ll_target(V, s, 0),
+                                        V.eq_a + (size_t)s * V.cap_sharp, V.eq_b + (size_t)s * V.cap_sharp, nullptr, qs, nn, rb, rcl, cellb, tab, perm, hist);
     } else {
         const int qb = item - qb_corner;
         const int nq = ok ? h.n_flat : 0;
         if (qb * qpb >= nq) return;
-        ll_associate_block<true>(V, s, qb, qpb, V.flat + (size_t)s * V.cap_flat, nq, ll_target(V, s, 1),
-                                 V.pq_a + (size_t)s * V.cap_flat, V.pq_b + (size_t)s * V.cap_flat,
-                                 V.pq_c + (size_t)s * V.cap_flat, qs, nn, rb, rcl, cellb, tab, perm, hist);
+        ll_associate_block<true, MONO>(V, s, qb, qpb, V.flat + (size_t)s * V.cap_flat, nq, ll_target(V, s, 1),
+                                       V.pq_a + (size_t)s * V.cap_flat, V.pq_b + (size_t)s * V.cap_flat,
+                                       V.pq_c + (size_t)s * V.cap_flat, qs, nn, rb, rcl, cellb, tab, perm, hist);
     }
 }
 
 void ll_launch_build_grid(const LLView &V, int first, int count, int carry, hipStream_t st, LLProfiler *prof)
 {
-    static size_t attr_bytes[LL_MAX_DEVICES] = {0};   /* 68 KiB histogram + static LDS exceeds the default dynamic-LDS limit */
-    ll_ensure_dynamic_lds(k_build_grid, (LL_GRID_NC + LL_GRID_NC / 16) * sizeof(int), attr_bytes);
+    static size_t attr_bytes[LL_MAX_DEVICES] = {0};   /* 68 KiB histogram + the chunk table + static LDS exceed the default dynamic-LDS limit */
+    const size_t lds = ll_grid_lds_bytes(V);
+    ll_ensure_dynamic_lds(k_build_grid, lds, attr_bytes);
     ll_prof_mark(prof, LL_K_GRID, st);
-    hipLaunchKernelGGL(k_build_grid, dim3(2 * (carry ? 1 : count)), dim3(LL_GB), (LL_GRID_NC + LL_GRID_NC / 16) * sizeof(int), st, V, first, carry ? 1 : count, carry);
+    hipLaunchKernelGGL(k_build_grid, dim3(2 * (carry ? 1 : count)), dim3(LL_GB), lds, st, V, first, carry ? 1 : count, carry);
     ll_prof_mark(prof, LL_K_END, st);
 }
 
@@ -653,6 +848,7 @@ void ll_launch_associate(const LLView &V, int first, int count, hipStream_t st, 
 #endif
     const int qbc = (V.cap_sharp + qpb - 1) / qpb, qbp = (V.cap_flat + qpb - 1) / qpb;
     ll_prof_mark(prof, LL_K_ASSOCIATE, st);
-    hipLaunchKernelGGL(k_associate, dim3(8 * (qbc + qbp) * ((count + 7) / 8)), dim3(LL_BLOCK), 0, st, V, first, count, qbc, qbp, qpb);
+    hipLaunchKernelGGL(k_associate<true>, dim3(8 * (qbc + qbp) * ((count + 7) / 8)), dim3(LL_BLOCK), 0, st, V, first, count, qbc, qbp, qpb);
+    hipLaunchKernelGGL(k_associate<false>, dim3(8 * (qbc + qbp) * ((count + 7) / 8)), dim3(LL_BLOCK), 0, st, V, first, count, qbc, qbp, qpb);   /* arbitrary targets only: leaves at once otherwise */
     ll_prof_mark(prof, LL_K_END, st);
 }

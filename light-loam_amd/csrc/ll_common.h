@@ -7,10 +7,19 @@
  *   ring_off   int    [B][R+1]     ring r is laserCloud[ring_off[r], ring_off[r+1]) (labels, curvature, C ABI)
  *   cloud      float4 [B][R][ring_cap]  laserCloud (x, y, z, intensity), every ring at a fixed stride (ring_cap = max_ring_points)
  *   label      int8   [B][NP]      cloudLabel   curv float [B][NP] (optional)
- *   ring_pub   u64 [B][R]          look-back words: the ring kernel writes its features straight at their final offsets in
- *   sharp / less_sharp / flat / less_flat float4 [B][cap] in the reference's publication order.
+ *   ring_rec, ring_cnt             k_ring_pick's lists per ring (local indices) and its three counts
+ *   sharp / less_sharp / flat      float4 [B][R*12 / R*120 / R*24], contiguous, in the reference's publication order (ring, segment, pick)
  *   carry_*    target clouds for the first slot of a batch (previous batch's last scan).
  *   corr / vote / neq / pose arrays for the odometry stages.
+ *
+ * Feature cloud layout -- the less-flat cloud (the only one whose per-ring size is decided by the kernel that writes it):
+ *   lflat      float4 [B][LFS >= R * ring_cap]   ring r's VoxelGrid centroids in its own row, ring_nlf[B][R] of them: no ring waits for another.
+ *   A point's PLACE is its float4 offset inside the slot (ring * ring_cap + k); its INDEX in the reference's contiguous cloud is
+ *   lf_pre[ring] + k, lf_pre[B][R+1] = the exclusive prefix of ring_nlf (k_build_grid writes it with hdr.n_less_flat).  Both orders
+ *   agree (ring-major), so everything that only compares -- ties towards the lower index, the ring-window bounds, the visiting order of
+ *   the second / third point -- runs on places; the C ABI converts places to indices where correspondences leave the library
+ *   (place -> index is a division, index -> place a search: the hot path never needs the latter).  A slot filled by
+ *   ll_upload_features, and the carry, hold the caller's contiguous cloud: hdr.lf_strided = 0, place = index.
  */
 #pragma once
 #include <hip/hip_runtime.h>
@@ -25,7 +34,6 @@
 #define LL_LSHARP_PER_SEG 20
 #define LL_FLAT_PER_SEG 4
 #define LL_SEGS 6
-#define LL_STAGE_SF (LL_SEGS * (LL_SHARP_PER_SEG + LL_FLAT_PER_SEG))      /* staged sharp + flat points per ring */
 /* what k_ring_pick (ll_pick.hip) hands to k_ring_features (ll_features.hip), per ring: the picked points' local indices --
  * sharp [0, 12), less-sharp [12, 132), flat [132, 156), entry = segment * per-segment capacity + pick order -- and the per-segment
  * counts (n_sharp, n_less_sharp, n_flat) x 6 at [156, 174) */
@@ -39,12 +47,29 @@
 #define LL_GRID_CELL 1.0f
 #define LL_GRID_ORG 64.0f
 #define LL_GRID_NC (LL_GRID_G * LL_GRID_G)
-/* ring tables stored behind the cell starts: first_ge[LL_TAB+1], last_le[LL_TAB+1], ok flag, cloud size */
+/* ring tables stored behind the cell starts: first_ge[LL_TAB+1], last_le[LL_TAB+1] (places), flags (1: the tables bound the walks,
+ * 2: the ring values never decrease along the cloud), cloud size, one past the last place */
 #define LL_TAB 160
-#define LL_GSTRIDE (LL_GRID_NC + 1 + 2 * (LL_TAB + 1) + 2)
+#define LL_TAB_WORDS (2 * (LL_TAB + 1) + 3)
+#define LL_GSTRIDE (LL_GRID_NC + 1 + LL_TAB_WORDS)
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
+#endif
+
+#ifdef __HIPCC__
+__device__ __forceinline__ int ll_cell_coord(float v)
+{
+    const int c = (int)floorf((v + LL_GRID_ORG) * (1.0f / LL_GRID_CELL));
+    return min(max(c, 0), LL_GRID_G - 1);
+}
+/* what k_build_grid's histogram sweep needs of a target point: its cell (14 bits) and the walk's scan id int(intensity)
+ * (laserOdometry.cpp:500, :664) as a byte, 0xFF when it lies outside the ring tables' range [0, LL_TAB) */
+__device__ __forceinline__ unsigned ll_grid_key(const float4 p)
+{
+    const int c = ll_cell_coord(p.y) * LL_GRID_G + ll_cell_coord(p.x), r = (int)p.w;
+    return (unsigned)c | ((r < 0 || r >= LL_TAB) ? 0xFFu : (unsigned)r) << 16;
+}
 #endif
 
 struct ScanHdr {
@@ -56,6 +81,7 @@ struct ScanHdr {
     int max_ring;
     int n_sharp, n_less_sharp, n_flat, n_less_flat;
     float so_lo_up, so_hi_dn;      /* ll_f32_ceil(startOri - pi/2), ll_f32_floor(startOri + 3pi/2): the wrap tests of :181-188 in f32 */
+    int lf_strided;                /* 1: the slot's less-flat cloud is ring-strided (an extracted scan); 0: contiguous (ll_upload_features) */
 };
 
 struct PairHdr {
@@ -88,14 +114,13 @@ struct LLView {
     float4 *cloud; int ring_cap, CS;   /* laserCloud, ring r of slot s at cloud[s * CS + r * ring_cap]; CS = R * ring_cap */
     int8_t *label; float *curv;
     /* features */
-    unsigned long long *ring_pub;  /* [B][R] look-back word of every ring: launch tag << 40 | its four feature counts */
-    float4 *stage_sf;              /* [B][R][LL_STAGE_SF] staged sharp + flat lists of the rings longer than 2304 points (max_ring_points > 2304 only) */
-    int epoch;                     /* the tag of the current k_ring_features launch (1 .. 2^24 - 2) */
-    int ring_split;                /* 1: k_ring_pick + k_ring_features<split> (two launches); 0: the fused kernel of rounds 1-3 (A/B reference) */
     unsigned short *ring_rec;      /* [B][R][LL_REC_U16] k_ring_pick's lists of one ring */
-    unsigned *ring_cnt;            /* [B][R] n_sharp | n_less_sharp << 8 | n_flat << 16 | 1 << 31 (the ring has segments) */
-    float *ring_box;               /* [B][R][8] min x, y, z, max x, y, z of the ring's segment points */
-    float4 *sharp, *lsharp, *flat, *lflat;
+    unsigned *ring_cnt;            /* [B][R] n_sharp | n_less_sharp << 8 | n_flat << 16 | 1 << 31 (the ring has segments): k_ring_pick -> k_ring_features, k_build_grid */
+    int *ring_nlf;                 /* [B][R] less-flat points of the ring (k_ring_features) */
+    int *tier_cnt; int *tier_list; /* max_ring_points > 2304 only: [4] and [3][B * R] -- the rings longer than 2304 / 3072 / 4608 points of the extract call in
+                                    * flight as slot << 8 | ring, per capacity tier 1..3 (the organise stage appends, the tier launches of the ring kernels read) */
+    int *lf_pre;                   /* [B][R+1] exclusive prefix of ring_nlf = the contiguous index of every ring's first less-flat point (k_build_grid) */
+    float4 *sharp, *lsharp, *flat, *lflat; int LFS;   /* lflat of slot s at lflat + s * LFS, LFS = max(CS, NP): ring-strided rows or a contiguous upload */
     /* targets */
     float4 *carry_corner, *carry_surf; int *carry_cnt;    /* carry_cnt[2] */
     /* NN grids of every slot's less-sharp (0) / less-flat (1) cloud and of the carry: cell starts + cell-ordered (x,y,z,index) */
@@ -112,7 +137,10 @@ struct LLView {
     double *pose_guess;            /* [B][7] para_q/para_t at entry of the hot path (laserOdometry.cpp:61-62) */
     double *neq;                   /* [B][44]: H[36] row-major, g[6], cost, rows */
     double *lm;                    /* [B][LL_LM_STRIDE] Levenberg-Marquardt state of the slot's current solve */
-    int carry_slot;                /* the slot whose target is the carry (first slot of the batch) */
+    int carry_slot;                /* the slot whose target is the carry (first slot of the batch) in the association call being enqueued */
+    int *assoc_tgt;                /* [B] the target ll_associate_batch searched for the slot: -1 the carry, >= 0 that slot, < -1 never associated.
+                                    * Vote, factors and the solves read the target from here: a later call over a sub-range cannot disagree
+                                    * with the association about whose points the correspondences name */
     unsigned long long *dbg;       /* [16] phase-timing counters (only written by -DLL_PHASE_TIMING builds) */
 };
 
@@ -227,15 +255,23 @@ __device__ __forceinline__ int ll_block_exscan_n(int v, int *sc, int &total)
 }
 __device__ __forceinline__ int ll_block_exscan(int v, int *sc, int &total) { return ll_block_exscan_n<LL_BLOCK / 64>(v, sc, total); }
 
-/* target clouds of slot s: features of slot s-1, or the carry for the batch's first slot */
+/* the target the slot's correspondences refer to: -1 = the carry, else a slot (its features).  Fixed by the association (assoc_tgt);
+ * before any association: the rule of the call being enqueued (first slot of the range -> carry, else the slot before) */
+__device__ __forceinline__ int ll_target_slot(const LLView &V, int s)
+{
+    const int t0 = V.assoc_tgt[s];
+    if (t0 < -1) return (s == V.carry_slot) ? -1 : s - 1;
+    return t0;
+}
+/* target clouds of slot s.  surf is addressed by PLACE (ll_common.h): ring-strided rows of an extracted slot, or contiguous */
 __device__ __forceinline__ void ll_targets(const LLView &V, int s, const float4 *&corner, int &mc, const float4 *&surf, int &ms)
 {
-    if (s == V.carry_slot) {
+    const int t = ll_target_slot(V, s);
+    if (t < 0) {
         corner = V.carry_corner; mc = V.carry_cnt[0]; surf = V.carry_surf; ms = V.carry_cnt[1];
     } else {
-        const int t = s - 1;
         corner = V.lsharp + (size_t)t * V.cap_lsharp; mc = V.hdr[t].n_less_sharp;
-        surf = V.lflat + (size_t)t * V.NP; ms = V.hdr[t].n_less_flat;
+        surf = V.lflat + (size_t)t * V.LFS; ms = V.hdr[t].n_less_flat;
         if (V.hdr[t].status != 0) { mc = 0; ms = 0; }
     }
 }
@@ -321,6 +357,7 @@ void ll_prof_mark(LLProfiler *p, int kernel_id, hipStream_t st);
 /* launchers implemented in the per-stage .hip files */
 void ll_launch_organize(const LLView &V, int first, int count, hipStream_t st, LLProfiler *prof);
 void ll_launch_cloud_flatten(const LLView &V, int slot, float4 *dst, hipStream_t st);
+void ll_launch_lflat_flatten(const LLView &V, int slot, float4 *dst, hipStream_t st);   /* the slot's less-flat cloud, contiguous (dst: >= NP points) */
 void ll_launch_features(const LLView &V, int first, int count, size_t lds_bytes, hipStream_t st, LLProfiler *prof);
 void ll_launch_pick(const LLView &V, int first, int count, hipStream_t st);
 void ll_launch_associate(const LLView &V, int first, int count, hipStream_t st, LLProfiler *prof);
@@ -331,5 +368,4 @@ void ll_launch_normal_equations(const LLView &V, int first, int count, int do_st
 void ll_launch_gn_step(const LLView &V, int first, int count, hipStream_t st, LLProfiler *prof);
 void ll_launch_rows(const LLView &V, int slot, const double *pose7_dev, double *r, double *Jq, double *Jt, hipStream_t st);
 size_t ll_features_lds_bytes(int max_ring);
-size_t ll_features_lds_bytes(int max_ring, int split);
 void ll_launch_debug_exact_math(const LLView &V, int op, const float *a, const float *b, const float *c, int n, float *out, hipStream_t st);

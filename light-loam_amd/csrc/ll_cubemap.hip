@@ -338,8 +338,12 @@ extern "C" int ll_cubemap_process_slot(ll_cubemap *cm, double *pose_w7, int slot
     CM_HIP(hipStreamSynchronize(ctx->stream));
     if (h.status != 0) { cm->err = "the slot holds no extracted scan"; return LL_ERR_STATE; }
     const LLView &V = ctx->V;
+    /* the less-flat cloud of an extracted slot lies in ring rows (ll_common.h): closed up on the device into the context's staging
+     * array, stream-ordered with everything below */
+    const float4 *surf_last = V.lflat + (size_t)slot * V.LFS;
+    if (h.lf_strided) { ll_launch_lflat_flatten(V, slot, ctx->cloud_flat, ctx->stream); surf_last = ctx->cloud_flat; }
     int rc = cm_prepare(cm, pose_w7 + 4, (const ll_point *)(V.lsharp + (size_t)slot * V.cap_lsharp), h.n_less_sharp,
-                        (const ll_point *)(V.lflat + (size_t)slot * V.NP), h.n_less_flat, true);
+                        (const ll_point *)surf_last, h.n_less_flat, true);
     if (rc) return rc;
     rc = ll_cubemap_optimize(cm, pose_w7, 2, nullptr, ran); if (rc) return rc;
     return ll_cubemap_update(cm, pose_w7);

@@ -47,10 +47,6 @@ struct ll_ctx {
 };
 
 
-/* 24-bit tag of the next k_ring_features launch in this context's look-back words (ring_pub), never 0: consecutive
- * launches on the same words must differ; per context, so contexts on different host threads do not share state */
-static inline void ll_next_epoch(ll_ctx *ctx) { ctx->V.epoch = ctx->V.epoch % 0xFFFFFE + 1; }
-
 #define LL_HIP(call)                                                                         \
     do {                                                                                     \
         hipError_t e_ = (call);                                                              \

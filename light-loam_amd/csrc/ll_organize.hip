@@ -46,6 +46,16 @@ __device__ __forceinline__ int ll_scan_id(const int *thr, const int *lut, int nb
     return (id > R - 1 || id < 0) ? -1 : id;
 }
 
+/* a ring longer than the common capacity goes on the work list of its tier (ll_launch_pick / ll_launch_features: 2304 < n <= 3072,
+ * <= 4608, beyond): the order of the entries is whatever the atomics make it -- no ring's result depends on another's */
+__device__ __forceinline__ void ll_tier_append(const LLView &V, int s, int r, int n)
+{
+    if (n <= 2304 || !V.tier_list) return;
+    const int t = n <= 3072 ? 1 : n <= 4608 ? 2 : 3;
+    const int pos = atomicAdd(&V.tier_cnt[t], 1);
+    V.tier_list[(size_t)(t - 1) * V.B * V.R + pos] = (s << 8) | r;
+}
+
 /* One workgroup per scan walks its input in order, tile after tile (LL_TILE points: lanes hold consecutive indices, so the
  * first / last set lane of a ballot is the smallest / largest index):
  *   search   the first and the last point that survive the filters (:109, :72) -> startOri, endOri (:114-126); nothing
@@ -103,6 +113,7 @@ __global__ __launch_bounds__(LL_BLOCK, LL_OWAVES) void k_organize(LLView V, int 
     ScanHdr h;
     h.start_ori = 0.0f; h.end_ori = 0.0f; h.first_kept = fk; h.last_kept = -1; h.half_idx = INT_MAX; h.n = 0; h.status = 0; h.max_ring = 0;
     h.n_sharp = h.n_less_sharp = h.n_flat = h.n_less_flat = 0; h.so_lo_up = 0.0f; h.so_hi_dn = 0.0f;
+    h.lf_strided = 1;                                                                 /* an extracted scan: ring-strided less-flat cloud (ll_common.h) */
     int *ring_off = V.ring_off + (size_t)s * (V.R + 1);
     if (fk == INT_MAX) {                                                              /* nothing survives: LL_ERR_EMPTY */
         if (tid <= V.R) ring_off[tid] = 0;
@@ -235,6 +246,7 @@ __global__ __launch_bounds__(LL_BLOCK, LL_OWAVES) void k_organize(LLView V, int 
         int run = 0, mx = 0;
         for (int r = 0; r < V.R; ++r) { const int c = ringtot[r]; ring_off[r] = run; run += c; mx = max(mx, c); }
         ring_off[V.R] = run;
+        if (mx > 2304 && mx <= V.max_ring) for (int r = 0; r < V.R; ++r) ll_tier_append(V, s, r, ringtot[r]);
         h.start_ori = start_ori; h.end_ori = end_ori; h.so_lo_up = so_lo_up; h.so_hi_dn = so_hi_dn;
         h.last_kept = lk; h.half_idx = half; h.n = run; h.max_ring = mx;
         if (mx > V.max_ring) h.status = -4;                                            /* LL_ERR_CAPACITY: the ring's tail was not stored */
@@ -407,10 +419,11 @@ __global__ __launch_bounds__(LL_BLOCK) void k_offsets(LLView V, int first, int c
         int run = 0, mx = 0;
         for (int r = 0; r < V.R; ++r) { ring_off[r] = run; run += ring_cnt[r]; mx = max(mx, ring_cnt[r]); }
         ring_off[V.R] = run;
+        if (mx > 2304 && mx <= V.max_ring && n_in > 0 && sh_lk >= 0) for (int r = 0; r < V.R; ++r) ll_tier_append(V, s, r, ring_cnt[r]);
         ScanHdr h = V.hdr[s];
         h.n = run; h.max_ring = mx; h.half_idx = sh_first_p; h.last_kept = sh_lk;
         h.n_sharp = h.n_less_sharp = h.n_flat = h.n_less_flat = 0;
-        h.status = 0;
+        h.status = 0; h.lf_strided = 1;
         if (n_in <= 0 || sh_lk < 0) { h.status = -5; h.n = 0; }                    /* LL_ERR_EMPTY */
         else {
             /* endOri (:115-126): -atan2f(last kept) + 2*pi in f64, stored f32, then the 3*pi / pi adjustment */
@@ -515,6 +528,27 @@ void ll_launch_cloud_flatten(const LLView &V, int slot, float4 *dst, hipStream_t
     hipLaunchKernelGGL(k_cloud_flatten, dim3(V.R), dim3(LL_BLOCK), 0, st, V, slot, dst);
 }
 
+/* the less-flat cloud as the reference publishes it -- ring after ring without gaps -- for the C ABI (ll_download_features) and the
+ * mapping stage (ll_cubemap_process_slot): the rows of an extracted slot closed up through lf_pre; an uploaded slot is contiguous already */
+__global__ __launch_bounds__(LL_BLOCK) void k_lflat_flatten(LLView V, int slot, float4 *dst)
+{
+    const int r = blockIdx.x;
+    const float4 *lf = V.lflat + (size_t)slot * V.LFS;
+    if (!V.hdr[slot].lf_strided) {
+        const int n = V.hdr[slot].n_less_flat;
+        for (int i = blockIdx.x * LL_BLOCK + threadIdx.x; i < n; i += gridDim.x * LL_BLOCK) dst[i] = lf[i];
+        return;
+    }
+    const int *pre = V.lf_pre + (size_t)slot * (V.R + 1);
+    const int o = pre[r], n = pre[r + 1] - o;
+    for (int i = threadIdx.x; i < n; i += LL_BLOCK) dst[o + i] = lf[(size_t)r * V.ring_cap + i];
+}
+
+void ll_launch_lflat_flatten(const LLView &V, int slot, float4 *dst, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_lflat_flatten, dim3(V.R), dim3(LL_BLOCK), 0, st, V, slot, dst);
+}
+
 /* ll_debug_exact_math: the device arithmetic of a1 on caller-supplied operands (see include/lightloam_hip.h) */
 __global__ __launch_bounds__(LL_BLOCK) void k_debug_exact_math(LLView V, int op, const float *a, const float *b, const float *c, int n, float *out)
 {
@@ -558,6 +592,7 @@ void ll_launch_debug_exact_math(const LLView &V, int op, const float *a, const f
 
 void ll_launch_organize(const LLView &V, int first, int count, hipStream_t st, LLProfiler *prof)
 {
+    if (V.tier_list) (void)hipMemsetAsync(V.tier_cnt, 0, 4 * sizeof(int), st);       /* the work lists of this extract call's long rings start empty */
     if (count > V.org_small) {
         ll_prof_mark(prof, LL_K_ORGANIZE, st);
         if (V.lut_nb > 0) hipLaunchKernelGGL(k_organize<true>, dim3(count), dim3(LL_BLOCK), 0, st, V, first, count);

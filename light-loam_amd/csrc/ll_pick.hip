@@ -74,30 +74,18 @@ __device__ __forceinline__ unsigned ll_pk_wave_max_u32(unsigned v)
 
 __device__ __forceinline__ bool ll_pk_bit(const unsigned *bm, int i) { return (bm[i >> 5] >> (i & 31)) & 1u; }
 
-/* ring_lo < ring length <= ring_hi: the rings this launch works on (ring_hi <= 384 SR + 6 keeps a segment within SR rows) */
+/* the ring r of slot s, if ring_lo < its length <= ring_hi (ring_hi <= 384 SR + 6 keeps a segment within SR rows): one wave */
 template <int SR>
-__device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, int count, int ring_lo, int ring_hi)
+__device__ __forceinline__ void ll_ring_pick_ring(const LLView &V, int s, int r, int ring_lo, int ring_hi, PickLds<SR> &L)
 {
     static_assert(SR <= 32, "row bitmasks are 32 bits wide");
     static_assert(2 * (SR + 2) + 2 <= 64, "the segment's gap words (L.gw) are cleared by one lane each");
-    __shared__ __attribute__((aligned(16))) PickLds<SR> lds_all[LL_PK_WAVES];
-    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
-    const int groups = (V.R + LL_PK_WAVES - 1) / LL_PK_WAVES;
-    int sl, grp;
-    {   /* block -> (scan, ring group): the rings of a scan on one XCD (its second kernel reads their lists from that L2) */
-        const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
-        sl = (jj / groups) * 8 + xcd; grp = jj % groups;
-        if (sl >= count) return;
-    }
-    const int r = grp * LL_PK_WAVES + wave;
-    if (r >= V.R) return;
-    const int s = first + sl;
+    const int lane = (int)threadIdx.x & 63;
     const ScanHdr h = V.hdr[s];
     const int off = V.ring_off[(size_t)s * (V.R + 1) + r];
     const int nr = V.ring_off[(size_t)s * (V.R + 1) + r + 1] - off;
     if (h.status != 0) return;
     if (nr <= ring_lo || nr > ring_hi) return;                        /* another tier's ring */
-    PickLds<SR> &L = lds_all[wave];
     unsigned short *rec_g = V.ring_rec + ((size_t)s * V.R + r) * LL_REC_U16;
     unsigned *rcnt = V.ring_cnt + (size_t)s * V.R + r;
     int8_t *label = V.label + (size_t)s * V.NP + off;
@@ -498,10 +486,42 @@ __device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, in
     if (lane == 0) *rcnt = segc | 0x80000000u;                        /* the ring's counts */
 }
 
+/* The launch of the common capacity (rings of at most 2304 points): one workgroup per (scan, ring group).  The tiers of longer rings
+ * (max_ring_points > 2304: a real HDL-64E under the linear 64-ring model) run over the WORK LIST k_organize filled for them
+ * (tier_list: slot << 8 | ring, tier_cnt entries): a fixed grid of waves takes entries in turn, so that a launch costs what its rings
+ * cost and not 64 x count workgroups that fetch a header and two offsets to find out they are not wanted. */
+template <int SR>
+__device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, int count, int ring_lo, int ring_hi, const int *list, const int *list_n)
+{
+    __shared__ __attribute__((aligned(16))) PickLds<SR> lds_all[LL_PK_WAVES];
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    if constexpr (SR > 6) {                                           /* a tier: always over its list (one body per kernel) */
+        const int n = *list_n;
+        for (int i = blockIdx.x * LL_PK_WAVES + wave; i < n; i += gridDim.x * LL_PK_WAVES) {
+            const int e = list[i];
+            ll_ring_pick_ring<SR>(V, e >> 8, e & 0xFF, ring_lo, ring_hi, lds_all[wave]);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   /* the next ring starts on a quiet tile */
+        }
+        return;
+    } else {
+    const int groups = (V.R + LL_PK_WAVES - 1) / LL_PK_WAVES;
+    int sl, grp;
+    {   /* block -> (scan, ring group): the rings of a scan on one XCD (its second kernel reads their lists from that L2) */
+        const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+        sl = (jj / groups) * 8 + xcd; grp = jj % groups;
+        if (sl >= count) return;
+    }
+    const int r = grp * LL_PK_WAVES + wave;
+    if (r >= V.R) return;
+    ll_ring_pick_ring<SR>(V, first + sl, r, ring_lo, ring_hi, lds_all[wave]);
+    }
+}
+
 /* one kernel per row count: the register cap is a property of the kernel (8 / 6 / 4 / 2 waves per SIMD) */
 #define LL_PICK_KERNEL(SR, WAVES, NVGPR)                                                                              \
     __global__ __launch_bounds__(64 * LL_PK_WAVES, WAVES) __attribute__((amdgpu_num_vgpr(NVGPR)))                      \
-    void k_ring_pick##SR(LLView V, int first, int count, int ring_lo, int ring_hi) { ll_ring_pick_body<SR>(V, first, count, ring_lo, ring_hi); }
+    void k_ring_pick##SR(LLView V, int first, int count, int ring_lo, int ring_hi, const int *list, const int *list_n)   \
+    { ll_ring_pick_body<SR>(V, first, count, ring_lo, ring_hi, list, list_n); }
 #if defined(LL_PK_W6_WAVES)
 LL_PICK_KERNEL(6, LL_PK_W6_WAVES, LL_PK_W6_VGPRS)
 LL_PICK_KERNEL(8, 6, 80)
@@ -520,19 +540,25 @@ LL_PICK_KERNEL(22, 2, 256)
 #endif
 
 template <typename K>
-static void ll_launch_ring_pick(K kernel, const LLView &V, int first, int count, int ring_lo, int ring_hi, hipStream_t st)
+static void ll_launch_ring_pick(K kernel, const LLView &V, int first, int count, int ring_lo, int ring_hi, int tier, int waves_per_simd, hipStream_t st)
 {
     const int groups = (V.R + LL_PK_WAVES - 1) / LL_PK_WAVES;
-    const int grid = 8 * groups * ((count + 7) / 8);
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * LL_PK_WAVES), 0, st, V, first, count, ring_lo, ring_hi);
+    int grid = 8 * groups * ((count + 7) / 8);
+    const int *list = nullptr, *list_n = nullptr;
+    if (tier > 0) {                                                   /* a tier of long rings: resident waves over the work list */
+        list = V.tier_list + (size_t)(tier - 1) * V.B * V.R; list_n = V.tier_cnt + tier;
+        const int resident = 256 * 4 * waves_per_simd / LL_PK_WAVES;
+        if (grid > resident) grid = resident;
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * LL_PK_WAVES), 0, st, V, first, count, ring_lo, ring_hi, list, list_n);
 }
 
 /* the tiers of ll_launch_features: rings of at most 2304 points in the six-row instantiation at eight waves per SIMD */
 void ll_launch_pick(const LLView &V, int first, int count, hipStream_t st)
 {
     const int cap = (V.max_ring + 255) / 256 * 256;
-    if (cap > 4608) ll_launch_ring_pick(k_ring_pick22, V, first, count, 4608, cap, st);
-    if (cap > 3072) ll_launch_ring_pick(k_ring_pick12, V, first, count, 3072, cap < 4608 ? cap : 4608, st);
-    if (cap > 2304) ll_launch_ring_pick(k_ring_pick8, V, first, count, 2304, cap < 3072 ? cap : 3072, st);
-    ll_launch_ring_pick(k_ring_pick6, V, first, count, INT_MIN, cap < 2304 ? cap : 2304, st);
+    if (cap > 4608) ll_launch_ring_pick(k_ring_pick22, V, first, count, 4608, cap, 3, 2, st);
+    if (cap > 3072) ll_launch_ring_pick(k_ring_pick12, V, first, count, 3072, cap < 4608 ? cap : 4608, 2, 4, st);
+    if (cap > 2304) ll_launch_ring_pick(k_ring_pick8, V, first, count, 2304, cap < 3072 ? cap : 3072, 1, 6, st);
+    ll_launch_ring_pick(k_ring_pick6, V, first, count, INT_MIN, cap < 2304 ? cap : 2304, 0, 8, st);
 }

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(LL_VT) void k_vote(LLView V, int first, int count, 
     if (my_sel) atomicAdd(&nsel_sh, my_sel);
     __syncthreads();
     if (tid == 0) {
-        PairHdr p; p.n_edge = n_e; p.n_plane = n_p; p.n_plane_sel = nsel_sh; p.target_slot = (s == V.carry_slot) ? -1 : s - 1;
+        PairHdr p; p.n_edge = n_e; p.n_plane = n_p; p.n_plane_sel = nsel_sh; p.target_slot = ll_target_slot(V, s);
         V.pair[s] = p;
     }
 }

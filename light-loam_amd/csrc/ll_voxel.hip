@@ -151,7 +151,7 @@ __global__ void k_vx_params(const int *bbox, const int *seg_off, int nseg, float
             min_b[c] = (int)floorf(mn * inv);
             div_b[c] = (int)floorf(mx * inv) - min_b[c] + 1;
         }
-        /* ... or where PCL's int voxel index would wrap (undefined in the reference): the same exit in oracle/ll_oracle.c and ll_features.hip */
+        /* ... or where PCL's int voxel index would wrap (undefined in the reference): the same exit in ll_features.hip and in the CPU checker under tests */
         o.too_small = d[0] * d[1] * d[2] > (long long)INT_MAX || (long long)div_b[0] * div_b[1] * div_b[2] > 0xffffffffLL;
         o.mul1 = div_b[0]; o.mul2 = div_b[0] * div_b[1];
         for (int c = 0; c < 3; ++c) o.fb[c] = (float)min_b[c];

@@ -119,7 +119,3 @@ def test_bench_uses_a_counter_file_only_on_a_matching_stamp(tmp_path, monkeypatc
         p.write_text(json.dumps(dict(good, **{key: val})))
         got, why = bench.issue_from_profile(args, ["k_ring_pick"], str(p))
         assert got is None and key in why
-    p.write_text(json.dumps(good))
-    monkeypatch.setenv("LIGHTLOAM_RING_SPLIT", "0")                              # the fused kernel's run: the split pipeline's counters do not apply
-    got, why = bench.issue_from_profile(args, ["k_ring_features"], str(p))
-    assert got is None and "fused" in why

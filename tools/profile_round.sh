@@ -32,9 +32,18 @@ python3 tools/sq_summary.py $O/pmc_sq_h > $O/${TAG}_sq_counters_hdl64.txt
 python3 tools/sq_issue.py $O/pmc_sq_h --batch 8192 --rings 64 --workload hdl64 > $O/sq_issue_hdl64.json
 cp $O/pmc_traffic_hdl64.json profiles/pmc_traffic_hdl64.json
 cp $O/sq_issue_hdl64.json profiles/sq_issue_hdl64.json
+# ... and for BASELINE config 5's shape (128 rings, 4096 scans per step): its dominant kernel is k_associate
+BS="python3 bench.py --rings 128 --steps 5 --warmup 1 --no-cpu-baseline --calibrate"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $O/pmc_fetch_s -o fetch -- $BS > $O/pmc_fetch_s.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d $O/pmc_write_s -o write -- $BS > $O/pmc_write_s.log 2>&1
+python3 tools/pmc_traffic.py $O/pmc_fetch_s $O/pmc_write_s --batch 4096 --rings 128 --workload synthetic > $O/pmc_traffic_s128.json
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY \
+    --kernel-trace -f csv -d $O/pmc_sq_s -o sq -- $BS > $O/pmc_sq_s.log 2>&1
+python3 tools/sq_summary.py $O/pmc_sq_s > $O/${TAG}_sq_counters_s128.txt
+python3 tools/sq_issue.py $O/pmc_sq_s --batch 4096 --rings 128 --workload synthetic > $O/sq_issue_s128.json
+cp $O/pmc_traffic_s128.json profiles/pmc_traffic_s128.json
+cp $O/sq_issue_s128.json profiles/sq_issue_s128.json
 python3 bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
-# fused ring kernel of rounds 1-3 beside the split pipeline, same box
-LIGHTLOAM_RING_SPLIT=0 python3 bench.py --no-cpu-baseline > $O/${TAG}_bench_fused_ring_kernel.json 2>/dev/null
 # the self-launching N-rank path on the one GPU of this pool (two ranks on device 0, gloo for the timing reduction: RCCL cannot share a device)
 python3 bench.py --gpus 2 --backend gloo --share-gpu --batch 2048 --no-cpu-baseline > $O/${TAG}_bench_gpus2_gloo_share_gpu.json 2>/dev/null
 # 9 distinct scans (the default of rounds 1-3) beside the 65 of the headline: what slot-to-slot diversity costs
@@ -54,5 +63,5 @@ python3 tools/soak_extract_s64.py 96 > $O/${TAG}_soak_extract_s64.log 2>&1
 python3 tools/soak_hot_path.py 256 2>&1 | grep -v amdgpu.ids > $O/${TAG}_soak_hot_path.log
 python3 tools/soak_frames.py 120 60 2>&1 | grep -v "amdgpu.ids\|RuntimeWarning\|org_s" > $O/${TAG}_soak_frames_short.log
 # keep what is merged back small: the raw counter tables and traces stay on the box
-rm -rf $O/prof_$TAG $O/prof_${TAG}_hdl64 $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_fetch_h $O/pmc_write_h $O/pmc_sq_h $O/liblightloam_hip_phase.so
+rm -rf $O/prof_$TAG $O/prof_${TAG}_hdl64 $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_fetch_h $O/pmc_write_h $O/pmc_sq_h $O/pmc_fetch_s $O/pmc_write_s $O/pmc_sq_s $O/liblightloam_hip_phase.so
 tail -n 3 $O/${TAG}_kernel_stats.txt; tail -c 600 $O/${TAG}_bench.json
