@@ -58,11 +58,15 @@ extern __shared__ __attribute__((aligned(16))) unsigned char ll_gsm[];
  * For an extracted slot this kernel is also where the scan's totals become known: the workgroup of the less-flat cloud scans the
  * per-ring counts into lf_pre and writes the four totals of the header (no ring of k_ring_features waited for another to learn them). */
 #define LL_GB 1024      /* threads: the kernel is a chain of latency-bound sweeps and LDS (68 KB) allows two workgroups per CU */
-/* Two 1024-thread workgroups per CU are 8 waves per SIMD, and the hardware admits the eighth wave only below 81 SGPRs
- * (MI355X_MICROARCH.md, residency: floor(800 / (ceil(sgpr / 16) * 16 + 16)) waves per SIMD; the occupancy query says 8 up to 96).
- * Rounds 1-4 compiled this kernel to 82 SGPRs without the bound: ONE workgroup per CU was resident. */
+/* Workgroups per CU.  Two 1024-thread workgroups are 8 waves per SIMD, and the hardware admits the eighth wave only below 81 SGPRs
+ * (MI355X_MICROARCH.md, residency: floor(800 / (ceil(sgpr / 16) * 16 + 16)) waves per SIMD; the occupancy query says 8 up to 96):
+ * rounds 1-4 compiled this kernel to 82 SGPRs, so ONE workgroup per CU was resident whatever the occupancy report said.  Round 5
+ * measured both on one box (profiles/r05_experiments/ab_build_grid_*.log): bound to 8 waves (78 SGPRs, two resident workgroups, 4 loads
+ * in flight per lane) 9.4-9.7 ms per 16384 scans, left at one workgroup with 8 loads in flight 8.9-9.2 -- every phase of the kernel
+ * takes 1.8-2.7x as long with a neighbour on the CU (instrumented build): it is bound by what a CU's LDS and memory pipes deliver,
+ * not by latency a second workgroup could hide. */
 #ifndef LL_GRID_WAVES
-#define LL_GRID_WAVES 8
+#define LL_GRID_WAVES 4
 #endif
 static size_t ll_grid_lds_bytes(const LLView &) { return (LL_GRID_NC + LL_GRID_NC / 16) * sizeof(int); }
 __global__ __launch_bounds__(LL_GB, LL_GRID_WAVES) void k_build_grid(LLView V, int first, int count, int carry)
@@ -88,6 +92,10 @@ __global__ __launch_bounds__(LL_GB, LL_GRID_WAVES) void k_build_grid(LLView V, i
     const float4 *pts; int m = 0; int *gstart; float4 *gpts;
     bool extracted = false;                                /* an extracted slot: the counts are per ring, the totals not yet known */
     int s = 0;
+    /* the per-ring counts are requested together with the header, before it is known whether they will be wanted (an extracted slot):
+     * one round trip at the head of the workgroup instead of two */
+    unsigned pc_spec = 0u; int nlf_spec = 0;
+    if (!carry && tid < V.R) { const size_t o = (size_t)(first + sl) * V.R + tid; pc_spec = V.ring_cnt[o]; nlf_spec = V.ring_nlf[o]; }
     if (carry) {
         pts = which ? V.carry_surf : V.carry_corner; m = V.carry_cnt[which];
         gstart = V.carry_gstart + (size_t)which * LL_GSTRIDE;
@@ -103,13 +111,14 @@ __global__ __launch_bounds__(LL_GB, LL_GRID_WAVES) void k_build_grid(LLView V, i
         else extracted = true;
     }
     __syncthreads();
+    LL_GPHASE_BEGIN();
     if (extracted) {
         /* the rings' counts: less-flat points (k_ring_features) or less-sharp picks (k_ring_pick) of every ring; the workgroup of
          * the less-flat cloud also sums the three small clouds' counts for the header */
         const int R = V.R;
         if (tid < LL_MAX_RINGS) {
-            const unsigned pc = tid < R ? V.ring_cnt[(size_t)s * R + tid] : 0u;
-            rcnt[tid] = which ? (tid < R ? V.ring_nlf[(size_t)s * R + tid] : 0) : (int)((pc >> 8) & 0xffu);
+            const unsigned pc = pc_spec;
+            rcnt[tid] = which ? nlf_spec : (int)((pc >> 8) & 0xffu);
             if (which) {
                 const int a = ll_wave_sum_i32((int)(pc & 0xffu)), b = ll_wave_sum_i32((int)((pc >> 8) & 0xffu)), c = ll_wave_sum_i32((int)((pc >> 16) & 0xffu));
                 if (lane == 0) { atomicAdd(&tot3[0], a); atomicAdd(&tot3[1], b); atomicAdd(&tot3[2], c); }
@@ -146,13 +155,16 @@ __global__ __launch_bounds__(LL_GB, LL_GRID_WAVES) void k_build_grid(LLView V, i
      * nothing per chunk (a per-chunk lookup table cost the sweeps 15 % of their time). */
     const int per_wave = (nch + NW - 1) / NW;
     const int cw0 = min(nch, wave * per_wave), cw1 = min(nch, cw0 + per_wave);
-    struct Cursor { int q, k, len; };
+    struct Cursor { int q, k, len, next_len; };     /* next_len: the following ring's length, read ahead (a VGPR holding a uniform value:
+                                                      * the LDS read is waited for at the next crossing, not where it is issued) */
+    auto ring_len = [&](int q) -> int { return q < LL_MAX_RINGS ? rcnt[q] : 1; };    /* beyond the table: a stopper for the skip loop */
     auto cursor_at = [&](int c) __attribute__((always_inline)) -> Cursor {       /* chunk c of the cloud (c < nch) */
-        Cursor cu; cu.q = 0; cu.k = c; cu.len = m;
+        Cursor cu; cu.q = 0; cu.k = c; cu.len = m; cu.next_len = 0;
         if (strided) {
             int lo = 0, hi = LL_MAX_RINGS;                                        /* the last ring whose first chunk is <= c and that holds a chunk */
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (__builtin_amdgcn_readfirstlane(cpre[mid]) <= c) lo = mid; else hi = mid; }
             cu.q = lo; cu.k = c - __builtin_amdgcn_readfirstlane(cpre[lo]); cu.len = __builtin_amdgcn_readfirstlane(rcnt[lo]);
+            cu.next_len = ring_len(lo + 1);
         }
         return cu;
     };
@@ -162,16 +174,19 @@ __global__ __launch_bounds__(LL_GB, LL_GRID_WAVES) void k_build_grid(LLView V, i
             place0 = cu.q * stride + cu.k * 64; nv = cu.len - cu.k * 64;
             if (++cu.k * 64 >= cu.len) {
                 cu.k = 0;
-                do { ++cu.q; cu.len = cu.q < LL_MAX_RINGS ? __builtin_amdgcn_readfirstlane(rcnt[cu.q]) : 1; } while (cu.len == 0);
+                do { ++cu.q; cu.len = __builtin_amdgcn_readfirstlane(cu.next_len); cu.next_len = ring_len(cu.q + 1); } while (cu.len == 0);
             }
         } else { place0 = cu.k * 64; nv = m - cu.k * 64; ++cu.k; }
     };
-    LL_GPHASE_BEGIN();
 #ifndef LL_GRID_UN
-#define LL_GRID_UN 4
+#define LL_GRID_UN 8
 #endif
-    constexpr int UN = LL_GRID_UN;                   /* independent loads in flight per lane: the kernel is latency-bound, and UN = 4 is what keeps it
-                                                       * at two workgroups per CU without scratch */
+    constexpr int UN = LL_GRID_UN;                   /* independent loads in flight per lane */
+/* One UNCONDITIONAL wait behind a batch of predicated loads.  Left to itself the compiler waits inside each `if (lane < nv)` block that
+ * uses a point; on the path around the block nothing was waited for, so at the join the destination registers still count as "in
+ * flight", and the next batch's address arithmetic -- which reuses them -- gets an s_waitcnt vmcnt(0) in front of EVERY load: one load
+ * in flight instead of UN (the sweeps ran 2.2x slower than the flat loops they replaced until this line went in). */
+#define LL_LOADS_LANDED() __builtin_amdgcn_s_waitcnt(0x0f70)                              /* vmcnt(0) */
 #define LL_WSHR1(x) __builtin_amdgcn_update_dpp(0, (int)(x), 0x138, 0xf, 0xf, false)      /* wave_shr:1: lane i <- lane i - 1 */
 #define LL_WSHL1(x) __builtin_amdgcn_update_dpp(0, (int)(x), 0x130, 0xf, 0xf, false)      /* wave_shl:1: lane i <- lane i + 1 */
     bool bad = false;
@@ -194,12 +209,13 @@ __global__ __launch_bounds__(LL_GB, LL_GRID_WAVES) void k_build_grid(LLView V, i
         Cursor cu = cursor_at(cw0);
         for (int c = cw0; c < cw1; c += UN) {
             float4 p[UN]; int pl[UN], nv[UN];
+            /* the cursor first, for all UN chunks, THEN the loads back to back: with the cursor's loop between two loads the compiler
+             * waits for the first (s_waitcnt vmcnt(0) at the loop's head) before it issues the second -- one load in flight, not UN */
 #pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                pl[u] = 0; nv[u] = 0;
-                if (c + u < cw1) take(cu, pl[u], nv[u]);
-                if (lane < nv[u]) p[u] = pts[pl[u] + lane];
-            }
+            for (int u = 0; u < UN; ++u) { pl[u] = 0; nv[u] = 0; if (c + u < cw1) take(cu, pl[u], nv[u]); }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) if (lane < nv[u]) p[u] = pts[pl[u] + lane];
+            LL_LOADS_LANDED();
 #pragma unroll
             for (int u = 0; u < UN; ++u) count_chunk(lane < nv[u] ? ll_grid_key(p[u]) : 0u, pl[u], nv[u]);
         }
@@ -221,11 +237,10 @@ __global__ __launch_bounds__(LL_GB, LL_GRID_WAVES) void k_build_grid(LLView V, i
         for (int c = cw0; c < cw1; c += UN) {
             float4 p[UN]; int pl[UN], nv[UN], pos[UN];
 #pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                pl[u] = 0; nv[u] = 0;
-                if (c + u < cw1) take(cu, pl[u], nv[u]);
-                if (lane < nv[u]) p[u] = pts[pl[u] + lane];
-            }
+            for (int u = 0; u < UN; ++u) { pl[u] = 0; nv[u] = 0; if (c + u < cw1) take(cu, pl[u], nv[u]); }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) if (lane < nv[u]) p[u] = pts[pl[u] + lane];
+            LL_LOADS_LANDED();
 #pragma unroll
             for (int u = 0; u < UN; ++u)
                 if (lane < nv[u]) { const int cc = ll_cell_coord(p[u].y) * LL_GRID_G + ll_cell_coord(p[u].x); pos[u] = atomicAdd(&hist[LL_HI(cc)], 1); }
@@ -238,6 +253,7 @@ __global__ __launch_bounds__(LL_GB, LL_GRID_WAVES) void k_build_grid(LLView V, i
         }
     }
 #undef LL_HI
+#undef LL_LOADS_LANDED
 #undef LL_WSHR1
 #undef LL_WSHL1
 
@@ -465,14 +481,18 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
                                                    int *out_a, int *out_b, int *out_c, float4 *qs, int *nn, int *rb, int *rcl, int *cellb_all, int *tab, unsigned char *perm, int *hist)
 {
     const int tid = threadIdx.x, lane = tid & 63;
-    for (int i = tid; i < LL_TAB_WORDS; i += LL_BLOCK) tab[i] = T.tab[i];             /* the ring tables: read by every query */
-    __syncthreads();
-    {   /* which of the two launches serves this target (uniform): the one compiled for clouds whose ring values never decrease -- every
-         * cloud the extract stage makes -- or the general one (arbitrary uploaded targets; tables that do not bound the walks) */
-        const int fl = tab[2 * (LL_TAB + 1)];
-        const bool fast = (fl & 3) == 3 && tab[2 * (LL_TAB + 1) + 1] == T.m;
+    {   /* which of the two launches serves this target (uniform, two scalar loads): the one compiled for clouds whose ring values never
+         * decrease -- every cloud the extract stage makes -- or the general one (arbitrary uploaded targets; tables that do not bound
+         * the walks).  The other launch's workgroup leaves before it has fetched anything else. */
+        const int fl = T.tab[2 * (LL_TAB + 1)], tm = T.tab[2 * (LL_TAB + 1) + 1];
+#ifdef LL_ASSOC_NO_MONO
+        const bool fast = false; (void)fl; (void)tm;                  /* A/B: everything through the general instantiation */
+#else
+        const bool fast = (fl & 3) == 3 && tm == T.m;
+#endif
         if (fast != MONO) return;
     }
+    for (int i = tid; i < LL_TAB_WORDS; i += LL_BLOCK) tab[i] = T.tab[i];             /* the ring tables: read by every query */
     const int qi = qblock * qpb + tid;                        /* qpb queries per workgroup: 256 in a batch, 32 (one pass) when few scans must fill the chip */
     const bool have = tid < qpb && qi < nq;
     /* a5: TransformToStart (s = 1 with DISTORTION 0, the reference's build): f64 rotate + translate, f32 store */
@@ -644,7 +664,45 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
                 auto w_bound = [&]() { const unsigned h2 = (unsigned)(k2 >> 32), h3 = (unsigned)(k3 >> 32); return __uint_as_float(PLANE ? max(h2, h3) : h2); };
                 auto w_sync = [&]() { k2 = ll_min8_u64(k2); if (PLANE) k3 = ll_min8_u64(k3); if (sub == 0) LL_STAT(st_sync); };
                 auto index_of = [&](unsigned long long k) { const int ord = (int)(unsigned)k; return (k == wnone) ? -1 : (ord < PEND ? c1 + ord : mc - ord); };   /* up: ord = j - c1 < PEND, down: ord = mc - j >= PEND */
+#ifdef LL_ASSOC_MONO_KEYS64
                 if (MONO) {
+                    /* A/B: the monotone tests (ring window, rj == rc) on the general loop's 64-bit (distance, order) keys */
+                    const unsigned wc = ((unsigned)c << 8) | (unsigned)rc;
+                    const unsigned wspan = (unsigned)(hi - lo);
+                    auto m_scan = [&](int st, int en) {
+                        for (int k0 = st + sub; k0 < en; k0 += 8 * LL_SCAN_UN) {
+                          float4 pp[LL_SCAN_UN];
+#pragma unroll
+                          for (int u = 0; u < LL_SCAN_UN; ++u) if (k0 + 8 * u < en) pp[u] = gpts[k0 + 8 * u];
+#pragma unroll
+                          for (int u = 0; u < LL_SCAN_UN; ++u) {
+                            if (k0 + 8 * u >= en) break;
+                            const float4 p = pp[u];
+                            const unsigned w = (unsigned)__float_as_int(p.w);
+                            const unsigned rj = w & 0xFFu;
+                            const int j = (int)(w >> 8);
+                            const bool in = (rj - (unsigned)lo) <= wspan && w != wc;
+                            const float d = ll_walk_d2(p, q.x, q.y, q.z);
+                            const int ord = j > c ? j - c1 : mc - j;
+                            const unsigned long long k = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)ord;
+                            const bool same = rj == (unsigned)rc;
+                            if (PLANE) {
+                                const unsigned long long ka = (in && same) ? k : wnone, kc = (in && !same) ? k : wnone;
+                                k2 = (ka < k2) ? ka : k2; k3 = (kc < k3) ? kc : k3;
+                            } else {
+                                const unsigned long long ka = (in && !same) ? k : wnone;
+                                k2 = (ka < k2) ? ka : k2;
+                            }
+                          }
+                        }
+                    };
+                    scan_near(m_scan, w_bound, w_sync);
+                    ll_grid_search(gstart, q.x, q.y, rmax, cellb, sub, 2, m_scan, w_bound, w_sync);
+                    res_b = index_of(k2); res_c = PLANE ? index_of(k3) : -1;
+                } else if (false) {
+#else
+                if (MONO) {
+#endif
                     /* The ring values never decrease along the target (every cloud the extract stage makes; k_build_grid checked it):
                      * j beyond c has ring >= rc and j before c ring <= rc, so "the walk's own ring" is rj == rc whatever the direction,
                      * "another ring" is rj != rc, and the place window (jlo, jhi) is the ring window lo <= rj <= hi.  The candidate's

@@ -37,7 +37,8 @@ __device__ __forceinline__ bool ll_xcd_map2(int id, int per_scan, int count, int
 }
 
 #ifndef LL_FWAVES_SPLIT
-#define LL_FWAVES_SPLIT 6     /* workgroups per CU (= waves per SIMD) of the 9-row instantiation */
+#define LL_FWAVES_SPLIT 7     /* workgroups per CU (= waves per SIMD) of the 9-row instantiation: 71 registers since the look-back left (80 with 23
+                               * of them spilled before), so seven fit without scratch: 15.1 ms per 16384 scans against 15.7 at six */
 #endif
 #define LL_NLIST 176      /* per segment slots: sharp[6][2] lsharp[6][20] flat[6][4] + counters[6][3] */
 
@@ -197,17 +198,18 @@ __device__ __forceinline__ void ll_ring_features_ring(const LLView &V, int s, in
 {
     static_assert(ROWS <= 32, "headm / endm hold one bit per row of a thread");
     const int tid = threadIdx.x, lane = tid & 63;
-    /* header and offsets fetched together -- the early exit below would otherwise put a memory round trip between them */
-    const ScanHdr h = V.hdr[s];
+    /* Everything the set-up needs from memory depends on (slot, ring) only: the earlier rings' pick counts (k_ring_pick's ring_cnt:
+     * complete, that launch is over -- thread q holds ring q's; their sums over q < r are this ring's offsets in the three contiguous
+     * small clouds: scanRegistration.cpp:273-279, :325), this ring's lists, the header's status and the ring's two offsets.  All of it
+     * is requested before anything is waited for, and the three exits are ONE test -- as separate tests each exit put a memory round
+     * trip of its own in front of the next load (four dependent trips at the head of a 23 us workgroup). */
+    const unsigned cnt_raw = tid < r ? V.ring_cnt[(size_t)s * V.R + tid] : 0u;
+    const unsigned short *rec = V.ring_rec + ((size_t)s * V.R + r) * LL_REC_U16;
+    const unsigned short rec_v = tid < 174 ? rec[tid] : (unsigned short)0;
+    const int status = V.hdr[s].status;
     const int off = V.ring_off[(size_t)s * (V.R + 1) + r];
     const int nr = V.ring_off[(size_t)s * (V.R + 1) + r + 1] - off;
-    if (h.status != 0) return;
-    if (nr <= ring_lo || nr > ring_hi) return;                        /* another tier's ring */
-    /* the earlier rings' counts of sharp / less-sharp / flat picks (k_ring_pick's ring_cnt: complete, that launch is over): thread q holds
-     * ring q's; their sums over q < r are this ring's offsets in the three contiguous small clouds (ring, segment, pick order:
-     * scanRegistration.cpp:273-279, :325).  Loaded now, summed when the outputs are written. */
-    unsigned cnt_q = 0u;
-    if (tid < r) cnt_q = V.ring_cnt[(size_t)s * V.R + tid] & 0x00ffffffu;
+    if ((status != 0) | (nr <= ring_lo) | (nr > ring_hi)) return;    /* a refused scan | another tier's ring */
     int *ring_nlf = V.ring_nlf + (size_t)s * V.R;
     if (nr <= 0) { if (tid == 0) ring_nlf[r] = 0; return; }          /* an empty ring: no segment, no list (k_ring_pick wrote ring_cnt = 0) */
     const int S = off + 5, E = off + nr - 6;                          /* scanStartInd / scanEndInd (:218-220) */
@@ -223,10 +225,7 @@ __device__ __forceinline__ void ll_ring_features_ring(const LLView &V, int s, in
     LL_PHASE_BEGIN();
     /* the pick's lists of this ring: local indices + per-segment counts -> L.lists; the less-sharp picks (label 1 / 2) -> bitmap:
      * less-flat = every segment point that is not one of them (:361-367) */
-    {
-        const unsigned short *rec = V.ring_rec + ((size_t)s * V.R + r) * LL_REC_U16;
-        if (tid < 174) L.lists[tid] = (int)rec[tid];
-    }
+    if (tid < 174) L.lists[tid] = (int)rec_v;
     __syncthreads();
     if (tid < LL_SEGS * LL_LSHARP_PER_SEG && tid % LL_LSHARP_PER_SEG < L.lists[157 + (tid / LL_LSHARP_PER_SEG) * 3]) {
         const int li = L.lists[12 + tid];
@@ -249,10 +248,10 @@ __device__ __forceinline__ void ll_ring_features_ring(const LLView &V, int s, in
         if (jl < LL_SEGS && tid % LL_LSHARP_PER_SEG < L.lists[157 + jl * 3]) { fpos[1] = ol + tid % LL_LSHARP_PER_SEG; fsrc1 = L.lists[12 + tid]; }
         if (jf < LL_SEGS && tid % LL_FLAT_PER_SEG < L.lists[158 + jf * 3]) { fpos[2] = of + tid % LL_FLAT_PER_SEG; fsrc2 = L.lists[132 + tid]; }
     };
-    /* this ring's offsets in sharp / less-sharp / flat: the sums of the earlier rings' counts (no waiting: see cnt_q above) */
+    /* this ring's offsets in sharp / less-sharp / flat: the sums of the earlier rings' counts (no waiting: cnt_raw came in with the header) */
     int roff[3] = {0, 0, 0};
     auto small_offsets = [&]() __attribute__((always_inline)) {
-        int v[3] = {(int)(cnt_q & 0xffu), (int)((cnt_q >> 8) & 0xffu), (int)((cnt_q >> 16) & 0xffu)};
+        int v[3] = {(int)(cnt_raw & 0xffu), (int)((cnt_raw >> 8) & 0xffu), (int)((cnt_raw >> 16) & 0xffu)};
 #pragma unroll
         for (int c = 0; c < 3; ++c) v[c] = ll_wave_sum_i32(v[c]);
         __syncthreads();
@@ -454,7 +453,7 @@ __device__ __forceinline__ void ll_ring_features_ring(const LLView &V, int s, in
 /* The launch of the common capacity: one workgroup per (scan, ring).  A tier of longer rings runs over the work list k_organize filled
  * for it (list != null: slot << 8 | ring, *list_n entries) with a fixed grid of resident workgroups taking entries in turn. */
 template <int ROWS>
-__global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES_SPLIT : ROWS <= 12 ? 5 : ROWS <= 18 ? 3 : 1)) void k_ring_features(LLView V, int first, int count, int ring_lo, int ring_hi,
+__global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES_SPLIT : ROWS <= 12 ? 4 : ROWS <= 18 ? 3 : 1)) void k_ring_features(LLView V, int first, int count, int ring_lo, int ring_hi,
                                                                                                                               const int *list, const int *list_n)
 {
     if constexpr (ROWS > 9) {                                         /* a tier: always over its list (one body per kernel: the register allocation of
@@ -497,7 +496,7 @@ void ll_launch_features(const LLView &V, int first, int count, size_t /* LDS of 
     /* one launch per capacity tier; every ring is worked on by exactly one of them, none waits for another */
     if (cap > 4608) ll_launch_ring_features<32>(V, first, count, grid, 4608, cap, 3, 1, st);   /* <= 8192 points: the per-thread row masks are 32 bits wide */
     if (cap > 3072) ll_launch_ring_features<18>(V, first, count, grid, 3072, cap < 4608 ? cap : 4608, 2, 3, st);
-    if (cap > 2304) ll_launch_ring_features<12>(V, first, count, grid, 2304, cap < 3072 ? cap : 3072, 1, 5, st);   /* two lasers of a 64-beam sensor in one bin: five workgroups per CU */
-    ll_launch_ring_features<9>(V, first, count, grid, INT_MIN, cap < 2304 ? cap : 2304, 0, 6, st);
+    if (cap > 2304) ll_launch_ring_features<12>(V, first, count, grid, 2304, cap < 3072 ? cap : 3072, 1, 4, st);   /* two lasers of a 64-beam sensor in one bin: four resident workgroups per CU (no scratch at 128 registers) */
+    ll_launch_ring_features<9>(V, first, count, grid, INT_MIN, cap < 2304 ? cap : 2304, 0, LL_FWAVES_SPLIT, st);
     ll_prof_mark(prof, LL_K_END, st);
 }

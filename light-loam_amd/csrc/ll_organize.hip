@@ -159,6 +159,11 @@ __global__ __launch_bounds__(LL_BLOCK, LL_OWAVES) void k_organize(LLView V, int 
         p[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < n_in) p[k] = raw[i];
     }
+    /* The first tile's points have landed before the walk starts, and every later tile's before the stores of the tile in front of it
+     * (the wait below): inside the loop the compiler then knows p[] to be complete and leaves the NEXT tile's loads in flight
+     * through the classification math.  (Without the two explicit waits it cannot tell how many of the predicated loads are
+     * outstanding and waits for vmcnt(0) -- i.e. also for the loads it has just issued -- at the first use of a point.) */
+    __builtin_amdgcn_s_waitcnt(0x0f70);                                                /* vmcnt(0) */
     int half = INT_MAX;                                                                /* half_idx once it is known (uniform) */
     for (int t = t0; t <= t1; ++t) {
         const int base = t * LL_TILE, buf = (t - t0) & 1;
@@ -219,6 +224,11 @@ __global__ __launch_bounds__(LL_BLOCK, LL_OWAVES) void k_organize(LLView V, int 
         for (int i = tid; i < (NK * NW) << bits; i += LL_BLOCK) cnt[buf ^ 1][i >> bits][i & ((1 << bits) - 1)] = 0;    /* the next tile's counters */
         if (half == INT_MAX) half = sh_half;
         __syncthreads();
+        /* One unconditional wait for the next tile's points (in flight since the top of this iteration) in front of the stores.  Without it
+         * the compiler -- which waited for this tile's points only inside the `kept` blocks above -- still counts their registers as in
+         * flight here and puts an s_waitcnt vmcnt(0) in front of EVERY store below: each of a thread's four stores then waits for the
+         * one before it to be acknowledged. */
+        __builtin_amdgcn_s_waitcnt(0x0f70);                                            /* vmcnt(0) */
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             const int r = my_ring[k];

@@ -81,15 +81,24 @@ __device__ __forceinline__ void ll_ring_pick_ring(const LLView &V, int s, int r,
     static_assert(SR <= 32, "row bitmasks are 32 bits wide");
     static_assert(2 * (SR + 2) + 2 <= 64, "the segment's gap words (L.gw) are cleared by one lane each");
     const int lane = (int)threadIdx.x & 63;
+    /* status, cloudSize and the ring's two offsets in one round trip, the exits one test (separate tests make each load wait for the
+     * branch in front of it) */
+#ifdef LL_PK_OLD_PROLOGUE
     const ScanHdr h = V.hdr[s];
     const int off = V.ring_off[(size_t)s * (V.R + 1) + r];
     const int nr = V.ring_off[(size_t)s * (V.R + 1) + r + 1] - off;
     if (h.status != 0) return;
-    if (nr <= ring_lo || nr > ring_hi) return;                        /* another tier's ring */
+    if (nr <= ring_lo || nr > ring_hi) return;
+    const int N = h.n;
+#else
+    const int status = V.hdr[s].status, N = V.hdr[s].n;
+    const int off = V.ring_off[(size_t)s * (V.R + 1) + r];
+    const int nr = V.ring_off[(size_t)s * (V.R + 1) + r + 1] - off;
+    if ((status != 0) | (nr <= ring_lo) | (nr > ring_hi)) return;    /* a refused scan | another tier's ring */
+#endif
     unsigned short *rec_g = V.ring_rec + ((size_t)s * V.R + r) * LL_REC_U16;
     unsigned *rcnt = V.ring_cnt + (size_t)s * V.R + r;
     int8_t *label = V.label + (size_t)s * V.NP + off;
-    const int N = h.n;
     const int S = off + 5, E = off + nr - 6;                          /* scanStartInd / scanEndInd (:218-220) */
     const bool active = (nr > 0) && (E - S >= 6);                     /* :248 */
     const int Lseg = active ? (E - S) : 0;

@@ -275,9 +275,9 @@ def _assert_extract_equal(api, orc, scan, rings, what, max_ring_points=2304, **p
 
 
 @pytest.mark.parametrize("lengths", [
-    # VLP-16 rings (elevation -15 + 2 k deg); lengths beyond 2304 go through the 12- / 18-row tier launches, are staged and moved by
-    # k_ring_place; the others are extracted by the main launch around the long rings' published counts
-    pytest.param([2600, 900, 1200, 0, 3500, 1800, 2305, 2304, 700, 0, 1500, 3073, 3072, 1000, 800, 2900], id="last ring long: the placer writes the scan's totals"),
+    # VLP-16 rings (elevation -15 + 2 k deg); lengths beyond 2304 go on the work lists of the 12- / 18-row tier launches (ll_organize.hip:
+    # ll_tier_append), the others are extracted by the main launch; every ring writes its own row, the totals come from k_build_grid
+    pytest.param([2600, 900, 1200, 0, 3500, 1800, 2305, 2304, 700, 0, 1500, 3073, 3072, 1000, 800, 2900], id="last ring long"),
     pytest.param([4400, 2400, 2500, 2600, 2700, 2800, 2900, 3000, 3100, 3200, 3300, 3400, 3500, 3600, 3700, 0], id="every ring long, last ring empty"),
     pytest.param([1000, 1100, 1200, 1300, 3000, 1500, 1600, 1700, 1800, 1900, 2000, 2100, 2200, 2300, 4000, 500], id="two long rings among short ones"),
 ])
@@ -294,9 +294,7 @@ def test_rings_of_every_tier_in_one_scan(api, orc, lengths):
 
 def test_many_long_rings_in_every_tier_of_a_64_ring_scan(api, orc):
     """A 64-ring scan with 21 rings of 2305 .. 3072 points and 19 of 3073 .. 4608 around short and empty ones: every tier launch of the
-    pick and of the voxel kernel carries a third of the scan, the main launch looks back across all of them.  (Written for round 4's
-    compact tier launches -- 16 workgroups per scan and tier, the last one looping over the overflow -- which measured slower than the
-    dense launches and were dropped; the scan stays as a parity case.)"""
+    pick and of the voxel kernel carries a third of the scan (their work lists hold 21 and 19 entries)."""
     rng = np.random.default_rng(64)
     lengths = []
     for k in range(64):
