@@ -127,15 +127,14 @@ __global__ __launch_bounds__(LL_GB, LL_GRID_WAVES) void k_build_grid(LLView V, i
         __syncthreads();
         if (tid < 64) {                                    /* wave 0: exclusive prefixes of the points and of the 64-point chunks, two halves */
             int carry_p = 0, carry_c = 0;
-#pragma unroll
-            for (int half = 0; half < LL_MAX_RINGS / 64; ++half) {
+            for (int half = 0; half * 64 < R; ++half) {                /* rings beyond R hold nothing: their prefixes are the totals (below) */
                 const int q = half * 64 + lane;
                 const int v = rcnt[q], c = (v + 63) >> 6;
                 const int ip = ll_wave_incl_scan(v), ic = ll_wave_incl_scan(c);
                 pre[q] = carry_p + ip - v; cpre[q] = carry_c + ic - c;
                 carry_p += __builtin_amdgcn_readlane(ip, 63); carry_c += __builtin_amdgcn_readlane(ic, 63);
             }
-            if (lane == 0) { pre[LL_MAX_RINGS] = carry_p; cpre[LL_MAX_RINGS] = carry_c; }
+            for (int q = (R + 63) / 64 * 64 + lane; q <= LL_MAX_RINGS; q += 64) { pre[q] = carry_p; cpre[q] = carry_c; }   /* incl. [LL_MAX_RINGS]: the totals */
         }
         __syncthreads();
         m = pre[LL_MAX_RINGS];
@@ -161,7 +160,7 @@ __global__ __launch_bounds__(LL_GB, LL_GRID_WAVES) void k_build_grid(LLView V, i
     auto cursor_at = [&](int c) __attribute__((always_inline)) -> Cursor {       /* chunk c of the cloud (c < nch) */
         Cursor cu; cu.q = 0; cu.k = c; cu.len = m; cu.next_len = 0;
         if (strided) {
-            int lo = 0, hi = LL_MAX_RINGS;                                        /* the last ring whose first chunk is <= c and that holds a chunk */
+            int lo = 0, hi = V.R;                                                 /* the last ring whose first chunk is <= c (it holds a chunk: cpre[q + 1] > c) */
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (__builtin_amdgcn_readfirstlane(cpre[mid]) <= c) lo = mid; else hi = mid; }
             cu.q = lo; cu.k = c - __builtin_amdgcn_readfirstlane(cpre[lo]); cu.len = __builtin_amdgcn_readfirstlane(rcnt[lo]);
             cu.next_len = ring_len(lo + 1);
@@ -263,12 +262,10 @@ __global__ __launch_bounds__(LL_GB, LL_GRID_WAVES) void k_build_grid(LLView V, i
      * down-window it undercuts:
      *   exists j < c with ring_j > hi(ring_c)   <=>   exists value b:  first_ge[hi(b) + 1] < last_eq[b]
      *   exists j > c with ring_j < lo(ring_c)   <=>   exists value b:  last_le[lo(b) - 1]  > first_eq[b]
-     * so validity is a check on the two 160-entry tables, no per-point scan.  The same tables say whether the ring values never
-     * decrease along the cloud (first_ge[b + 1] > last_eq[b] for every value b): the extract stage's clouds are like that, and
-     * k_associate's second / third-point search then needs neither the direction of the walk nor the place window per candidate. ---- */
+     * so validity is a check on the two 160-entry tables, no per-point scan. ---- */
     LL_GPHASE(11);
     __syncthreads();
-    int *tab = gstart + LL_GRID_NC + 1;              /* first_ge[LL_TAB+1], last_le[LL_TAB+1], flags, m, one past the last place */
+    int *tab = gstart + LL_GRID_NC + 1;              /* first_ge[LL_TAB+1], last_le[LL_TAB+1], ok flag, m, one past the last place */
     /* first_ge = suffix minimum of the first places, last_le = prefix maximum of the last ones: wave 0, three
      * 64-entry chunks with shuffle scans, the running value carried between chunks */
     __shared__ int fge[LL_TAB + 1], lle[LL_TAB + 1];
@@ -296,7 +293,7 @@ __global__ __launch_bounds__(LL_GB, LL_GRID_WAVES) void k_build_grid(LLView V, i
             carry_max = __shfl(x, 63);
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        bool viol = false, unsorted = false;
+        bool viol = false;
         for (int ch = 0; ch < NCH; ++ch) {
             const int bv = ch * 64 + lane;
             if (bv < LL_TAB && feq[bv] != INT_MAX) {
@@ -304,13 +301,11 @@ __global__ __launch_bounds__(LL_GB, LL_GRID_WAVES) void k_build_grid(LLView V, i
                 const int fg = (hi + 1 > LL_TAB) ? pend : fge[max(hi + 1, 0)];
                 const int ll = (lo - 1 < 0) ? -1 : lle[min(lo - 1, LL_TAB)];
                 if (fg < leq[bv] || ll > feq[bv]) viol = true;
-                if (fge[bv + 1] < leq[bv]) unsorted = true;                 /* a larger ring value before the last point of value bv */
             }
         }
-        const bool any_viol = __ballot(viol) != 0ull, any_unsorted = __ballot(unsorted) != 0ull;
+        const bool any_viol = __ballot(viol) != 0ull;
         if (lane == 0) {
-            const int ok = (okflag && !any_viol) ? 1 : 0;
-            tab[2 * (LL_TAB + 1)] = ok | ((ok && !any_unsorted) ? 2 : 0);
+            tab[2 * (LL_TAB + 1)] = (okflag && !any_viol) ? 1 : 0;
             tab[2 * (LL_TAB + 1) + 1] = m;
             tab[2 * (LL_TAB + 1) + 2] = pend;
         }
@@ -475,23 +470,12 @@ __device__ __forceinline__ void ll_grid_search(const int *gstart, float qx, floa
     }
 }
 
-template <bool PLANE, bool MONO>
+template <bool PLANE>
 __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int qblock, int qpb,
                                                    const float4 *queries, int nq, const TargetRef T,
                                                    int *out_a, int *out_b, int *out_c, float4 *qs, int *nn, int *rb, int *rcl, int *cellb_all, int *tab, unsigned char *perm, int *hist)
 {
     const int tid = threadIdx.x, lane = tid & 63;
-    {   /* which of the two launches serves this target (uniform, two scalar loads): the one compiled for clouds whose ring values never
-         * decrease -- every cloud the extract stage makes -- or the general one (arbitrary uploaded targets; tables that do not bound
-         * the walks).  The other launch's workgroup leaves before it has fetched anything else. */
-        const int fl = T.tab[2 * (LL_TAB + 1)], tm = T.tab[2 * (LL_TAB + 1) + 1];
-#ifdef LL_ASSOC_NO_MONO
-        const bool fast = false; (void)fl; (void)tm;                  /* A/B: everything through the general instantiation */
-#else
-        const bool fast = (fl & 3) == 3 && tm == T.m;
-#endif
-        if (fast != MONO) return;
-    }
     for (int i = tid; i < LL_TAB_WORDS; i += LL_BLOCK) tab[i] = T.tab[i];             /* the ring tables: read by every query */
     const int qi = qblock * qpb + tid;                        /* qpb queries per workgroup: 256 in a batch, 32 (one pass) when few scans must fill the chip */
     const bool have = tid < qpb && qi < nq;
@@ -664,108 +648,9 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
                 auto w_bound = [&]() { const unsigned h2 = (unsigned)(k2 >> 32), h3 = (unsigned)(k3 >> 32); return __uint_as_float(PLANE ? max(h2, h3) : h2); };
                 auto w_sync = [&]() { k2 = ll_min8_u64(k2); if (PLANE) k3 = ll_min8_u64(k3); if (sub == 0) LL_STAT(st_sync); };
                 auto index_of = [&](unsigned long long k) { const int ord = (int)(unsigned)k; return (k == wnone) ? -1 : (ord < PEND ? c1 + ord : mc - ord); };   /* up: ord = j - c1 < PEND, down: ord = mc - j >= PEND */
-#ifdef LL_ASSOC_MONO_KEYS64
-                if (MONO) {
-                    /* A/B: the monotone tests (ring window, rj == rc) on the general loop's 64-bit (distance, order) keys */
-                    const unsigned wc = ((unsigned)c << 8) | (unsigned)rc;
-                    const unsigned wspan = (unsigned)(hi - lo);
-                    auto m_scan = [&](int st, int en) {
-                        for (int k0 = st + sub; k0 < en; k0 += 8 * LL_SCAN_UN) {
-                          float4 pp[LL_SCAN_UN];
-#pragma unroll
-                          for (int u = 0; u < LL_SCAN_UN; ++u) if (k0 + 8 * u < en) pp[u] = gpts[k0 + 8 * u];
-#pragma unroll
-                          for (int u = 0; u < LL_SCAN_UN; ++u) {
-                            if (k0 + 8 * u >= en) break;
-                            const float4 p = pp[u];
-                            const unsigned w = (unsigned)__float_as_int(p.w);
-                            const unsigned rj = w & 0xFFu;
-                            const int j = (int)(w >> 8);
-                            const bool in = (rj - (unsigned)lo) <= wspan && w != wc;
-                            const float d = ll_walk_d2(p, q.x, q.y, q.z);
-                            const int ord = j > c ? j - c1 : mc - j;
-                            const unsigned long long k = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)ord;
-                            const bool same = rj == (unsigned)rc;
-                            if (PLANE) {
-                                const unsigned long long ka = (in && same) ? k : wnone, kc = (in && !same) ? k : wnone;
-                                k2 = (ka < k2) ? ka : k2; k3 = (kc < k3) ? kc : k3;
-                            } else {
-                                const unsigned long long ka = (in && !same) ? k : wnone;
-                                k2 = (ka < k2) ? ka : k2;
-                            }
-                          }
-                        }
-                    };
-                    scan_near(m_scan, w_bound, w_sync);
-                    ll_grid_search(gstart, q.x, q.y, rmax, cellb, sub, 2, m_scan, w_bound, w_sync);
-                    res_b = index_of(k2); res_c = PLANE ? index_of(k3) : -1;
-                } else if (false) {
-#else
-                if (MONO) {
-#endif
-                    /* The ring values never decrease along the target (every cloud the extract stage makes; k_build_grid checked it):
-                     * j beyond c has ring >= rc and j before c ring <= rc, so "the walk's own ring" is rj == rc whatever the direction,
-                     * "another ring" is rj != rc, and the place window (jlo, jhi) is the ring window lo <= rj <= hi.  The candidate's
-                     * direction and visiting order are then needed only to break a tie between EQUAL distances: the loop keeps a 32-bit
-                     * key (the distance bits) and the place beside it, and the order is computed where two equal distances meet and
-                     * where the eight lanes share their best. */
-                    const unsigned dnone = __float_as_uint(dmax);
-                    unsigned d2 = dnone, d3 = dnone; int j2 = -1, j3 = -1;            /* (dmax, none): only d < dmax undercuts it */
-                    const unsigned wc = ((unsigned)c << 8) | (unsigned)rc;            /* the closest point's own packed word */
-                    const unsigned wspan = (unsigned)(hi - lo);
-                    auto ord_of = [&](int j) -> unsigned { return j < 0 ? 0u : (unsigned)(j > c ? j - c1 : mc - j); };   /* "none" goes first: nothing ties it away */
-                    auto m_scan = [&](int st, int en) {
-                        for (int k0 = st + sub; k0 < en; k0 += 8 * LL_SCAN_UN) {
-                          float4 pp[LL_SCAN_UN];
-#pragma unroll
-                          for (int u = 0; u < LL_SCAN_UN; ++u) if (k0 + 8 * u < en) pp[u] = gpts[k0 + 8 * u];
-#pragma unroll
-                          for (int u = 0; u < LL_SCAN_UN; ++u) {
-                            if (k0 + 8 * u >= en) break;
-                            const float4 p = pp[u];
-                            LL_STAT(st_w);
-                            const unsigned w = (unsigned)__float_as_int(p.w);
-                            const unsigned rj = w & 0xFFu;
-                            const bool in = (rj - (unsigned)lo) <= wspan && w != wc;
-                            const unsigned d = __float_as_uint(ll_walk_d2(p, q.x, q.y, q.z));
-                            const bool same = rj == (unsigned)rc;
-                            const int j = (int)(w >> 8);
-                            if (PLANE) {
-                                const bool ma = in && same, mb = in && !same;
-                                bool ta = ma && d < d2, tb = mb && d < d3;
-                                if ((ma && d == d2) || (mb && d == d3)) {             /* equal distances: the walk's order decides (rare) */
-                                    if (ma && d == d2 && ord_of(j) < ord_of(j2)) ta = true;
-                                    if (mb && d == d3 && ord_of(j) < ord_of(j3)) tb = true;
-                                }
-                                d2 = ta ? d : d2; j2 = ta ? j : j2;
-                                d3 = tb ? d : d3; j3 = tb ? j : j3;
-                            } else {
-                                const bool ma = in && !same;
-                                bool ta = ma && d < d2;
-                                if (ma && d == d2 && ord_of(j) < ord_of(j2)) ta = true;
-                                d2 = ta ? d : d2; j2 = ta ? j : j2;
-                            }
-                          }
-                        }
-                    };
-                    auto m_bound = [&]() { return __uint_as_float(PLANE ? max(d2, d3) : d2); };
-                    auto m_sync = [&]() {                                            /* the group's best = the lexicographic minimum of (distance, order) */
-                        unsigned long long k = ll_min8_u64(((unsigned long long)d2 << 32) | ord_of(j2));
-                        d2 = (unsigned)(k >> 32); j2 = index_of(k == ((unsigned long long)dnone << 32) ? wnone : k);
-                        if (PLANE) {
-                            k = ll_min8_u64(((unsigned long long)d3 << 32) | ord_of(j3));
-                            d3 = (unsigned)(k >> 32); j3 = index_of(k == ((unsigned long long)dnone << 32) ? wnone : k);
-                        }
-                        if (sub == 0) LL_STAT(st_sync);
-                    };
-                    scan_near(m_scan, m_bound, m_sync);
-                    ll_grid_search(gstart, q.x, q.y, rmax, cellb, sub, 2, m_scan, m_bound, m_sync);
-                    res_b = j2; res_c = PLANE ? j3 : -1;
-                } else {
                 scan_near(w_scan, w_bound, w_sync);
                 ll_grid_search(gstart, q.x, q.y, rmax, cellb, sub, 2, w_scan, w_bound, w_sync);
                 res_b = index_of(k2); res_c = PLANE ? index_of(k3) : -1;
-                }
             }
         }
         if (sub == 0) { nn[ql] = closest; rb[ql] = res_b; rcl[ql] = res_c; }
@@ -778,7 +663,7 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
     const int closest = have ? nn[tid] : -1;
     int res_b = rb[tid], res_c = rcl[tid];
 
-    if (!MONO && !tab_ok) {
+    if (!tab_ok) {
         /* fallback: the reference's sequential walks, one query at a time per wave.  They run over INDICES; a ring-strided target
          * (an extracted slot -- whose tables can only fail on degenerate intensities) is addressed through its prefix table:
          * place -> index by a division, index -> place by a search.  Rare by construction, exact always. */
@@ -847,11 +732,10 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
 
 /* 2nd launch bound = waves per SIMD.  Left alone the compiler spends 106 SGPRs and lands on 7; asked for 8 it fits in 78
  * with the same 60 VGPRs and no scratch -- the kernel is latency-bound, one more wave per SIMD is worth 17 % (A/B, one box).
- * MONO: the instantiation for targets whose ring values never decrease along the cloud (k_build_grid's flag 2: every cloud the extract
- * stage makes); the general instantiation -- direction and place window per candidate, and the sequential walks as the always-exact
- * fallback -- is a launch of its own behind it whose workgroups leave at once for such a target.  One kernel holding both paid for the
- * rarely used one in the hot one: 120 bytes of scratch per lane against 12, twice the code. */
-template <bool MONO>
+ * (Round 5 built a second instantiation for targets whose ring values never decrease along the cloud -- ring-window test instead
+ * of the place window, class = rj == rc, 32-bit distance keys -- as a launch of its own in front of this one: index-exact, 2 % faster
+ * on the 64-ring synthetic scans, 8 % SLOWER on the denser 128-ring and HDL-64E targets, with either key width; removed again.
+ * profiles/r05_experiments/ab_assoc_monotone_variants_*.log) */
 __global__ __launch_bounds__(LL_BLOCK, 8) void k_associate(LLView V, int first, int count, int qb_corner, int qb_plane, int qpb)
 {
     /* All query blocks of a scan on ONE XCD (workgroup b runs on XCD b % 8): they search the same target grid, and an XCD's 4 MB L2 is
@@ -861,7 +745,7 @@ __global__ __launch_bounds__(LL_BLOCK, 8) void k_associate(LLView V, int first, 
     const int sl = (jb / per) * 8 + xcd, item = jb % per;
     if (sl >= count) return;
     const int s = first + sl;
-    if (MONO && item == 0 && threadIdx.x == 0) V.assoc_tgt[s] = (s == V.carry_slot) ? -1 : s - 1;   /* whose points this slot's correspondences name from now on */
+    if (item == 0 && threadIdx.x == 0) V.assoc_tgt[s] = (s == V.carry_slot) ? -1 : s - 1;   /* whose points this slot's correspondences name from now on */
     __shared__ float4 qs[LL_BLOCK];
     __shared__ int nn[LL_BLOCK], rb[LL_BLOCK], rcl[LL_BLOCK];
     __shared__ int cellb[(LL_BLOCK / 8) * 3 * LL_RING_CELLS];
@@ -873,13 +757,13 @@ __global__ __launch_bounds__(LL_BLOCK, 8) void k_associate(LLView V, int first, 
     if (item < qb_corner) {
         const int nq = ok ? h.n_sharp : 0;
         if (item * qpb >= nq) return;
-        ll_associate_block<false, MONO>(V, s, item, qpb, V.sharp + (size_t)s * V.cap_sharp, nq, ll_target(V, s, 0),
-                                        V.eq_a + (size_t)s * V.cap_sharp, V.eq_b + (size_t)s * V.cap_sharp, nullptr, qs, nn, rb, rcl, cellb, tab, perm, hist);
+        ll_associate_block<false>(V, s, item, qpb, V.sharp + (size_t)s * V.cap_sharp, nq, ll_target(V, s, 0),
+                                  V.eq_a + (size_t)s * V.cap_sharp, V.eq_b + (size_t)s * V.cap_sharp, nullptr, qs, nn, rb, rcl, cellb, tab, perm, hist);
     } else {
         const int qb = item - qb_corner;
         const int nq = ok ? h.n_flat : 0;
         if (qb * qpb >= nq) return;
-        ll_associate_block<true, MONO>(V, s, qb, qpb, V.flat + (size_t)s * V.cap_flat, nq, ll_target(V, s, 1),
+        ll_associate_block<true>(V, s, qb, qpb, V.flat + (size_t)s * V.cap_flat, nq, ll_target(V, s, 1),
                                        V.pq_a + (size_t)s * V.cap_flat, V.pq_b + (size_t)s * V.cap_flat,
                                        V.pq_c + (size_t)s * V.cap_flat, qs, nn, rb, rcl, cellb, tab, perm, hist);
     }
@@ -906,7 +790,6 @@ void ll_launch_associate(const LLView &V, int first, int count, hipStream_t st, 
 #endif
     const int qbc = (V.cap_sharp + qpb - 1) / qpb, qbp = (V.cap_flat + qpb - 1) / qpb;
     ll_prof_mark(prof, LL_K_ASSOCIATE, st);
-    hipLaunchKernelGGL(k_associate<true>, dim3(8 * (qbc + qbp) * ((count + 7) / 8)), dim3(LL_BLOCK), 0, st, V, first, count, qbc, qbp, qpb);
-    hipLaunchKernelGGL(k_associate<false>, dim3(8 * (qbc + qbp) * ((count + 7) / 8)), dim3(LL_BLOCK), 0, st, V, first, count, qbc, qbp, qpb);   /* arbitrary targets only: leaves at once otherwise */
+    hipLaunchKernelGGL(k_associate, dim3(8 * (qbc + qbp) * ((count + 7) / 8)), dim3(LL_BLOCK), 0, st, V, first, count, qbc, qbp, qpb);
     ll_prof_mark(prof, LL_K_END, st);
 }

@@ -47,8 +47,8 @@
 #define LL_GRID_CELL 1.0f
 #define LL_GRID_ORG 64.0f
 #define LL_GRID_NC (LL_GRID_G * LL_GRID_G)
-/* ring tables stored behind the cell starts: first_ge[LL_TAB+1], last_le[LL_TAB+1] (places), flags (1: the tables bound the walks,
- * 2: the ring values never decrease along the cloud), cloud size, one past the last place */
+/* ring tables stored behind the cell starts: first_ge[LL_TAB+1], last_le[LL_TAB+1] (places), ok flag (the tables bound the walks),
+ * cloud size, one past the last place */
 #define LL_TAB 160
 #define LL_TAB_WORDS (2 * (LL_TAB + 1) + 3)
 #define LL_GSTRIDE (LL_GRID_NC + 1 + LL_TAB_WORDS)

@@ -76,26 +76,19 @@ __device__ __forceinline__ bool ll_pk_bit(const unsigned *bm, int i) { return (b
 
 /* the ring r of slot s, if ring_lo < its length <= ring_hi (ring_hi <= 384 SR + 6 keeps a segment within SR rows): one wave */
 template <int SR>
-__device__ __forceinline__ void ll_ring_pick_ring(const LLView &V, int s, int r, int ring_lo, int ring_hi, PickLds<SR> &L)
+__device__ __forceinline__ void ll_ring_pick_ring(const LLView &V, int s, int r, int ring_lo, int ring_hi)
 {
     static_assert(SR <= 32, "row bitmasks are 32 bits wide");
     static_assert(2 * (SR + 2) + 2 <= 64, "the segment's gap words (L.gw) are cleared by one lane each");
-    const int lane = (int)threadIdx.x & 63;
+    __shared__ __attribute__((aligned(16))) PickLds<SR> lds_all[LL_PK_WAVES];
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
     /* status, cloudSize and the ring's two offsets in one round trip, the exits one test (separate tests make each load wait for the
      * branch in front of it) */
-#ifdef LL_PK_OLD_PROLOGUE
-    const ScanHdr h = V.hdr[s];
-    const int off = V.ring_off[(size_t)s * (V.R + 1) + r];
-    const int nr = V.ring_off[(size_t)s * (V.R + 1) + r + 1] - off;
-    if (h.status != 0) return;
-    if (nr <= ring_lo || nr > ring_hi) return;
-    const int N = h.n;
-#else
     const int status = V.hdr[s].status, N = V.hdr[s].n;
     const int off = V.ring_off[(size_t)s * (V.R + 1) + r];
     const int nr = V.ring_off[(size_t)s * (V.R + 1) + r + 1] - off;
     if ((status != 0) | (nr <= ring_lo) | (nr > ring_hi)) return;    /* a refused scan | another tier's ring */
-#endif
+    PickLds<SR> &L = lds_all[wave];
     unsigned short *rec_g = V.ring_rec + ((size_t)s * V.R + r) * LL_REC_U16;
     unsigned *rcnt = V.ring_cnt + (size_t)s * V.R + r;
     int8_t *label = V.label + (size_t)s * V.NP + off;
@@ -500,19 +493,9 @@ __device__ __forceinline__ void ll_ring_pick_ring(const LLView &V, int s, int r,
  * (tier_list: slot << 8 | ring, tier_cnt entries): a fixed grid of waves takes entries in turn, so that a launch costs what its rings
  * cost and not 64 x count workgroups that fetch a header and two offsets to find out they are not wanted. */
 template <int SR>
-__device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, int count, int ring_lo, int ring_hi, const int *list, const int *list_n)
+__device__ __forceinline__ void ll_ring_pick_grid(const LLView &V, int first, int count, int ring_lo, int ring_hi)
 {
-    __shared__ __attribute__((aligned(16))) PickLds<SR> lds_all[LL_PK_WAVES];
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    if constexpr (SR > 6) {                                           /* a tier: always over its list (one body per kernel) */
-        const int n = *list_n;
-        for (int i = blockIdx.x * LL_PK_WAVES + wave; i < n; i += gridDim.x * LL_PK_WAVES) {
-            const int e = list[i];
-            ll_ring_pick_ring<SR>(V, e >> 8, e & 0xFF, ring_lo, ring_hi, lds_all[wave]);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   /* the next ring starts on a quiet tile */
-        }
-        return;
-    } else {
     const int groups = (V.R + LL_PK_WAVES - 1) / LL_PK_WAVES;
     int sl, grp;
     {   /* block -> (scan, ring group): the rings of a scan on one XCD (its second kernel reads their lists from that L2) */
@@ -522,52 +505,59 @@ __device__ __forceinline__ void ll_ring_pick_body(const LLView &V, int first, in
     }
     const int r = grp * LL_PK_WAVES + wave;
     if (r >= V.R) return;
-    ll_ring_pick_ring<SR>(V, first + sl, r, ring_lo, ring_hi, lds_all[wave]);
+    ll_ring_pick_ring<SR>(V, first + sl, r, ring_lo, ring_hi);
+}
+template <int SR>
+__device__ __forceinline__ void ll_ring_pick_list(const LLView &V, int ring_lo, int ring_hi, const int *list, const int *list_n)
+{
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int n = *list_n;
+    for (int i = blockIdx.x * LL_PK_WAVES + wave; i < n; i += gridDim.x * LL_PK_WAVES) {
+        const int e = list[i];
+        ll_ring_pick_ring<SR>(V, e >> 8, e & 0xFF, ring_lo, ring_hi);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       /* the next ring starts on a quiet tile */
     }
 }
 
-/* one kernel per row count: the register cap is a property of the kernel (8 / 6 / 4 / 2 waves per SIMD) */
+/* one kernel per row count: the register cap is a property of the kernel (8 / 6 / 4 / 2 waves per SIMD).  The six-row kernel is the
+ * grid launch of the common capacity (its signature and body as in round 4: two more kernel arguments cost it 0.2 ms per 16384 scans
+ * through the register allocation); the others are the tiers, over their lists */
 #define LL_PICK_KERNEL(SR, WAVES, NVGPR)                                                                              \
     __global__ __launch_bounds__(64 * LL_PK_WAVES, WAVES) __attribute__((amdgpu_num_vgpr(NVGPR)))                      \
-    void k_ring_pick##SR(LLView V, int first, int count, int ring_lo, int ring_hi, const int *list, const int *list_n)   \
-    { ll_ring_pick_body<SR>(V, first, count, ring_lo, ring_hi, list, list_n); }
-#if defined(LL_PK_W6_WAVES)
-LL_PICK_KERNEL(6, LL_PK_W6_WAVES, LL_PK_W6_VGPRS)
-LL_PICK_KERNEL(8, 6, 80)
-LL_PICK_KERNEL(12, 4, 128)
-LL_PICK_KERNEL(22, 2, 256)
-#elif LL_PK_TILE_ROWS >= 6
+    void k_ring_pick##SR(LLView V, int first, int count, int ring_lo, int ring_hi) { ll_ring_pick_grid<SR>(V, first, count, ring_lo, ring_hi); }
+#define LL_PICK_TIER_KERNEL(SR, WAVES, NVGPR)                                                                         \
+    __global__ __launch_bounds__(64 * LL_PK_WAVES, WAVES) __attribute__((amdgpu_num_vgpr(NVGPR)))                      \
+    void k_ring_pick##SR(LLView V, int ring_lo, int ring_hi, const int *list, const int *list_n) { ll_ring_pick_list<SR>(V, ring_lo, ring_hi, list, list_n); }
+#if LL_PK_TILE_ROWS >= 6
 LL_PICK_KERNEL(6, 5, 96)         /* 7.7 KB of LDS per wave: five waves per SIMD */
-LL_PICK_KERNEL(8, 4, 128)
-LL_PICK_KERNEL(12, 2, 128)
-LL_PICK_KERNEL(22, 1, 256)
+LL_PICK_TIER_KERNEL(8, 4, 128)
+LL_PICK_TIER_KERNEL(12, 2, 128)
+LL_PICK_TIER_KERNEL(22, 1, 256)
 #else
 LL_PICK_KERNEL(6, 8, 64)
-LL_PICK_KERNEL(8, 6, 80)
-LL_PICK_KERNEL(12, 4, 128)
-LL_PICK_KERNEL(22, 2, 256)
+LL_PICK_TIER_KERNEL(8, 6, 80)
+LL_PICK_TIER_KERNEL(12, 4, 128)
+LL_PICK_TIER_KERNEL(22, 2, 256)
 #endif
 
+/* a tier of long rings: resident waves over the work list the organise stage filled */
 template <typename K>
-static void ll_launch_ring_pick(K kernel, const LLView &V, int first, int count, int ring_lo, int ring_hi, int tier, int waves_per_simd, hipStream_t st)
+static void ll_launch_ring_pick_tier(K kernel, const LLView &V, int count, int ring_lo, int ring_hi, int tier, int waves_per_simd, hipStream_t st)
 {
     const int groups = (V.R + LL_PK_WAVES - 1) / LL_PK_WAVES;
     int grid = 8 * groups * ((count + 7) / 8);
-    const int *list = nullptr, *list_n = nullptr;
-    if (tier > 0) {                                                   /* a tier of long rings: resident waves over the work list */
-        list = V.tier_list + (size_t)(tier - 1) * V.B * V.R; list_n = V.tier_cnt + tier;
-        const int resident = 256 * 4 * waves_per_simd / LL_PK_WAVES;
-        if (grid > resident) grid = resident;
-    }
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * LL_PK_WAVES), 0, st, V, first, count, ring_lo, ring_hi, list, list_n);
+    const int resident = 256 * 4 * waves_per_simd / LL_PK_WAVES;
+    if (grid > resident) grid = resident;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * LL_PK_WAVES), 0, st, V, ring_lo, ring_hi, V.tier_list + (size_t)(tier - 1) * V.B * V.R, V.tier_cnt + tier);
 }
 
 /* the tiers of ll_launch_features: rings of at most 2304 points in the six-row instantiation at eight waves per SIMD */
 void ll_launch_pick(const LLView &V, int first, int count, hipStream_t st)
 {
     const int cap = (V.max_ring + 255) / 256 * 256;
-    if (cap > 4608) ll_launch_ring_pick(k_ring_pick22, V, first, count, 4608, cap, 3, 2, st);
-    if (cap > 3072) ll_launch_ring_pick(k_ring_pick12, V, first, count, 3072, cap < 4608 ? cap : 4608, 2, 4, st);
-    if (cap > 2304) ll_launch_ring_pick(k_ring_pick8, V, first, count, 2304, cap < 3072 ? cap : 3072, 1, 6, st);
-    ll_launch_ring_pick(k_ring_pick6, V, first, count, INT_MIN, cap < 2304 ? cap : 2304, 0, 8, st);
+    if (cap > 4608) ll_launch_ring_pick_tier(k_ring_pick22, V, count, 4608, cap, 3, 2, st);
+    if (cap > 3072) ll_launch_ring_pick_tier(k_ring_pick12, V, count, 3072, cap < 4608 ? cap : 4608, 2, 4, st);
+    if (cap > 2304) ll_launch_ring_pick_tier(k_ring_pick8, V, count, 2304, cap < 3072 ? cap : 3072, 1, 6, st);
+    const int groups = (V.R + LL_PK_WAVES - 1) / LL_PK_WAVES;
+    hipLaunchKernelGGL(k_ring_pick6, dim3(8 * groups * ((count + 7) / 8)), dim3(64 * LL_PK_WAVES), 0, st, V, first, count, INT_MIN, cap < 2304 ? cap : 2304);
 }
