@@ -450,7 +450,7 @@ def test_random_irregular_scans_stress(api, orc):
 def test_two_contexts_on_two_host_threads(api, synth):
     """One ll_ctx per host thread is the contract (the reference nodes are single-threaded spinners); two contexts driven
     concurrently from two threads must not disturb each other: same features, correspondences counts and poses as the same
-    work run alone.  (The look-back launch tag and the scratch buffers are per context; ctypes releases the GIL in calls.)"""
+    work run alone.  (Scratch buffers, work lists and the association's target records are per context; ctypes releases the GIL in calls.)"""
     import threading
     cfg = synth.default_cfg(16)
     n = 24

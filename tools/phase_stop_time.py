@@ -11,10 +11,9 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STOPS = [(0, "p1 curvature + gap flags"), (1, "p2 suppression extents"), (2, "p3 per-segment pick"),
-         (3, "p4a compaction + bounds + voxel keys"), (4, "p4b voxel sort"), (12, "p4c gather + run heads + scan"),
-         (13, "p4e centroid sums (own range)"), (5, "p4f runs continued into later lanes"),
-         (7, "p4d labels + list gather + look-back wait"), (9, "p5 stores (full kernel)")]
+STOPS = [(3, "lists + bitmap + segment loads + bounds + voxel keys"), (4, "voxel sort"), (12, "gather + run heads + scan"),
+         (13, "centroid sums (own range)"), (5, "runs continued into later lanes"),
+         (7, "centroid stores + list gather + small-cloud offsets"), (9, "small-list stores (full kernel)")]
 
 
 def lib(stop):

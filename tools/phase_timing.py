@@ -27,9 +27,8 @@ buf = (C.c_ulonglong * 16)()
 ctx._ck(ctx.lib.ll_debug_counters(ctx.h, buf, 1))
 ctx.extract(0, B)
 ctx._ck(ctx.lib.ll_debug_counters(ctx.h, buf, 1))
-names = [(0, "p1 curvature+keys"), (1, "p2 suppression extents"), (2, "p3 per-segment pick"), (3, "p4a compact+bounds+voxel keys"),
-         (4, "p4b voxel sort"), (12, "p4c gather + run heads + scan"), (7, "p4d look-back publish + wait"), (13, "p4e centroid sums (own range)"),
-         (5, "p4f runs continued into later threads"), (6, "p5 outputs")]
+names = [(3, "lists + bitmap + loads + bounds + voxel keys"), (4, "voxel sort"), (12, "gather + run heads + scan"), (13, "centroid sums (own range)"),
+         (5, "runs continued into later threads"), (7, "centroid stores + list gather + offsets"), (6, "small-list stores")]
 n = max(1, buf[15])
 tot = sum(buf[i] for i, _ in names)
 print(f"k_ring_features phase timing over {buf[15]} workgroups (s_memtime cycles per workgroup, thread 0 wall):")
