@@ -83,10 +83,11 @@ __global__ __launch_bounds__(LL_GB, LL_GRID_WAVES) void k_build_grid(LLView V, i
     __shared__ int feq[LL_TAB + 1], leq[LL_TAB + 1];
     __shared__ int okflag;
     __shared__ int rcnt[LL_MAX_RINGS], pre[LL_MAX_RINGS + 1], cpre[LL_MAX_RINGS + 1];   /* per ring: points, index of the first, chunk of the first */
-    __shared__ int tot3[2][3];
+    __shared__ int tot3[3];
     for (int i = tid; i < LL_GRID_NC + LL_GRID_NC / 16; i += LL_GB) hist[i] = 0;
     for (int i = tid; i <= LL_TAB; i += LL_GB) { feq[i] = INT_MAX; leq[i] = -1; }
     if (tid == 0) okflag = (V.nearby >= 0.0) ? 1 : 0;
+    if (tid < 3) tot3[tid] = 0;
 
     const float4 *pts; int m = 0; int *gstart; float4 *gpts;
     bool extracted = false;                                /* an extracted slot: the counts are per ring, the totals not yet known */
@@ -109,20 +110,21 @@ __global__ __launch_bounds__(LL_GB, LL_GRID_WAVES) void k_build_grid(LLView V, i
         else if (!h.lf_strided) m = which ? h.n_less_flat : h.n_less_sharp;         /* ll_upload_features: the caller's counts */
         else extracted = true;
     }
+    __syncthreads();
     LL_GPHASE_BEGIN();
-    if (extracted && tid < LL_MAX_RINGS) {
-        /* the rings' counts: less-flat points (k_ring_features) or less-sharp picks (k_ring_pick) of every ring; the workgroup of
-         * the less-flat cloud also sums the three small clouds' counts for the header (waves 0 and 1: one slot each, no atomics) */
-        const unsigned pc = pc_spec;
-        rcnt[tid] = which ? nlf_spec : (int)((pc >> 8) & 0xffu);
-        if (which) {
-            const int a = ll_wave_sum_i32((int)(pc & 0xffu)), b = ll_wave_sum_i32((int)((pc >> 8) & 0xffu)), c = ll_wave_sum_i32((int)((pc >> 16) & 0xffu));
-            if (lane == 0) { tot3[wave][0] = a; tot3[wave][1] = b; tot3[wave][2] = c; }
-        }
-    }
-    __syncthreads();                                       /* the cleared tables and the rings' counts */
     if (extracted) {
+        /* the rings' counts: less-flat points (k_ring_features) or less-sharp picks (k_ring_pick) of every ring; the workgroup of
+         * the less-flat cloud also sums the three small clouds' counts for the header */
         const int R = V.R;
+        if (tid < LL_MAX_RINGS) {
+            const unsigned pc = pc_spec;
+            rcnt[tid] = which ? nlf_spec : (int)((pc >> 8) & 0xffu);
+            if (which) {
+                const int a = ll_wave_sum_i32((int)(pc & 0xffu)), b = ll_wave_sum_i32((int)((pc >> 8) & 0xffu)), c = ll_wave_sum_i32((int)((pc >> 16) & 0xffu));
+                if (lane == 0) { atomicAdd(&tot3[0], a); atomicAdd(&tot3[1], b); atomicAdd(&tot3[2], c); }
+            }
+        }
+        __syncthreads();
         if (tid < 64) {                                    /* wave 0: exclusive prefixes of the points and of the 64-point chunks, two halves */
             int carry_p = 0, carry_c = 0;
             for (int half = 0; half * 64 < R; ++half) {                /* rings beyond R hold nothing: their prefixes are the totals (below) */
@@ -139,11 +141,9 @@ __global__ __launch_bounds__(LL_GB, LL_GRID_WAVES) void k_build_grid(LLView V, i
         if (which) {
             /* rings beyond R hold no point: pre[R] = the total.  lf_pre: what turns a place into the reference's index (C ABI, carry copy) */
             if (tid <= R) V.lf_pre[(size_t)s * (R + 1) + tid] = pre[tid];
-            if (tid == 0) {
-                ScanHdr *hh = &V.hdr[s];
-                hh->n_sharp = tot3[0][0] + tot3[1][0]; hh->n_less_sharp = tot3[0][1] + tot3[1][1]; hh->n_flat = tot3[0][2] + tot3[1][2]; hh->n_less_flat = m;
-            }
+            if (tid == 0) { ScanHdr *hh = &V.hdr[s]; hh->n_sharp = tot3[0]; hh->n_less_sharp = tot3[1]; hh->n_flat = tot3[2]; hh->n_less_flat = m; }
         }
+        __syncthreads();
     }
     const bool strided = extracted && which != 0;
     const int stride = V.ring_cap;

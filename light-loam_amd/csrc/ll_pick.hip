@@ -298,15 +298,10 @@ __device__ __forceinline__ void ll_ring_pick_ring(const LLView &V, int s, int r,
         const bool compact = nc <= LL_PK_COMPACT;                     /* else: a segment full of corners, its rows as they are */
         const int ncr = (nc + 63) >> 6;
         unsigned ck[LL_PK_CROWS]; int cli[LL_PK_CROWS];               /* masked key (0 = not eligible); local index | suppression extents << 16 */
-        {
-            /* the lane id computed afresh: the compiler would otherwise keep the LDS address `base + 4 lane` from the kernel's entry alive
-             * across the whole segment loop -- in scratch -- and every segment would pay a scratch round trip to get it back */
-            const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 #pragma unroll
-            for (int rr = 0; rr < LL_PK_CROWS; ++rr) {
-                ck[rr] = 0u; cli[rr] = 0;
-                if (compact && rr < ncr && rr * 64 + ln < nc) { ck[rr] = L.c.wkey[rr * 64 + ln]; cli[rr] = (int)L.c.wli[rr * 64 + ln]; }
-            }
+        for (int rr = 0; rr < LL_PK_CROWS; ++rr) {
+            ck[rr] = 0u; cli[rr] = 0;
+            if (compact && rr < ncr && rr * 64 + lane < nc) { ck[rr] = L.c.wkey[rr * 64 + lane]; cli[rr] = (int)L.c.wli[rr * 64 + lane]; }
         }
         /* the next segment's first tile travels during the pick (the candidates are in registers, their LDS rows are dead) */
         __builtin_amdgcn_s_waitcnt(0xc07f);                           /* lgkmcnt(0) */

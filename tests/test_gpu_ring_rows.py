@@ -118,3 +118,50 @@ def test_uploaded_and_extracted_slots_mix(api, orc, drive):
     finally:
         orc.set_nn_mode(0)
         ctx.close()
+
+
+def test_irregular_ring_rows_as_association_targets(api, orc):
+    """Scans whose rings hold 0, 3, 9, ... 64, 65, 129, 400 points (empty rows, rows shorter than a 64-point chunk, rows ending on and
+    just behind a chunk edge) as each other's targets: k_build_grid's walk over the ring rows -- prefix table, chunk cursor, the rows'
+    ragged ends -- must hand k_associate exactly the reference's clouds, for refused scans too (no target: no correspondence)."""
+    from test_gpu_parity import _vlp16_ring, _ring_scan
+    rng = np.random.default_rng(5150)
+    scans = []
+    for s in range(24):
+        rings = []
+        for k in range(16):
+            n = int(rng.choice([0, 3, 9, 12, 17, 30, 47, 63, 64, 65, 128, 129, 250, 400], p=[.06, .04, .05, .05, .08, .1, .1, .08, .08, .08, .08, .08, .06, .06]))
+            if n == 0:
+                continue
+            base = rng.uniform(2.0, 12.0)
+            r = base * (1.0 + rng.uniform(0.0005, 0.01) * np.cumsum(rng.standard_normal(n)))
+            r = np.where(rng.random(n) < rng.uniform(0.0, 0.3), r * rng.uniform(1.2, 2.0), r)
+            rings.append(_vlp16_ring(-15 + 2 * k, n, np.abs(r) + 0.35, phase=rng.random()))
+        if not rings:
+            rings.append(_vlp16_ring(1, 40, 5.0))
+        scans.append(_ring_scan(rings))
+    P = orc.params(16, minimum_range=0.3)
+    refs = [orc.extract(sc, P) for sc in scans]
+    ctx = api.Context(api.default_params(16, batch=len(scans), max_points=max(map(len, scans)) + 8, minimum_range=0.3))
+    orc.set_nn_mode(1)
+    try:
+        for k, sc in enumerate(scans):
+            ctx.upload_scan(k, sc)
+        ctx.extract(0, len(scans))
+        pose = np.array([0.0, 0.0, 0.002, 1.0, 0.05, -0.02, 0.0]); pose[:4] /= np.linalg.norm(pose[:4])
+        ctx.set_target_from_slot(0)
+        ctx.associate(1, len(scans) - 1, pose); ctx.vote(1, len(scans) - 1, False)
+        checked = 0
+        for k in range(1, len(scans)):
+            if refs[k]["rc"] != 0:
+                assert ctx.scan_info(k).status != 0
+                continue
+            tgt = refs[k - 1] if refs[k - 1]["rc"] == 0 else dict(less_sharp=np.zeros((0, 4), np.float32), less_flat=np.zeros((0, 4), np.float32))
+            f = ctx.features(k)
+            assert_bit_equal(f["less_flat"], refs[k]["less_flat"], f"scan {k} less_flat")
+            _check_corr(ctx, orc, k, refs[k], tgt, pose)
+            checked += 1
+        assert checked >= 18
+    finally:
+        orc.set_nn_mode(0)
+        ctx.close()
