@@ -437,7 +437,7 @@ __global__ void k_copy_carry(LLView V, int slot)
     for (int i = gtid; i < mc; i += gsz) V.carry_corner[i] = V.lsharp[(size_t)slot * V.cap_lsharp + i];
     const float4 *lf = V.lflat + (size_t)slot * V.LFS;
     if (!h.lf_strided) { for (int i = gtid; i < ms; i += gsz) V.carry_surf[i] = lf[i]; }
-    else {
+    else if (ms > 0) {                                                   /* (a refused scan: no target, and its prefix table is not this scan's) */
         const int *pre = V.lf_pre + (size_t)slot * (V.R + 1);
         const int wave = gtid >> 6, nwaves = gsz >> 6, lane = gtid & 63;
         for (int r = wave; r < V.R; r += nwaves) {                       /* a wave per ring row */

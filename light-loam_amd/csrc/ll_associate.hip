@@ -8,8 +8,11 @@
  *
  * k_build_grid (one workgroup per (scan, cloud)) builds what replaces the kd-tree:
  *   - a uniform 2-D (x, y) cell grid: LDS histogram over 128 x 128 cells of 1 m, exclusive scan, scatter of
- *     (x, y, z, original index << 8 | ring) into cell order.  Points outside +-64 m saturate into the border
- *     cells, whose rectangles are treated as unbounded outwards;
+ *     (x, y, z, place << 8 | ring) into cell order -- a point's PLACE is its float4 offset in the slot's cloud: its index for a
+ *     contiguous cloud, ring * ring_cap + k for the ring rows of an extracted less-flat cloud (ll_common.h); places order like
+ *     the reference's indices.  Points outside +-64 m saturate into the border cells, whose rectangles are treated as
+ *     unbounded outwards;
+ *   - for an extracted slot, first: the rings' counts -> the prefix table lf_pre (place -> index) and the header's four totals;
  *   - ring tables first_ge[v] = min{j : ring_j >= v}, last_le[v] = max{j : ring_j <= v} (ring_j = int(intensity_j))
  *     and a flag saying whether they reproduce the reference's sequential walk bounds for EVERY start index
  *     (true whenever ring ids never run more than NEARBY_SCAN ahead/behind of their position, as in any cloud
@@ -18,7 +21,7 @@
  *   K=1 search   cells visited in Chebyshev rings around the query's cell, a cell skipped only when its rectangle
  *                is provably farther than the best so far, the ring loop stopped when the whole next ring is.
  *                Distance = FLANN L2_Simple in f32 ((dx*dx + dy*dy) + dz*dz, no FMA); equal distances -> lowest
- *                original index (traversal-dependent in the kd-tree; defined here and in the oracle).  Only
+ *                place = lowest original index (traversal-dependent in the kd-tree; defined here and in the oracle).  Only
  *                neighbours closer than DISTANCE_SQ_THRESHOLD are ever used (:497 / :659): at most 7 rings.
  *   ring walks   (:504-553, :668-721) are sequential loops over a contiguous index window with early breaks and a
  *                running minimum under strict '<'.  With valid tables the window is (last_le[..], first_ge[..]),
@@ -547,7 +550,7 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
         if (q.w != 0.0f && M > 0) {
             /* ---- exact K=1 NN within nn_max ----
              * One 64-bit key per candidate: the distance's bits (non-negative floats order like their bits) above the packed
-             * word index << 8 | ring, so "closer, or as close with the lower index" is one unsigned minimum, and the winner's
+             * word place << 8 | ring, so "closer, or as close with the lower index" is one unsigned minimum, and the winner's
              * ring (closestPointScanID, :500 / :664) comes with it. */
             /* "none yet" = (dmax, 0): only a candidate with d < dmax undercuts it -- one AT the limit has the same upper word and a
              * lower word >= 0, so it does not (:497 / :659 accept d < DISTANCE_SQ_THRESHOLD only) */
