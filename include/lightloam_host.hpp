@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -246,34 +247,68 @@ public:
      * owns.  all_gather(send, recv, bytes): `bytes` from every rank into recv, rank-major (ncclAllGather / MPI_Allgather;
      * the buffers handed over are host memory).  Every rank passes the same scan and ends with the same parameters[]. */
     void set_shard(int rank, int world) { check(ll_cubemap_set_shard(cm_, rank, world)); world_ = world; }
+    /* Failure discipline: nothing here throws between two collectives.  A rank whose library call failed remembers it, skips its
+     * remaining library calls of the frame but still takes part in every all_gather of the sequence; the ranks exchange a status
+     * word with the counts and once per outer iteration, so that ALL of them leave the frame at the same point -- each with an
+     * exception (its own error, or "a peer failed") -- instead of one leaving and the others waiting in a gather for ever. */
     template <class AllGather>
     bool process_tile_parallel(const std::vector<PointXYZI> &laserCloudCornerLast, const std::vector<PointXYZI> &laserCloudSurfLast,
                                AllGather &&all_gather, const ll_lm_options *opt = nullptr) {
-        check(ll_cubemap_prepare(cm_, parameters + 4, (const ll_point *)laserCloudCornerLast.data(), (int)laserCloudCornerLast.size(),
-                                 (const ll_point *)laserCloudSurfLast.data(), (int)laserCloudSurfLast.size()));
-        int cnt[4];
-        check(ll_cubemap_info(cm_, nullptr, cnt));
-        std::vector<int> all_cnt((size_t)2 * world_);
-        all_gather(cnt, all_cnt.data(), 2 * sizeof(int));
-        long tot[2] = {0, 0};
-        for (int r = 0; r < world_; ++r) { tot[0] += all_cnt[2 * r]; tot[1] += all_cnt[2 * r + 1]; }
+        std::string local_err;                                                            /* first failure on this rank */
+        auto step = [&](int rc, const char *what) { if (rc != LL_OK && local_err.empty()) local_err = std::string(what); return rc == LL_OK; };
+        auto any_failed = [&]() {                                                         /* one int per rank: a collective of its own */
+            int mine = local_err.empty() ? 0 : 1;
+            std::vector<int> all((size_t)world_);
+            all_gather(&mine, all.data(), sizeof(int));
+            for (int v : all) if (v) return true;
+            return false;
+        };
+        auto leave = [&]() { throw Error(LL_ERR_STATE, local_err.empty() ? std::string("process_tile_parallel: another rank failed") : local_err); };
+        int cnt[4] = {0, 0, 0, 0};
+        if (step(ll_cubemap_prepare(cm_, parameters + 4, (const ll_point *)laserCloudCornerLast.data(), (int)laserCloudCornerLast.size(),
+                                    (const ll_point *)laserCloudSurfLast.data(), (int)laserCloudSurfLast.size()), ll_cubemap_last_error(cm_)))
+            step(ll_cubemap_info(cm_, nullptr, cnt), ll_cubemap_last_error(cm_));
+        int mine[3] = {cnt[0], cnt[1], local_err.empty() ? 0 : 1};
+        std::vector<int> all_cnt((size_t)3 * world_);
+        all_gather(mine, all_cnt.data(), 3 * sizeof(int));
+        long tot[2] = {0, 0}; bool failed = false;
+        for (int r = 0; r < world_; ++r) { tot[0] += all_cnt[3 * r]; tot[1] += all_cnt[3 * r + 1]; failed = failed || all_cnt[3 * r + 2] != 0; }
+        if (failed) leave();
         const bool ran = tot[0] > 10 && tot[1] > 50;                                      /* :1822 */
         if (ran) {
             ll_map *m = ll_cubemap_map(cm_);
             const size_t nc = (size_t)cnt[2] * 5, ns = (size_t)cnt[3] * 5;
-            std::vector<float> cn(nc * 4 + 4), sn(ns * 4 + 4), acn(cn.size() * world_), asn(sn.size() * world_);
-            std::vector<int> ci(nc + 1), si(ns + 1), aci(ci.size() * world_), asi(si.size() * world_);
+            /* ONE all_gather per outer iteration: a rank's status word and its four candidate arrays travel as one packed record
+             * [status | corner (x, y, z, d) | corner ids | surf (x, y, z, d) | surf ids] (every rank holds the whole scan, so the
+             * records have one size); the receiver lays the parts out rank-major again for ll_map_associate_merged.  (Four gathers
+             * and a status gather per iteration were five host-staged collectives, each with its own stream synchronisation.) */
+            const size_t o_cn = 4, o_ci = o_cn + nc * 16, o_sn = o_ci + nc * 4, o_si = o_sn + ns * 16, rec = o_si + ns * 4;
+            std::vector<unsigned char> pack(rec), all(rec * (size_t)world_);
+            std::vector<float> acn(nc * 4 * world_ + 4), asn(ns * 4 * world_ + 4);
+            std::vector<int> aci(nc * world_ + 1), asi(ns * world_ + 1);
             for (int it = 0; it < 2; ++it) {                                              /* :1832 */
-                mcheck(m, ll_map_knn_partial(m, parameters, cn.data(), ci.data(), sn.data(), si.data()));
-                /* gather exactly the used part so that the parts sit back to back */
-                acn.resize(nc * 4 * world_); asn.resize(ns * 4 * world_); aci.resize(nc * world_); asi.resize(ns * world_);
-                if (nc) { all_gather(cn.data(), acn.data(), nc * 4 * sizeof(float)); all_gather(ci.data(), aci.data(), nc * sizeof(int)); }
-                if (ns) { all_gather(sn.data(), asn.data(), ns * 4 * sizeof(float)); all_gather(si.data(), asi.data(), ns * sizeof(int)); }
-                mcheck(m, ll_map_associate_merged(m, parameters, world_, acn.data(), aci.data(), asn.data(), asi.data()));
-                mcheck(m, ll_map_solve(m, parameters, opt));
+                if (local_err.empty())
+                    step(ll_map_knn_partial(m, parameters, (float *)(pack.data() + o_cn), (int *)(pack.data() + o_ci),
+                                            (float *)(pack.data() + o_sn), (int *)(pack.data() + o_si)), ll_map_last_error(m));
+                const int mine_st = local_err.empty() ? 0 : 1;
+                std::memcpy(pack.data(), &mine_st, sizeof(int));
+                all_gather(pack.data(), all.data(), rec);
+                bool bad = false;
+                for (int r = 0; r < world_; ++r) {
+                    const unsigned char *q = all.data() + (size_t)r * rec;
+                    int st; std::memcpy(&st, q, sizeof(int)); bad = bad || st != 0;
+                    std::memcpy((unsigned char *)acn.data() + (size_t)r * nc * 16, q + o_cn, nc * 16);
+                    std::memcpy((unsigned char *)aci.data() + (size_t)r * nc * 4, q + o_ci, nc * 4);
+                    std::memcpy((unsigned char *)asn.data() + (size_t)r * ns * 16, q + o_sn, ns * 16);
+                    std::memcpy((unsigned char *)asi.data() + (size_t)r * ns * 4, q + o_si, ns * 4);
+                }
+                if (bad) leave();                                                         /* every rank takes this exit in the same iteration */
+                if (step(ll_map_associate_merged(m, parameters, world_, acn.data(), aci.data(), asn.data(), asi.data()), ll_map_last_error(m)))
+                    step(ll_map_solve(m, parameters, opt), ll_map_last_error(m));
             }
+            if (any_failed()) leave();                                                    /* the last iteration's merge / solve */
         }
-        check(ll_cubemap_update(cm_, parameters));
+        check(ll_cubemap_update(cm_, parameters));                                        /* local to the rank: no collective behind it in this frame */
         return ran;
     }
     double parameters[7] = {0, 0, 0, 1, 0, 0, 0};                 /* :81-83 */
