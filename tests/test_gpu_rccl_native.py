@@ -79,3 +79,26 @@ def test_cpp_rccl_row_parallel_and_tile_parallel(tmp_path, orc, synth, api):
     for k in range(n_frames):
         for r in range(world):
             assert tile[k, r].tobytes() == tile[k, world].tobytes(), (k, r)   # the split search is exact: bit-identical to the unsplit map
+
+
+def test_cpp_tile_parallel_ranks_leave_a_failing_frame_together(tmp_path, orc, synth, api):
+    """include/lightloam_host.hpp, LaserMapping::process_tile_parallel: no exception between two collectives.  Three ranks as three
+    host threads (the all_gather = a barrier + memcpy between them); one rank's ll_cubemap_prepare fails -> all three come back
+    with an exception, nobody waits in a gather (tests/native/tile_parallel_exits.cpp has a 60 s watchdog)."""
+    from lightloam_amd import build
+    lib_dir = os.path.dirname(build.lib_path())
+    exe = str(tmp_path / "tile_parallel_exits")
+    subprocess.check_call(["g++", "-O2", "-std=c++14", "-pthread", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "native", "tile_parallel_exits.cpp"), "-o", exe,
+                           "-L", lib_dir, "-llightloam_hip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
+    cfg = synth.default_cfg(16)
+    P = orc.params(16)
+    for k in range(2):
+        f = orc.extract(synth.scan(cfg, k), P)
+        np.ascontiguousarray(f["less_sharp"], "<f4").tofile(tmp_path / f"corner_{k}.bin")
+        np.ascontiguousarray(f["less_flat"], "<f4").tofile(tmp_path / f"surf_{k}.bin")
+        _pose7(synth.pose(cfg, k), (0.05 * k, -0.03, 0.01)).astype("<f8").tofile(tmp_path / f"odom_{k}.bin")
+    out = subprocess.run([exe, str(tmp_path), "2"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "left the failing frame together" in out.stdout
+
