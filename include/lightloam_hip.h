@@ -370,6 +370,9 @@ int ll_debug_counters(ll_ctx *ctx, unsigned long long *out16, int reset);
 /* one float4 streaming copy of `bytes` in + `bytes` out ("k_calib_copy"): the known-byte-count launch that calibrates
  * rocprofv3's FETCH_SIZE / WRITE_SIZE counters (tools/pmc_traffic.py) */
 int ll_debug_calibration_copy(ll_ctx *ctx, unsigned long long bytes);
+/* One stage's kernel(s) on their own over slots that hold what the stage reads: 0 organise, 1 pick, 2 voxel filter + lists, 3 grid tables,
+ * 4 association, 5 vote, 6 normal equations (timing probes only; LL_ERR_ARG for another stage). */
+int ll_debug_launch_stage(ll_ctx *ctx, int stage, int first, int count);
 /* The DEVICE's evaluation of the arithmetic that must equal the host libm bit for bit (scanRegistration.cpp:139, :177 call
  * atan / atan2 / sqrt of glibc), over host arrays a, b, c (n floats each; unused ones may be NULL), results in out (n x 4 B):
  *   op 0  atanf(a)                    op 1  atan2f(a, b), general path     op 2  atan2f(a, b), k_classify's fast path

@@ -22,7 +22,7 @@ EXPORTS = [
     "ll_download_features", "ll_set_target", "ll_upload_features", "ll_set_target_from_slot", "ll_associate_batch", "ll_get_pair_info",
     "ll_download_edge_corr", "ll_download_plane_corr", "ll_vote_batch", "ll_download_vote",
     "ll_normal_equations_batch", "ll_download_normal_equations", "ll_gn_step_batch", "ll_download_pose",
-    "ll_residual_jacobian", "ll_hot_path_batch", "ll_algorithmic_bytes", "ll_profile_enable", "ll_profile_read", "ll_set_pose_guess", "ll_debug_counters", "ll_vote_host", "ll_debug_calibration_copy", "ll_debug_exact_math", "ll_upload_scan_async", "ll_upload_scans_async", "ll_upload_scans_async_strided", "ll_stream_record", "ll_stream_wait", "ll_hot_path_chain", "ll_synchronize_copy", "ll_host_alloc", "ll_host_free",
+    "ll_residual_jacobian", "ll_hot_path_batch", "ll_algorithmic_bytes", "ll_profile_enable", "ll_profile_read", "ll_set_pose_guess", "ll_debug_counters", "ll_vote_host", "ll_debug_calibration_copy", "ll_debug_launch_stage", "ll_debug_exact_math", "ll_upload_scan_async", "ll_upload_scans_async", "ll_upload_scans_async_strided", "ll_stream_record", "ll_stream_wait", "ll_hot_path_chain", "ll_synchronize_copy", "ll_host_alloc", "ll_host_free",
     "ll_lm_default_options", "ll_lm_solve_batch", "ll_odometry_frames",
     "ll_map_create", "ll_map_destroy", "ll_map_last_error", "ll_map_set_map", "ll_map_set_scan", "ll_map_associate",
     "ll_map_residual_jacobian", "ll_map_get_counts", "ll_map_get_map_sizes", "ll_map_download_edges", "ll_map_download_planes", "ll_map_normal_equations", "ll_map_optimize",

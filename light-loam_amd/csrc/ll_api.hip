@@ -108,6 +108,12 @@ extern "C" int ll_create(int device, const ll_params *p, ll_ctx **out)
     ctx->p = *p; ctx->device = device;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { g_create_err = "hipStreamCreate failed"; delete ctx; return LL_ERR_DEVICE; }
     for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { g_create_err = "hipEventCreate failed"; ll_destroy(ctx); return LL_ERR_DEVICE; }
+    {   /* once per device and process: the voxel sort takes its ranks from returning LDS adds (ll_features.hip) */
+        static int order_checked[LL_MAX_DEVICES] = {0};        /* 0 not yet, 1 holds, -1 does not */
+        int &oc = order_checked[device < LL_MAX_DEVICES ? device : 0];
+        if (oc == 0 || device >= LL_MAX_DEVICES) oc = ll_lds_atomic_order_ok(ctx->stream) ? 1 : -1;
+        if (oc < 0) { g_create_err = "this device does not serve the lanes of a returning LDS add in lane order (the voxel sort depends on it)"; ll_destroy(ctx); return LL_ERR_DEVICE; }
+    }
     ctx->ev_ok = true;
 
     LLView &V = ctx->V;
@@ -1441,6 +1447,27 @@ extern "C" int ll_residual_jacobian(ll_ctx *ctx, int slot, const double *pose7, 
 __global__ void k_calib_copy(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+/* One stage's launch on its own (tools/experiments/overlap_probe.py: which kernels gain from running beside which): 0 organise, 1 pick,
+ * 2 voxel filter + lists, 3 grid tables, 4 association, 5 vote, 6 normal equations + step -- the launches of ll_hot_path_batch, one stage per call.
+ * The slots must hold what the stage reads. */
+extern "C" int ll_debug_launch_stage(ll_ctx *ctx, int stage, int first, int count)
+{
+    int rc = check_range(ctx, first, count); if (rc) return rc;
+    LL_HIP(hipSetDevice(ctx->device));
+    switch (stage) {
+    case 0: ll_launch_organize(ctx->V, first, count, ctx->stream, &ctx->prof); break;
+    case 1: ll_launch_features(ctx->V, first, count, ctx->feat_lds, ctx->stream, &ctx->prof, 1); break;
+    case 2: ll_launch_features(ctx->V, first, count, ctx->feat_lds, ctx->stream, &ctx->prof, 2); break;
+    case 3: ll_launch_build_grid(ctx->V, first, count, 0, ctx->stream, &ctx->prof); break;
+    case 4: ll_launch_associate(ctx->V, first, count, ctx->stream, &ctx->prof); break;
+    case 5: ll_launch_vote(ctx->V, first, count, 1, ctx->stream, &ctx->prof); break;
+    case 6: ll_launch_normal_equations(ctx->V, first, count, 1, ctx->stream, &ctx->prof); break;
+    default: ctx->err = "no such stage"; return LL_ERR_ARG;
+    }
+    LL_HIP(hipGetLastError());
+    return LL_OK;
 }
 
 extern "C" int ll_debug_calibration_copy(ll_ctx *ctx, unsigned long long bytes)

@@ -358,7 +358,7 @@ void ll_prof_mark(LLProfiler *p, int kernel_id, hipStream_t st);
 void ll_launch_organize(const LLView &V, int first, int count, hipStream_t st, LLProfiler *prof);
 void ll_launch_cloud_flatten(const LLView &V, int slot, float4 *dst, hipStream_t st);
 void ll_launch_lflat_flatten(const LLView &V, int slot, float4 *dst, hipStream_t st);   /* the slot's less-flat cloud, contiguous (dst: >= NP points) */
-void ll_launch_features(const LLView &V, int first, int count, size_t lds_bytes, hipStream_t st, LLProfiler *prof);
+void ll_launch_features(const LLView &V, int first, int count, size_t lds_bytes, hipStream_t st, LLProfiler *prof, int what = 3);   /* what: 1 = the pick kernel, 2 = the voxel kernel */
 void ll_launch_pick(const LLView &V, int first, int count, hipStream_t st);
 void ll_launch_associate(const LLView &V, int first, int count, hipStream_t st, LLProfiler *prof);
 void ll_launch_build_grid(const LLView &V, int first, int count, int carry, hipStream_t st, LLProfiler *prof);
@@ -368,4 +368,5 @@ void ll_launch_normal_equations(const LLView &V, int first, int count, int do_st
 void ll_launch_gn_step(const LLView &V, int first, int count, hipStream_t st, LLProfiler *prof);
 void ll_launch_rows(const LLView &V, int slot, const double *pose7_dev, double *r, double *Jq, double *Jt, hipStream_t st);
 size_t ll_features_lds_bytes(int max_ring);
+bool ll_lds_atomic_order_ok(hipStream_t st);             /* the LDS serves the lanes of one returning add in lane order (ll_features.hip: the sort's ranks) */
 void ll_launch_debug_exact_math(const LLView &V, int op, const float *a, const float *b, const float *c, int n, float *out, hipStream_t st);

@@ -49,7 +49,9 @@ struct FeatLds {
     int *lists;                /* [LL_NLIST] */
     int *cnt;                  /* [32 * ROWS * 4 + 1] radix counters */
     int *sc;                   /* [64] scan scratch [0..15], per-wave bounds [32..55] */
+    float4 *stash;             /* [LL_NSTASH] the picked points of the three small lists, entry t of each list in its owner thread's slot */
 };
+#define LL_NSTASH (LL_SEGS * (LL_SHARP_PER_SEG + LL_LSHARP_PER_SEG + LL_FLAT_PER_SEG))     /* 156 */
 
 static size_t ll_feat_rows(size_t mr) { return (mr / 256 <= 9) ? 9 : (mr / 256 <= 12) ? 12 : (mr / 256 <= 18) ? 18 : 32; }   /* the ROWS instantiation that will run */
 
@@ -62,6 +64,7 @@ size_t ll_features_lds_bytes(int max_ring)      /* max_ring: the ring capacity o
     b += 4 * (mr / 32 + 2);                  /* bitmap */
     b += 4 * LL_NLIST;
     b += 4 * 64;
+    b += 16 * LL_NSTASH;
     return (b + 15) / 16 * 16 + 64;
 }
 
@@ -71,6 +74,7 @@ __device__ __forceinline__ FeatLds ll_carve(unsigned char *base, int max_ring)
     const size_t rows = (mr / 256 <= 9) ? 9 : (mr / 256 <= 12) ? 12 : (mr / 256 <= 18) ? 18 : 32;
     FeatLds L;
     unsigned char *p = base;
+    L.stash = (float4 *)p; p += 16 * LL_NSTASH;
     L.k32 = (unsigned *)p; p += 4 * mr;
     L.cnt = (int *)p; p += 4 * (32 * rows * 4 + 4);
     L.picked = (unsigned *)p; p += 4 * (mr / 32 + 2);
@@ -118,7 +122,9 @@ __device__ __forceinline__ void ll_radix_sort(unsigned *k32, unsigned short *k16
         for (int i = tid; i < NW * ND; i += LL_BLOCK) cnt[i] = 0;
         __syncthreads();                                        /* also: every thread holds its records in registers */
         int *wc = cnt + wave * ND;                              /* this wave's counters */
-        int rnk[ROWS], pre[ROWS];
+        int rnk[ROWS];
+#ifdef LL_SORT_MATCH_ANY         /* rounds 2-5: the rank inside the row from a match-any (4 vector instructions per digit bit), the earlier rows' count by a read */
+        int pre[ROWS];
 #pragma unroll
         for (int k = 0; k < ROWS; ++k) {
             rnk[k] = 0; pre[k] = 0;
@@ -127,14 +133,24 @@ __device__ __forceinline__ void ll_radix_sort(unsigned *k32, unsigned short *k16
                 unsigned mlo, mhi;
                 ll_match_any(d, BITS, ~0ull, mlo, mhi);
                 rnk[k] = ll_match_rank(mlo, mhi);
-                pre[k] = __hip_atomic_load(&wc[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   /* records of the earlier rows of this wave with digit d ... (an
-                                                                                 * atomic load: it must see the rows' adds, whatever the compiler would like to merge) */
-                if (rnk[k] == 0) atomicAdd(&wc[d], ll_match_count(mlo, mhi));   /* ... bumped by an LDS add that does not wait for the read:
-                                                                                 * the wave's LDS operations execute in order, so the next row's read sees it */
+                pre[k] = __hip_atomic_load(&wc[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (rnk[k] == 0) atomicAdd(&wc[d], ll_match_count(mlo, mhi));
             }
         }
 #pragma unroll
         for (int k = 0; k < ROWS; ++k) rnk[k] += pre[k];
+#else
+        /* ONE returning LDS add per row: the value that comes back is (records of this wave's earlier rows with digit d) + (lower lanes of
+         * this row with digit d) -- a wave's LDS instructions execute in order, and the lanes of one ds_add_rtn that hit the same counter
+         * are served in ascending lane order.  The ISA manual does not promise the second; ll_create checks it on the device
+         * (ll_lds_atomic_order_ok, tools/ubench/lds_atomic_order.hip: 9.4e8 lanes, none out of order) and refuses a device where it
+         * does not hold.  The nine adds of a thread go out back to back and are waited for once, behind the counter scan. */
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) {
+            rnk[k] = 0;
+            if (k < myrows) rnk[k] = __hip_atomic_fetch_add(&wc[(int)((e32[k] >> sh) & DM)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+#endif
         __syncthreads();
         {   /* exclusive scan of the (digit, wave) table in digit-major order: thread d owns digit d */
             int v[NW]; int s = 0;
@@ -171,6 +187,47 @@ __device__ __forceinline__ void ll_radix_sort(unsigned *k32, unsigned short *k16
         else pass(std::integral_constant<int, 8>{}, sh);
         sh += bits; rem -= bits;
     }
+}
+
+/* The property the sort's ranks rest on, checked once per device by ll_create: within one returning LDS add, lanes that hit the same counter get
+ * their values in ascending lane order (and a later instruction of the wave sees the earlier one's adds).  Digit patterns: uniform over 2^b
+ * values, b = 0..8, as they lie and scattered over the lanes.  out[0] += lanes that disagreed with a match-any count. */
+__global__ __launch_bounds__(256) void k_lds_atomic_order(int iters, unsigned *out)
+{
+    __shared__ int cnt[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned s = 0x9E3779B9u * (blockIdx.x * 256 + threadIdx.x + 1);
+    auto rnd = [&]() { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; };
+    unsigned bad = 0;
+    for (int it = 0; it < iters; ++it) {
+        const int b = it % 9;
+        int d = (int)(rnd() & ((1u << b) - 1u));
+        if (it & 1) d = __shfl(d, (lane * 7 + it) & 63);
+        const int d2 = (int)(rnd() & ((1u << b) - 1u));
+        for (int i = lane; i < 256; i += 64) cnt[wave][i] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int got = __hip_atomic_fetch_add(&cnt[wave][d], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int got2 = __hip_atomic_fetch_add(&cnt[wave][d2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        unsigned mlo, mhi;
+        ll_match_any(d, 8, ~0ull, mlo, mhi);
+        const int want = ll_match_rank(mlo, mhi);
+        int want2 = 0;
+        for (int l = 0; l < 64; ++l) { const int dl = __shfl(d, l), dl2 = __shfl(d2, l); want2 += (dl == d2) + (l < lane && dl2 == d2); }
+        bad += (got != want) + (got2 != want2);
+    }
+    if (bad) atomicAdd(out, bad);
+}
+bool ll_lds_atomic_order_ok(hipStream_t st)
+{
+    unsigned *d = nullptr, h = 1;
+    if (hipMalloc(&d, sizeof(unsigned)) != hipSuccess) return false;
+    bool ok = hipMemsetAsync(d, 0, sizeof(unsigned), st) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(k_lds_atomic_order, dim3(256), dim3(256), 0, st, 90, d);
+        ok = hipMemcpyAsync(&h, d, sizeof(unsigned), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess && h == 0;
+    }
+    (void)hipFree(d);
+    return ok;
 }
 
 __device__ __forceinline__ bool ll_bit(const unsigned *bm, int i) { return (bm[i >> 5] >> (i & 31)) & 1u; }
@@ -233,9 +290,9 @@ __device__ __forceinline__ void ll_ring_features_ring(const LLView &V, int s, in
     }
     __syncthreads();
 
-    /* the picked points of the per-segment lists: thread t holds the local index of entry t of each list and its position
+    /* the picked points of the per-segment lists: thread t owns entry t of each list; its position
      * (segment, pick order) among the ring's sharp / less-sharp / flat points, -1 = no entry */
-    int fsrc0 = 0, fsrc1 = 0, fsrc2 = 0; int fpos[3] = {-1, -1, -1};
+    int fpos[3] = {-1, -1, -1};
     auto gather_lists = [&]() __attribute__((always_inline)) {
         const int js = tid / LL_SHARP_PER_SEG, jl = tid / LL_LSHARP_PER_SEG, jf = tid / LL_FLAT_PER_SEG;
         int os = 0, ol = 0, of = 0;
@@ -244,9 +301,9 @@ __device__ __forceinline__ void ll_ring_features_ring(const LLView &V, int s, in
             if (j < jl) ol += L.lists[157 + j * 3];
             if (j < jf) of += L.lists[158 + j * 3];
         }
-        if (js < LL_SEGS && tid % LL_SHARP_PER_SEG < L.lists[156 + js * 3]) { fpos[0] = os + tid % LL_SHARP_PER_SEG; fsrc0 = L.lists[tid]; }
-        if (jl < LL_SEGS && tid % LL_LSHARP_PER_SEG < L.lists[157 + jl * 3]) { fpos[1] = ol + tid % LL_LSHARP_PER_SEG; fsrc1 = L.lists[12 + tid]; }
-        if (jf < LL_SEGS && tid % LL_FLAT_PER_SEG < L.lists[158 + jf * 3]) { fpos[2] = of + tid % LL_FLAT_PER_SEG; fsrc2 = L.lists[132 + tid]; }
+        if (js < LL_SEGS && tid % LL_SHARP_PER_SEG < L.lists[156 + js * 3]) fpos[0] = os + tid % LL_SHARP_PER_SEG;
+        if (jl < LL_SEGS && tid % LL_LSHARP_PER_SEG < L.lists[157 + jl * 3]) fpos[1] = ol + tid % LL_LSHARP_PER_SEG;
+        if (jf < LL_SEGS && tid % LL_FLAT_PER_SEG < L.lists[158 + jf * 3]) fpos[2] = of + tid % LL_FLAT_PER_SEG;
     };
     /* this ring's offsets in sharp / less-sharp / flat: the sums of the earlier rings' counts (no waiting: cnt_raw came in with the header) */
     int roff[3] = {0, 0, 0};
@@ -272,19 +329,35 @@ __device__ __forceinline__ void ll_ring_features_ring(const LLView &V, int s, in
             /* The segment points go to the sort as they lie, in the sort's own (wave, row, lane) order -- coalesced rows, no compaction
              * scan, no trip through LDS: a less-sharp pick (not less-flat, :361-367) just carries the all-ones key that the padding
              * of the last row carries and ends up behind the m real records. */
-            const int nrows_w = (Lseg + LL_BLOCK - 1) / LL_BLOCK;                  /* rows per wave, uniform */
+            /* Record g IS the ring's point g (local index): the five points in front of the first segment are records that never become
+             * less-flat.  A wave's load instruction then covers 64 points from a multiple of 64 = eight whole 128-byte lines; with the
+             * records starting at the first segment point (80 bytes into a line) every instruction straddled a ninth line that the next
+             * one asked for again -- and this chip's L2 sends EVERY request for a line that is still on its way across the fabric
+             * (profiles/r05_fetch_granule.txt): 14 % more lines fetched than the ring has. */
+            const int nrec = Lseg + 5;
+            const int nrows_w = (nrec + LL_BLOCK - 1) / LL_BLOCK;                   /* rows per wave, uniform */
             const int wbase = __builtin_amdgcn_readfirstlane(tid >> 6) * nrows_w * 64;
             float px[ROWS], py[ROWS], pz[ROWS];
             unsigned mem = 0;                                                        /* bit k: record wbase + k * 64 + lane is less-flat */
 #pragma unroll
             for (int k = 0; k < ROWS; ++k) {
                 const int g = wbase + k * 64 + lane;
-                if (k < nrows_w && g < Lseg) {
-                    const float4 p = cloud[off + g + 5];
+                if (k < nrows_w && g >= 5 && g < nrec) {
+                    const float4 p = cloud[off + g];
                     px[k] = p.x; py[k] = p.y; pz[k] = p.z;
-                    if (!ll_bit(L.picked, g + 5)) mem |= 1u << k;
+                    if (!ll_bit(L.picked, g)) mem |= 1u << k;
                 }
             }
+            /* The picked points of the three small lists are fetched HERE, behind the row's own loads: their lines are on their way into the
+             * L2 (every pick is a segment point) -- at the end of the workgroup, ~20 us later, half of them had left it again and came
+             * over the fabric a third time.  Entry t of each list belongs to thread t from here to its store: parked in LDS meanwhile. */
+            const bool hv0 = tid < LL_SEGS * LL_SHARP_PER_SEG && tid % LL_SHARP_PER_SEG < L.lists[156 + (tid / LL_SHARP_PER_SEG) * 3];
+            const bool hv1 = tid < LL_SEGS * LL_LSHARP_PER_SEG && tid % LL_LSHARP_PER_SEG < L.lists[157 + (tid / LL_LSHARP_PER_SEG) * 3];
+            const bool hv2 = tid < LL_SEGS * LL_FLAT_PER_SEG && tid % LL_FLAT_PER_SEG < L.lists[158 + (tid / LL_FLAT_PER_SEG) * 3];
+            float4 q0, q1, q2;
+            if (hv0) q0 = cloud[off + L.lists[tid]];
+            if (hv1) q1 = cloud[off + L.lists[12 + tid]];
+            if (hv2) q2 = cloud[off + L.lists[132 + tid]];
             float mnx = INFINITY, mny = INFINITY, mnz = INFINITY, mxx = -INFINITY, mxy = -INFINITY, mxz = -INFINITY;
 #pragma unroll
             for (int k = 0; k < ROWS; ++k)
@@ -295,6 +368,9 @@ __device__ __forceinline__ void ll_ring_features_ring(const LLView &V, int s, in
             mnx = ll_wave_min_f32(mnx); mny = ll_wave_min_f32(mny); mnz = ll_wave_min_f32(mnz);
             mxx = ll_wave_max_f32(mxx); mxy = ll_wave_max_f32(mxy); mxz = ll_wave_max_f32(mxz);
             if (lane == 0) { float *w = fs + (tid >> 6) * 6; w[0] = mnx; w[1] = mny; w[2] = mnz; w[3] = mxx; w[4] = mxy; w[5] = mxz; }
+            if (hv0) L.stash[tid] = q0;
+            if (hv1) L.stash[12 + tid] = q1;
+            if (hv2) L.stash[132 + tid] = q2;
             { int nls_ = 0; for (int j = 0; j < LL_SEGS; ++j) nls_ += L.lists[157 + j * 3]; m = Lseg - nls_; }   /* every pick is a segment point */
             __syncthreads();
             float mn[3] = {fs[0], fs[1], fs[2]}, mx[3] = {fs[3], fs[4], fs[5]};
@@ -345,11 +421,11 @@ __device__ __forceinline__ void ll_ring_features_ring(const LLView &V, int s, in
                             const int i2 = (int)(floorf(pz[k] * inv) - fb2);
                             e32[k] = (unsigned)(i0 + i1 * mul1 + i2 * mul2);
                         }
-                        e16[k] = (unsigned short)(wbase + k * 64 + lane + 5);       /* payload: local index */
+                        e16[k] = (unsigned short)(wbase + k * 64 + lane);           /* payload: local index */
                     }
                 }
                 LL_PHASE(3);
-                ll_radix_sort<ROWS, true>(L.k32, L.k16, Lseg, key_bits, L.cnt, L.sc, tid, e32, e16);
+                ll_radix_sort<ROWS, true>(L.k32, L.k16, nrec, key_bits, L.cnt, L.sc, tid, e32, e16);
                 LL_PHASE(4);
                 __syncthreads();
                 sorted_ok = true;
@@ -411,19 +487,32 @@ __device__ __forceinline__ void ll_ring_features_ring(const LLView &V, int s, in
                         if (cn && u < c_n) { sx += qx; sy += qy; sz += qz; si += qw; ++cn; }
                     }
 #undef LL_SHL1
+                /* the centroids of the runs that ended inside the range leave now, in voxel order, for the ring's own row (:376: lessFlatScanDS
+                 * appended ring after ring): their registers are free for the points the open run still has to fetch */
+#pragma unroll
+                for (int u = 0; u < ROWS; ++u) if (u < perm && ((endm >> u) & 1u)) out[o++] = pt[u];
                 float4 last = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 if (cn) {
+                    /* four at a time: the keys and indices of the next four sorted places (LDS), the points of those that still belong to
+                     * the run requested TOGETHER, added in order.  (One by one, each point was a dependent LDS -> memory round trip; a ring
+                     * that sweeps the ground close to the sensor puts ten points into a voxel, its runs span several threads, and the
+                     * workgroup waited at the next barrier for the longest of these chains: a fifth of its time.) */
                     const unsigned vid = L.k32[b1 - 1];
-                    for (int e = b1 + c_n; e < m && L.k32[e] == vid; ++e) {
-                        const float4 q = cloud[off + L.k16[e]];
-                        sx += q.x; sy += q.y; sz += q.z; si += q.w; ++cn;
+                    for (int e = b1 + c_n; e < m; e += 4) {
+                        unsigned kk[4]; int ii[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { kk[u] = (e + u < m) ? L.k32[e + u] : ~vid; ii[u] = (e + u < m) ? (int)L.k16[e + u] : 0; }
+                        const int n = (kk[0] != vid) ? 0 : (kk[1] != vid) ? 1 : (kk[2] != vid) ? 2 : (kk[3] != vid) ? 3 : 4;
+                        float4 q[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) if (u < n) q[u] = cloud[off + ii[u]];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) if (u < n) { sx += q[u].x; sy += q[u].y; sz += q[u].z; si += q[u].w; ++cn; }
+                        if (n < 4) break;
                     }
                     const float fn = (float)cn; last = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
                 }
                 LL_PHASE(5);
-                /* the centroids, in voxel order, into the ring's own row (:376: lessFlatScanDS appended ring after ring) */
-#pragma unroll
-                for (int u = 0; u < ROWS; ++u) if (u < perm && ((endm >> u) & 1u)) out[o++] = pt[u];
                 if (cn) out[o] = last;
                 gather_lists(); small_offsets();
                 offsets_done = true;
@@ -435,14 +524,10 @@ __device__ __forceinline__ void ll_ring_features_ring(const LLView &V, int s, in
 
     /* ---------------- the three small lists -> the published clouds at this ring's offsets, in (segment, pick order) ---------------- */
     if (!offsets_done) { gather_lists(); small_offsets(); }              /* rings without a less-flat point */
-    {   /* the three loads together, then the three stores */
-        float4 p0, p1, p2;
-        if (fpos[0] >= 0) p0 = cloud[off + fsrc0];
-        if (fpos[1] >= 0) p1 = cloud[off + fsrc1];
-        if (fpos[2] >= 0) p2 = cloud[off + fsrc2];
-        if (fpos[0] >= 0) V.sharp[(size_t)s * V.cap_sharp + roff[0] + fpos[0]] = p0;
-        if (fpos[1] >= 0) V.lsharp[(size_t)s * V.cap_lsharp + roff[1] + fpos[1]] = p1;
-        if (fpos[2] >= 0) V.flat[(size_t)s * V.cap_flat + roff[2] + fpos[2]] = p2;
+    {   /* the points were parked in LDS by this thread when the ring was read (a list has entries only where the ring has a segment) */
+        if (fpos[0] >= 0) V.sharp[(size_t)s * V.cap_sharp + roff[0] + fpos[0]] = L.stash[tid];
+        if (fpos[1] >= 0) V.lsharp[(size_t)s * V.cap_lsharp + roff[1] + fpos[1]] = L.stash[12 + tid];
+        if (fpos[2] >= 0) V.flat[(size_t)s * V.cap_flat + roff[2] + fpos[2]] = L.stash[132 + tid];
     }
     LL_PHASE(6);
 #ifdef LL_PHASE_TIMING
@@ -485,13 +570,16 @@ static void ll_launch_ring_features(const LLView &V, int first, int count, int g
     hipLaunchKernelGGL((k_ring_features<ROWS>), dim3(grid), dim3(LL_BLOCK), lds_bytes, st, V, first, count, ring_lo, ring_hi, list, list_n);
 }
 
-void ll_launch_features(const LLView &V, int first, int count, size_t /* LDS of the largest tier: checked by ll_create */, hipStream_t st, LLProfiler *prof)
+void ll_launch_features(const LLView &V, int first, int count, size_t /* LDS of the largest tier: checked by ll_create */, hipStream_t st, LLProfiler *prof, int what)
 {
     const int groups = (count + 7) / 8;
     const int grid = 8 * V.R * groups;
     const int cap = (V.max_ring + 255) / 256 * 256;
-    ll_prof_mark(prof, LL_K_PICK, st);
-    ll_launch_pick(V, first, count, st);
+    if (what & 1) {
+        ll_prof_mark(prof, LL_K_PICK, st);
+        ll_launch_pick(V, first, count, st);
+    }
+    if (!(what & 2)) { ll_prof_mark(prof, LL_K_END, st); return; }
     ll_prof_mark(prof, LL_K_RING_FEATURES, st);
     /* one launch per capacity tier; every ring is worked on by exactly one of them, none waits for another */
     if (cap > 4608) ll_launch_ring_features<32>(V, first, count, grid, 4608, cap, 3, 1, st);   /* <= 8192 points: the per-thread row masks are 32 bits wide */
