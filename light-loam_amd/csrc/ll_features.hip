@@ -115,55 +115,50 @@ __device__ __forceinline__ void ll_radix_sort(unsigned *k32, unsigned short *k16
     }
     if (key_bits <= 0) return;                                  /* one voxel (or none): already in order */
     const int lo = 0, hi = key_bits;                            /* the caller's bound on the keys: no reduction over them to find the varying bits */
+    /* Wave-private counters at a fixed stride of 256, zero whenever a pass begins: a wave clears its own table (before the first pass, and behind
+     * its own scatter in every pass -- its LDS instructions execute in order, nobody else touches the table then). */
+    int *wc = cnt + wave * 256;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wc[j * 64 + lane] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     auto pass = [&](auto bits_tag, int sh) __attribute__((always_inline)) {
         constexpr int BITS = decltype(bits_tag)::value;
         constexpr int ND = 1 << BITS;
         constexpr unsigned DM = (unsigned)ND - 1u;
-        for (int i = tid; i < NW * ND; i += LL_BLOCK) cnt[i] = 0;
-        __syncthreads();                                        /* also: every thread holds its records in registers */
-        int *wc = cnt + wave * ND;                              /* this wave's counters */
+        constexpr int NJ = (ND + 63) / 64;                      /* digits per lane */
         int rnk[ROWS];
-#ifdef LL_SORT_MATCH_ANY         /* rounds 2-5: the rank inside the row from a match-any (4 vector instructions per digit bit), the earlier rows' count by a read */
-        int pre[ROWS];
-#pragma unroll
-        for (int k = 0; k < ROWS; ++k) {
-            rnk[k] = 0; pre[k] = 0;
-            if (k < myrows) {
-                const int d = (int)((e32[k] >> sh) & DM);
-                unsigned mlo, mhi;
-                ll_match_any(d, BITS, ~0ull, mlo, mhi);
-                rnk[k] = ll_match_rank(mlo, mhi);
-                pre[k] = __hip_atomic_load(&wc[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (rnk[k] == 0) atomicAdd(&wc[d], ll_match_count(mlo, mhi));
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < ROWS; ++k) rnk[k] += pre[k];
-#else
         /* ONE returning LDS add per row: the value that comes back is (records of this wave's earlier rows with digit d) + (lower lanes of
          * this row with digit d) -- a wave's LDS instructions execute in order, and the lanes of one ds_add_rtn that hit the same counter
          * are served in ascending lane order.  The ISA manual does not promise the second; ll_create checks it on the device
          * (ll_lds_atomic_order_ok, tools/ubench/lds_atomic_order.hip: 9.4e8 lanes, none out of order) and refuses a device where it
-         * does not hold.  The nine adds of a thread go out back to back and are waited for once, behind the counter scan. */
+         * does not hold.  The nine adds of a thread go out back to back and are waited for once, behind the counter scan.
+         * (Rounds 2-5 took the rank from a match-any, four vector instructions per digit bit and row: a third of the kernel's vector work.) */
 #pragma unroll
         for (int k = 0; k < ROWS; ++k) {
             rnk[k] = 0;
             if (k < myrows) rnk[k] = __hip_atomic_fetch_add(&wc[(int)((e32[k] >> sh) & DM)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-#endif
-        __syncthreads();
-        {   /* exclusive scan of the (digit, wave) table in digit-major order: thread d owns digit d */
-            int v[NW]; int s = 0;
+        __syncthreads();                                        /* every wave's counts are complete */
+        /* Every wave works out the bases of ITS OWN counters by itself -- exclusive scan over the (digit, wave) table in digit-major order;
+         * lane l holds the digits l, l + 64, ... -- instead of one workgroup-wide scan (three barriers, two trips through LDS). */
+        int own[NJ];
+        {
+            int carry = 0;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) { v[w] = (tid < ND) ? cnt[w * ND + tid] : 0; s += v[w]; }
-            int total;
-            int run = ll_block_exscan(s, sc, total);
-            if (tid < ND) {
+            for (int j = 0; j < NJ; ++j) {
+                const int d = j * 64 + lane;
+                int tot = 0, below = 0;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) { cnt[w * ND + tid] = run; run += v[w]; }
+                for (int w = 0; w < NW; ++w) { const int c = (d < ND) ? cnt[w * 256 + d] : 0; tot += c; below += (w < wave) ? c : 0; }
+                const int inc = ll_wave_incl_scan(tot);
+                own[j] = carry + inc - tot + below;
+                carry += __builtin_amdgcn_readlane(inc, 63);
             }
         }
-        __syncthreads();
+        __syncthreads();                                        /* every wave has read the counts: the bases may overwrite them */
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) if (j * 64 + lane < ND) wc[j * 64 + lane] = own[j];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
         for (int k = 0; k < ROWS; ++k) {
             if (k < myrows) {
@@ -172,6 +167,9 @@ __device__ __forceinline__ void ll_radix_sort(unsigned *k32, unsigned short *k16
                 k32[pos] = e32[k]; k16[pos] = e16[k];
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) if (j * 64 + lane < ND) wc[j * 64 + lane] = 0;       /* ready for the next pass */
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < ROWS; ++k) {
@@ -256,11 +254,12 @@ __device__ __forceinline__ void ll_ring_features_ring(const LLView &V, int s, in
     static_assert(ROWS <= 32, "headm / endm hold one bit per row of a thread");
     const int tid = threadIdx.x, lane = tid & 63;
     /* Everything the set-up needs from memory depends on (slot, ring) only: the earlier rings' pick counts (k_ring_pick's ring_cnt:
-     * complete, that launch is over -- thread q holds ring q's; their sums over q < r are this ring's offsets in the three contiguous
+     * complete, that launch is over -- in every wave lane q holds ring q's; their sums over q < r are this ring's offsets in the three contiguous
      * small clouds: scanRegistration.cpp:273-279, :325), this ring's lists, the header's status and the ring's two offsets.  All of it
      * is requested before anything is waited for, and the three exits are ONE test -- as separate tests each exit put a memory round
      * trip of its own in front of the next load (four dependent trips at the head of a 23 us workgroup). */
-    const unsigned cnt_raw = tid < r ? V.ring_cnt[(size_t)s * V.R + tid] : 0u;
+    const unsigned cnt_raw0 = lane < r ? V.ring_cnt[(size_t)s * V.R + lane] : 0u;          /* every wave holds all the rings' counts: lane q has ring q's */
+    const unsigned cnt_raw1 = lane + 64 < r ? V.ring_cnt[(size_t)s * V.R + lane + 64] : 0u;  /* ... and ring q + 64's (LL_MAX_RINGS = 128) */
     const unsigned short *rec = V.ring_rec + ((size_t)s * V.R + r) * LL_REC_U16;
     const unsigned short rec_v = tid < 174 ? rec[tid] : (unsigned short)0;
     const int status = V.hdr[s].status;
@@ -276,13 +275,11 @@ __device__ __forceinline__ void ll_ring_features_ring(const LLView &V, int s, in
     const float4 *cloud = V.cloud + (size_t)s * V.CS + (size_t)r * V.ring_cap - off;          /* cloud[off + li] = the ring's point li */
     FeatLds L = ll_carve(ll_smem, ring_hi);
     float *fs = (float *)(L.sc + 32);                                 /* 24 floats: per-wave bounds */
-    const int nwords = (nr + 31) / 32 + 1;
-    for (int i = tid; i < nwords; i += LL_BLOCK) L.picked[i] = 0;
-
     LL_PHASE_BEGIN();
     /* the pick's lists of this ring: local indices + per-segment counts -> L.lists; the less-sharp picks (label 1 / 2) -> bitmap:
      * less-flat = every segment point that is not one of them (:361-367) */
     if (tid < 174) L.lists[tid] = (int)rec_v;
+    { const int nwords = (nr + 31) / 32 + 1; for (int i = tid; i < nwords; i += LL_BLOCK) L.picked[i] = 0; }
     __syncthreads();
     if (tid < LL_SEGS * LL_LSHARP_PER_SEG && tid % LL_LSHARP_PER_SEG < L.lists[157 + (tid / LL_LSHARP_PER_SEG) * 3]) {
         const int li = L.lists[12 + tid];
@@ -305,17 +302,14 @@ __device__ __forceinline__ void ll_ring_features_ring(const LLView &V, int s, in
         if (jl < LL_SEGS && tid % LL_LSHARP_PER_SEG < L.lists[157 + jl * 3]) fpos[1] = ol + tid % LL_LSHARP_PER_SEG;
         if (jf < LL_SEGS && tid % LL_FLAT_PER_SEG < L.lists[158 + jf * 3]) fpos[2] = of + tid % LL_FLAT_PER_SEG;
     };
-    /* this ring's offsets in sharp / less-sharp / flat: the sums of the earlier rings' counts (no waiting: cnt_raw came in with the header) */
+    /* this ring's offsets in sharp / less-sharp / flat: the sums of the earlier rings' counts (no waiting: the counts came in with the header) */
     int roff[3] = {0, 0, 0};
     auto small_offsets = [&]() __attribute__((always_inline)) {
-        int v[3] = {(int)(cnt_raw & 0xffu), (int)((cnt_raw >> 8) & 0xffu), (int)((cnt_raw >> 16) & 0xffu)};
+        static_assert(LL_MAX_RINGS <= 128, "two counts per lane");
+        int v[3] = {(int)(cnt_raw0 & 0xffu) + (int)(cnt_raw1 & 0xffu), (int)((cnt_raw0 >> 8) & 0xffu) + (int)((cnt_raw1 >> 8) & 0xffu),
+                    (int)((cnt_raw0 >> 16) & 0xffu) + (int)((cnt_raw1 >> 16) & 0xffu)};
 #pragma unroll
-        for (int c = 0; c < 3; ++c) v[c] = ll_wave_sum_i32(v[c]);
-        __syncthreads();
-        if (lane == 0) for (int c = 0; c < 3; ++c) L.sc[32 + (tid >> 6) * 4 + c] = v[c];
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { int t = 0; for (int w = 0; w < LL_BLOCK / 64; ++w) t += L.sc[32 + w * 4 + c]; roff[c] = t; }
+        for (int c = 0; c < 3; ++c) roff[c] = ll_wave_sum_i32(v[c]);      /* a wave-wide sum in every wave: no barrier, no LDS */
     };
 
     /* ---------------- VoxelGrid of the less-flat points (:361-376) ---------------- */
@@ -451,7 +445,19 @@ __device__ __forceinline__ void ll_ring_features_ring(const LLView &V, int s, in
                         prev = vk[u]; has_prev = true;
                     }
             }
-            int o = ll_block_exscan(__popc(headm), L.sc, n_lf_out);
+            /* places of the thread's centroids in the ring's row: prefix over the run heads (wave scan + the earlier waves' totals through slots
+             * of their own, written here and nowhere else: one barrier, none behind the reads) */
+            int o;
+            {
+                const int nh = __popc(headm), inc = ll_wave_incl_scan(nh);
+                const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+                if (lane == 63) L.sc[20 + wv] = inc;
+                __syncthreads();
+                int before = 0, tot = 0;
+#pragma unroll
+                for (int w = 0; w < LL_BLOCK / 64; ++w) { const int t = L.sc[20 + w]; before += (w < wv) ? t : 0; tot += t; }
+                o = before + inc - nh; n_lf_out = tot;
+            }
             LL_PHASE(12);
             /* CentroidPoint<PointXYZI>: f32 sums from zero in input order, divided by float(n).  A run that ends inside the
              * thread's range leaves its centroid in the registers of its last point (bit u of endm) */
