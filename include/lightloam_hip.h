@@ -91,6 +91,9 @@ typedef struct {
 
 /* ---------------------------------------------------------------- lifecycle */
 void        ll_default_params(ll_params *p, int n_scans);
+/* ll_create: LL_ERR_ARG for parameters outside their ranges, LL_ERR_DEVICE when `device` is no usable gfx950 device -- the library has no CPU path
+ * -- or fails the one-off check of a hardware behaviour the voxel filter's sort relies on (the lanes of one returning LDS add are served in lane
+ * order: ll_features.hip), LL_ERR_HIP when an allocation fails; ll_last_error(NULL) says which. */
 int         ll_create(int device, const ll_params *p, ll_ctx **out);
 void        ll_destroy(ll_ctx *ctx);
 const char *ll_last_error(const ll_ctx *ctx);      /* ctx may be NULL: last create error */

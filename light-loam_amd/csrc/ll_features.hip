@@ -6,12 +6,16 @@
  * One 256-thread workgroup per (scan, ring):
  *   lists    the pick's lists of this ring -> LDS; the less-sharp picks (label 1 / 2) -> a bitmap: less-flat = every segment point that
  *            is not one of them (:361-367)
- *   keys     the segment points are loaded in the sort's own (wave, row, lane) order -- coalesced rows, no compaction scan; bounding box,
- *            PCL's voxel index (a pick carries the all-ones key of the last row's padding and sorts behind the real records)
- *   sort     stable LSD radix sort by (voxel, input order): ceil(bits / 8) passes of 5..8-bit digits, wave-private counters, rank inside
- *            a row by a v_bitop3 match-any
+ *   keys     the ring's points are loaded in the sort's own (wave, row, lane) order, record g = point g: every load instruction covers
+ *            eight whole 128-byte lines, no compaction scan; the picked points of the three small lists are fetched right behind them
+ *            and parked in LDS; bounding box, PCL's voxel index (a pick, and the five points in front of the first segment, carry the
+ *            all-ones key of the last row's padding and sort behind the real records)
+ *   sort     stable LSD radix sort by (voxel, input order): ceil(bits / 8) passes of 5..8-bit digits; wave-private counters; a record's
+ *            rank = what one returning LDS add per row hands back (lane order of such an add: checked on the device by ll_create);
+ *            every wave scans the bases of its own counters; three barriers per pass
  *   sums     voxel runs summed left to right in f32 by the thread that owns the run head (PCL sorts by voxel only; oracle and HIP path
- *            define input order inside a voxel), continued from the next lane by a one-lane wave shift, / float(n)
+ *            define input order inside a voxel), continued from the next lane by a one-lane wave shift and beyond it from the cloud,
+ *            four points at a time, / float(n)
  *   outputs  NO hand-over between the rings of a scan (rounds 1-4 passed the rings' counts forward through a decoupled look-back:
  *            polling, an in-order-dispatch assumption, a time-out status).  The less-flat centroids go to the ring's OWN row of the
  *            ring-strided cloud -- lflat[slot][ring][ring_cap] -- with the count in ring_nlf[slot][ring]; the three small lists go to
@@ -20,7 +24,7 @@
  *            into the prefix table lf_pre and the scan's totals; readers of the less-flat cloud address it as (ring, place in the
  *            ring) -- see ll_common.h "feature cloud layout".
  * Capacity tiers (ll_launch_features): rings of at most 2304 points -- every ring of a 2048-column sensor -- run the 9-row instantiation
- * at six workgroups per CU whatever max_ring_points is; longer rings (a real HDL-64E under the linear 64-ring model puts two lasers
+ * at seven workgroups per CU whatever max_ring_points is; longer rings (a real HDL-64E under the linear 64-ring model puts two lasers
  * into some bins) run in the 12- / 18- / 32-row instantiations.  With no hand-over the tiers are independent launches in any order.
  * HBM traffic per ring point: 16 B read (+ the gather's second read behind the sort), 16 B per feature written.
  */
@@ -37,8 +41,8 @@ __device__ __forceinline__ bool ll_xcd_map2(int id, int per_scan, int count, int
 }
 
 #ifndef LL_FWAVES_SPLIT
-#define LL_FWAVES_SPLIT 7     /* workgroups per CU (= waves per SIMD) of the 9-row instantiation: 71 registers since the look-back left (80 with 23
-                               * of them spilled before), so seven fit without scratch: 15.1 ms per 16384 scans against 15.7 at six */
+#define LL_FWAVES_SPLIT 7     /* workgroups per CU (= waves per SIMD) of the 9-row instantiation: 66 registers, no scratch, 19-22 KB of LDS.  Six are
+                               * 4 % slower, eight (64 registers, fits at the S64 capacity) 3 % slower: DESIGN.md 14.7 */
 #endif
 #define LL_NLIST 176      /* per segment slots: sharp[6][2] lsharp[6][20] flat[6][4] + counters[6][3] */
 
@@ -47,20 +51,18 @@ struct FeatLds {
     unsigned short *k16;       /* [mr] sort payload (local index) */
     unsigned *picked;          /* bitmap over local index: the less-sharp picks */
     int *lists;                /* [LL_NLIST] */
-    int *cnt;                  /* [32 * ROWS * 4 + 1] radix counters */
-    int *sc;                   /* [64] scan scratch [0..15], per-wave bounds [32..55] */
+    int *cnt;                  /* [4 waves][256] radix counters */
+    int *sc;                   /* [64] scan scratch [0..15], the waves' run-head totals [20..23], per-wave bounds [32..55] */
     float4 *stash;             /* [LL_NSTASH] the picked points of the three small lists, entry t of each list in its owner thread's slot */
 };
 #define LL_NSTASH (LL_SEGS * (LL_SHARP_PER_SEG + LL_LSHARP_PER_SEG + LL_FLAT_PER_SEG))     /* 156 */
 
-static size_t ll_feat_rows(size_t mr) { return (mr / 256 <= 9) ? 9 : (mr / 256 <= 12) ? 12 : (mr / 256 <= 18) ? 18 : 32; }   /* the ROWS instantiation that will run */
 
 size_t ll_features_lds_bytes(int max_ring)      /* max_ring: the ring capacity of the LAUNCH (a tier of ll_launch_features) */
 {
     const size_t mr = (size_t)((max_ring + 255) / 256 * 256);
-    const size_t rows = ll_feat_rows(mr);
     size_t b = 4 * mr + 2 * mr;              /* k32 + k16 */
-    b += 4 * (32 * rows * 4 + 4);            /* radix counters */
+    b += 4 * (LL_BLOCK / 64 * 256 + 4);      /* radix counters */
     b += 4 * (mr / 32 + 2);                  /* bitmap */
     b += 4 * LL_NLIST;
     b += 4 * 64;
@@ -71,12 +73,11 @@ size_t ll_features_lds_bytes(int max_ring)      /* max_ring: the ring capacity o
 __device__ __forceinline__ FeatLds ll_carve(unsigned char *base, int max_ring)
 {
     const size_t mr = (size_t)((max_ring + 255) / 256 * 256);
-    const size_t rows = (mr / 256 <= 9) ? 9 : (mr / 256 <= 12) ? 12 : (mr / 256 <= 18) ? 18 : 32;
     FeatLds L;
     unsigned char *p = base;
     L.stash = (float4 *)p; p += 16 * LL_NSTASH;
     L.k32 = (unsigned *)p; p += 4 * mr;
-    L.cnt = (int *)p; p += 4 * (32 * rows * 4 + 4);
+    L.cnt = (int *)p; p += 4 * (LL_BLOCK / 64 * 256 + 4);
     L.picked = (unsigned *)p; p += 4 * (mr / 32 + 2);
     L.lists = (int *)p; p += 4 * LL_NLIST;
     L.sc = (int *)p; p += 4 * 64;
@@ -88,16 +89,17 @@ __device__ __forceinline__ FeatLds ll_carve(unsigned char *base, int max_ring)
  * Record g lives in wave g / (64 * nrows), row (g / 64) % nrows, lane g % 64 (nrows = rows per wave), so that the order
  * (wave, row, lane) is the input order.  Its destination is
  *   #(records with a smaller digit) + #(same digit, earlier wave) + #(same digit, same wave, earlier row) + rank in its row:
- * every wave counts into its own 2^BITS counters, one row after the other (a wave's LDS operations execute in order, so
- * the counter a row reads already holds the rows before it), the rank inside the row comes from a wave match-any, and one
- * workgroup exclusive scan over the digit-major (digit, wave) table turns the counters into bases.  Wave-private counters
- * make the table small enough for digits of up to 8 bits: the keys are below 2^key_bits (the caller knows: the voxel grid's
+ * every wave counts into its own 2^BITS counters with ONE returning LDS add per row (a wave's LDS operations execute in order, so
+ * the value a row gets back holds the rows before it, and the lanes of one add that hit the same counter are served in lane order:
+ * the value is also the rank inside the row), and every wave turns the counters of the digit-major (digit, wave) table into the
+ * bases of its OWN counters by an exclusive scan it does alone.  Wave-private counters (at a fixed stride of 256, cleared by their
+ * wave) make the table small enough for digits of up to 8 bits: the keys are below 2^key_bits (the caller knows: the voxel grid's
  * dimensions), which takes ceil(key_bits / 8) passes of 5..8-bit digits (three for the usual 17..24 bits of a ring's voxel indices).
  * The last row is padded with all-ones keys that take part like records (they stay at the end, no per-record guards);
  * rows beyond it are skipped.  Keys must be < 0xffffffff.  Stability makes the result ordered by (k32, original
  * position): exactly the (voxel, input order) order the oracle defines. */
 template <int ROWS, bool PRELOADED = false>
-__device__ __forceinline__ void ll_radix_sort(unsigned *k32, unsigned short *k16, int n, int key_bits, int *cnt, int *sc, int tid,
+__device__ __forceinline__ void ll_radix_sort(unsigned *k32, unsigned short *k16, int n, int key_bits, int *cnt, int tid,
                                               const unsigned *pre32 = nullptr, const unsigned short *pre16 = nullptr)
 {
     constexpr int NW = LL_BLOCK / 64;
@@ -246,7 +248,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char ll_smem[];
 #define LL_PHASE(i) do {} while (0)
 #endif
 
-/* 2nd launch bound = waves per SIMD: six 256-thread workgroups per CU for the common 2304-point capacity (<= 80 VGPRs).
+/* One ring.  (The kernel's 2nd launch bound = waves per SIMD: seven 256-thread workgroups per CU for the common 2304-point capacity, <= 72 VGPRs.)
  * ring_lo < ring length <= ring_hi: the rings this launch works on (ring_hi, a multiple of 256 <= 256 ROWS, also sizes its LDS). */
 template <int ROWS>
 __device__ __forceinline__ void ll_ring_features_ring(const LLView &V, int s, int r, int ring_lo, int ring_hi)
@@ -419,7 +421,7 @@ __device__ __forceinline__ void ll_ring_features_ring(const LLView &V, int s, in
                     }
                 }
                 LL_PHASE(3);
-                ll_radix_sort<ROWS, true>(L.k32, L.k16, nrec, key_bits, L.cnt, L.sc, tid, e32, e16);
+                ll_radix_sort<ROWS, true>(L.k32, L.k16, nrec, key_bits, L.cnt, tid, e32, e16);
                 LL_PHASE(4);
                 __syncthreads();
                 sorted_ok = true;
