@@ -294,6 +294,7 @@ __device__ __forceinline__ void ll_ring_pick_ring(const LLView &V, int s, int r,
                 nc += __popcll(m);
             }
         }
+        if (lane < 4 && nc + lane < LL_PK_COMPACT) L.c.wkey[nc + lane] = 0u;        /* the rank loop below reads four keys at a time: zeros behind the last */
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         const bool compact = nc <= LL_PK_COMPACT;                     /* else: a segment full of corners, its rows as they are */
         const int ncr = (nc + 63) >> 6;
@@ -302,6 +303,17 @@ __device__ __forceinline__ void ll_ring_pick_ring(const LLView &V, int s, int r,
         for (int rr = 0; rr < LL_PK_CROWS; ++rr) {
             ck[rr] = 0u; cli[rr] = 0;
             if (compact && rr < ncr && rr * 64 + lane < nc) { ck[rr] = L.c.wkey[rr * 64 + lane]; cli[rr] = (int)L.c.wli[rr * 64 + lane]; }
+        }
+        /* rank of every candidate of a one-row corner pass (descending curvature; sorted_walk below), from the keys while they still lie in LDS:
+         * one broadcast read brings four keys to every lane -- two vector instructions per key; fetched lane by lane with v_readlane (round 4)
+         * it was three and the scalar-register hazards between them: 0.35 ms of the kernel's 12.3 */
+        int rank_pre = 0;
+        if (compact && ncr <= 1 && nc > 0) {
+            const unsigned key0 = ck[0];
+            for (int t = 0; t < nc; t += 4) {
+                const uint4 k4 = *(const uint4 *)&L.c.wkey[t];
+                rank_pre += (k4.x > key0 ? 1 : 0) + (k4.y > key0 ? 1 : 0) + (k4.z > key0 ? 1 : 0) + (k4.w > key0 ? 1 : 0);
+            }
         }
         /* the next segment's first tile travels during the pick (the candidates are in registers, their LDS rows are dead) */
         __builtin_amdgcn_s_waitcnt(0xc07f);                           /* lgkmcnt(0) */
@@ -404,15 +416,7 @@ __device__ __forceinline__ void ll_ring_pick_ring(const LLView &V, int s, int r,
              * its suppression range.  Per pick two v_readlane, one range compare and a handful of scalar instructions instead of
              * six dependent DPP steps with their wait states.  Returns false (nothing done) when two candidates tie. */
             auto sorted_walk = [&]() __attribute__((always_inline)) -> bool {
-                const unsigned key0 = ck[0];
-                int rank = 0;
-                for (int t = 0; t < nc; t += 4) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const unsigned kt = (unsigned)__builtin_amdgcn_readlane((int)key0, t + u);   /* lanes beyond nc hold 0: never greater */
-                        rank += (kt > key0) ? 1 : 0;
-                    }
-                }
+                int rank = rank_pre;                                  /* candidates with a larger curvature (equal ones: left to the arg-max loop) */
                 rank = (lane < nc) ? rank : lane;                     /* the idle lanes keep their places */
                 const int sA = __builtin_amdgcn_ds_permute(rank * 4, cli[0]);   /* lane rank <- (local index | extents << 16); 0 where nobody wrote */
                 const unsigned long long got = __ballot(sA != 0);
