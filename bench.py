@@ -818,7 +818,10 @@ def main():
                                      "counter_traffic_frac_of_measured_stream_rate": traffic_of_stream,
                                      "rule": "bound = hbm when the counter traffic's (or the algorithmic bytes') fraction of the measured streaming rate "
                                              "(profiles/r05_stream_rate.json; the 8 TB/s peak without it) is the largest of the four, else issue; "
-                                             "unknown without a counter pass of this code"}
+                                             "unknown without a counter pass of this code",
+                                     "caveat": "the label names the LARGEST of the four fractions, not a saturated unit: below ~0.9 nothing is.  DESIGN.md 14.7: "
+                                               "k_ring_features got ~1 % faster for 15 % fewer bytes and again for 31 % fewer vector instructions; fewer "
+                                               "barriers bought 1-3 %"}
             issue_out["model"] = ("valu_busy = SQ_INSTS_VALU / (%d SIMDs x %.1f GHz / %.1f cycles x launch time); salu_busy = SQ_INSTS_SALU / "
                                   "(%d scalar units x %.1f GHz x launch time)" % (N_SIMD, CLOCK_GHZ, VALU_CYCLES, N_SIMD // 4, CLOCK_GHZ))
         whole_alg_bytes_per_step = ab["ext"] + ab["assoc"] + ab["vote"] + ab["rj"]
