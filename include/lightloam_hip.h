@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LL_ABI_VERSION 2          /* 2: ll_params.distortion */
+#define LL_ABI_VERSION 3          /* 2: ll_params.distortion; 3: ll_params.voxel_sort_ranks, .input_stride_floats */
 
 typedef struct ll_ctx ll_ctx;
 
@@ -71,6 +71,13 @@ typedef struct {
     int   distortion;         /* DISTORTION of laserOdometry.cpp:23.  0 (default) = the reference's build: s = 1.  1 = its other compile-time
                                  path: every point's interpolation ratio s = (intensity - int(intensity)) / SCAN_PERIOD in TransformToStart
                                  (:81-88) and in LidarEdgeFactor / LidarPlaneFactor_modify (:570-571, :740-741, lidarFactor.hpp:25-27) */
+    int   voxel_sort_ranks;   /* the VoxelGrid sort's ranking (ll_features.hip).  0 (default) = auto: ranks from one returning LDS add per row when
+                                 the device passes ll_create's lane-order check, else from a match-any; 1 = always the match-any (tests; same clouds
+                                 bit for bit, ~0.7 % of that kernel slower) */
+    int   input_stride_floats;/* floats per point of the RESIDENT raw scan: 4 (default; KITTI .bin, PointXYZ: x, y, z, one unused float) or 3
+                                 (x, y, z packed: scanRegistration.cpp:105-106 keeps nothing else, so a streamed scan crosses PCIe and is read by
+                                 the organise stage at 12 instead of 16 bytes per point).  ll_upload_scan repacks any caller stride into it; the
+                                 asynchronous uploads take their buffers in exactly this layout */
 } ll_params;
 
 /* Per-scan sizes produced by the extract stage. */
@@ -92,8 +99,8 @@ typedef struct {
 /* ---------------------------------------------------------------- lifecycle */
 void        ll_default_params(ll_params *p, int n_scans);
 /* ll_create: LL_ERR_ARG for parameters outside their ranges, LL_ERR_DEVICE when `device` is no usable gfx950 device -- the library has no CPU path
- * -- or fails the one-off check of a hardware behaviour the voxel filter's sort relies on (the lanes of one returning LDS add are served in lane
- * order: ll_features.hip), LL_ERR_HIP when an allocation fails; ll_last_error(NULL) says which. */
+ * --, LL_ERR_HIP when an allocation fails or the one-off lane-order check of the voxel filter's sort could not run (a device that fails the check
+ * itself is served by the sort's other ranking, ll_params.voxel_sort_ranks); ll_last_error(NULL) says which. */
 int         ll_create(int device, const ll_params *p, ll_ctx **out);
 void        ll_destroy(ll_ctx *ctx);
 const char *ll_last_error(const ll_ctx *ctx);      /* ctx may be NULL: last create error */
@@ -105,8 +112,9 @@ int         ll_synchronize(ll_ctx *ctx);
  * Replaces pcl::fromROSMsg of the /rslidar_points message (scanRegistration.cpp:105-106, :453).
  * xyz: n points of `stride_floats` floats each (>= 3; 4 = KITTI .bin / PointXYZ padding).              */
 int ll_upload_scan(ll_ctx *ctx, int slot, const float *host_xyz, int stride_floats, int n);
-/* Streaming input (BASELINE config 5): the same upload, asynchronous on the context's COPY stream.  xyz4: n x (x, y, z, .)
- * floats, 16-byte stride, ideally page-locked (ll_host_alloc); it must not be modified until the copy has run.  The copy
+/* Streaming input (BASELINE config 5): the same upload, asynchronous on the context's COPY stream.  xyz4: n points in the context's RESIDENT
+ * layout -- (x, y, z, .) at a 16-byte stride by default, (x, y, z) packed at 12 bytes with ll_params.input_stride_floats = 3 (nothing is
+ * repacked on the way: a quarter fewer bytes cross PCIe) --, ideally page-locked (ll_host_alloc); it must not be modified until the copy has run.  The copy
  * stream (1) and the compute stream (0: every stage call) are ordered by caller-named events 0 .. 7, never by blocking the
  * host: ll_stream_record marks "everything enqueued on that stream so far", ll_stream_wait makes what is enqueued on a stream
  * from now on wait for a mark (a never-recorded event: no wait).  Slots in two halves + two events per half = a double
@@ -115,7 +123,8 @@ int ll_upload_scan(ll_ctx *ctx, int slot, const float *host_xyz, int stride_floa
 #define LL_STREAM_COPY 1
 int   ll_upload_scan_async(ll_ctx *ctx, int slot, const float *xyz4, int n);
 int   ll_upload_scans_async(ll_ctx *ctx, int first, int count, const float *const *xyz4, const int *n);   /* slots first .. first+count-1 */
-/* the same for a run of slots out of ONE page-locked staging area, scan i at base + i * stride_bytes (stride a multiple of 16):
+/* the same for a run of slots out of ONE page-locked staging area, scan i at base + i * stride_bytes (stride a multiple of 16; of 4 in the
+ * 12-byte layout):
  * two enqueues for the whole run (a per-scan feed is bounded by the host cost of the copy calls, not by PCIe) */
 int   ll_upload_scans_async_strided(ll_ctx *ctx, int first, int count, const float *base, size_t stride_bytes, const int *n);
 int   ll_stream_record(ll_ctx *ctx, int stream, int event_id);
@@ -361,6 +370,12 @@ int ll_hot_path_batch(ll_ctx *ctx, int first, int count, const double *host_pose
 /* The same pass continuing a batch that an earlier call opened: the target of slot `first` is slot first - 1, not the carry
  * (a batch processed in pieces -- e.g. the halves of a double-buffered stream -- gives the results of one call over the whole). */
 int ll_hot_path_chain(ll_ctx *ctx, int first, int count, int vote_enable);
+/* Schedule of the association stage inside ll_hot_path_batch / _chain for calls (chunks) of at least 512 scans.  on = 1 (default): the
+ * target grids of one quarter of the range are built while the quarter before it is searched, on two HIP streams ordered by events
+ * (the two kernels take ~10 % less time side by side than in a row).  on = 0: one stream, kernel after kernel -- the schedule under
+ * which ll_profile_read's k_build_grid / k_associate figures are each kernel's own time.  Results are identical either way.
+ * LIGHTLOAM_ONE_STREAM=1 in the environment makes 0 the default of new contexts. */
+int ll_set_two_stream(ll_ctx *ctx, int on);
 
 /* ---------------------------------------------------------------- measurement
  * With profiling on, every kernel launched by the stage calls is bracketed by HIP events on the ctx stream.

@@ -54,10 +54,11 @@ public:
     /* max_ring_points: capacity of one scan line (0: the library default, 2304 = a 2048-column sensor; real HDL-64E / KITTI data
      * under the linear 64-ring model of scanRegistration.cpp:162 needs 4608 -- some bins hold two lasers) */
     explicit Context(int scan_line, int batch = 2, int device = 0, double minimum_range = -1.0,
-                     float lowerBound = -24.9f, float upBound = 2.0f, int distortion = 0, int max_ring_points = 0) {
+                     float lowerBound = -24.9f, float upBound = 2.0f, int distortion = 0, int max_ring_points = 0, int input_stride_floats = 4) {
         ll_default_params(&p_, scan_line);
         p_.batch = batch;
         p_.distortion = distortion;
+        p_.input_stride_floats = input_stride_floats;                           /* 3: the resident scan keeps x, y, z only, as pcl::fromROSMsg into PointXYZ does (:105-106) */
         if (max_ring_points > 0) p_.max_ring_points = max_ring_points;
         if (minimum_range >= 0) p_.minimum_range = (float)minimum_range;       /* nh.param("minimum_range") :438 */
         p_.lower_bound = lowerBound; p_.up_bound = upBound;                     /* nh.param("lowerBound" / "upBound") :439-440 */
@@ -254,8 +255,11 @@ public:
     template <class AllGather>
     bool process_tile_parallel(const std::vector<PointXYZI> &laserCloudCornerLast, const std::vector<PointXYZI> &laserCloudSurfLast,
                                AllGather &&all_gather, const ll_lm_options *opt = nullptr) {
-        std::string local_err;                                                            /* first failure on this rank */
-        auto step = [&](int rc, const char *what) { if (rc != LL_OK && local_err.empty()) local_err = std::string(what); return rc == LL_OK; };
+        std::string local_err; int local_rc = LL_OK;                                      /* first failure on this rank: message + its code */
+        /* the message is fetched AFTER the call: as a second argument of step() it would be evaluated in an unspecified order (GCC:
+         * right to left, i.e. before the failing call has assigned the error string it points into) */
+        auto step = [&](int rc, auto last_err) { if (rc != LL_OK && local_err.empty()) { local_rc = rc; local_err = std::string(last_err()); } return rc == LL_OK; };
+        auto cm_err = [&]() { return ll_cubemap_last_error(cm_); };
         auto any_failed = [&]() {                                                         /* one int per rank: a collective of its own */
             int mine = local_err.empty() ? 0 : 1;
             std::vector<int> all((size_t)world_);
@@ -263,11 +267,11 @@ public:
             for (int v : all) if (v) return true;
             return false;
         };
-        auto leave = [&]() { throw Error(LL_ERR_STATE, local_err.empty() ? std::string("process_tile_parallel: another rank failed") : local_err); };
+        auto leave = [&]() { if (local_err.empty()) throw Error(LL_ERR_STATE, std::string("process_tile_parallel: another rank failed")); throw Error(local_rc, local_err); };
         int cnt[4] = {0, 0, 0, 0};
         if (step(ll_cubemap_prepare(cm_, parameters + 4, (const ll_point *)laserCloudCornerLast.data(), (int)laserCloudCornerLast.size(),
-                                    (const ll_point *)laserCloudSurfLast.data(), (int)laserCloudSurfLast.size()), ll_cubemap_last_error(cm_)))
-            step(ll_cubemap_info(cm_, nullptr, cnt), ll_cubemap_last_error(cm_));
+                                    (const ll_point *)laserCloudSurfLast.data(), (int)laserCloudSurfLast.size()), cm_err))
+            step(ll_cubemap_info(cm_, nullptr, cnt), cm_err);
         int mine[3] = {cnt[0], cnt[1], local_err.empty() ? 0 : 1};
         std::vector<int> all_cnt((size_t)3 * world_);
         all_gather(mine, all_cnt.data(), 3 * sizeof(int));
@@ -277,6 +281,7 @@ public:
         const bool ran = tot[0] > 10 && tot[1] > 50;                                      /* :1822 */
         if (ran) {
             ll_map *m = ll_cubemap_map(cm_);
+            auto m_err = [&]() { return ll_map_last_error(m); };
             const size_t nc = (size_t)cnt[2] * 5, ns = (size_t)cnt[3] * 5;
             /* ONE all_gather per outer iteration: a rank's status word and its four candidate arrays travel as one packed record
              * [status | corner (x, y, z, d) | corner ids | surf (x, y, z, d) | surf ids] (every rank holds the whole scan, so the
@@ -289,7 +294,7 @@ public:
             for (int it = 0; it < 2; ++it) {                                              /* :1832 */
                 if (local_err.empty())
                     step(ll_map_knn_partial(m, parameters, (float *)(pack.data() + o_cn), (int *)(pack.data() + o_ci),
-                                            (float *)(pack.data() + o_sn), (int *)(pack.data() + o_si)), ll_map_last_error(m));
+                                            (float *)(pack.data() + o_sn), (int *)(pack.data() + o_si)), m_err);
                 const int mine_st = local_err.empty() ? 0 : 1;
                 std::memcpy(pack.data(), &mine_st, sizeof(int));
                 all_gather(pack.data(), all.data(), rec);
@@ -303,8 +308,8 @@ public:
                     std::memcpy((unsigned char *)asi.data() + (size_t)r * ns * 4, q + o_si, ns * 4);
                 }
                 if (bad) leave();                                                         /* every rank takes this exit in the same iteration */
-                if (step(ll_map_associate_merged(m, parameters, world_, acn.data(), aci.data(), asn.data(), asi.data()), ll_map_last_error(m)))
-                    step(ll_map_solve(m, parameters, opt), ll_map_last_error(m));
+                if (step(ll_map_associate_merged(m, parameters, world_, acn.data(), aci.data(), asn.data(), asi.data()), m_err))
+                    step(ll_map_solve(m, parameters, opt), m_err);
             }
             if (any_failed()) leave();                                                    /* the last iteration's merge / solve */
         }

@@ -58,8 +58,10 @@ public:
     RcclWorld &operator=(const RcclWorld &) = delete;
     int size() const { return (int)comms_.size(); }
     ncclComm_t comm(int rank) const { return comms_[(size_t)rank]; }
-    /* a communicator that RcclRank::abort() has already torn down must not be destroyed again */
+    /* a communicator that RcclRank::abort() has already torn down must not be destroyed again: a rank built with this world as
+     * its owner calls forget() from abort() itself */
     void release(int rank) { comms_[(size_t)rank] = nullptr; }
+    void forget(ncclComm_t c) noexcept { for (ncclComm_t &x : comms_) if (x == c) x = nullptr; }
 private:
     std::vector<ncclComm_t> comms_;
 };
@@ -67,7 +69,9 @@ private:
 /* a rank: its communicator, the context whose stream carries the collectives, device staging for host-side gathers */
 class RcclRank {
 public:
-    RcclRank(ncclComm_t comm, ll_ctx *ctx, int device) : comm_(comm), stream_((hipStream_t)ll_stream(ctx)), device_(device) {
+    /* owner: the RcclWorld the communicator came from (nullptr: the caller built it and destroys it); abort() tells it that the
+     * communicator is gone, so that ~RcclWorld does not destroy it a second time whichever way the stack unwinds */
+    RcclRank(ncclComm_t comm, ll_ctx *ctx, int device, RcclWorld *owner = nullptr) : comm_(comm), stream_((hipStream_t)ll_stream(ctx)), device_(device), owner_(owner) {
         LL_RCCL_CHECK(ncclCommCount(comm_, &world_));
         LL_RCCL_CHECK(ncclCommUserRank(comm_, &rank_));
         LL_RCCL_HIP(hipSetDevice(device_));
@@ -84,7 +88,12 @@ public:
     void all_reduce_neq() { LL_RCCL_CHECK(ncclAllReduce(neq_, neq_, 44, ncclDouble, ncclSum, comm_, stream_)); ++n_allreduce; }
     bool try_all_reduce_neq() noexcept { if (ncclAllReduce(neq_, neq_, 44, ncclDouble, ncclSum, comm_, stream_) != ncclSuccess) return false; ++n_allreduce; return true; }
     /* give up on the communicator: the peers' pending collectives return with an error instead of waiting for this rank */
-    void abort() noexcept { if (comm_ && !aborted_) { (void)ncclCommAbort(comm_); aborted_ = true; } }
+    void abort() noexcept {
+        if (comm_ && !aborted_) {
+            (void)ncclCommAbort(comm_); aborted_ = true;
+            if (owner_) owner_->forget(comm_);
+        }
+    }
     bool aborted() const { return aborted_; }
     /* `bytes` from every rank into recv, rank-major; host buffers (the shape LaserMapping::process_tile_parallel asks for) */
     void all_gather_host(const void *send, void *recv, size_t bytes) {
@@ -110,6 +119,7 @@ private:
     void *neq_ = nullptr, *send_ = nullptr, *recv_ = nullptr;
     size_t cap_ = 0;
     bool aborted_ = false;
+    RcclWorld *owner_ = nullptr;
 };
 
 /* laserMapping.cpp:1822-2095 row-parallel: `m` holds the whole map and THIS rank's slice of the stack clouds (ll_map_set_scan).

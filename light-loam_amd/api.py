@@ -23,7 +23,7 @@ EXPORTS = [
     "ll_download_edge_corr", "ll_download_plane_corr", "ll_vote_batch", "ll_download_vote",
     "ll_normal_equations_batch", "ll_download_normal_equations", "ll_gn_step_batch", "ll_download_pose",
     "ll_residual_jacobian", "ll_hot_path_batch", "ll_algorithmic_bytes", "ll_profile_enable", "ll_profile_read", "ll_set_pose_guess", "ll_debug_counters", "ll_vote_host", "ll_debug_calibration_copy", "ll_debug_launch_stage", "ll_debug_exact_math", "ll_upload_scan_async", "ll_upload_scans_async", "ll_upload_scans_async_strided", "ll_stream_record", "ll_stream_wait", "ll_hot_path_chain", "ll_synchronize_copy", "ll_host_alloc", "ll_host_free",
-    "ll_lm_default_options", "ll_lm_solve_batch", "ll_odometry_frames",
+    "ll_lm_default_options", "ll_lm_solve_batch", "ll_odometry_frames", "ll_set_two_stream",
     "ll_map_create", "ll_map_destroy", "ll_map_last_error", "ll_map_set_map", "ll_map_set_scan", "ll_map_associate",
     "ll_map_residual_jacobian", "ll_map_get_counts", "ll_map_get_map_sizes", "ll_map_download_edges", "ll_map_download_planes", "ll_map_normal_equations", "ll_map_optimize",
     "ll_cubemap_create", "ll_cubemap_destroy", "ll_cubemap_last_error", "ll_cubemap_prepare", "ll_cubemap_optimize", "ll_cubemap_update",
@@ -42,7 +42,7 @@ class Params(C.Structure):
                 ("max_ring_points", C.c_int), ("batch", C.c_int), ("curv_threshold", C.c_float),
                 ("gap_sq_threshold", C.c_float), ("leaf_size", C.c_float), ("nn_dist_sq_max", C.c_float),
                 ("nearby_scan", C.c_float), ("huber_delta", C.c_float), ("write_curvature", C.c_int),
-                ("chunk", C.c_int), ("distortion", C.c_int)]
+                ("chunk", C.c_int), ("distortion", C.c_int), ("voxel_sort_ranks", C.c_int), ("input_stride_floats", C.c_int)]
 
 
 class ScanInfo(C.Structure):
@@ -94,17 +94,18 @@ class PinnedStaging:
     """`count` scan slots of `stride_points` points each in ONE page-locked area: what an ingest thread fills and
     ll_upload_scans_async_strided copies with two enqueues"""
 
-    def __init__(self, count, stride_points):
+    def __init__(self, count, stride_points, floats_per_point=4):
         self.lib = load_library()
-        self.count, self.stride = int(count), int(stride_points) * 16
+        self.fpp = int(floats_per_point)             # the context's resident layout (Params.input_stride_floats): 4, or 3 = x, y, z packed
+        self.count, self.stride = int(count), int(stride_points) * 4 * self.fpp
         self.ptr = self.lib.ll_host_alloc(self.count * self.stride)
         if not self.ptr:
             raise MemoryError("ll_host_alloc failed")
         self.n = (C.c_int * self.count)()
 
     def put(self, i, xyz4):
-        a = np.ascontiguousarray(xyz4, np.float32)
-        assert a.ndim == 2 and a.shape[1] == 4 and a.nbytes <= self.stride
+        a = np.ascontiguousarray(np.asarray(xyz4, np.float32)[:, :self.fpp])   # an ingest thread's repack (KITTI .bin records carry a 4th float)
+        assert a.ndim == 2 and a.shape[1] == self.fpp and a.nbytes <= self.stride
         C.memmove(self.ptr + i * self.stride, a.ctypes.data, a.nbytes)
         self.n[i] = len(a)
 
@@ -122,9 +123,9 @@ class PinnedStaging:
 class PinnedScan:
     """an (n, 4) float32 scan in page-locked host memory (ll_host_alloc): the source of ll_upload_scan_async"""
 
-    def __init__(self, xyz4):
-        a = np.ascontiguousarray(xyz4, np.float32)
-        assert a.ndim == 2 and a.shape[1] == 4
+    def __init__(self, xyz4, floats_per_point=4):
+        a = np.ascontiguousarray(np.asarray(xyz4, np.float32)[:, :int(floats_per_point)])
+        assert a.ndim == 2 and a.shape[1] == int(floats_per_point)
         self.n = len(a)
         self.lib = load_library()
         self.ptr = self.lib.ll_host_alloc(max(a.nbytes, 16))
@@ -363,6 +364,10 @@ class Context:
     def hot_path(self, first=0, count=1, pose=None, vote=True):
         p = self._poses(pose, count)
         self._ck(self.lib.ll_hot_path_batch(self.h, first, count, _ptr(p), int(bool(vote))))
+
+    def set_two_stream(self, on=True):
+        """association stage of hot_path on two streams (default) or kernel after kernel (ll_set_two_stream)"""
+        self._ck(self.lib.ll_set_two_stream(self.h, int(bool(on))))
 
     def profile_enable(self, on=True):
         self._ck(self.lib.ll_profile_enable(self.h, int(bool(on))))

@@ -4,13 +4,15 @@
  * code object is unusable, ll_create fails with LL_ERR_DEVICE.
  */
 #include "ll_internal.h"
+#include <mutex>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
 
 static const char *const kKernelNames[LL_K_COUNT] = {"k_classify", "k_offsets", "k_scatter", "k_ring_features", "k_organize",
-                                                     "k_associate", "k_vote", "k_normal_equations", "k_gn_step", "k_build_grid", "k_first_kept", "k_ring_pick"};
+                                                     "k_associate", "k_vote", "k_normal_equations", "k_gn_step", "k_build_grid", "k_first_kept", "k_ring_pick",
+                                                     "k_build_grid||k_associate"};
 
 void ll_prof_mark(LLProfiler *p, int kernel_id, hipStream_t st)
 {
@@ -44,6 +46,8 @@ extern "C" void ll_default_params(ll_params *p, int n_scans)
     p->curv_threshold = 0.1f; p->gap_sq_threshold = 0.05f; p->leaf_size = 0.2f;
     p->nn_dist_sq_max = 25.0f; p->nearby_scan = 2.5f; p->huber_delta = 0.1f;
     p->write_curvature = 0;
+    p->voxel_sort_ranks = 0;     /* auto */
+    p->input_stride_floats = 4;  /* KITTI .bin / PointXYZ */
 }
 
 extern "C" const char *ll_last_error(const ll_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
@@ -70,6 +74,8 @@ extern "C" void ll_destroy(ll_ctx *ctx)
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->ev_ok) for (auto &e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
+    if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+    for (auto &e : ctx->ev_ts) if (e) (void)hipEventDestroy(e);
     for (auto &e : ctx->ev_x) if (e) (void)hipEventDestroy(e);
     for (auto &e : ctx->prof.ev) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -82,6 +88,8 @@ extern "C" int ll_create(int device, const ll_params *p, ll_ctx **out)
     *out = nullptr;
     if (p->n_scans < 1 || p->n_scans > LL_MAX_RINGS || p->batch < 1 || p->max_points < 32 || p->max_points > 400000 ||
         p->max_ring_points < 32 || p->max_ring_points > 8192) { g_create_err = "bad parameter"; return LL_ERR_ARG; }
+    if (p->voxel_sort_ranks < 0 || p->voxel_sort_ranks > 1) { g_create_err = "voxel_sort_ranks must be 0 (auto) or 1 (match-any)"; return LL_ERR_ARG; }
+    if (p->input_stride_floats != 0 && p->input_stride_floats != 3 && p->input_stride_floats != 4) { g_create_err = "input_stride_floats must be 4 (default) or 3"; return LL_ERR_ARG; }
     if (!(p->nn_dist_sq_max > 0.0f) || p->nn_dist_sq_max > 36.0f) {
         /* the cell search is exact for any radius; the bound keeps the worst case (no neighbour: every ring of 1 m cells
          * inside the radius is looked up) at 13 x 13 cells */
@@ -108,16 +116,30 @@ extern "C" int ll_create(int device, const ll_params *p, ll_ctx **out)
     ctx->p = *p; ctx->device = device;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { g_create_err = "hipStreamCreate failed"; delete ctx; return LL_ERR_DEVICE; }
     for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { g_create_err = "hipEventCreate failed"; ll_destroy(ctx); return LL_ERR_DEVICE; }
-    {   /* once per device and process: the voxel sort takes its ranks from returning LDS adds (ll_features.hip) */
-        static int order_checked[LL_MAX_DEVICES] = {0};        /* 0 not yet, 1 holds, -1 does not */
-        int &oc = order_checked[device < LL_MAX_DEVICES ? device : 0];
-        if (oc == 0 || device >= LL_MAX_DEVICES) oc = ll_lds_atomic_order_ok(ctx->stream) ? 1 : -1;
-        if (oc < 0) { g_create_err = "this device does not serve the lanes of a returning LDS add in lane order (the voxel sort depends on it)"; ll_destroy(ctx); return LL_ERR_DEVICE; }
+    /* Once per device and process: does the LDS serve the lanes of one returning add in lane order (the fast ranking of the voxel
+     * sort, ll_features.hip)?  A device that does not -- other silicon, a microcode change -- is served by the match-any ranking of
+     * rounds 2-5 instead (bit-identical clouds, ~0.7 % of k_ring_features slower on MI355X); it is NOT refused.  A check that could not
+     * run (allocation / launch failure) is an LL_ERR_HIP of this call and is not cached.  The cache is guarded: contexts are created from
+     * several host threads (tests/native/tile_parallel_exits.cpp); a device index beyond the cache is checked every time. */
+    int sort_match_any = (p->voxel_sort_ranks == 1) ? 1 : 0;
+    if (!sort_match_any) {
+        static std::mutex order_mu;
+        static int order_checked[LL_MAX_DEVICES] = {0};        /* 0 not yet, 1 holds, 2 does not */
+        std::lock_guard<std::mutex> lock(order_mu);
+        int oc = device < LL_MAX_DEVICES ? order_checked[device] : 0;
+        if (oc == 0) {
+            const int r = ll_lds_atomic_order_ok(ctx->stream);
+            if (r < 0) { g_create_err = "the LDS lane-order check could not run (hipMalloc / launch / copy failed)"; ll_destroy(ctx); return LL_ERR_HIP; }
+            oc = r ? 1 : 2;
+            if (device < LL_MAX_DEVICES) order_checked[device] = oc;
+        }
+        if (oc == 2) sort_match_any = 1;
     }
     ctx->ev_ok = true;
 
     LLView &V = ctx->V;
     std::memset(&V, 0, sizeof(V));
+    V.sort_match_any = sort_match_any;
     const int B = p->batch, R = p->n_scans;
     const int NP = (p->max_points + LL_TILE - 1) / LL_TILE * LL_TILE;
     V.B = B; V.NP = NP; V.T = NP / LL_TILE; V.R = R; V.ring_model = p->ring_model;
@@ -140,6 +162,7 @@ extern "C" int ll_create(int device, const ll_params *p, ll_ctx **out)
     float4 *raw = nullptr; int *n_in = nullptr;
     ok = ok && dev_alloc(ctx, raw, BN, false) && dev_alloc(ctx, n_in, B);
     V.raw = raw; V.n_in = n_in;
+    V.raw_stride = (p->input_stride_floats == 3) ? 3 : 4;
     V.org_small = LL_ORG_SMALL;
     if (const char *e = std::getenv("LIGHTLOAM_ORG_SMALL")) {                   /* tests: 0 sends every call through k_organize */
         const int v = std::atoi(e);
@@ -202,6 +225,7 @@ extern "C" int ll_create(int device, const ll_params *p, ll_ctx **out)
     ctx->h_stage_pts = NP;
     if (hipHostMalloc((void **)&ctx->h_stage, (size_t)NP * sizeof(float4), hipHostMallocDefault) != hipSuccess) { g_create_err = "hipHostMalloc failed"; ll_destroy(ctx); return LL_ERR_HIP; }
     ctx->n_in_host.assign(B, 0);
+    if (const char *e = std::getenv("LIGHTLOAM_ONE_STREAM")) ctx->two_stream = (std::atoi(e) != 0) ? 0 : 1;
     *out = ctx;
     return LL_OK;
 }
@@ -239,9 +263,12 @@ extern "C" int ll_upload_scan(ll_ctx *ctx, int slot, const float *xyz, int strid
     LLView &V = ctx->V;
     float4 *dst = const_cast<float4 *>(V.raw) + (size_t)slot * V.NP;
     if (n > 0) {
-        if (stride == 4) std::memcpy(ctx->h_stage, xyz, (size_t)n * 16);
-        else for (int i = 0; i < n; ++i) ctx->h_stage[i] = make_float4(xyz[(size_t)i * stride], xyz[(size_t)i * stride + 1], xyz[(size_t)i * stride + 2], 0.0f);
-        LL_HIP(hipMemcpyAsync(dst, ctx->h_stage, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+        /* the caller's stride -> the resident one (pcl::fromROSMsg into PointXYZ keeps x, y, z only, :105-106) */
+        const int rs = V.raw_stride;
+        if (stride == rs) std::memcpy(ctx->h_stage, xyz, (size_t)n * rs * 4);
+        else if (rs == 4) for (int i = 0; i < n; ++i) ctx->h_stage[i] = make_float4(xyz[(size_t)i * stride], xyz[(size_t)i * stride + 1], xyz[(size_t)i * stride + 2], 0.0f);
+        else { float *d3 = (float *)ctx->h_stage; for (int i = 0; i < n; ++i) { d3[3 * i] = xyz[(size_t)i * stride]; d3[3 * i + 1] = xyz[(size_t)i * stride + 1]; d3[3 * i + 2] = xyz[(size_t)i * stride + 2]; } }
+        LL_HIP(hipMemcpyAsync(dst, ctx->h_stage, (size_t)n * rs * 4, hipMemcpyHostToDevice, ctx->stream));
     }
     ctx->n_in_host[slot] = n;
     LL_HIP(hipMemcpyAsync(const_cast<int *>(V.n_in) + slot, &ctx->n_in_host[slot], sizeof(int), hipMemcpyHostToDevice, ctx->stream));
@@ -296,7 +323,7 @@ extern "C" int ll_upload_scan_async(ll_ctx *ctx, int slot, const float *xyz4, in
     if (n > ctx->p.max_points) { ctx->err = "scan larger than max_points"; return LL_ERR_CAPACITY; }
     rc = ensure_copy_stream(ctx); if (rc) return rc;
     LLView &V = ctx->V;
-    if (n > 0) LL_HIP(hipMemcpyAsync(const_cast<float4 *>(V.raw) + (size_t)slot * V.NP, xyz4, (size_t)n * 16, hipMemcpyHostToDevice, ctx->copy_stream));
+    if (n > 0) LL_HIP(hipMemcpyAsync(const_cast<float4 *>(V.raw) + (size_t)slot * V.NP, xyz4, (size_t)n * V.raw_stride * 4, hipMemcpyHostToDevice, ctx->copy_stream));
     ctx->n_in_host[slot] = n;
     enqueue_counts(ctx, slot, &n, 1);
     LL_HIP(hipGetLastError());
@@ -317,17 +344,18 @@ extern "C" int ll_upload_scans_async(ll_ctx *ctx, int first, int count, const fl
 extern "C" int ll_upload_scans_async_strided(ll_ctx *ctx, int first, int count, const float *base, size_t stride_bytes, const int *n)
 {
     int rc = check_range(ctx, first, count); if (rc) return rc;
-    if (!base || !n || (stride_bytes & 15)) { ctx->err = "bad strided upload arguments"; return LL_ERR_ARG; }
+    const size_t pt = (size_t)ctx->V.raw_stride * 4;             /* bytes per resident point: 16, or 12 (ll_params.input_stride_floats = 3) */
+    if (!base || !n || (stride_bytes & (pt == 16 ? 15 : 3))) { ctx->err = "bad strided upload arguments"; return LL_ERR_ARG; }
     rc = ensure_copy_stream(ctx); if (rc) return rc;
     int nmax = 0;
     for (int i = 0; i < count; ++i) {
-        if (n[i] < 0 || n[i] > ctx->p.max_points || (size_t)n[i] * 16 > stride_bytes) { ctx->err = "scan larger than max_points / the stride"; return LL_ERR_CAPACITY; }
+        if (n[i] < 0 || n[i] > ctx->p.max_points || (size_t)n[i] * pt > stride_bytes) { ctx->err = "scan larger than max_points / the stride"; return LL_ERR_CAPACITY; }
         nmax = n[i] > nmax ? n[i] : nmax;
         ctx->n_in_host[first + i] = n[i];
     }
     LLView &V = ctx->V;
     if (nmax > 0)
-        LL_HIP(hipMemcpy2DAsync(const_cast<float4 *>(V.raw) + (size_t)first * V.NP, (size_t)V.NP * 16, base, stride_bytes, (size_t)nmax * 16, (size_t)count,
+        LL_HIP(hipMemcpy2DAsync(const_cast<float4 *>(V.raw) + (size_t)first * V.NP, (size_t)V.NP * 16, base, stride_bytes, (size_t)nmax * pt, (size_t)count,
                                 hipMemcpyHostToDevice, ctx->copy_stream));
     enqueue_counts(ctx, first, n, count);
     LL_HIP(hipGetLastError());
@@ -548,6 +576,7 @@ LLLmOpt ll_to_dev_opt(const ll_lm_options *opt)
     o.min_radius = d.min_radius; o.min_relative_decrease = d.min_relative_decrease; o.min_lm_diagonal = d.min_lm_diagonal;
     o.max_lm_diagonal = d.max_lm_diagonal; o.function_tolerance = d.function_tolerance; o.gradient_tolerance = d.gradient_tolerance;
     o.parameter_tolerance = d.parameter_tolerance; o.jacobi_scaling = d.jacobi_scaling;
+    o.nan_poisons_pose = 0;
     return o;
 }
 
@@ -599,6 +628,47 @@ extern "C" int ll_odometry_frames(ll_ctx *ctx, int first, int count, const doubl
 }
 
 static int hot_path(ll_ctx *ctx, int first, int count, const double *host_pose_guess, int vote_enable, int chain);
+
+/* The association stage of a hot-path call on TWO streams.  k_build_grid (one 1024-thread workgroup per CU, waiting on LDS sweeps and a
+ * divergent scatter) and k_associate (eight waves per SIMD of dependent L2 round trips, half of the vector issue slots idle) are the one
+ * pair of kernels of the path that take less time side by side than one after the other (tools/experiments/overlap_probe.py: 89 % of the
+ * sum).  The slot range is cut into pieces; the grid of piece i + 1 is built on the context's stream while piece i is searched on the second
+ * one -- piece i's targets are its own slots' predecessors, i.e. the grids of pieces <= i, complete when event i fires.  Events only, no
+ * host synchronisation; the context's stream waits for the last search before the vote.  Results do not depend on the schedule.
+ * With the per-kernel profiler on, the whole stage is ONE interval ("k_build_grid||k_associate"): the two kernels' own durations are only
+ * defined when they run alone (ll_set_two_stream(ctx, 0), which bench.py uses for its per-kernel pass). */
+#define LL_TWO_STREAM_MIN 512        /* scans per hot-path call (chunk) below which the stage stays on one stream: the pieces must still fill the chip */
+#define LL_TWO_STREAM_PIECES 4
+static int association_two_streams(ll_ctx *ctx, int f, int n)
+{
+    if (!ctx->stream2) LL_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    for (int i = 0; i <= LL_TWO_STREAM_PIECES; ++i)
+        if (!ctx->ev_ts[i]) LL_HIP(hipEventCreateWithFlags(&ctx->ev_ts[i], hipEventDisableTiming));
+    hipStream_t s1 = ctx->stream, s2 = ctx->stream2;
+    constexpr int P = LL_TWO_STREAM_PIECES;
+    /* pieces of whole groups of eight scans (the kernels deal eight scans to the eight XCDs) */
+    int lo[P + 1];
+    for (int i = 0; i <= P; ++i) { lo[i] = (int)((long long)n * i / P) & ~7; }
+    lo[0] = 0; lo[P] = n;
+    ll_prof_mark(&ctx->prof, LL_K_ASSOC_STAGE, s1);
+    ll_launch_build_grid(ctx->V, f + lo[0], lo[1] - lo[0], 0, s1, nullptr);
+    LL_HIP(hipEventRecord(ctx->ev_ts[0], s1));
+    for (int i = 0; i < P; ++i) {
+        if (i + 1 < P && lo[i + 2] > lo[i + 1]) {
+            ll_launch_build_grid(ctx->V, f + lo[i + 1], lo[i + 2] - lo[i + 1], 0, s1, nullptr);
+            LL_HIP(hipEventRecord(ctx->ev_ts[i + 1], s1));
+        }
+        if (lo[i + 1] > lo[i]) {
+            LL_HIP(hipStreamWaitEvent(s2, ctx->ev_ts[i], 0));
+            ll_launch_associate(ctx->V, f + lo[i], lo[i + 1] - lo[i], s2, nullptr);
+        }
+    }
+    LL_HIP(hipEventRecord(ctx->ev_ts[P], s2));
+    LL_HIP(hipStreamWaitEvent(s1, ctx->ev_ts[P], 0));
+    ll_prof_mark(&ctx->prof, LL_K_END, s1);
+    return LL_OK;
+}
+
 extern "C" int ll_hot_path_batch(ll_ctx *ctx, int first, int count, const double *host_pose_guess, int vote_enable)
 {
     return hot_path(ctx, first, count, host_pose_guess, vote_enable, 0);
@@ -625,12 +695,23 @@ static int hot_path(ll_ctx *ctx, int first, int count, const double *host_pose_g
         const int f = first + c0, n = (count - c0 < chunk) ? count - c0 : chunk;
         ll_launch_organize(ctx->V, f, n, ctx->stream, &ctx->prof);
         ll_launch_features(ctx->V, f, n, ctx->feat_lds, ctx->stream, &ctx->prof);
-        ll_launch_build_grid(ctx->V, f, n, 0, ctx->stream, &ctx->prof);
-        ll_launch_associate(ctx->V, f, n, ctx->stream, &ctx->prof);
+        if (!ctx->two_stream || n < LL_TWO_STREAM_MIN) {
+            ll_launch_build_grid(ctx->V, f, n, 0, ctx->stream, &ctx->prof);
+            ll_launch_associate(ctx->V, f, n, ctx->stream, &ctx->prof);
+        } else {
+            rc = association_two_streams(ctx, f, n); if (rc) return rc;
+        }
         ll_launch_vote(ctx->V, f, n, vote_enable, ctx->stream, &ctx->prof);
         ll_launch_normal_equations(ctx->V, f, n, 1, ctx->stream, &ctx->prof);
     }
     LL_HIP(hipGetLastError());
+    return LL_OK;
+}
+
+extern "C" int ll_set_two_stream(ll_ctx *ctx, int on)
+{
+    if (!ctx) return LL_ERR_ARG;
+    ctx->two_stream = on ? 1 : 0;
     return LL_OK;
 }
 
@@ -1103,7 +1184,8 @@ extern "C" int ll_map_evaluate(ll_map *m, double *neq44)
 static int map_lm_stage(ll_map *m, int stage, const double *neq44_sum, const ll_lm_options *opt)
 {
     if (!m || (stage != 1 && !neq44_sum)) return LL_ERR_ARG;
-    const LLLmOpt o = ll_to_dev_opt(opt);
+    LLLmOpt o = ll_to_dev_opt(opt);
+    o.nan_poisons_pose = 1;                                     /* a failing rank's NaN record must reach every rank's pose (lightloam_rccl.hpp) */
     if (o.max_num_iterations < 0 || o.max_num_iterations > 64) { m->err = "max_num_iterations out of range"; return LL_ERR_ARG; }   /* as ll_map_optimize */
     LLM_HIP(hipSetDevice(m->ctx->device));
     hipStream_t st = m->ctx->stream;
@@ -1139,7 +1221,8 @@ extern "C" int ll_map_evaluate_dev(ll_map *m, double *neq44_dev)
 static int map_lm_stage_dev(ll_map *m, int stage, const double *neq44_sum_dev, const ll_lm_options *opt)
 {
     if (!m || (stage != 1 && !neq44_sum_dev)) return LL_ERR_ARG;
-    const LLLmOpt o = ll_to_dev_opt(opt);
+    LLLmOpt o = ll_to_dev_opt(opt);
+    o.nan_poisons_pose = 1;
     if (o.max_num_iterations < 0 || o.max_num_iterations > 64) { m->err = "max_num_iterations out of range"; return LL_ERR_ARG; }   /* as ll_map_optimize */
     LLM_HIP(hipSetDevice(m->ctx->device));
     hipStream_t st = m->ctx->stream;
@@ -1566,9 +1649,9 @@ extern "C" int ll_algorithmic_bytes(ll_ctx *ctx, int first, int count, double *b
     double be = 0, ba = 0, bv = 0, br = 0;
     for (int i = 0; i < count; ++i) {
         const ScanHdr &s = h[i];
-        if (s.status != 0) { be += 16.0 * ctx->n_in_host[first + i]; continue; }
+        if (s.status != 0) { be += 4.0 * ctx->V.raw_stride * ctx->n_in_host[first + i]; continue; }
         /* SURVEY.md section 8d */
-        be += 16.0 * ctx->n_in_host[first + i] + 16.0 * s.n + 16.0 * (s.n_sharp + s.n_less_sharp + s.n_flat + s.n_less_flat) + 1.0 * s.n;
+        be += 4.0 * ctx->V.raw_stride * ctx->n_in_host[first + i] + 16.0 * s.n + 16.0 * (s.n_sharp + s.n_less_sharp + s.n_flat + s.n_less_flat) + 1.0 * s.n;
         const int mc = (i == 0) ? carry[0] : h[i - 1].n_less_sharp, ms = (i == 0) ? carry[1] : h[i - 1].n_less_flat;
         ba += 16.0 * (s.n_sharp + s.n_flat) + 16.0 * (mc + ms) + 8.0 * p[i].n_edge + 12.0 * p[i].n_plane;
         bv += 32.0 * p[i].n_plane + 8.0 * p[i].n_plane_sel;

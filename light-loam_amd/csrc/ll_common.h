@@ -93,6 +93,7 @@ struct LLView {
     /* configuration */
     int B, NP, T, R, ring_model, max_ring, write_curv;
     int distortion;                /* 0: the reference's build (DISTORTION 0); 1: per-point interpolation ratio s in TransformToStart and the factors */
+    int sort_match_any;            /* k_ring_features: rank the voxel sort's records by a match-any instead of the returning LDS add's lane order (ll_features.hip) */
     int org_small;                 /* calls of at most this many scans take the tile-parallel organise kernels (LL_ORG_SMALL; test override) */
     float thres, lower_bound, factor;
     const int *ring_thr;           /* [R + 1] ll_ring_thresholds: keys of the smallest t = z / sqrt(x^2 + y^2) of every ring */
@@ -107,6 +108,7 @@ struct LLView {
     int cap_sharp, cap_lsharp, cap_flat;      /* per-scan capacities R*12, R*120, R*24 */
     /* organise */
     const float4 *raw; const int *n_in;
+    int raw_stride;                /* floats per resident raw point: 4, or 3 = x, y, z packed (ll_params.input_stride_floats); a slot's area is NP float4 either way */
     /* scratch of the tile-parallel organise path (calls of at most LL_ORG_SMALL scans), indexed by the position in the launch */
     float *ori; int8_t *ring;
     int *tile_hist; int *tile_base; int *tile_first_p; int *tile_first_kept; int *tile_last_kept;
@@ -153,6 +155,7 @@ struct LLLmOpt {
     double initial_radius, max_radius, min_radius, min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
     double function_tolerance, gradient_tolerance, parameter_tolerance;
     int jacobi_scaling;
+    int nan_poisons_pose;          /* staged mapping solves (ll_map_lm_*): a NaN cost / row count in the summed record poisons the pose (ll_lm_step.h) */
 };
 void ll_launch_lm_solve(const LLView &V, int first, int count, const LLLmOpt &o, hipStream_t st);
 void ll_launch_lm_begin(const LLView &V, int first, int count, const LLLmOpt &o, hipStream_t st);
@@ -278,7 +281,9 @@ __device__ __forceinline__ void ll_targets(const LLView &V, int s, const float4 
 
 /* per-kernel HIP-event profiler (ll_api.hip); mark(id) = "kernel id starts here, the previous one ended" */
 enum { LL_K_CLASSIFY = 0, LL_K_OFFSETS, LL_K_SCATTER, LL_K_RING_FEATURES, LL_K_ORGANIZE, LL_K_ASSOCIATE, LL_K_VOTE,
-       LL_K_NORMAL_EQ, LL_K_GN_STEP, LL_K_GRID, LL_K_FIRST, LL_K_PICK, LL_K_COUNT, LL_K_END = -1 };
+       LL_K_NORMAL_EQ, LL_K_GN_STEP, LL_K_GRID, LL_K_FIRST, LL_K_PICK,
+       LL_K_ASSOC_STAGE,     /* not a kernel: k_build_grid and k_associate of a hot-path call running side by side on two streams (ll_api.hip) */
+       LL_K_COUNT, LL_K_END = -1 };
 /* ---- mapping stage (ll_mapping.hip): one scan against the clouds gathered from the cube map ---- */
 struct LLGrid3 {                       /* dense cell grid over a cloud's bounding box */
     float org[3]; float cell; int dim[3]; int ncell;
@@ -368,5 +373,5 @@ void ll_launch_normal_equations(const LLView &V, int first, int count, int do_st
 void ll_launch_gn_step(const LLView &V, int first, int count, hipStream_t st, LLProfiler *prof);
 void ll_launch_rows(const LLView &V, int slot, const double *pose7_dev, double *r, double *Jq, double *Jt, hipStream_t st);
 size_t ll_features_lds_bytes(int max_ring);
-bool ll_lds_atomic_order_ok(hipStream_t st);             /* the LDS serves the lanes of one returning add in lane order (ll_features.hip: the sort's ranks) */
+int ll_lds_atomic_order_ok(hipStream_t st);              /* 1 / 0 / -1 (could not run): the LDS serves the lanes of one returning add in lane order (ll_features.hip: the sort's ranks) */
 void ll_launch_debug_exact_math(const LLView &V, int op, const float *a, const float *b, const float *c, int n, float *out, hipStream_t st);

@@ -98,7 +98,7 @@ __device__ __forceinline__ FeatLds ll_carve(unsigned char *base, int max_ring)
  * The last row is padded with all-ones keys that take part like records (they stay at the end, no per-record guards);
  * rows beyond it are skipped.  Keys must be < 0xffffffff.  Stability makes the result ordered by (k32, original
  * position): exactly the (voxel, input order) order the oracle defines. */
-template <int ROWS, bool PRELOADED = false>
+template <int ROWS, bool PRELOADED = false, bool MATCH = false>
 __device__ __forceinline__ void ll_radix_sort(unsigned *k32, unsigned short *k16, int n, int key_bits, int *cnt, int tid,
                                               const unsigned *pre32 = nullptr, const unsigned short *pre16 = nullptr)
 {
@@ -132,13 +132,36 @@ __device__ __forceinline__ void ll_radix_sort(unsigned *k32, unsigned short *k16
         /* ONE returning LDS add per row: the value that comes back is (records of this wave's earlier rows with digit d) + (lower lanes of
          * this row with digit d) -- a wave's LDS instructions execute in order, and the lanes of one ds_add_rtn that hit the same counter
          * are served in ascending lane order.  The ISA manual does not promise the second; ll_create checks it on the device
-         * (ll_lds_atomic_order_ok, tools/ubench/lds_atomic_order.hip: 9.4e8 lanes, none out of order) and refuses a device where it
-         * does not hold.  The nine adds of a thread go out back to back and are waited for once, behind the counter scan.
+         * (ll_lds_atomic_order_ok, tools/ubench/lds_atomic_order.hip: 9.4e8 lanes, none out of order) and selects the match-any
+         * ranking below (MATCH) for a device where it does not hold.  The nine adds of a thread go out back to back and are waited for once, behind the counter scan.
          * (Rounds 2-5 took the rank from a match-any, four vector instructions per digit bit and row: a third of the kernel's vector work.) */
+        if constexpr (!MATCH) {
 #pragma unroll
-        for (int k = 0; k < ROWS; ++k) {
-            rnk[k] = 0;
-            if (k < myrows) rnk[k] = __hip_atomic_fetch_add(&wc[(int)((e32[k] >> sh) & DM)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int k = 0; k < ROWS; ++k) {
+                rnk[k] = 0;
+                if (k < myrows) rnk[k] = __hip_atomic_fetch_add(&wc[(int)((e32[k] >> sh) & DM)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        } else {
+            /* The ranking that needs no promise from the LDS arbiter (the sort of rounds 2-5; ll_create selects it for a device that
+             * fails the lane-order check, ll_params.voxel_sort_ranks = 1 forces it): the rank inside the row from a match-any of the
+             * digit (four vector instructions per digit bit), the earlier rows' count by a read of the wave's counter, which the
+             * first lane of every digit group then bumps by the group's size -- a wave's LDS operations execute in order, so the next
+             * row's read sees it.  Same destinations, bit for bit; ~0.7 % of the kernel's time slower on MI355X (round 5, A/B). */
+            int pre[ROWS];
+#pragma unroll
+            for (int k = 0; k < ROWS; ++k) {
+                rnk[k] = 0; pre[k] = 0;
+                if (k < myrows) {
+                    const int d = (int)((e32[k] >> sh) & DM);
+                    unsigned mlo, mhi;
+                    ll_match_any(d, BITS, ~0ull, mlo, mhi);
+                    rnk[k] = ll_match_rank(mlo, mhi);
+                    pre[k] = __hip_atomic_load(&wc[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   /* an atomic load: it must see the rows' adds */
+                    if (rnk[k] == 0) atomicAdd(&wc[d], ll_match_count(mlo, mhi));
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < ROWS; ++k) rnk[k] += pre[k];
         }
         __syncthreads();                                        /* every wave's counts are complete */
         /* Every wave works out the bases of ITS OWN counters by itself -- exclusive scan over the (digit, wave) table in digit-major order;
@@ -192,7 +215,7 @@ __device__ __forceinline__ void ll_radix_sort(unsigned *k32, unsigned short *k16
 /* The property the sort's ranks rest on, checked once per device by ll_create: within one returning LDS add, lanes that hit the same counter get
  * their values in ascending lane order (and a later instruction of the wave sees the earlier one's adds).  Digit patterns: uniform over 2^b
  * values, b = 0..8, as they lie and scattered over the lanes.  out[0] += lanes that disagreed with a match-any count. */
-__global__ __launch_bounds__(256) void k_lds_atomic_order(int iters, unsigned *out)
+__global__ __launch_bounds__(256, LL_FWAVES_SPLIT) void k_lds_atomic_order(int iters, unsigned *out)
 {
     __shared__ int cnt[4][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -217,17 +240,21 @@ __global__ __launch_bounds__(256) void k_lds_atomic_order(int iters, unsigned *o
     }
     if (bad) atomicAdd(out, bad);
 }
-bool ll_lds_atomic_order_ok(hipStream_t st)
+/* 1: the property holds, 0: it does not, -1: the check could not run (allocation / launch failure: nothing learnt about the device).
+ * Launched at the sort kernel's own residency and beyond -- eight 256-thread workgroups per CU, every wave of the chip adding into
+ * its private table at once, as k_ring_features<9> runs at seven -- so that the arbiter is asked under the contention it works under. */
+int ll_lds_atomic_order_ok(hipStream_t st)
 {
     unsigned *d = nullptr, h = 1;
-    if (hipMalloc(&d, sizeof(unsigned)) != hipSuccess) return false;
-    bool ok = hipMemsetAsync(d, 0, sizeof(unsigned), st) == hipSuccess;
-    if (ok) {
-        hipLaunchKernelGGL(k_lds_atomic_order, dim3(256), dim3(256), 0, st, 90, d);
-        ok = hipMemcpyAsync(&h, d, sizeof(unsigned), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess && h == 0;
+    if (hipMalloc(&d, sizeof(unsigned)) != hipSuccess) return -1;
+    bool ran = hipMemsetAsync(d, 0, sizeof(unsigned), st) == hipSuccess;
+    if (ran) {
+        hipLaunchKernelGGL(k_lds_atomic_order, dim3(2048), dim3(256), 0, st, 45, d);
+        ran = hipGetLastError() == hipSuccess && hipMemcpyAsync(&h, d, sizeof(unsigned), hipMemcpyDeviceToHost, st) == hipSuccess &&
+              hipStreamSynchronize(st) == hipSuccess;
     }
     (void)hipFree(d);
-    return ok;
+    return ran ? (h == 0 ? 1 : 0) : -1;
 }
 
 __device__ __forceinline__ bool ll_bit(const unsigned *bm, int i) { return (bm[i >> 5] >> (i & 31)) & 1u; }
@@ -250,7 +277,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char ll_smem[];
 
 /* One ring.  (The kernel's 2nd launch bound = waves per SIMD: seven 256-thread workgroups per CU for the common 2304-point capacity, <= 72 VGPRs.)
  * ring_lo < ring length <= ring_hi: the rings this launch works on (ring_hi, a multiple of 256 <= 256 ROWS, also sizes its LDS). */
-template <int ROWS>
+template <int ROWS, bool MATCH>
 __device__ __forceinline__ void ll_ring_features_ring(const LLView &V, int s, int r, int ring_lo, int ring_hi)
 {
     static_assert(ROWS <= 32, "headm / endm hold one bit per row of a thread");
@@ -421,7 +448,7 @@ __device__ __forceinline__ void ll_ring_features_ring(const LLView &V, int s, in
                     }
                 }
                 LL_PHASE(3);
-                ll_radix_sort<ROWS, true>(L.k32, L.k16, nrec, key_bits, L.cnt, tid, e32, e16);
+                ll_radix_sort<ROWS, true, MATCH>(L.k32, L.k16, nrec, key_bits, L.cnt, tid, e32, e16);
                 LL_PHASE(4);
                 __syncthreads();
                 sorted_ok = true;
@@ -545,7 +572,7 @@ __device__ __forceinline__ void ll_ring_features_ring(const LLView &V, int s, in
 
 /* The launch of the common capacity: one workgroup per (scan, ring).  A tier of longer rings runs over the work list k_organize filled
  * for it (list != null: slot << 8 | ring, *list_n entries) with a fixed grid of resident workgroups taking entries in turn. */
-template <int ROWS>
+template <int ROWS, bool MATCH>
 __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES_SPLIT : ROWS <= 12 ? 4 : ROWS <= 18 ? 3 : 1)) void k_ring_features(LLView V, int first, int count, int ring_lo, int ring_hi,
                                                                                                                               const int *list, const int *list_n)
 {
@@ -554,28 +581,36 @@ __global__ __launch_bounds__(LL_BLOCK, (ROWS <= 9 ? LL_FWAVES_SPLIT : ROWS <= 12
         const int n = *list_n;
         for (int i = blockIdx.x; i < n; i += gridDim.x) {
             const int e = list[i];
-            ll_ring_features_ring<ROWS>(V, e >> 8, e & 0xFF, ring_lo, ring_hi);
+            ll_ring_features_ring<ROWS, MATCH>(V, e >> 8, e & 0xFF, ring_lo, ring_hi);
             __syncthreads();                                          /* the next ring's set-up overwrites what this one's last reads used */
         }
     } else {
         int sl, r;
         if (!ll_xcd_map2(blockIdx.x, V.R, count, sl, r)) return;
-        ll_ring_features_ring<ROWS>(V, first + sl, r, ring_lo, ring_hi);
+        ll_ring_features_ring<ROWS, MATCH>(V, first + sl, r, ring_lo, ring_hi);
     }
 }
 
-template <int ROWS>
-static void ll_launch_ring_features(const LLView &V, int first, int count, int grid, int ring_lo, int ring_hi, int tier, int wg_per_cu, hipStream_t st)
+template <int ROWS, bool MATCH>
+static void ll_launch_ring_features_as(const LLView &V, int first, int count, int grid, int ring_lo, int ring_hi, int tier, int wg_per_cu, hipStream_t st)
 {
     static size_t attr_bytes[LL_MAX_DEVICES] = {0};
     const size_t lds_bytes = ll_features_lds_bytes(ring_hi);
-    ll_ensure_dynamic_lds(k_ring_features<ROWS>, lds_bytes, attr_bytes);
+    ll_ensure_dynamic_lds(k_ring_features<ROWS, MATCH>, lds_bytes, attr_bytes);
     const int *list = nullptr, *list_n = nullptr;
     if (tier > 0) {
         list = V.tier_list + (size_t)(tier - 1) * V.B * V.R; list_n = V.tier_cnt + tier;
         if (grid > 256 * wg_per_cu) grid = 256 * wg_per_cu;
     }
-    hipLaunchKernelGGL((k_ring_features<ROWS>), dim3(grid), dim3(LL_BLOCK), lds_bytes, st, V, first, count, ring_lo, ring_hi, list, list_n);
+    hipLaunchKernelGGL((k_ring_features<ROWS, MATCH>), dim3(grid), dim3(LL_BLOCK), lds_bytes, st, V, first, count, ring_lo, ring_hi, list, list_n);
+}
+/* V.sort_match_any: the sort's ranking that does not lean on the LDS arbiter's lane order (ll_create: the device failed the check, or
+ * ll_params.voxel_sort_ranks asked for it) */
+template <int ROWS>
+static void ll_launch_ring_features(const LLView &V, int first, int count, int grid, int ring_lo, int ring_hi, int tier, int wg_per_cu, hipStream_t st)
+{
+    if (V.sort_match_any) ll_launch_ring_features_as<ROWS, true>(V, first, count, grid, ring_lo, ring_hi, tier, wg_per_cu, st);
+    else ll_launch_ring_features_as<ROWS, false>(V, first, count, grid, ring_lo, ring_hi, tier, wg_per_cu, st);
 }
 
 void ll_launch_features(const LLView &V, int first, int count, size_t /* LDS of the largest tier: checked by ll_create */, hipStream_t st, LLProfiler *prof, int what)

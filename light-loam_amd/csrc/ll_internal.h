@@ -42,6 +42,10 @@ struct ll_ctx {
     double *d_fb_s = nullptr; size_t fb_s_cap = 0; bool fb_has_s = false;   /* per-block s of the edge / plane blocks (ll_factor_blocks_set_s) */
     /* streaming input (ll_upload_scan_async): a second stream for host -> device copies, ordered against the compute stream by
      * ll_stream_record / ll_stream_wait; the point counts go down by value (k_set_counts), not from a staging cell */
+    /* the association stage of ll_hot_path_batch on two streams: k_build_grid of piece i + 1 beside k_associate of piece i */
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_ts[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int two_stream = 1;             /* ll_set_two_stream; LIGHTLOAM_ONE_STREAM=1 in the environment turns it off at ll_create */
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_x[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   /* ll_stream_record / ll_stream_wait */
 };

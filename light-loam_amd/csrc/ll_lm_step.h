@@ -3,7 +3,9 @@
  * levenberg_marquardt_strategy.cc as laserOdometry.cpp:820-825 / laserMapping.cpp:2072-2082 configure it), shared by the
  * odometry solve (ll_factors.hip) and the mapping solve (ll_mapping.hip).  State layout (doubles): 0-6 x, 7 cost, 8-43 H,
  * 44-49 g, 50-55 jacobi scale, 56 radius, 57 decrease_factor, 58 iteration, 59 done, 60-66 candidate, 67 model_cost_change,
- * 68 pending, 69 successes, 70 initial cost.
+ * 68 pending, 69 successes, 70 initial cost, 71 poisoned (LLLmOpt::nan_poisons_pose: the summed normal equations carried a NaN
+ * cost or row count -- the record a failing rank of a row-parallel solve contributes, lightloam_rccl.hpp -- and every later step
+ * leaves a NaN pose, so that the healthy ranks' ll_map_get_pose reports LL_ERR_STATE instead of a finite, un-optimised pose).
  */
 #pragma once
 #include "ll_common.h"
@@ -11,9 +13,14 @@
 
 /* the three steps on one solve: L = its state (LL_LM_STRIDE doubles), in = the normal equations at `pose`, pose = where the next
  * evaluation happens (global or LDS) */
-__device__ __forceinline__ void ll_lm_begin_one(double *L, const double *in, const double *pose, const LLLmOpt &o)
+__device__ __forceinline__ bool ll_lm_record_is_nan(const double *in) { return in[42] != in[42] || in[43] != in[43]; }
+__device__ __forceinline__ void ll_lm_poison(double *pose) { for (int k = 0; k < 7; ++k) pose[k] = __builtin_nan(""); }
+
+__device__ __forceinline__ void ll_lm_begin_one(double *L, const double *in, double *pose, const LLLmOpt &o)
 {
     for (int k = 0; k < 7; ++k) L[k] = pose[k];
+    L[71] = (o.nan_poisons_pose && ll_lm_record_is_nan(in)) ? 1.0 : 0.0;
+    if (L[71] != 0.0) ll_lm_poison(pose);
     L[7] = in[42];
     for (int k = 0; k < 36; ++k) L[8 + k] = in[k];
     for (int k = 0; k < 6; ++k) L[44 + k] = in[36 + k];
@@ -24,6 +31,7 @@ __device__ __forceinline__ void ll_lm_begin_one(double *L, const double *in, con
 __device__ __forceinline__ void ll_lm_propose_one(double *L, double *pose, const LLLmOpt &o)
 {
     L[68] = 0.0;
+    if (L[71] != 0.0) { ll_lm_poison(pose); return; }
     if (L[59] == 0.0) {
         /* FinalizeIterationAndCheckIfMinimizerCanContinue */
         bool stop = (int)L[58] >= o.max_num_iterations || L[56] < o.min_radius;
@@ -68,6 +76,8 @@ __device__ __forceinline__ void ll_lm_propose_one(double *L, double *pose, const
 
 __device__ __forceinline__ void ll_lm_accept_one(double *L, const double *in, double *pose, const LLLmOpt &o)
 {
+    if (o.nan_poisons_pose && ll_lm_record_is_nan(in)) L[71] = 1.0;
+    if (L[71] != 0.0) { L[68] = 0.0; ll_lm_poison(pose); return; }
     if (L[59] == 0.0 && L[68] != 0.0) {
         const double cc = in[42], cost = L[7];
         double step_norm = 0.0, x_norm = 0.0;

@@ -16,6 +16,28 @@ __device__ __forceinline__ bool ll_xcd_map(int id, int per_scan, int count, int 
     return scan < count;
 }
 
+/* The resident raw scan of a slot (ll_params.input_stride_floats): 4 floats per point (KITTI .bin / PointXYZ: x, y, z and one float the
+ * reference never reads, scanRegistration.cpp:105-106) or 3 (x, y, z packed -- a quarter fewer bytes over PCIe and out of HBM).  A slot's
+ * area starts at the same 16 NP-byte stride either way; raw[i] is the point as (x, y, z, 0).  S3 is a template argument where the
+ * register allocation matters (k_organize) and a run-time flag on the node-style path. */
+struct __attribute__((packed, aligned(4))) LLXyz { float x, y, z; };
+template <bool S3>
+struct LLRaw {
+    const float *b;
+    __device__ __forceinline__ float4 operator[](int i) const {
+        if (S3) { const LLXyz q = ((const LLXyz *)b)[i]; return make_float4(q.x, q.y, q.z, 0.0f); }     /* one global_load_dwordx3 */
+        return ((const float4 *)b)[i];
+    }
+};
+struct LLRawAny {
+    const float *b; bool s3;
+    __device__ __forceinline__ float4 operator[](int i) const {
+        if (s3) { const LLXyz q = ((const LLXyz *)b)[i]; return make_float4(q.x, q.y, q.z, 0.0f); }
+        return ((const float4 *)b)[i];
+    }
+};
+__device__ __forceinline__ const float *ll_raw_base(const LLView &V, int s) { return (const float *)(V.raw + (size_t)s * V.NP); }
+
 __device__ __forceinline__ bool ll_keep(const float4 p, float thres)
 {
     /* pcl::removeNaNFromPointCloud (:109) then x*x + y*y + z*z < thres*thres -> drop (:72), all f32 */
@@ -73,14 +95,14 @@ __device__ __forceinline__ void ll_tier_append(const LLView &V, int s, int r, in
 #ifndef LL_OWAVES
 #define LL_OWAVES 6       /* workgroups per CU (= waves per SIMD) of k_organize: 4 / 5 / 6 / 7 measured 7.88 / 7.31 / 7.00 / 7.00 ms per 8192 scans */
 #endif
-template <bool LUT>
+template <bool LUT, bool S3>
 __global__ __launch_bounds__(LL_BLOCK, LL_OWAVES) void k_organize(LLView V, int first, int count)
 {
     if ((int)blockIdx.x >= count) return;
     const int s = first + blockIdx.x;
     const int n_in = V.n_in[s];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const float4 *raw = V.raw + (size_t)s * V.NP;
+    const LLRaw<S3> raw = {ll_raw_base(V, s)};
     constexpr int NK = LL_TILE / LL_BLOCK, NW = LL_BLOCK / 64;
 
     __shared__ int thr[LL_MAX_RINGS + 2];
@@ -286,7 +308,7 @@ __global__ __launch_bounds__(LL_FK_THREADS) void k_first_kept(LLView V, int firs
     const int s = first + blockIdx.x;
     const int n_in = V.n_in[s];
     const int tid = threadIdx.x;
-    const float4 *raw = V.raw + (size_t)s * V.NP;
+    const LLRawAny raw = {ll_raw_base(V, s), V.raw_stride == 3};
     __shared__ int sh_first;
     if (tid == 0) sh_first = INT_MAX;
     __syncthreads();
@@ -326,7 +348,7 @@ __global__ __launch_bounds__(LL_BLOCK) void k_classify(LLView V, int first, int 
     const int base = tile * LL_TILE;
     if (base >= n_in) return;
     const int tid = threadIdx.x;
-    const float4 *raw = V.raw + (size_t)s * V.NP;
+    const LLRawAny raw = {ll_raw_base(V, s), V.raw_stride == 3};
 
     __shared__ int sh_first_p, sh_fk, sh_lk;
     __shared__ int hist[LL_MAX_RINGS];
@@ -477,7 +499,7 @@ __global__ __launch_bounds__(LL_BLOCK) void k_scatter(LLView V, int first, int c
     for (int i = tid; i < NK * NW * LL_MAX_RINGS; i += LL_BLOCK) (&cnt[0][0])[i] = 0;
     __syncthreads();
 
-    const float4 *raw = V.raw + (size_t)s * V.NP;
+    const LLRawAny raw = {ll_raw_base(V, s), V.raw_stride == 3};
     const float *ori = V.ori + (size_t)sl * V.NP;
     const int8_t *ring = V.ring + (size_t)sl * V.NP;
     int bits = 0; while ((1 << bits) < V.R) ++bits;
@@ -605,8 +627,11 @@ void ll_launch_organize(const LLView &V, int first, int count, hipStream_t st, L
     if (V.tier_list) (void)hipMemsetAsync(V.tier_cnt, 0, 4 * sizeof(int), st);       /* the work lists of this extract call's long rings start empty */
     if (count > V.org_small) {
         ll_prof_mark(prof, LL_K_ORGANIZE, st);
-        if (V.lut_nb > 0) hipLaunchKernelGGL(k_organize<true>, dim3(count), dim3(LL_BLOCK), 0, st, V, first, count);
-        else hipLaunchKernelGGL(k_organize<false>, dim3(count), dim3(LL_BLOCK), 0, st, V, first, count);
+        const bool s3 = V.raw_stride == 3;
+        if (V.lut_nb > 0) { if (s3) hipLaunchKernelGGL((k_organize<true, true>), dim3(count), dim3(LL_BLOCK), 0, st, V, first, count);
+                            else hipLaunchKernelGGL((k_organize<true, false>), dim3(count), dim3(LL_BLOCK), 0, st, V, first, count); }
+        else { if (s3) hipLaunchKernelGGL((k_organize<false, true>), dim3(count), dim3(LL_BLOCK), 0, st, V, first, count);
+               else hipLaunchKernelGGL((k_organize<false, false>), dim3(count), dim3(LL_BLOCK), 0, st, V, first, count); }
         ll_prof_mark(prof, LL_K_END, st);
         return;
     }

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(api):
     lib = api.load_library()
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     assert not missing, missing
-    assert lib.ll_abi_version() == 2          # 2: ll_params.distortion
+    assert lib.ll_abi_version() == 3          # 3: ll_params.voxel_sort_ranks, .input_stride_floats
     assert sorted(api.EXPORTS) == sorted(s for s in declared_symbols())
 
 
@@ -48,6 +48,12 @@ def test_create_validates_before_touching_a_device(api):
     with pytest.raises(api.LightLoamError) as e:
         api.Context(api.default_params(64, batch=0))
     assert e.value.code == -2
+    for bad in (dict(voxel_sort_ranks=2), dict(input_stride_floats=5), dict(input_stride_floats=2)):
+        with pytest.raises(api.LightLoamError) as e:
+            api.Context(api.default_params(64, **bad))
+        assert e.value.code == -2, bad
+    p = api.default_params(64)
+    assert (p.voxel_sort_ranks, p.input_stride_floats) == (0, 4)     # auto ranking; KITTI .bin / PointXYZ stride
 
 
 def test_no_cpu_fallback(api):

@@ -220,3 +220,34 @@ def test_an_undefined_pose_is_an_error_not_a_result(scene, api):
     again, ran = m.optimize(scene["guess"])
     assert ran and again.tobytes() == good.tobytes()
     m.close(); ctx.close()
+
+
+@pytest.mark.parametrize("when", ["begin", "accept"])
+def test_a_peers_nan_record_reaches_the_healthy_ranks_pose(scene, api, when):
+    """Round-5 advice: in the row-parallel solve a failing rank contributes a record of NaNs to the all-reduce (lightloam_rccl.hpp,
+    parallel.map_optimize_row_parallel).  A HEALTHY rank that steps its LM state with the NaN sum must end with an error, not with a
+    finite un-optimised pose and LL_OK: ll_map_lm_begin / _accept carry an explicit status (ll_lm_step.h, state slot 71), every later
+    step leaves a NaN pose, and ll_map_get_pose reports LL_ERR_STATE.  The next frame (set_pose + a clean sequence) works again."""
+    ctx = api.Context(api.default_params(scene["rings"], batch=1, max_points=4096))
+    m = api.Map(ctx, len(scene["corner_map"]) + 8, len(scene["surf_map"]) + 8, len(scene["corner_stack"]) + 8, len(scene["surf_stack"]) + 8)
+    m.set_map(scene["corner_map"], scene["surf_map"]); m.set_scan(scene["corner_stack"], scene["surf_stack"])
+    nan_rec = np.full(44, np.nan)
+
+    def sequence(poison):
+        m.set_pose(scene["guess"]); m.associate(None)
+        rec = m.evaluate()
+        m.lm_begin(nan_rec if poison == "begin" else rec)
+        for k in range(4):
+            m.lm_propose()
+            rec = m.evaluate()
+            m.lm_accept(nan_rec if (poison == "accept" and k == 1) else rec)
+        return m.pose()
+
+    with pytest.raises(api.LightLoamError) as e:
+        sequence(when)
+    assert e.value.code == -7, e.value                                           # LL_ERR_STATE on the healthy rank too
+    good = sequence(None)
+    assert np.isfinite(good).all()
+    ref, ran = m.optimize(scene["guess"], n_outer=1)
+    assert ran and np.abs(good - ref).max() < 1e-7
+    m.close(); ctx.close()
