@@ -226,6 +226,8 @@ extern "C" int ll_create(int device, const ll_params *p, ll_ctx **out)
     if (hipHostMalloc((void **)&ctx->h_stage, (size_t)NP * sizeof(float4), hipHostMallocDefault) != hipSuccess) { g_create_err = "hipHostMalloc failed"; ll_destroy(ctx); return LL_ERR_HIP; }
     ctx->n_in_host.assign(B, 0);
     if (const char *e = std::getenv("LIGHTLOAM_ONE_STREAM")) ctx->two_stream = (std::atoi(e) != 0) ? 0 : 1;
+    ctx->ts_pieces = LL_TWO_STREAM_PIECES;
+    if (const char *e = std::getenv("LIGHTLOAM_TS_PIECES")) { const int v = std::atoi(e); if (v >= 2 && v <= LL_TWO_STREAM_MAX_PIECES) ctx->ts_pieces = v; }   /* A/B runs */
     *out = ctx;
     return LL_OK;
 }
@@ -638,16 +640,15 @@ static int hot_path(ll_ctx *ctx, int first, int count, const double *host_pose_g
  * With the per-kernel profiler on, the whole stage is ONE interval ("k_build_grid||k_associate"): the two kernels' own durations are only
  * defined when they run alone (ll_set_two_stream(ctx, 0), which bench.py uses for its per-kernel pass). */
 #define LL_TWO_STREAM_MIN 512        /* scans per hot-path call (chunk) below which the stage stays on one stream: the pieces must still fill the chip */
-#define LL_TWO_STREAM_PIECES 4
 static int association_two_streams(ll_ctx *ctx, int f, int n)
 {
     if (!ctx->stream2) LL_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-    for (int i = 0; i <= LL_TWO_STREAM_PIECES; ++i)
+    const int P = ctx->ts_pieces;
+    for (int i = 0; i <= P; ++i)
         if (!ctx->ev_ts[i]) LL_HIP(hipEventCreateWithFlags(&ctx->ev_ts[i], hipEventDisableTiming));
     hipStream_t s1 = ctx->stream, s2 = ctx->stream2;
-    constexpr int P = LL_TWO_STREAM_PIECES;
     /* pieces of whole groups of eight scans (the kernels deal eight scans to the eight XCDs) */
-    int lo[P + 1];
+    int lo[LL_TWO_STREAM_MAX_PIECES + 1];
     for (int i = 0; i <= P; ++i) { lo[i] = (int)((long long)n * i / P) & ~7; }
     lo[0] = 0; lo[P] = n;
     ll_prof_mark(&ctx->prof, LL_K_ASSOC_STAGE, s1);

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(LL_GB, LL_GRID_WAVES) void k_build_grid(LLView V, i
             carry_max = __shfl(x, 63);
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        bool viol = false;
+        bool viol = false, nonmono = false;
         for (int ch = 0; ch < NCH; ++ch) {
             const int bv = ch * 64 + lane;
             if (bv < LL_TAB && feq[bv] != INT_MAX) {
@@ -304,11 +304,15 @@ __global__ __launch_bounds__(LL_GB, LL_GRID_WAVES) void k_build_grid(LLView V, i
                 const int fg = (hi + 1 > LL_TAB) ? pend : fge[max(hi + 1, 0)];
                 const int ll = (lo - 1 < 0) ? -1 : lle[min(lo - 1, LL_TAB)];
                 if (fg < leq[bv] || ll > feq[bv]) viol = true;
+                if (fge[bv + 1] < leq[bv]) nonmono = true;           /* a point of a higher ring in front of a point of ring bv */
             }
         }
-        const bool any_viol = __ballot(viol) != 0ull;
+        const bool any_viol = __ballot(viol) != 0ull, any_nonmono = __ballot(nonmono) != 0ull;
         if (lane == 0) {
-            tab[2 * (LL_TAB + 1)] = (okflag && !any_viol) ? 1 : 0;
+            /* bit 0: the tables bound the walks; bit 1: the ring values never decrease along the cloud (every cloud the extract stage
+             * produces) -- then "same scan line" is rj == rc and the place window is the ring window, which is what lets k_associate
+             * keep per-ring minima while it looks for the nearest neighbour */
+            tab[2 * (LL_TAB + 1)] = ((okflag && !any_viol) ? 1 : 0) | ((okflag && !any_viol && !any_nonmono) ? 2 : 0);
             tab[2 * (LL_TAB + 1) + 1] = m;
             tab[2 * (LL_TAB + 1) + 2] = pend;
         }
@@ -389,7 +393,8 @@ __device__ __forceinline__ void ll_ring_entry(int ring, int e, int cx, int cy, i
 #ifndef LL_SCAN_UN
 #define LL_SCAN_UN 2              /* point loads a lane keeps in flight while scanning a cell */
 #endif
-#define LL_RING_CELLS 24          /* entries (rows / side cells) whose bounds are fetched per round; wider rings take several rounds */
+#define LL_RING_CELLS 18          /* entries (rows / side cells) whose bounds are fetched per round -- the sweep beyond ring 2 at the default radius is 18 row
+                                   * ranges; wider sweeps take several rounds */
 
 /* squared distance from (qx, qy) to the rectangle of cells [xa, xb] of row yy, shrunk by a 1 mm margin so that float rounding
  * in ll_cell_coord can never make it an over-estimate; border cells are unbounded outwards */
@@ -473,10 +478,34 @@ __device__ __forceinline__ void ll_grid_search(const int *gstart, float qx, floa
     }
 }
 
+/* ---- k_associate: ONE traversal for the nearest neighbour and its ring-window partners (round 6) ----
+ * Rounds 1-5 searched twice: K=1, then -- the nearest point c and its ring rc known -- a second pruned search over the SAME near cells
+ * for the second / third point (2.5 of the kernel's 6 ms re-scanned cells the first search had just read).  For a target whose ring
+ * values never decrease along the cloud (bit 1 of the table flags: every extracted cloud) the partners are "the nearest other point on
+ * ring rc" and "the nearest point on the rings rc +- 1, rc +- 2" (:504-553, :668-721), so the first traversal can collect them before rc
+ * is known: every candidate it computes a distance for also goes, by its ring, into a small per-query table in LDS --
+ *   TMIN[v] = min (distance bits << 32 | place << 8 | ring)  over the candidates of ring v EXCEPT the nearest neighbour itself
+ *   TMAX[v] = max (~distance bits << 32 | place << 8 | ring) over the same candidates: the same distance with the HIGHEST place
+ * -- for LL_ATAB_W ring values around the ring the query's own elevation predicts (the neighbour lies within its distance of the query,
+ * so within a few rings of that).  "Except the nearest neighbour" without knowing it: a lane withholds the candidate that is its running
+ * minimum and hands it to the table only when a better one replaces it (or when the group's shared minimum turns out to be another
+ * lane's); the one key never handed over is the final minimum c.  Both updates are NON-returning LDS atomics: nothing in the scan loop
+ * waits for them.  When c and rc are known, TMIN[rc] is the nearest OTHER point of ring rc and TMIN[rc +- 1], TMIN[rc +- 2] are those
+ * rings' nearest points -- exactly the minima, over everything the first traversal visited, that the second search used to recompute;
+ * they become its starting bounds, the near entries the first traversal already scanned are skipped (a bit per lane and entry), and
+ * the SAME frontier goes on outward only while an unvisited rectangle can still beat them.  Exactness: equal distances inside one ring
+ * are the only case in which the table's order (lowest place) and the walks' visiting order can disagree; they show as TMIN and TMAX
+ * naming different places, and such a query -- like one whose window rc +- NEARBY_SCAN leaves the table, or a target that is not
+ * monotone -- simply starts the second search from nothing with no entry marked visited: the search of rounds 1-5, same code. */
+#ifndef LL_ATAB_W
+#define LL_ATAB_W 14              /* ring values per query table: 32 groups x 2 tables x 14 x 8 B = 7 KB of the workgroup's 20 KB */
+#endif
+#define LL_ATAB_BACK 7            /* the table covers rings [predicted - 7, predicted + 6] */
+
 template <bool PLANE>
 __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int qblock, int qpb,
                                                    const float4 *queries, int nq, const TargetRef T,
-                                                   int *out_a, int *out_b, int *out_c, float4 *qs, int *nn, int *rb, int *rcl, int *cellb_all, int *tab, unsigned char *perm, int *hist)
+                                                   int *out_a, int *out_b, int *out_c, float4 *qs, unsigned long long *rtab_all, int *cellb_all, int *tab, unsigned char *perm, int *hist)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     for (int i = tid; i < LL_TAB_WORDS; i += LL_BLOCK) tab[i] = T.tab[i];             /* the ring tables: read by every query */
@@ -484,6 +513,7 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
     const bool have = tid < qpb && qi < nq;
     /* a5: TransformToStart (s = 1 with DISTORTION 0, the reference's build): f64 rotate + translate, f32 store */
     float sx = 0.f, sy = 0.f, sz = 0.f;
+    int pred = 0;
     if (have) {
         const double *pose = V.pose + (size_t)s * 7;
         const float4 p = queries[qi];
@@ -499,8 +529,13 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
             ll_rotate(qs4, v, rr);
             sx = (float)(rr[0] + sr * pose[4]); sy = (float)(rr[1] + sr * pose[5]); sz = (float)(rr[2] + sr * pose[6]);
         }
+        /* where the per-ring table is centred: the ring the query's own elevation falls into in the target's frame (the sensor model's
+         * formula, scanRegistration.cpp:139-162) -- a guess that only decides how often the table is used, never a result */
+        const float t_el = sz / sqrtf(sx * sx + sy * sy);
+        pred = (t_el == t_el) ? ll_ring_of_t(t_el, V.ring_model, V.R, V.lower_bound, V.factor) : 0;
+        pred = min(max(pred, 0), 250);
     }
-    qs[tid] = make_float4(sx, sy, sz, have ? 1.0f : 0.0f);
+    qs[tid] = make_float4(sx, sy, sz, __int_as_float(have ? pred + 1 : 0));
     if (tid < 64) hist[tid] = 0;
     __syncthreads();
     /* The eight queries of a wave advance in lockstep, so they should cost about the same: the block's queries are dealt to
@@ -531,14 +566,17 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
 
     const int g = tid >> 3, sub = tid & 7;
     int *cellb = cellb_all + g * (3 * LL_RING_CELLS);
+    unsigned long long *rtab = rtab_all + g * (2 * LL_ATAB_W);   /* T1 [0, W), T2 [W, 2 W) of this group's current query */
     const int rmax = (int)ceilf(sqrtf(V.nn_max) / LL_GRID_CELL) + 1;
     const float4 *gpts = T.gpts; const int *gstart = T.gstart;
     const float4 *tgt = T.pts; const int M = T.m;
-    const bool tab_ok = (tab[2 * (LL_TAB + 1)] & 1) != 0 && tab[2 * (LL_TAB + 1) + 1] == M;
+    const int tflags = tab[2 * (LL_TAB + 1)];
+    const bool tab_ok = (tflags & 1) != 0 && tab[2 * (LL_TAB + 1) + 1] == M;
+    const bool use_table = tab_ok && (tflags & 2) != 0;          /* monotone rings: classes by ring value (workgroup-uniform) */
     const int PEND = tab[2 * (LL_TAB + 1) + 2];                  /* one past the last place of the target cloud (= M when it is contiguous) */
     const float dmax = V.nn_max;
-#ifdef LL_ASSOC_STATS   /* tools/assoc_stats.py: candidates scanned by the two searches, sweep rounds, queries -> V.dbg[0..3] corners, [4..7] planes */
-    unsigned long long st_nn = 0, st_w = 0, st_sync = 0, st_q = 0;
+#ifdef LL_ASSOC_STATS   /* tools/assoc_stats.py: candidates scanned by the two searches, sweep rounds, queries -> V.dbg[0..3] corners, [4..7] planes; [12], [13]: queries that did not use their table */
+    unsigned long long st_nn = 0, st_w = 0, st_sync = 0, st_q = 0, st_fb = 0;
 #define LL_STAT(x) (++(x))
 #else
 #define LL_STAT(x) do {} while (0)
@@ -546,8 +584,9 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
     for (int pass = 0; pass < qpb / 32; ++pass) {
         const int ql = perm[((pass * (LL_BLOCK / 64) + (g >> 3)) << 3) + (g & 7)];
         const float4 q = qs[ql];
+        const int qtag = __float_as_int(q.w);
         int closest = -1, res_b = -1, res_c = -1;
-        if (q.w != 0.0f && M > 0) {
+        if (qtag != 0 && M > 0) {
             /* ---- exact K=1 NN within nn_max ----
              * One 64-bit key per candidate: the distance's bits (non-negative floats order like their bits) above the packed
              * word place << 8 | ring, so "closer, or as close with the lower index" is one unsigned minimum, and the winner's
@@ -556,6 +595,20 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
              * lower word >= 0, so it does not (:497 / :659 accept d < DISTANCE_SQ_THRESHOLD only) */
             const unsigned long long knone = (unsigned long long)__float_as_uint(dmax) << 32;
             unsigned long long kb = knone;
+            const unsigned rq0 = (unsigned)(qtag - 1 - LL_ATAB_BACK);          /* first ring value of the table (may be "negative": unsigned compare below) */
+            if (use_table) {
+                for (int e = sub; e < 2 * LL_ATAB_W; e += 8) rtab[e] = (e < LL_ATAB_W) ? knone : 0ull;   /* TMIN [0, W), TMAX [W, 2 W) */
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            }
+            /* hand a key to the table (a candidate that is not, or no longer, this lane's running minimum) */
+            auto table_put = [&](unsigned long long k) __attribute__((always_inline)) {
+                const unsigned rel = ((unsigned)k & 0xFFu) - rq0;
+                if (rel < (unsigned)LL_ATAB_W) {
+                    (void)__hip_atomic_fetch_min(&rtab[rel], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    (void)__hip_atomic_fetch_max(&rtab[LL_ATAB_W + rel], k ^ 0xFFFFFFFF00000000ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            };
+            unsigned vis = 0u;                                                  /* bit e: THIS lane scanned its share of near entry e in the first traversal */
             /* The query's own cell and the four entries of Chebyshev ring 1 (row below, row above, left and right cell) serve
              * BOTH searches: lane e of the group fetches entry e's bounds once and keeps them in its registers, the scans get
              * them by a lane broadcast.  Own cell, share the best, the ring-1 entries the bound still admits, share again;
@@ -570,12 +623,15 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
                     if (!(a_lb > dmax)) { a_st = gstart[yy * LL_GRID_G + xa]; a_en = gstart[yy * LL_GRID_G + xb + 1]; }
                 }
             }
-            auto scan_near = [&](auto scan, auto bound, auto sync) __attribute__((always_inline)) {
+            /* near entries: first traversal marks what it scans, the second one skips what is marked */
+            auto scan_near = [&](auto scan, auto bound, auto sync, auto first_tag) __attribute__((always_inline)) {
+                constexpr bool FIRST = decltype(first_tag)::value;
                 auto entry = [&](auto e_tag) __attribute__((always_inline)) {
                     constexpr int e = decltype(e_tag)::value;
                     const int st = ll_bcast8<e>(a_st), en = ll_bcast8<e>(a_en);
                     const float lb = __int_as_float(ll_bcast8<e>(__float_as_int(a_lb)));
-                    if (st < en && !(lb > bound())) scan(st, en);
+                    if (FIRST) { if (st < en && !(lb > bound())) { scan(st, en); vis |= 1u << e; } }
+                    else if (!((vis >> e) & 1u) && st < en && !(lb > bound())) scan(st, en);
                 };
                 entry(std::integral_constant<int, 0>{}); sync();
                 entry(std::integral_constant<int, 1>{}); entry(std::integral_constant<int, 2>{});
@@ -596,19 +652,27 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
                             diff = q.y - p.y; d += diff * diff;
                             diff = q.z - p.z; d += diff * diff;
                             const unsigned long long k = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w);
-                            kb = (k < kb) ? k : kb;                           /* d < dmax is implied: kb starts at (dmax, 0) */
+                            const bool better = k < kb;                       /* d < dmax is implied: kb starts at (dmax, 0) */
+                            if (use_table) table_put(better ? kb : k);        /* the displaced minimum, or the candidate itself (knone lands nowhere: min with itself) */
+                            kb = better ? k : kb;
                         }
                     }
                 };
             auto nn_bound = [&]() { return __uint_as_float((unsigned)(kb >> 32)); };
-            auto nn_sync = [&]() { kb = ll_min8_u64(kb); if (sub == 0) LL_STAT(st_sync); };
+            /* share the minimum; a lane whose own minimum lost hands it to the table */
+            auto nn_sync = [&]() {
+                const unsigned long long gmin = ll_min8_u64(kb);
+                if (use_table && kb != gmin) table_put(kb);
+                kb = gmin;
+                if (sub == 0) LL_STAT(st_sync);
+            };
             if (sub == 0) LL_STAT(st_q);
-            scan_near(nn_scan, nn_bound, nn_sync);
+            scan_near(nn_scan, nn_bound, nn_sync, std::true_type{});
             ll_grid_search(gstart, q.x, q.y, rmax, cellb, sub, 2, nn_scan, nn_bound, nn_sync);
             int rc = 0;
             if (kb != knone) { closest = (int)((unsigned)kb >> 8); rc = (int)((unsigned)kb & 0xFFu); }   /* :497 / :659: d < DISTANCE_SQ_THRESHOLD */
 
-            /* ---- second / third point inside the ring window, table-bounded cell search ----
+            /* ---- second / third point inside the ring window ----
              * The walks' "if (d < min) take" over their visiting order is the lexicographic minimum of (d, visiting order):
              * again one 64-bit key, distance bits above the order; the index is recovered from the order at the end. */
             if (closest >= 0 && tab_ok) {
@@ -619,6 +683,29 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
                 const int c1 = c + 1, mc = PEND + c - 1;                                       /* c, j, jlo, jhi: PLACES in the target cloud (their order is the index order) */
                 const unsigned long long wnone = (unsigned long long)__float_as_uint(dmax) << 32;           /* (dmax, 0): strict d < dmax as above (:512, :520, :677 ...) */
                 unsigned long long k2 = wnone, k3 = wnone;
+                if (use_table) {
+                    /* what the first traversal left in the table.  Usable when the window [lo, hi] lies inside the table and no ring of it holds
+                     * two candidates at its minimal distance; else the search below starts from nothing (vis = 0) */
+                    const unsigned long long gm = 0xFFull << (lane & 56);
+                    const bool inside = lo >= (int)rq0 && hi < (int)rq0 + LL_ATAB_W && hi - lo < 8;   /* rq0 may be negative: ring - rq0 wraps correctly */
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const int v = lo + sub;                                                     /* lane `sub` reads ring lo + sub (the window holds <= 8 values: `inside`) */
+                    unsigned long long kk = knone; bool tie = false;
+                    if (inside && v <= hi) {
+                        kk = rtab[v - (int)rq0];
+                        const unsigned long long kx = rtab[LL_ATAB_W + v - (int)rq0];
+                        tie = kk < knone && (unsigned)kk != (unsigned)kx;                     /* two places at the ring's minimal distance */
+                    }
+                    if (inside && (__ballot(tie) & gm) == 0ull) {
+                        if (kk < knone) {
+                            const int j = (int)((unsigned)kk >> 8);
+                            const int ord = (j > c) ? j - c1 : mc - j;
+                            const unsigned long long key = (kk & 0xFFFFFFFF00000000ull) | (unsigned)ord;
+                            if (PLANE) { if (v == rc) k2 = key; else k3 = key; }
+                            else if (v != rc) k2 = key;
+                        }
+                    } else { vis = 0u; LL_STAT(st_fb); }
+                } else vis = 0u;
                 auto w_scan = [&](int st, int en) {
                         for (int k0 = st + sub; k0 < en; k0 += 8 * LL_SCAN_UN) {
                           float4 pp[LL_SCAN_UN];
@@ -651,25 +738,39 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
                 auto w_bound = [&]() { const unsigned h2 = (unsigned)(k2 >> 32), h3 = (unsigned)(k3 >> 32); return __uint_as_float(PLANE ? max(h2, h3) : h2); };
                 auto w_sync = [&]() { k2 = ll_min8_u64(k2); if (PLANE) k3 = ll_min8_u64(k3); if (sub == 0) LL_STAT(st_sync); };
                 auto index_of = [&](unsigned long long k) { const int ord = (int)(unsigned)k; return (k == wnone) ? -1 : (ord < PEND ? c1 + ord : mc - ord); };   /* up: ord = j - c1 < PEND, down: ord = mc - j >= PEND */
-                scan_near(w_scan, w_bound, w_sync);
+                if (use_table) w_sync();                                         /* the table's minima, shared: the bound every lane starts from */
+                scan_near(w_scan, w_bound, w_sync, std::false_type{});
                 ll_grid_search(gstart, q.x, q.y, rmax, cellb, sub, 2, w_scan, w_bound, w_sync);
                 res_b = index_of(k2); res_c = PLANE ? index_of(k3) : -1;
             }
         }
-        if (sub == 0) { nn[ql] = closest; rb[ql] = res_b; rcl[ql] = res_c; }
+        if (sub == 0 && ql < qpb) {
+            const int qo = qblock * qpb + ql;
+            if (qo < nq) {
+                /* :556 / :723; a target whose tables do not bound the walks: the nearest point now, the partners from the walks below */
+                const bool valid = closest >= 0 && res_b >= 0 && (!PLANE || res_c >= 0);
+                out_a[qo] = (valid || !tab_ok) ? closest : -1;
+                out_b[qo] = valid ? res_b : -1;
+                if (PLANE) out_c[qo] = valid ? res_c : -1;
+            }
+        }
     }
 #ifdef LL_ASSOC_STATS
-    { unsigned long long *d = V.dbg + (PLANE ? 4 : 0); atomicAdd(d, st_nn); atomicAdd(d + 1, st_w); atomicAdd(d + 2, st_sync); atomicAdd(d + 3, st_q); }
+    { unsigned long long *d = V.dbg + (PLANE ? 4 : 0); atomicAdd(d, st_nn); atomicAdd(d + 1, st_w); atomicAdd(d + 2, st_sync); atomicAdd(d + 3, st_q);
+      atomicAdd(V.dbg + (PLANE ? 13 : 12), st_fb); }
 #endif
 #undef LL_STAT
-    __syncthreads();
-    const int closest = have ? nn[tid] : -1;
-    int res_b = rb[tid], res_c = rcl[tid];
+    if (tab_ok) return;                                                          /* workgroup-uniform */
 
-    if (!tab_ok) {
-        /* fallback: the reference's sequential walks, one query at a time per wave.  They run over INDICES; a ring-strided target
-         * (an extracted slot -- whose tables can only fail on degenerate intensities) is addressed through its prefix table:
-         * place -> index by a division, index -> place by a search.  Rare by construction, exact always. */
+    /* fallback: the reference's sequential walks, one query at a time per wave.  They run over INDICES; a ring-strided target
+     * (an extracted slot -- whose tables can only fail on degenerate intensities) is addressed through its prefix table:
+     * place -> index by a division, index -> place by a search.  Rare by construction, exact always.  The nearest points come back
+     * from the output array the pass loop parked them in (other lanes of this workgroup wrote them: L1-bypassing loads behind a fence). */
+    __threadfence();
+    __syncthreads();
+    const int closest = have ? __hip_atomic_load(&out_a[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+    int res_b = -1, res_c = -1;
+    {
         const int *tpre = T.pre; const int tstride = T.stride, RR = V.R;
         auto to_index = [&](int place) -> int { if (!tpre) return place; const int q = place / tstride; return tpre[q] + (place - q * tstride); };
         auto to_place = [&](int idx) -> int {
@@ -678,7 +779,6 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tpre[mid] <= idx) lo = mid; else hi = mid; }
             return lo * tstride + (idx - tpre[lo]);
         };
-        res_b = -1; res_c = -1;
         for (int qq = 0; qq < 64; ++qq) {
             const int cp = __shfl(closest, qq);
             if (cp < 0) continue;
@@ -735,10 +835,8 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
 
 /* 2nd launch bound = waves per SIMD.  Left alone the compiler spends 106 SGPRs and lands on 7; asked for 8 it fits in 78
  * with the same 60 VGPRs and no scratch -- the kernel is latency-bound, one more wave per SIMD is worth 17 % (A/B, one box).
- * (Round 5 built a second instantiation for targets whose ring values never decrease along the cloud -- ring-window test instead
- * of the place window, class = rj == rc, 32-bit distance keys -- as a launch of its own in front of this one: index-exact, 2 % faster
- * on the 64-ring synthetic scans, 8 % SLOWER on the denser 128-ring and HDL-64E targets, with either key width; removed again.
- * profiles/r05_experiments/ab_assoc_monotone_variants_*.log) */
+ * LDS: 4 KB queries + 6.8 KB entry bounds + 7 KB ring tables + 1.3 KB walk tables + 0.5 KB = 19.6 of the 20 KB that eight
+ * workgroups per CU leave each. */
 __global__ __launch_bounds__(LL_BLOCK, 8) void k_associate(LLView V, int first, int count, int qb_corner, int qb_plane, int qpb)
 {
     /* All query blocks of a scan on ONE XCD (workgroup b runs on XCD b % 8): they search the same target grid, and an XCD's 4 MB L2 is
@@ -750,7 +848,7 @@ __global__ __launch_bounds__(LL_BLOCK, 8) void k_associate(LLView V, int first, 
     const int s = first + sl;
     if (item == 0 && threadIdx.x == 0) V.assoc_tgt[s] = (s == V.carry_slot) ? -1 : s - 1;   /* whose points this slot's correspondences name from now on */
     __shared__ float4 qs[LL_BLOCK];
-    __shared__ int nn[LL_BLOCK], rb[LL_BLOCK], rcl[LL_BLOCK];
+    __shared__ unsigned long long rtab[(LL_BLOCK / 8) * 2 * LL_ATAB_W];
     __shared__ int cellb[(LL_BLOCK / 8) * 3 * LL_RING_CELLS];
     __shared__ int tab[LL_TAB_WORDS];
     __shared__ unsigned char perm[LL_BLOCK];
@@ -761,14 +859,14 @@ __global__ __launch_bounds__(LL_BLOCK, 8) void k_associate(LLView V, int first, 
         const int nq = ok ? h.n_sharp : 0;
         if (item * qpb >= nq) return;
         ll_associate_block<false>(V, s, item, qpb, V.sharp + (size_t)s * V.cap_sharp, nq, ll_target(V, s, 0),
-                                  V.eq_a + (size_t)s * V.cap_sharp, V.eq_b + (size_t)s * V.cap_sharp, nullptr, qs, nn, rb, rcl, cellb, tab, perm, hist);
+                                  V.eq_a + (size_t)s * V.cap_sharp, V.eq_b + (size_t)s * V.cap_sharp, nullptr, qs, rtab, cellb, tab, perm, hist);
     } else {
         const int qb = item - qb_corner;
         const int nq = ok ? h.n_flat : 0;
         if (qb * qpb >= nq) return;
         ll_associate_block<true>(V, s, qb, qpb, V.flat + (size_t)s * V.cap_flat, nq, ll_target(V, s, 1),
                                        V.pq_a + (size_t)s * V.cap_flat, V.pq_b + (size_t)s * V.cap_flat,
-                                       V.pq_c + (size_t)s * V.cap_flat, qs, nn, rb, rcl, cellb, tab, perm, hist);
+                                       V.pq_c + (size_t)s * V.cap_flat, qs, rtab, cellb, tab, perm, hist);
     }
 }
 

@@ -10,6 +10,8 @@
 #include <cstring>
 
 #define LL_PROF_EVENTS 8192
+#define LL_TWO_STREAM_PIECES 4
+#define LL_TWO_STREAM_MAX_PIECES 8
 struct LLProfiler {
     bool on = false;
     std::vector<hipEvent_t> ev;
@@ -45,6 +47,7 @@ struct ll_ctx {
     /* the association stage of ll_hot_path_batch on two streams: k_build_grid of piece i + 1 beside k_associate of piece i */
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_ts[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int ts_pieces = 4;              /* pieces the slot range of a call is cut into (LIGHTLOAM_TS_PIECES: A/B runs) */
     int two_stream = 1;             /* ll_set_two_stream; LIGHTLOAM_ONE_STREAM=1 in the environment turns it off at ll_create */
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_x[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   /* ll_stream_record / ll_stream_wait */
