@@ -725,9 +725,9 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_read(reset=True)
-    # The timed region ran the library's default schedule: k_build_grid and k_associate side by side on two streams (ll_set_two_stream),
-    # which the event profiler records as ONE interval.  Their own durations -- each kernel alone on the chip, what a roofline figure is
-    # defined on -- come from a short pass on one stream behind the timed region (not part of `value`).
+    # With LIGHTLOAM_TWO_STREAM=1 the timed region runs k_build_grid and k_associate side by side on two streams (ll_set_two_stream; off by
+    # default: measured, no gain), which the event profiler records as ONE interval.  Their own durations -- each kernel alone on the chip,
+    # what a roofline figure is defined on -- then come from a short pass on one stream behind the timed region (not part of `value`).
     STAGE = "k_build_grid||k_associate"
     stage_two_stream_ms = None
     if STAGE in prof and prof[STAGE][1]:
@@ -883,7 +883,7 @@ def main():
                          "kernel_ms_per_step": ms_of,
                          "association_stage": None if stage_two_stream_ms is None else {
                              "schedule": "timed region: k_build_grid of one quarter of the batch beside k_associate of the quarter before it, two HIP "
-                                         "streams ordered by events (the library's default, ll_set_two_stream); kernel_ms_per_step's k_build_grid / "
+                                         "streams ordered by events (LIGHTLOAM_TWO_STREAM=1 / ll_set_two_stream); kernel_ms_per_step's k_build_grid / "
                                          "k_associate: each kernel alone, from 3 one-stream steps behind the timed region",
                              "two_stream_ms_per_step": stage_two_stream_ms * launches_per_step,
                              "one_stream_ms_per_step": ms_of.get("k_build_grid", 0.0) + ms_of.get("k_associate", 0.0),

@@ -370,11 +370,11 @@ int ll_hot_path_batch(ll_ctx *ctx, int first, int count, const double *host_pose
 /* The same pass continuing a batch that an earlier call opened: the target of slot `first` is slot first - 1, not the carry
  * (a batch processed in pieces -- e.g. the halves of a double-buffered stream -- gives the results of one call over the whole). */
 int ll_hot_path_chain(ll_ctx *ctx, int first, int count, int vote_enable);
-/* Schedule of the association stage inside ll_hot_path_batch / _chain for calls (chunks) of at least 512 scans.  on = 1 (default): the
- * target grids of one quarter of the range are built while the quarter before it is searched, on two HIP streams ordered by events
- * (the two kernels take ~10 % less time side by side than in a row).  on = 0: one stream, kernel after kernel -- the schedule under
- * which ll_profile_read's k_build_grid / k_associate figures are each kernel's own time.  Results are identical either way.
- * LIGHTLOAM_ONE_STREAM=1 in the environment makes 0 the default of new contexts. */
+/* Schedule of the association stage inside ll_hot_path_batch / _chain for calls (chunks) of at least 512 scans.  on = 0 (default): one
+ * stream, kernel after kernel.  on = 1: the target grids of one quarter of the range are built while the quarter before it is searched,
+ * on two HIP streams ordered by events.  Results are identical either way; on the MI355X boxes of round 6 the second schedule was never
+ * faster (profiles/r06_experiments/two_stream_pieces.log), which is why it is not the default.  LIGHTLOAM_TWO_STREAM=1 in the environment
+ * makes 1 the default of new contexts. */
 int ll_set_two_stream(ll_ctx *ctx, int on);
 
 /* ---------------------------------------------------------------- measurement

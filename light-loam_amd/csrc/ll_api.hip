@@ -225,7 +225,7 @@ extern "C" int ll_create(int device, const ll_params *p, ll_ctx **out)
     ctx->h_stage_pts = NP;
     if (hipHostMalloc((void **)&ctx->h_stage, (size_t)NP * sizeof(float4), hipHostMallocDefault) != hipSuccess) { g_create_err = "hipHostMalloc failed"; ll_destroy(ctx); return LL_ERR_HIP; }
     ctx->n_in_host.assign(B, 0);
-    if (const char *e = std::getenv("LIGHTLOAM_ONE_STREAM")) ctx->two_stream = (std::atoi(e) != 0) ? 0 : 1;
+    if (const char *e = std::getenv("LIGHTLOAM_TWO_STREAM")) ctx->two_stream = (std::atoi(e) != 0) ? 1 : 0;
     ctx->ts_pieces = LL_TWO_STREAM_PIECES;
     if (const char *e = std::getenv("LIGHTLOAM_TS_PIECES")) { const int v = std::atoi(e); if (v >= 2 && v <= LL_TWO_STREAM_MAX_PIECES) ctx->ts_pieces = v; }   /* A/B runs */
     *out = ctx;
@@ -631,14 +631,16 @@ extern "C" int ll_odometry_frames(ll_ctx *ctx, int first, int count, const doubl
 
 static int hot_path(ll_ctx *ctx, int first, int count, const double *host_pose_guess, int vote_enable, int chain);
 
-/* The association stage of a hot-path call on TWO streams.  k_build_grid (one 1024-thread workgroup per CU, waiting on LDS sweeps and a
- * divergent scatter) and k_associate (eight waves per SIMD of dependent L2 round trips, half of the vector issue slots idle) are the one
- * pair of kernels of the path that take less time side by side than one after the other (tools/experiments/overlap_probe.py: 89 % of the
- * sum).  The slot range is cut into pieces; the grid of piece i + 1 is built on the context's stream while piece i is searched on the second
- * one -- piece i's targets are its own slots' predecessors, i.e. the grids of pieces <= i, complete when event i fires.  Events only, no
- * host synchronisation; the context's stream waits for the last search before the vote.  Results do not depend on the schedule.
- * With the per-kernel profiler on, the whole stage is ONE interval ("k_build_grid||k_associate"): the two kernels' own durations are only
- * defined when they run alone (ll_set_two_stream(ctx, 0), which bench.py uses for its per-kernel pass). */
+/* The association stage of a hot-path call on TWO streams -- built in round 6, measured, and OFF by default (ll_set_two_stream(ctx, 1) or
+ * LIGHTLOAM_TWO_STREAM=1 turns it on).  Round 5's probe had k_build_grid and k_associate finish in 89 % of the sum of their times when both
+ * were simply launched side by side, so the slot range is cut into pieces here: the grid of piece i + 1 is built on the context's stream
+ * while piece i is searched on a second one -- piece i's targets are its own slots' predecessors, i.e. the grids of pieces <= i, complete
+ * when event i fires.  Events only, no host synchronisation; the context's stream waits for the last search before the vote; results do not
+ * depend on the schedule (tests/test_gpu_variants.py).  Measured on one box with 2 / 3 / 4 / 6 / 8 pieces of a 16384-scan step
+ * (profiles/r06_experiments/two_stream_pieces.log): the stage takes 20.3-21.3 ms on two streams against 20.3-20.7 ms kernel after kernel --
+ * never less.  Both kernels ask for a whole CU (k_build_grid: one 1024-thread workgroup with 72 KB of LDS; k_associate: eight workgroups that
+ * take all 160 KB), so the dispatcher alternates between them CU by CU instead of interleaving them, and the dependent pieces add their
+ * tails.  With the per-kernel profiler on, the two-stream stage is ONE interval ("k_build_grid||k_associate"). */
 #define LL_TWO_STREAM_MIN 512        /* scans per hot-path call (chunk) below which the stage stays on one stream: the pieces must still fill the chip */
 static int association_two_streams(ll_ctx *ctx, int f, int n)
 {

@@ -48,7 +48,7 @@ struct ll_ctx {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_ts[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int ts_pieces = 4;              /* pieces the slot range of a call is cut into (LIGHTLOAM_TS_PIECES: A/B runs) */
-    int two_stream = 1;             /* ll_set_two_stream; LIGHTLOAM_ONE_STREAM=1 in the environment turns it off at ll_create */
+    int two_stream = 0;             /* ll_set_two_stream; LIGHTLOAM_TWO_STREAM=1 in the environment turns it on at ll_create (measured: no gain, ll_api.hip) */
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_x[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   /* ll_stream_record / ll_stream_wait */
 };

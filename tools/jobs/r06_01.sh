@@ -4,7 +4,7 @@ O=gpurun_out; mkdir -p $O
 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | grep -v amdgpu.ids | tail -15 > $O/r06_01_pytest.log
 tail -3 $O/r06_01_pytest.log
 bash tools/ab_bench.sh > $O/r06_01_ab_s64.log 2>&1; cat $O/r06_01_ab_s64.log
-LIGHTLOAM_ONE_STREAM=1 timeout 600 python bench.py --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | grep '^{"metric' | python -c "
+LIGHTLOAM_TWO_STREAM=0 timeout 600 python bench.py --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | grep '^{"metric' | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); print('tree one-stream: %.0f scans/s %.2f ms' % (d['value'], d['ms_per_step']))" | tee -a $O/r06_01_ab_s64.log
 for st in 4 3; do
   timeout 600 python bench.py --stream-input --input-stride $st --no-cpu-baseline > $O/r06_01_stream_s64_stride$st.json 2>/dev/null
