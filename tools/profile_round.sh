@@ -43,6 +43,17 @@ python3 tools/sq_summary.py $O/pmc_sq_s > $O/${TAG}_sq_counters_s128.txt
 python3 tools/sq_issue.py $O/pmc_sq_s --batch 4096 --rings 128 --workload synthetic > $O/sq_issue_s128.json
 cp $O/pmc_traffic_s128.json profiles/pmc_traffic_s128.json
 cp $O/sq_issue_s128.json profiles/sq_issue_s128.json
+# ... and for BASELINE config 1's shape (16 rings, 32768 scans per step), so that no committed bench line says "bound: unknown"
+BV="python3 bench.py --rings 16 --steps 5 --warmup 1 --no-cpu-baseline --calibrate"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $O/pmc_fetch_v -o fetch -- $BV > $O/pmc_fetch_v.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d $O/pmc_write_v -o write -- $BV > $O/pmc_write_v.log 2>&1
+python3 tools/pmc_traffic.py $O/pmc_fetch_v $O/pmc_write_v --batch 32768 --rings 16 --workload synthetic > $O/pmc_traffic_s16.json
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY \
+    --kernel-trace -f csv -d $O/pmc_sq_v -o sq -- $BV > $O/pmc_sq_v.log 2>&1
+python3 tools/sq_summary.py $O/pmc_sq_v > $O/${TAG}_sq_counters_s16.txt
+python3 tools/sq_issue.py $O/pmc_sq_v --batch 32768 --rings 16 --workload synthetic > $O/sq_issue_s16.json
+cp $O/pmc_traffic_s16.json profiles/pmc_traffic_s16.json
+cp $O/sq_issue_s16.json profiles/sq_issue_s16.json
 python3 bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 # the self-launching N-rank path on the one GPU of this pool (two ranks on device 0, gloo for the timing reduction: RCCL cannot share a device)
 python3 bench.py --gpus 2 --backend gloo --share-gpu --batch 2048 --no-cpu-baseline > $O/${TAG}_bench_gpus2_gloo_share_gpu.json 2>/dev/null
@@ -63,5 +74,5 @@ python3 tools/soak_extract_s64.py 96 > $O/${TAG}_soak_extract_s64.log 2>&1
 python3 tools/soak_hot_path.py 256 2>&1 | grep -v amdgpu.ids > $O/${TAG}_soak_hot_path.log
 python3 tools/soak_frames.py 120 60 2>&1 | grep -v "amdgpu.ids\|RuntimeWarning\|org_s" > $O/${TAG}_soak_frames_short.log
 # keep what is merged back small: the raw counter tables and traces stay on the box
-rm -rf $O/prof_$TAG $O/prof_${TAG}_hdl64 $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_fetch_h $O/pmc_write_h $O/pmc_sq_h $O/pmc_fetch_s $O/pmc_write_s $O/pmc_sq_s $O/liblightloam_hip_phase.so
+rm -rf $O/prof_$TAG $O/prof_${TAG}_hdl64 $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_fetch_h $O/pmc_write_h $O/pmc_sq_h $O/pmc_fetch_s $O/pmc_write_s $O/pmc_sq_s $O/pmc_fetch_v $O/pmc_write_v $O/pmc_sq_v $O/liblightloam_hip_phase.so
 tail -n 3 $O/${TAG}_kernel_stats.txt; tail -c 600 $O/${TAG}_bench.json
