@@ -451,6 +451,19 @@ __device__ __forceinline__ void ll_ring_features_ring(const LLView &V, int s, in
                 ll_radix_sort<ROWS, true, MATCH>(L.k32, L.k16, nrec, key_bits, L.cnt, tid, e32, e16);
                 LL_PHASE(4);
                 __syncthreads();
+#ifdef LL_SORT_CHECK    /* -DLL_SORT_CHECK (tools/soak_extract*.py with LL_SORT_CHECK_LIB): the sort's result IS ordered by (voxel, input order) -- the property
+                         * the ranking from returning LDS adds rests on, asserted on every ring of a soak instead of inferred from equal clouds.  V.dbg[9] counts
+                         * adjacent pairs out of order, V.dbg[10] the pairs looked at. */
+                {
+                    unsigned bad = 0, seen = 0;
+                    for (int i = tid; i + 1 < m; i += LL_BLOCK) {
+                        const unsigned ka = L.k32[i], kb = L.k32[i + 1];
+                        bad += (ka > kb || (ka == kb && L.k16[i] >= L.k16[i + 1])) ? 1u : 0u; ++seen;
+                    }
+                    if (bad) atomicAdd(&V.dbg[9], (unsigned long long)bad);
+                    atomicAdd(&V.dbg[10], (unsigned long long)seen);
+                }
+#endif
                 sorted_ok = true;
             }
         }

@@ -9,6 +9,16 @@ from oracle import orc
 import test_gpu_parity as T
 from conftest import assert_bit_equal
 api.load_library(); orc.build()
+SORT_SEEN, SORT_BAD = [0], [0]
+
+
+def sort_check(ctx):
+    """-DLL_SORT_CHECK builds count, per context, the adjacent pairs of every ring's sorted records and those out of order"""
+    if os.environ.get("LL_SORT_CHECK"):
+        import ctypes as C
+        buf = (C.c_ulonglong * 16)(); ctx._ck(ctx.lib.ll_debug_counters(ctx.h, buf, 0))
+        SORT_SEEN[0] += buf[10]; SORT_BAD[0] += buf[9]
+
 bad = 0; checked = 0
 FIRST = int(sys.argv[2]) if len(sys.argv) > 2 else 0           # soak_extract.py <seeds> [first seed]
 for seed in range(FIRST, FIRST + (int(sys.argv[1]) if len(sys.argv) > 1 else 6)):
@@ -47,6 +57,9 @@ for seed in range(FIRST, FIRST + (int(sys.argv[1]) if len(sys.argv) > 1 else 6))
         for name in ("sharp", "less_sharp", "flat", "less_flat"):
             assert_bit_equal(f[name], ref[name], f"seed {seed} scan {k} {name}")
         checked += 1
-    ctx.close()
+    sort_check(ctx); ctx.close()
     print("seed", seed, "ok, checked so far", checked, flush=True)
 print("soak passed:", checked, "scans")
+if os.environ.get("LL_SORT_CHECK"):      # the library is a -DLL_SORT_CHECK build (LIGHTLOAM_HIP_LIB): the voxel sort's order asserted on every ring
+    print("sort check: %d adjacent sorted pairs looked at, %d out of (voxel, input order) order" % (SORT_SEEN[0], SORT_BAD[0]))
+    assert SORT_SEEN[0] > 0 and SORT_BAD[0] == 0

@@ -8,6 +8,16 @@ from lightloam_amd import api, synth
 from oracle import orc
 from conftest import assert_bit_equal
 api.load_library(); orc.build()
+SORT_SEEN, SORT_BAD = [0], [0]
+
+
+def sort_check(ctx):
+    """-DLL_SORT_CHECK builds count, per context, the adjacent pairs of every ring's sorted records and those out of order"""
+    if os.environ.get("LL_SORT_CHECK"):
+        import ctypes as C
+        buf = (C.c_ulonglong * 16)(); ctx._ck(ctx.lib.ll_debug_counters(ctx.h, buf, 0))
+        SORT_SEEN[0] += buf[10]; SORT_BAD[0] += buf[9]
+
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 96
 total = 0
 for name, kw in (("ringmajor", {}), ("azmajor_jitter_nan", dict(order=1, az_jitter_deg=0.4, drop_prob=0.03, emit_nan=1)), ("ringmajor_jitter_drop", dict(az_jitter_deg=0.7, drop_prob=0.1))):
@@ -39,6 +49,9 @@ for name, kw in (("ringmajor", {}), ("azmajor_jitter_nan", dict(order=1, az_jitt
         assert (ges == es).all() and (gea == ea).all() and (geb == eb).all(), (name, k, "edge")
         assert (gps == ps).all() and (gpa == pa).all() and (gpb == pb).all() and (gpc == pc).all(), (name, k, "plane")
     orc.set_nn_mode(0)
-    ctx.close(); total += N
+    sort_check(ctx); ctx.close(); total += N
     print(name, "ok", flush=True)
 print("soak passed:", total, "scans")
+if os.environ.get("LL_SORT_CHECK"):      # the library is a -DLL_SORT_CHECK build (LIGHTLOAM_HIP_LIB): the voxel sort's order asserted on every ring
+    print("sort check: %d adjacent sorted pairs looked at, %d out of (voxel, input order) order" % (SORT_SEEN[0], SORT_BAD[0]))
+    assert SORT_SEEN[0] > 0 and SORT_BAD[0] == 0
