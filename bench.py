@@ -773,8 +773,8 @@ def main():
         raise SystemExit(f"bench self-check failed on rank {rank}: {len(bad)} slot(s), first {bad[:5]}")
     kernel_bytes = {
         "k_first_kept": 0.0, "k_offsets": 0.0, "k_gn_step": 0.0,
-        "k_organize": 16.0 * tot["n_in"] + 16.0 * tot["n"],          # read the raw scan, write laserCloud (one pass)
-        "k_classify": 16.0 * tot["n_in"],                            # (tile-parallel path of small calls) read the raw scan
+        "k_organize": 4.0 * args.input_stride * tot["n_in"] + 16.0 * tot["n"],   # read the raw scan, write laserCloud (one pass)
+        "k_classify": 4.0 * args.input_stride * tot["n_in"],                            # (tile-parallel path of small calls) read the raw scan
         "k_scatter": 16.0 * tot["n"],                                # (tile-parallel path) write laserCloud
         # the ring stage is two launches since round 4 (ll_pick.hip, ll_features.hip)
         "k_ring_pick": 17.0 * tot["n"],                               # read laserCloud, write labels (+ 352 B of lists per ring)
@@ -863,6 +863,8 @@ def main():
                        "ring_pipeline": "k_ring_pick + k_ring_features; ring-strided less-flat cloud, no hand-over between the rings of a scan",
                        "self_check": "every slot: status 0, correspondences > 0, finite pose; equal scan pairs -> bit-identical poses",
                        "points_per_scan_in": int(info.n_in), "points_per_scan_kept": int(info.n),
+                       "input_bytes_per_point": 4 * args.input_stride,
+                       "association": "k_associate in one traversal (per-ring minima collected while the nearest neighbour is searched)",
                        "parallelism": f"scan-parallel x{world}, no data-path collective"},
             "roofline": {"bound": bound, "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,

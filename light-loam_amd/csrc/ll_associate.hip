@@ -837,7 +837,10 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
  * with the same 60 VGPRs and no scratch -- the kernel is latency-bound, one more wave per SIMD is worth 17 % (A/B, one box).
  * LDS: 4 KB queries + 6.8 KB entry bounds + 7 KB ring tables + 1.3 KB walk tables + 0.5 KB = 19.6 of the 20 KB that eight
  * workgroups per CU leave each. */
-__global__ __launch_bounds__(LL_BLOCK, 8) void k_associate(LLView V, int first, int count, int qb_corner, int qb_plane, int qpb)
+#ifndef LL_ASSOC_WAVES
+#define LL_ASSOC_WAVES 8          /* waves per SIMD = workgroups per CU the kernel is compiled for (A/B: 4 with more loads in flight per lane) */
+#endif
+__global__ __launch_bounds__(LL_BLOCK, LL_ASSOC_WAVES) void k_associate(LLView V, int first, int count, int qb_corner, int qb_plane, int qpb)
 {
     /* All query blocks of a scan on ONE XCD (workgroup b runs on XCD b % 8): they search the same target grid, and an XCD's 4 MB L2 is
      * private -- dealt round-robin over the XCDs, every scan's target would be fetched into all eight of them. */

@@ -66,8 +66,11 @@ python3 tools/rocpd_summary.py $O/prof_${TAG}_hdl64/${TAG}h_results.db > $O/${TA
 # the other shapes and BASELINE config 5 (stream of scans over PCIe, 64 and 128 rings)
 python3 bench.py --rings 128 --no-cpu-baseline > $O/${TAG}_bench_s128.json 2>/dev/null
 python3 bench.py --rings 16 --no-cpu-baseline > $O/${TAG}_bench_s16.json 2>/dev/null
-python3 bench.py --stream-input --no-cpu-baseline > $O/${TAG}_stream_input.json 2>/dev/null
-python3 bench.py --stream-input --rings 128 --no-cpu-baseline > $O/${TAG}_stream_input_s128.json 2>/dev/null
+# (12-byte points = ll_params.input_stride_floats 3: the 4th float of a .bin record never crosses PCIe; the 16-byte contract beside it)
+python3 bench.py --stream-input --input-stride 3 --no-cpu-baseline > $O/${TAG}_stream_input.json 2>/dev/null
+python3 bench.py --stream-input --input-stride 3 --rings 128 --no-cpu-baseline > $O/${TAG}_stream_input_s128.json 2>/dev/null
+python3 bench.py --stream-input --no-cpu-baseline > $O/${TAG}_stream_input_16_byte_points.json 2>/dev/null
+python3 bench.py --stream-input --rings 128 --no-cpu-baseline > $O/${TAG}_stream_input_s128_16_byte_points.json 2>/dev/null
 # the full soaks behind tests/test_gpu_soak.py
 python3 tools/soak_extract.py 8 > $O/${TAG}_soak_extract.log 2>&1
 python3 tools/soak_extract_s64.py 96 > $O/${TAG}_soak_extract_s64.log 2>&1
