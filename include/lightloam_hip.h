@@ -265,11 +265,7 @@ int ll_map_optimize(ll_map *m, double *pose_w7, int n_outer, const ll_lm_options
  * all-reduces it (RCCL over xGMI: 28 unique doubles matter) and feeds the sum to ll_map_lm_begin / ll_map_lm_accept,
  * so that every rank advances an identical Levenberg-Marquardt state:
  *     associate;  evaluate -> all-reduce -> lm_begin;  repeat max_num_iterations x { lm_propose; evaluate -> all-reduce -> lm_accept }
- * ll_map_optimize is exactly this sequence on one rank without the all-reduce.
- * A summed record whose cost or row count is NaN -- what a rank whose own step failed contributes (lightloam_rccl.hpp, parallel.py: a record
- * of NaNs, so that the sequence of collectives is never left half way) -- POISONS the solve on every rank: ll_map_lm_begin / _accept
- * note it in the LM state, every later step leaves a NaN pose, and ll_map_get_pose returns LL_ERR_STATE on the healthy ranks too
- * (never a finite, un-optimised pose with LL_OK).  ll_map_set_pose + a clean sequence starts over.                          */
+ * ll_map_optimize is exactly this sequence on one rank without the all-reduce.                                          */
 int ll_map_set_pose(ll_map *m, const double *pose_w7);
 int ll_map_get_pose(ll_map *m, double *pose_w7);                                        /* LL_ERR_STATE: the pose on the device is undefined (NaN) */
 int ll_map_evaluate(ll_map *m, double *neq44);                                           /* at the map's current pose */
