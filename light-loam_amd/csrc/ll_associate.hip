@@ -497,10 +497,18 @@ __device__ __forceinline__ void ll_grid_search(const int *gstart, float qx, floa
  * are the only case in which the table's order (lowest place) and the walks' visiting order can disagree; they show as TMIN and TMAX
  * naming different places, and such a query -- like one whose window rc +- NEARBY_SCAN leaves the table, or a target that is not
  * monotone -- simply starts the second search from nothing with no entry marked visited: the search of rounds 1-5, same code. */
+#ifndef LL_ASSOC_CORNER_ROWS
+#define LL_ASSOC_CORNER_ROWS 1          /* corner queries take the 3 x 3 cells around them as three rows */
+#endif
+#ifndef LL_ASSOC_PLANE_ROWS_BELOW
+#define LL_ASSOC_PLANE_ROWS_BELOW 64    /* ... plane queries too when their own cell holds fewer points than this */
+#endif
 #ifndef LL_ATAB_W
 #define LL_ATAB_W 14              /* ring values per query table: 32 groups x 2 tables x 14 x 8 B = 7 KB of the workgroup's 20 KB */
 #endif
-#define LL_ATAB_BACK 7            /* the table covers rings [predicted - 7, predicted + 6] */
+#ifndef LL_ATAB_BACK
+#define LL_ATAB_BACK (LL_ATAB_W / 2)   /* the table covers rings [predicted - 7, predicted + 6] */
+#endif
 
 template <bool PLANE>
 __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int qblock, int qpb,
@@ -535,20 +543,25 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
         pred = (t_el == t_el) ? ll_ring_of_t(t_el, V.ring_model, V.R, V.lower_bound, V.factor) : 0;
         pred = min(max(pred, 0), 250);
     }
-    qs[tid] = make_float4(sx, sy, sz, __int_as_float(have ? pred + 1 : 0));
     if (tid < 64) hist[tid] = 0;
-    __syncthreads();
     /* The eight queries of a wave advance in lockstep, so they should cost about the same: the block's queries are dealt to
      * the (pass, wave, group) slots in the order of the population of their own cell -- what both searches scan first and the
      * best predictor of their length.  Counting sort over 32 population classes; any order inside a class (no result depends
      * on it).  Slot p of the order is worked on in pass p / 32 by wave (p / 8) % 4: every wave gets every fourth octet. */
     {
         int cls = 31;                                                       /* queries beyond nq / without targets: one class, skipped together */
+        int rows3 = 0;
         if (have && T.m > 0) {
             const int cell = ll_cell_coord(sy) * LL_GRID_G + ll_cell_coord(sx);
             const int cnt = T.gstart[cell + 1] - T.gstart[cell];
             cls = min(30, cnt >> 3);
+            /* how the 3 x 3 cells around the query are taken (below): as three whole rows where the target is sparse around it -- every corner
+             * query (the less-sharp cloud holds 0.4 points per cell), a plane query whose own cell holds few points -- else as five entries,
+             * own cell first, so that a dense cell's neighbours can still be pruned by what the own cell gave */
+            rows3 = (PLANE ? cnt < LL_ASSOC_PLANE_ROWS_BELOW : LL_ASSOC_CORNER_ROWS) ? 1 : 0;
         }
+        qs[tid] = make_float4(sx, sy, sz, __int_as_float(have ? ((pred + 1) | (rows3 << 16)) : 0));
+        __syncthreads();
         const bool dealt = tid < qpb;                                       /* one-pass workgroups order their 32 queries only */
         const int rank = dealt ? atomicAdd(&hist[cls], 1) : 0;
         __syncthreads();
@@ -595,7 +608,7 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
              * lower word >= 0, so it does not (:497 / :659 accept d < DISTANCE_SQ_THRESHOLD only) */
             const unsigned long long knone = (unsigned long long)__float_as_uint(dmax) << 32;
             unsigned long long kb = knone;
-            const unsigned rq0 = (unsigned)(qtag - 1 - LL_ATAB_BACK);          /* first ring value of the table (may be "negative": unsigned compare below) */
+            const unsigned rq0 = (unsigned)((qtag & 0xFFFF) - 1 - LL_ATAB_BACK);          /* first ring value of the table (may be "negative": unsigned compare below) */
             if (use_table) {
                 for (int e = sub; e < 2 * LL_ATAB_W; e += 8) rtab[e] = (e < LL_ATAB_W) ? knone : 0ull;   /* TMIN [0, W), TMAX [W, 2 W) */
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -609,14 +622,22 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
                 }
             };
             unsigned vis = 0u;                                                  /* bit e: THIS lane scanned its share of near entry e in the first traversal */
-            /* The query's own cell and the four entries of Chebyshev ring 1 (row below, row above, left and right cell) serve
-             * BOTH searches: lane e of the group fetches entry e's bounds once and keeps them in its registers, the scans get
-             * them by a lane broadcast.  Own cell, share the best, the ring-1 entries the bound still admits, share again;
-             * only a search that is still open after that (its bound reaches beyond the 3 x 3 cells) goes on ring by ring. */
+            /* The 3 x 3 cells around the query serve BOTH searches: lane e of the group fetches entry e's bounds once and keeps them in its
+             * registers, the scans get them by a lane broadcast.  Two layouts (round 6; the kernel's cost is per visited range, not per
+             * candidate).  Dense surroundings -- a plane query whose own cell holds >= LL_ASSOC_PLANE_ROWS_BELOW points: FIVE entries, the own
+             * cell, then the row below, the row above, the left and the right cell; own cell, share the best, the ring-1 entries the bound
+             * still admits, share again.  Sparse surroundings -- every corner query (the less-sharp cloud holds 0.4 points per cell), the
+             * other plane queries: THREE entries, the own ROW [cx - 1, cx + 1] (one contiguous range of the cell-ordered array), then the row
+             * below and the row above: two dependent scans fewer per search, a handful of candidates more.  Only a search that is still open
+             * after that (its bound reaches beyond the 3 x 3 cells) goes on ring by ring. */
             int a_st = 0, a_en = 0; float a_lb = 0.0f;
+            constexpr bool CROWS = !PLANE && LL_ASSOC_CORNER_ROWS;             /* every corner query: entries 3, 4 do not exist in the code */
+            const bool rows3 = CROWS || (qtag >> 16) != 0;                     /* uniform in the group: the query's own choice (set-up above) */
             if (sub < 5) {
                 const int cx = ll_cell_coord(q.x), cy = ll_cell_coord(q.y);
-                int x0, x1, yy; ll_ring_entry(sub ? 1 : 0, sub ? sub - 1 : 0, cx, cy, x0, x1, yy);
+                int x0, x1, yy;
+                if (rows3) { x0 = cx - 1; x1 = sub < 3 ? cx + 1 : cx - 2; yy = sub == 0 ? cy : (sub == 1 ? cy - 1 : cy + 1); }   /* own row, row below, row above; entries 3, 4 empty */
+                else ll_ring_entry(sub ? 1 : 0, sub ? sub - 1 : 0, cx, cy, x0, x1, yy);
                 const int xa = max(x0, 0), xb = min(x1, LL_GRID_G - 1);
                 if (xa <= xb && yy >= 0 && yy < LL_GRID_G) {
                     a_lb = ll_range_lb2(q.x, q.y, xa, xb, yy);
@@ -635,7 +656,11 @@ __device__ __forceinline__ void ll_associate_block(const LLView &V, int s, int q
                 };
                 entry(std::integral_constant<int, 0>{}); sync();
                 entry(std::integral_constant<int, 1>{}); entry(std::integral_constant<int, 2>{});
-                entry(std::integral_constant<int, 3>{}); entry(std::integral_constant<int, 4>{});
+                if constexpr (!CROWS) {
+                    /* entries 3, 4 are empty for a query that takes rows; the queries of a wave are dealt by the population of their own cell,
+                     * so a wave is usually all rows or all entries: skip the two when no lane of the wave has them */
+                    if (__ballot(!rows3) != 0ull) { entry(std::integral_constant<int, 3>{}); entry(std::integral_constant<int, 4>{}); }
+                }
                 sync();
             };
             auto nn_scan = [&](int st, int en) {

@@ -1,0 +1,9 @@
+#!/bin/bash
+# round 6, call 11: k_associate near entries as three rows (corners / corners + planes), narrower ring tables
+O=gpurun_out; mkdir -p $O
+for v in rowsc rowscp; do
+  echo "== $v"; LIGHTLOAM_HIP_LIB=$GRAFT_REPO_ROOT/_ab/lib$v.so timeout 600 python -m pytest tests/test_gpu_associate_edge.py tests/test_golden.py tests/test_gpu_parity.py -m gpu -x -q 2>&1 | grep -v amdgpu.ids | tail -2
+done 2>&1 | tee $O/r06_11_pytest.log
+bash tools/ab_once.sh > $O/r06_11_ab_s64.log 2>&1; cat $O/r06_11_ab_s64.log
+bash tools/ab_once.sh --workload hdl64 > $O/r06_11_ab_hdl64.log 2>&1; cat $O/r06_11_ab_hdl64.log
+bash tools/ab_once.sh --rings 128 > $O/r06_11_ab_s128.log 2>&1; cat $O/r06_11_ab_s128.log
