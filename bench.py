@@ -697,7 +697,7 @@ def main():
         ctx.hot_path(0, args.batch, None, vote=True)     # pose restarts from the stored guess, device-to-device
 
     # box calibration: a FIXED micro-run (the extract stage of the first 512 slots, three times, untimed warm-up first), HIP-event time
-    # of the ring kernels -- the boxes of the pool differ by up to 30 % in exactly these kernels, so a slow
+    # of the ring kernels -- the boxes of the pool differ by up to 30 % in exactly these kernels (docs/rounds/r03.md 12.3a), so a slow
     # draw shows here instead of looking like a regression of the headline
     calib_n = min(512, args.batch)
     ctx.extract(0, calib_n); ctx.synchronize()
@@ -840,7 +840,7 @@ def main():
                                      "rule": "bound = hbm when the counter traffic's (or the algorithmic bytes') fraction of the measured streaming rate "
                                              "(profiles/r05_stream_rate.json; the 8 TB/s peak without it) is the largest of the four, else issue; "
                                              "unknown without a counter pass of this code",
-                                     "caveat": "the label names the LARGEST of the four fractions, not a saturated unit: below ~0.9 nothing is.  DESIGN.md 14.7: "
+                                     "caveat": "the label names the LARGEST of the four fractions, not a saturated unit: below ~0.9 nothing is.  docs/rounds/r05.md 14.7: "
                                                "k_ring_features got ~1 % faster for 15 % fewer bytes and again for 31 % fewer vector instructions; fewer "
                                                "barriers bought 1-3 %"}
             issue_out["model"] = ("valu_busy = SQ_INSTS_VALU / (%d SIMDs x %.1f GHz / %.1f cycles x launch time); salu_busy = SQ_INSTS_SALU / "
