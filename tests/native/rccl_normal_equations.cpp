@@ -72,7 +72,7 @@ int main(int argc, char **argv)
                             return std::vector<PointXYZI>(v.begin() + (long)a, v.begin() + (long)b);
                         };
                         mo.setScan(slice(sc), slice(ss));
-                        RcclRank rk(rw.comm(r), ctx.get(), r);
+                        RcclRank rk(rw.comm(r), ctx.get(), r, &rw);
                         double p[7]; std::memcpy(p, guess, sizeof(p));
                         map_optimize_row_parallel(mo.get(), rk, p, 2, nullptr);
                         std::memcpy(&pose_of[(size_t)r * 7], p, sizeof(p));
@@ -93,7 +93,7 @@ int main(int argc, char **argv)
                     try {
                         Context ctx(16, 1, r);
                         MapOptimizer mo(ctx, (int)mc.size() + 16, (int)ms.size() + 16, (int)sc.size() + 16, (int)ss.size() + 16);
-                        RcclRank rk(rw.comm(r), ctx.get(), r);
+                        RcclRank rk(rw.comm(r), ctx.get(), r, &rw);
                         double p[7]; std::memcpy(p, guess, sizeof(p));
                         mo.setInputClouds(std::vector<PointXYZI>(mc.begin(), mc.begin() + 8), ms);      // 8 corner points: too small
                         mo.setScan(sc, ss);
@@ -145,7 +145,7 @@ int main(int argc, char **argv)
                         Context ctx(16, 1, r);
                         LaserMapping shard(ctx, 0.4f, 0.8f, 4096, 32768, 1 << 20);
                         shard.set_shard(r, world);
-                        RcclRank rk(rw.comm(r), ctx.get(), r);
+                        RcclRank rk(rw.comm(r), ctx.get(), r, &rw);
                         for (int k = 0; k < n_frames; ++k) {
                             const double *o = &odom[(size_t)k * 7];
                             shard.transformAssociateToMap(o, o + 4);
